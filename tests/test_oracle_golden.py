@@ -1,0 +1,108 @@
+"""Pins the CPU oracle against the reference's own golden vectors.
+
+tests/core/layers/mlu/qwen2_attention_test.cpp:254-328 hard-codes the first 10 outputs of
+Qwen2Attention (qkv_proj+bias -> neox RoPE -> KV write -> attention -> o_proj) for
+  * prefill  B=2, S=128                     (PrefillTest  :254-290)
+  * decode   B=4, kv_len=257, paged cache   (DecodeTest   :292-328)
+with seeded_tensor inputs (tests_utils.cpp:189-274).  The goldens are MLU-kernel outputs in bf16, so
+agreement is asserted to a few bf16 ulps rather than the test's own 1e-5 (a different accumulation
+order already moves the last bf16 bit).
+"""
+import math
+
+import torch
+
+from oracle import oracle as orc
+
+H, NQ, NKV, D, BS, NBLK = 1024, 16, 8, 128, 16, 100
+PFX = "qwen2_attention_test."
+
+
+def _weights():
+    q_size, kv_size = NQ * D, NKV * D
+
+    def seeded(name, shape):
+        t = orc.seeded_tensor(PFX + name, shape, torch.bfloat16)
+        return t / torch.sqrt(torch.tensor(t.size(0), dtype=torch.bfloat16))  # :104-106
+
+    w = dict(q=seeded("q_proj.weight", (q_size, H)), k=seeded("k_proj.weight", (kv_size, H)),
+             v=seeded("v_proj.weight", (kv_size, H)), qb=seeded("q_proj.bias", (q_size,)),
+             kb=seeded("k_proj.bias", (kv_size,)), vb=seeded("v_proj.bias", (kv_size,)),
+             o=seeded("o_proj.weight", (H, q_size)))
+    w["qkv"] = torch.cat([w["q"], w["k"], w["v"]], 0).contiguous()
+    w["qkv_b"] = torch.cat([w["qb"], w["kb"], w["vb"]], 0).contiguous()
+    return w
+
+
+def _caches():
+    # MLU layout [blocks, heads, block_size, d] (:65-70) -> ours [blocks, block_size, heads, d]
+    kc = orc.make_noise(PFX + "k_cache", (NBLK, NKV, BS, D), 0.01).permute(0, 2, 1, 3).contiguous()
+    vc = orc.make_noise(PFX + "v_cache", (NBLK, NKV, BS, D), 0.01).permute(0, 2, 1, 3).contiguous()
+    return kc, vc
+
+
+def _layer(hidden, positions, w, kc, vc, slots, mode, **kw):
+    q_size, kv_size = NQ * D, NKV * D
+    qkv = orc.matmul(hidden, w["qkv"], w["qkv_b"])
+    q, k, v = qkv[:, :q_size], qkv[:, q_size:q_size + kv_size], qkv[:, q_size + kv_size:]
+    cache = orc.build_cos_sin_cache(2048, D, 1000000.0, torch.bfloat16)
+    orc.rotary_embedding(positions, q, k, cache, D, is_neox=True)
+    T = hidden.shape[0]
+    k3, v3 = k.unflatten(-1, (NKV, D)), v.unflatten(-1, (NKV, D))
+    orc.reshape_paged_cache(slots, k3, v3, kc, vc)
+    scale = math.sqrt(1.0 / D)
+    if mode == "prefill":
+        attn = orc.attention_varlen(q.unflatten(-1, (NQ, D)), k3, v3, kw["cu"], kw["cu"], scale, causal=True)
+    else:
+        attn = orc.paged_attention(q.unflatten(-1, (NQ, D)), kc, vc, kw["cu_q"], kw["kv_lens"],
+                                   kw["block_table"], scale, causal=False)
+    return orc.matmul(attn, w["o"])
+
+
+def _block_num(seq_len):
+    return (seq_len + BS - 1) // BS + 1
+
+
+def _assert_close_bf16(got, expected, ulps):
+    exp = torch.tensor(expected, dtype=torch.float32)
+    got = got.float()
+    tol = ulps * exp.abs() * 2.0 ** -8
+    assert torch.all((got - exp).abs() <= tol), (got, exp)
+
+
+def test_prefill_golden():
+    B, S = 2, 128
+    w = _weights()
+    kc, vc = _caches()
+    hidden = orc.make_noise(PFX + "prefill.hidden_states", (B * S, H), 0.02)
+    positions = torch.arange(S).repeat(B)
+    per = _block_num(S) * BS
+    slots = torch.tensor([b * per + i for b in range(B) for i in range(S)], dtype=torch.int32)
+    cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32)
+    out = _layer(hidden, positions, w, kc, vc, slots, "prefill", cu=cu)
+    expected = [0.6796875, 0.67578125, 0.6875, 0.65625, 0.6640625, 0.6796875, 0.68359375, 0.67578125,
+                0.6796875, 0.66796875]
+    _assert_close_bf16(out.flatten()[:10], expected, ulps=2)
+
+
+def test_decode_golden():
+    B, S = 4, 256
+    w = _weights()
+    kc, vc = _caches()
+    hidden = orc.make_noise(PFX + "decode.hidden_states", (B, H), 0.02)
+    positions = torch.full((B,), S)
+    kv = S + 1
+    nblk = _block_num(kv)
+    per = nblk * BS
+    slots = torch.tensor([b * per + (kv - 1) for b in range(B)], dtype=torch.int32)
+    table = torch.arange(B * nblk, dtype=torch.int32).view(B, nblk)
+    out = _layer(hidden, positions, w, kc, vc, slots, "decode", cu_q=torch.arange(B + 1, dtype=torch.int32),
+                 kv_lens=torch.full((B,), kv, dtype=torch.int32), block_table=table)
+    expected = [0.0005264282, 0.0008239746, 0.0005722046, 0.0006027222, 0.000831604, 0.0004405975,
+                0.001037598, 0.001083374, 0.000289917, 0.0007820129]
+    got = out.flatten()[:10].float()
+    exp = torch.tensor(expected)
+    # outputs are sums of ~2048 mean-zero terms of size 1e-5: compare on the vector, 3% of its norm
+    assert (got - exp).norm() / exp.norm() < 3e-2, (got, exp)
+    assert torch.all((got - exp).abs() <= 4e-5), (got, exp)
+
