@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- decode-step throughput of the xLLM hot path on MI355X (BASELINE.json metric).
+
+A "step" is ONE decode iteration of the full Qwen2-7B W8A8 model (28 layers + final norm + lm_head + greedy
+argmax) over a synthetic fixed-shape batch: bs=256 sequences with ctx=4096 cached tokens each, paged KV
+(block 128, shuffled non-contiguous pages), inputs resident in HBM before the timed region.  Every layer runs
+the reference's op order (xllm_amd/layers.py) through the C ABI of include/xllm_mi355.h -- hand-written
+gfx950 kernels only; the oracle is used for the cpu_baseline leg alone.
+
+Multi-GPU (one process per GPU, launched by torch.distributed.run): tensor parallel over RCCL/xGMI with the
+reference's sharding (heads / columns, all-reduce after o_proj and down_proj, all-gather of logits).
+Qwen2-7B has 28 heads, so valid TP is {1,2,4} (qwen2_attention.cpp:54-65): N=8 runs TP=4 x DP=2 with the
+global batch split across the two replicas.  Total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (model, mode, global batch, ctx)
+    "cfg3": ("qwen2_7b", "int8", 256, 4096),   # BASELINE.json metric config (configs[2])
+    "cfg2": ("qwen2_7b", "16bit", 64, 2048),   # configs[1]
+    "tiny": ("qwen2_0_5b", "int8", 8, 512),    # CPU-sized smoke shape
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--config", default="cfg3", choices=list(CONFIGS))
+    p.add_argument("--no-fuse", action="store_true", help="reference op order without the N1 quant fusions")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
+    return p.parse_args()
+
+
+def build_metadata(B, ctx, block_size, device, seed):
+    """BatchInputBuilder-shaped decode metadata (framework/batch/batch_input_builder.cpp:739-830, 904-938)."""
+    from xllm_amd.attention import AttentionMetadata
+    pages = (ctx + block_size - 1) // block_size
+    n_blocks = int(B * pages * 1.1) + 1
+    g = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(n_blocks, generator=g)[: B * pages].to(torch.int32).view(B, pages)
+    pos = ctx - 1  # the new token
+    slots = perm[:, pos // block_size] * block_size + pos % block_size
+    md = AttentionMetadata(
+        q_cu_seq_lens=torch.arange(B + 1, dtype=torch.int32, device=device),
+        kv_cu_seq_lens=torch.arange(0, (B + 1) * ctx, ctx, dtype=torch.int32, device=device),
+        kv_seq_lens=torch.full((B,), ctx, dtype=torch.int32, device=device),
+        slot_mapping=slots.to(torch.int32).to(device),
+        block_table=perm.contiguous().to(device),
+        max_query_len=1, max_seq_len=ctx, is_prefill=False, is_chunked_prefill=False)
+    return md, n_blocks
+
+
+def cpu_baseline(args_model, mode, ctx, block_size):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores on a bounded sample:
+    ONE decoder layer, decode step, B_s sequences at the full ctx; extrapolated to L layers + lm_head."""
+    import ctypes as C
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    a = args_model
+    Bs = 8
+    g = torch.Generator().manual_seed(0)
+    pages = (ctx + block_size - 1) // block_size
+    nb = Bs * pages
+    kc = torch.randn(nb, block_size, a.n_kv_heads, a.head_dim, generator=g).bfloat16()
+    vc = torch.randn(nb, block_size, a.n_kv_heads, a.head_dim, generator=g).bfloat16()
+    table = torch.randperm(nb, generator=g).to(torch.int32).view(Bs, pages)
+    kv_lens = torch.full((Bs,), ctx, dtype=torch.int32)
+    cu_q = torch.arange(Bs + 1, dtype=torch.int32)
+    H, I = a.hidden_size, a.intermediate_size
+    qsz, kvsz = a.n_heads * a.head_dim, a.n_kv_heads * a.head_dim
+    mk = lambda n, k: (torch.randint(-127, 128, (n, k), generator=g, dtype=torch.int8), torch.rand(n, generator=g) * 1e-3)
+    w_qkv, w_o, w_gu, w_dn = mk(qsz + 2 * kvsz, H), mk(H, qsz), mk(2 * I, H), mk(H, I)
+    nw = (torch.rand(H, generator=g) + 0.5).bfloat16()
+    x = torch.randn(Bs, H, generator=g).bfloat16()
+    res = torch.randn(Bs, H, generator=g).bfloat16()
+    cache = orc.build_cos_sin_cache(ctx, a.head_dim, a.rope_theta, torch.bfloat16)
+    pos = torch.full((Bs,), ctx - 1)
+    slots = (table[:, (ctx - 1) // block_size] * block_size + (ctx - 1) % block_size).to(torch.int32)
+
+    def lin(inp, w):
+        q, s = orc.scaled_quantize(inp)
+        return orc.scaled_matmul(q, w[0], s, w[1], torch.bfloat16)
+
+    def layer():
+        h, r = x.clone(), res.clone()
+        orc.fused_add_rms_norm(h, r, nw, a.rms_norm_eps)
+        qkv = lin(h, w_qkv)
+        q, k, v = qkv[:, :qsz], qkv[:, qsz:qsz + kvsz], qkv[:, qsz + kvsz:]
+        orc.rotary_embedding(pos, q, k, cache, a.head_dim)
+        orc.reshape_paged_cache(slots, k.unflatten(-1, (a.n_kv_heads, a.head_dim)),
+                                v.unflatten(-1, (a.n_kv_heads, a.head_dim)), kc, vc)
+        at = orc.paged_attention(q.unflatten(-1, (a.n_heads, a.head_dim)), kc, vc, cu_q, kv_lens, table,
+                                 a.head_dim ** -0.5)
+        o = lin(at, w_o)
+        orc.fused_add_rms_norm(o, r, nw, a.rms_norm_eps)
+        gu = lin(o, w_gu)
+        act = torch.empty(Bs, I, dtype=torch.bfloat16)
+        orc.act_and_mul(act, gu, "silu")
+        return lin(act, w_dn)
+
+    layer()  # warm (page-in)
+    t0 = time.perf_counter()
+    layer()
+    t_layer = time.perf_counter() - t0
+    # lm_head on the sample: [Bs,H] x [V,H]^T in 16-bit; time a 1/16 slice of V and scale
+    Vs = a.vocab_size // 16
+    lw = (torch.randn(Vs, H, generator=g) * 0.02).bfloat16()
+    t0 = time.perf_counter()
+    orc.matmul(x, lw)
+    t_head = (time.perf_counter() - t0) * 16
+    t_step = t_layer * a.n_layers + t_head
+    return {"value": round(Bs / t_step, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (OpenMP, {cores} threads): 1 decoder layer x 1 decode step, {Bs} sequences at "
+                      f"ctx={ctx} (x{a.n_layers} layers) + lm_head on 1/16 of the vocab (x16); "
+                      f"t_layer={t_layer:.3f}s t_lm_head={t_head:.3f}s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from xllm_amd import layers, parallel
+    from xllm_amd.attention import KVCache
+
+    model_name, mode, gbatch, ctx = CONFIGS[a.config]
+    margs = getattr(layers.ModelArgs, model_name)()
+    block_size = 128
+    tp_size = world if world in (1, 2, 4) else 4
+    if margs.n_heads % tp_size:
+        tp_size = 2 if margs.n_heads % 2 == 0 and world % 2 == 0 else 1
+    dp_size = world // tp_size
+    tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_size) if world > 1 else (None, 0))
+    B = gbatch // dp_size
+    dtype = torch.bfloat16
+
+    model = layers.Qwen2Model(margs, mode, dtype, dev, seed=1234, tp=tp_pg, fuse=not a.no_fuse)
+    md, n_blocks = build_metadata(B, ctx, block_size, dev, seed=dp_rank)
+    nkv_l = model.layers[0].nkv
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    kv_caches = []
+    for _ in model.layers:
+        kc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
+        vc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
+        kv_caches.append(KVCache(kc, vc))
+    tokens = torch.randint(0, margs.vocab_size, (B,), device=dev, generator=gen)
+    positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+
+    # per-launch HIP events around the dominant kernel (paged decode attention) on the launch stream
+    from xllm_amd import ops
+    attn_events = []
+    orig_paged = ops.paged_attention
+    record = {"on": False}
+
+    def timed_paged(*args, **kw):
+        if not record["on"]:
+            return orig_paged(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_paged(*args, **kw)
+        e1.record()
+        attn_events.append((e0, e1))
+        return out
+
+    ops.paged_attention = timed_paged
+
+    def step():
+        hidden = model.forward(tokens, positions, md, kv_caches)
+        logits = model.logits(hidden)
+        return torch.argmax(logits, dim=-1)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    record["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    record["on"] = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    tok_s = gbatch * a.steps / elapsed
+
+    attn_ms = sum(e0.elapsed_time(e1) for e0, e1 in attn_events) / max(len(attn_events), 1)
+    nq_l = model.layers[0].nq
+    d = margs.head_dim
+    # algorithmic bytes per launch: K+V of every cached token once + Q in + O out
+    attn_bytes = B * (ctx * nkv_l * d * 2 * 2 + 2 * nq_l * d * 2)
+    achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "decode_attn_pmc.json")
+    if os.path.exists(pmc) and world == 1 and a.config == "cfg3":
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if a.micro and rank == 0:
+        micro(model, md, kv_caches, tokens, positions, B, sys.stderr)
+
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/s, Qwen2-7B int8 bs=256 ctx=4096" if a.config == "cfg3" else f"decode tokens/s ({a.config})",
+            "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int8" if mode == "int8" else "bf16", "data": "synthetic",
+            "config": {"workload": f"{model_name} {'W8A8 int8' if mode == 'int8' else 'bf16'} decode step, "
+                                   f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
+                                   f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
+                       "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
+                       "quant_fusion": not a.no_fuse},
+            "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+split-KV merge)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4),
+                         "launches_timed": len(attn_events)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def micro(model, md, kv_caches, tokens, positions, B, fh):
+    """per-operator timings of one layer (cuda events, 20 iterations each) -- tuning aid, not the metric"""
+    from xllm_amd import ops
+    L = model.layers[0]
+    dev = tokens.device
+    H, I = model.args.hidden_size, L.I
+    x = torch.randn(B, H, device=dev).bfloat16()
+    res = torch.randn(B, H, device=dev).bfloat16()
+    qkv = torch.randn(B, L.q_size + 2 * L.kv_size, device=dev).bfloat16()
+    gu = torch.randn(B, 2 * I, device=dev).bfloat16()
+    kvc = kv_caches[0]
+
+    def t(name, fn, bytes_=None, flops=None, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        extra = ""
+        if bytes_:
+            extra += f"  {bytes_ / us / 1e3:8.1f} GB/s"
+        if flops:
+            extra += f"  {flops / us / 1e6:8.1f} TOP/s"
+        print(f"[micro] {name:34s} {us:9.1f} us{extra}", file=fh)
+
+    q8, s8 = ops.scaled_quantize(x)
+    t("rms_norm+int8 quant (fused add)", lambda: ops.rms_norm_dynamic_int8_quant(x, L.input_norm_w, 1e-6, residual=res),
+      bytes_=B * H * (2 + 2 + 2 + 1))
+    for nm, lin, inp in (("qkv", L.qkv_proj, q8), ("gate_up", L.gate_up_proj, q8)):
+        N, K = lin.weight.shape
+        t(f"scaled_matmul {nm} [{B}x{N}x{K}]", lambda lin=lin: ops.scaled_matmul(q8, lin.weight, s8, lin.w_scale, torch.bfloat16, lin.bias),
+          bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
+    at = torch.randn(B, L.q_size, device=dev).bfloat16()
+    qa, sa = ops.scaled_quantize(at)
+    N, K = L.o_proj.weight.shape
+    t(f"scaled_matmul o [{B}x{N}x{K}]", lambda: ops.scaled_matmul(qa, L.o_proj.weight, sa, L.o_proj.w_scale, torch.bfloat16),
+      bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
+    qd, sd = ops.act_and_mul_dynamic_int8_quant(gu)
+    N, K = L.down_proj.weight.shape
+    t(f"scaled_matmul down [{B}x{N}x{K}]", lambda: ops.scaled_matmul(qd, L.down_proj.weight, sd, L.down_proj.w_scale, torch.bfloat16),
+      bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
+    t("silu_mul+int8 quant", lambda: ops.act_and_mul_dynamic_int8_quant(gu), bytes_=B * I * 5)
+    t("rope", lambda: ops.rotary_embedding(positions, qkv[:, :L.q_size], qkv[:, L.q_size:L.q_size + L.kv_size], model.cos_sin, True, head_size=L.d))
+    q3 = qkv[:, :L.q_size].unflatten(-1, (L.nq, L.d))
+    ctx = md.max_seq_len
+    t("paged decode attention", lambda: ops.paged_attention(q3, kvc.k_cache, kvc.v_cache, None, md.kv_seq_lens, md.block_table, 1, ctx, L.attn.scale),
+      bytes_=B * (ctx * L.nkv * L.d * 4 + 4 * L.nq * L.d))
+    h = torch.randn(B, H, device=dev).bfloat16()
+    V = model.lm_head.weight.shape[0]
+    t(f"lm_head matmul [{B}x{V}x{H}]", lambda: ops.matmul(h, model.lm_head.weight), bytes_=V * H * 2, flops=2 * B * V * H, n=5)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,213 @@
+/*
+ * xllm_mi355.h -- C ABI of the MI355X (gfx950 / CDNA4) kernel backend for xLLM's
+ * decode/prefill hot path.
+ *
+ * Every entry point replaces one operator of the reference's kernel boundary
+ * (xllm/core/kernels/ops_api.h, per-backend headers kernels/cuda/cuda_ops_api.h and
+ * kernels/dcu/dcu_ops_api.h) or one attention mode of the per-backend AttentionImpl
+ * (xllm/core/layers/dcu/attention.h:31-51).  The reference interface each one binds to is
+ * cited on the declaration.  INTEGRATION.md shows the `#elif defined(USE_MI355)` shim a
+ * maintainer adds to ops_api.cpp (shim/mi355_ops_api.{h,cpp} in this repo is that shim).
+ *
+ * Conventions
+ *   - plain pointers and sizes; all pointers are DEVICE pointers unless stated; nothing is
+ *     allocated inside; `workspace` (where present) is caller provided, size from the
+ *     matching *_workspace_bytes() call.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host
+ *     synchronisation and reads no device data on the host => HIP-graph capturable
+ *     (the reference's DCU path is not: kernels/dcu/group_gemm.cpp:45).
+ *   - return 0 on success, <0 on error (XM_ERR_*); xllm_mi355_strerror() maps codes to text.
+ *     The C++ shim turns non-zero into TORCH_CHECK(false, ...) (reference: CHECK/TORCH_CHECK).
+ *   - dtype codes XM_F32/XM_BF16/XM_F16 select the 16/32-bit "scalar_t" of the reference's
+ *     DISPATCH_FLOATING_TYPES.
+ */
+#ifndef XLLM_MI355_H_
+#define XLLM_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XM_API __attribute__((visibility("default")))
+
+enum { XM_F32 = 0, XM_BF16 = 1, XM_F16 = 2 };
+enum {
+  XM_OK = 0,
+  XM_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, misalignment) */
+  XM_ERR_UNSUPPORTED = -2, /* shape / dtype outside what the kernels implement */
+  XM_ERR_HIP = -3,         /* a HIP runtime call failed (launch error) */
+  XM_ERR_WORKSPACE = -4    /* workspace too small */
+};
+enum { XM_ACT_SILU = 0, XM_ACT_GELU = 1, XM_ACT_GELU_TANH = 2 };
+
+XM_API const char* xllm_mi355_strerror(int code);
+XM_API int xllm_mi355_abi_version(void);
+
+/* ---- KV write ------------------------------------------------------------------------------
+ * kernel::reshape_paged_cache (ops_api.h:31) -> cuda::reshape_paged_cache
+ * (kernels/cuda/reshape_paged_cache.cu:65-100).  k/v [T, nkv, d] with token strides (elements),
+ * caches [n_blocks, block_size, nkv, d]; slot<0 skipped; slot/block_size >= n_blocks is silently
+ * skipped as out of range (the reference would write out of bounds).  elt_bytes 2 or 4. */
+XM_API int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const void* v,
+                                          void* k_cache, void* v_cache, int64_t n_tokens,
+                                          int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                                          int64_t n_blocks, int64_t k_stride, int64_t v_stride,
+                                          int elt_bytes, void* stream);
+
+/* dcu::build_block_table_from_paged_kv_cuda (kernels/dcu/build_block_table_from_paged_kv.hip:74-110):
+ * CSR (indptr[B+1], indices[total_pages]) -> dense [B, total_pages] int32, -1 padded. */
+XM_API int xllm_mi355_build_block_table_from_paged_kv(const int32_t* indptr, const int32_t* indices,
+                                                      int32_t batch, int32_t total_pages,
+                                                      int32_t* block_table, void* stream);
+
+/* ---- RMSNorm family ------------------------------------------------------------------------
+ * kernel::fused_layernorm (ops_api.h:43) -> cuda::rms_norm / cuda::fused_add_rms_norm
+ * (kernels/cuda/norm.cu:430-512).  in_stride = token stride of `input` in elements. */
+XM_API int xllm_mi355_rms_norm(void* out, const void* input, const void* weight, float eps,
+                               int64_t n_tokens, int64_t hidden, int64_t in_stride, int dtype,
+                               void* stream);
+XM_API int xllm_mi355_fused_add_rms_norm(void* input, void* residual, const void* weight, float eps,
+                                         int64_t n_tokens, int64_t hidden, int64_t in_stride,
+                                         int dtype, void* stream);
+/* kernel::rms_norm_static_fp8_quant / fused_add_rms_norm_static_fp8_quant (ops_api.h:168,172)
+ * -> kernels/cuda/norm.cu:517-640.  residual may be NULL (no add).  out is e4m3fn bytes. */
+XM_API int xllm_mi355_rms_norm_static_fp8_quant(uint8_t* out, const void* input, void* residual,
+                                                const void* weight, const float* scale, float eps,
+                                                int64_t n_tokens, int64_t hidden, int64_t in_stride,
+                                                int dtype, void* stream);
+/* "next" N1 fusion (MLU fused_layernorm(dynamic_quant) param.h:243-277): norm (+residual) then
+ * per-token int8 quant of the normalised row in one pass: out_q [T,H] int8, out_scale [T] f32.
+ * Arithmetic == rms_norm followed by scaled_quantize on its 16-bit output. residual may be NULL. */
+XM_API int xllm_mi355_rms_norm_dynamic_int8_quant(int8_t* out_q, float* out_scale, const void* input,
+                                                  void* residual, const void* weight, float eps,
+                                                  int64_t n_tokens, int64_t hidden, int64_t in_stride,
+                                                  int dtype, void* stream);
+
+/* ---- RoPE ----------------------------------------------------------------------------------
+ * kernel::apply_rotary (ops_api.h:27) -> cuda::rotary_embedding (kernels/cuda/rope.cu:156-250).
+ * positions int64 [T]; q [T, nq*head_size], k optional (NULL) [T, nk*head_size], token strides in
+ * elements, head_stride = head_size; cos_sin_cache [max_pos, rot_dim] = [cos(rot/2) || sin(rot/2)]. */
+XM_API int xllm_mi355_rotary_embedding(const int64_t* positions, void* q, void* k,
+                                       const void* cos_sin_cache, int64_t n_tokens, int64_t n_q_heads,
+                                       int64_t n_k_heads, int64_t head_size, int64_t rot_dim,
+                                       int64_t q_stride, int64_t k_stride, int64_t head_stride,
+                                       int is_neox, int dtype, void* stream);
+/* cuda::fused_qk_norm_rope (kernels/cuda/cuda_ops_api.h:235-249, fused_qknorm_rope.cu:388-...):
+ * per-head RMSNorm(q),(k) + RoPE inside packed qkv [T,(nq+nk+nv)*d]; cache dtype = cache_dtype. */
+XM_API int xllm_mi355_fused_qk_norm_rope(void* qkv, int64_t n_tokens, int64_t n_q, int64_t n_k,
+                                         int64_t n_v, int64_t head_dim, float eps, const void* q_weight,
+                                         const void* k_weight, const void* cos_sin_cache,
+                                         int cache_dtype, int interleaved, const int64_t* positions,
+                                         int dtype, void* stream);
+
+/* ---- activation ----------------------------------------------------------------------------
+ * kernel::active (ops_api.h:29) -> cuda::act_and_mul (kernels/cuda/activation.cu:143-185).
+ * input [T, 2*d] contiguous, out [T, d]. */
+XM_API int xllm_mi355_act_and_mul(void* out, const void* input, int64_t n_tokens, int64_t d,
+                                  int act_mode, int dtype, void* stream);
+/* "next" N1 fusion (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815): silu(gate)*up then
+ * per-token int8 quant; == act_and_mul followed by scaled_quantize. */
+XM_API int xllm_mi355_act_and_mul_dynamic_int8_quant(int8_t* out_q, float* out_scale, const void* input,
+                                                     int64_t n_tokens, int64_t d, int act_mode,
+                                                     int dtype, void* stream);
+
+/* ---- int8 W8A8 -----------------------------------------------------------------------------
+ * kernel::scaled_quantize (ops_api.h:95) -> dcu::scaled_quantize (kernels/dcu/scaled_quantize.hip:411-...)
+ * per-token symmetric int8: x [M,K] (dtype) -> q [M,K] int8, scale [M] f32. */
+XM_API int xllm_mi355_scaled_quantize(const void* x, int8_t* out, float* out_scale, int64_t M,
+                                      int64_t K, int dtype, void* stream);
+/* kernel::scaled_matmul (ops_api.h:98) -> dcu::scaled_matmul (kernels/dcu/scaled_matmul.cpp:103-300):
+ * out[m,n] = r16( int32(sum_k a[m,k]*w[n,k]) * a_scale[m] * w_scale[n] + bias[n] ); a [M,K] int8,
+ * w [N,K] int8 row-major, bias (out dtype) may be NULL; out dtype XM_BF16 / XM_F16. K % 16 == 0.
+ * acc_out (optional, may be NULL): raw int32 accumulators [M,N] (parity tests). */
+XM_API int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_scale,
+                                    const float* w_scale, const void* bias, void* out, int32_t* acc_out,
+                                    int64_t M, int64_t N, int64_t K, int out_dtype, void* stream);
+
+/* optional scratch for the int8 split-K path of scaled_matmul (>= M*N*4 bytes; the reference operator
+ * has no workspace argument, so it is registered once per stream owner; NULL disables split-K). */
+XM_API int xllm_mi355_set_gemm_workspace(void* workspace, size_t bytes);
+
+/* ---- fp8 (OCP e4m3fn) ------------------------------------------------------------------------
+ * kernel::static_scaled_fp8_quant (ops_api.h:160) -> kernels/cuda/fp8_quant.cu:115-155 */
+XM_API int xllm_mi355_static_scaled_fp8_quant(uint8_t* out, const void* input, const float* scale,
+                                              int64_t numel, int dtype, void* stream);
+/* kernel::fp8_scaled_quantize (ops_api.h:151) -> kernels/cuda/fp8_scaled_quantize.cpp:20-50:
+ * dynamic per-tensor scale = max(amax/448, 1e-12) written to scale_out[1] (device), then quant.
+ * scale_in != NULL => static (scale_out ignored). */
+XM_API int xllm_mi355_fp8_scaled_quantize(uint8_t* out, const void* input, const float* scale_in,
+                                          float* scale_out, int64_t numel, int dtype, void* stream);
+/* kernel::fp8_scaled_matmul (ops_api.h:156) -> cutlass_scaled_mm (cutlass_w8a8/scaled_mm_entry.cu:55-116):
+ * out = r16( a_scale * (w_scale * sum_fp32 a*w) + bias ); a [M,K] e4m3, w [N,K] e4m3 row-major
+ * (the reference passes b.t() of it); a_scale numel 1 or M, w_scale numel 1 or N. K % 16 == 0. */
+XM_API int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale,
+                                        int64_t a_scale_numel, const float* w_scale,
+                                        int64_t w_scale_numel, const void* bias, void* out, int64_t M,
+                                        int64_t N, int64_t K, int out_dtype, void* stream);
+
+/* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
+ * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 8 == 0. */
+XM_API int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M,
+                             int64_t N, int64_t K, int dtype, void* stream);
+
+/* ---- attention -----------------------------------------------------------------------------
+ * AttentionImpl::forward modes (layers/dcu/flash_attention.cpp:167-288, arg set of
+ * prefix_prefill_varlen_fwd / prefix_decode_varlen_fwd :45-94).
+ *
+ * prefill: packed q [Tq,nq,d] (token stride q_stride), k/v [Tk,nkv,d] (k_stride/v_stride),
+ * cu_q/cu_k int32 [B+1], out [Tq, nq*d] contiguous; causal = bottom-right aligned;
+ * window_left < 0 => unbounded. */
+XM_API int xllm_mi355_prefill_attention(const void* q, const void* k, const void* v, void* out,
+                                        const int32_t* cu_q, const int32_t* cu_k, int64_t batch,
+                                        int64_t n_q_heads, int64_t n_kv_heads, int64_t head_dim,
+                                        int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                        int64_t max_q_len, float scale, int causal,
+                                        int64_t window_left, int dtype, void* stream);
+/* paged (decode when max_q_len == 1, chunked prefill otherwise): q packed by cu_q [B+1];
+ * caches [n_blocks, block_size, nkv, d]; kv_lens int32 [B]; block_table int32 [B, max_blocks]
+ * (padding entries never read -- kv_lens decides; 0-padded or -1-padded both fine);
+ * workspace: xllm_mi355_paged_attention_workspace_bytes(). */
+XM_API size_t xllm_mi355_paged_attention_workspace_bytes(int64_t batch, int64_t n_q_heads,
+                                                         int64_t head_dim_v, int64_t max_q_len,
+                                                         int64_t total_q_tokens);
+XM_API int xllm_mi355_paged_attention(const void* q, const void* k_cache, const void* v_cache,
+                                      void* out, const int32_t* cu_q, const int32_t* kv_lens,
+                                      const int32_t* block_table, int64_t max_blocks, int64_t batch,
+                                      int64_t total_q_tokens, int64_t n_q_heads, int64_t n_kv_heads,
+                                      int64_t head_dim, int64_t block_size, int64_t n_blocks,
+                                      int64_t q_stride, int64_t max_q_len, int64_t max_kv_len,
+                                      float scale, int causal, int64_t window_left, int dtype,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+/* flash_mla::dense_decode (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] = [q_nope*W_kc || q_pe],
+ * k_cache [n_blocks, block_size, 1, 576]; out [B, H, head_size_v] = softmax(scale q k^T) k[:, :512]. */
+XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,
+                                 const int32_t* seqlens_k, const int32_t* block_table,
+                                 int64_t max_blocks, int64_t batch, int64_t n_heads, int64_t head_dim,
+                                 int64_t head_dim_v, int64_t block_size, int64_t n_blocks,
+                                 int64_t max_kv_len, float scale, int dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* ---- MoE -----------------------------------------------------------------------------------
+ * kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (kernels/cuda/moe/moe_compute_index.cu:111-160)
+ * expert_id [T,topk] int32 -> src_dst[T*topk], dst_src[T*topk], expert_sizes[E]; DETERMINISTIC
+ * (stable by expanded row index) unlike the reference's atomics order. workspace >= 4*(E+1)*... see .hip */
+XM_API int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int64_t topk,
+                                        int64_t n_experts, int32_t* src_dst, int32_t* dst_src,
+                                        int32_t* expert_sizes, void* stream);
+/* kernel::moe_combine_result (ops_api.h:77) -> cuda::moe_combine_result (moe/moe_combine.cu:64-...) */
+XM_API int xllm_mi355_moe_combine(void* out, const void* gemm2, const float* weights, int64_t n_tokens,
+                                  int64_t topk, int64_t hidden, int dtype, void* stream);
+/* kernel::group_gemm (ops_api.h:57) -> dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74):
+ * rows of `a` sorted by expert; out[off_e:off_e+M_e] = a[...] @ w[e]^T, w [E,N,K]; token_count is a
+ * DEVICE int32 [E] (no host read). max_rows = a's row count. */
+XM_API int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out,
+                                 int64_t max_rows, int64_t n_experts, int64_t N, int64_t K, int dtype,
+                                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XLLM_MI355_H_ */

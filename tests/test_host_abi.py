@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and
+exports every symbol include/xllm_mi355.h declares; the product path refuses CPU tensors (no fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _built():
+    import __graft_entry__ as g
+    from xllm_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        os.environ["XLLM_MI355_SKIP_SHIM"] = "1"
+        g.build()
+    return _lib
+
+
+def test_header_symbols_all_exported():
+    _lib = _built()
+    hdr = open(os.path.join(ROOT, "include", "xllm_mi355.h")).read()
+    declared = set(re.findall(r"XM_API\s+[\w\s\*]+?\b(xllm_mi355_\w+)\s*\(", hdr))
+    assert len(declared) >= 25
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\b(xllm_mi355_\w+)\b", out))
+    missing = declared - exported
+    assert not missing, f"declared in include/xllm_mi355.h but not exported: {sorted(missing)}"
+    assert set(_lib.exported_symbols()) <= exported | {"xllm_mi355_strerror"}
+
+
+def test_library_loads_without_gpu_and_reports_errors():
+    _lib = _built()
+    l = _lib.lib()
+    assert l.xllm_mi355_abi_version() == 1
+    assert b"invalid" in l.xllm_mi355_strerror(-1)
+    # argument validation happens before any device work
+    assert l.xllm_mi355_rms_norm(None, None, None, 1e-6, 1, 8, 8, 1, None) == -1
+    assert l.xllm_mi355_scaled_matmul(None, None, None, None, None, None, None, 1, 1, 16, 1, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    from xllm_amd import ops
+    from xllm_amd._lib import Mi355Error
+    x = torch.randn(2, 64).bfloat16()
+    with pytest.raises(Mi355Error):
+        ops.rms_norm(torch.empty_like(x), x, torch.ones(64).bfloat16(), 1e-6)
+    with pytest.raises(Mi355Error):
+        ops.scaled_quantize(x)
+
+
+def test_product_path_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "xllm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"

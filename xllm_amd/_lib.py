@@ -1,0 +1,80 @@
+"""ctypes binding of include/xllm_mi355.h.  There is NO fallback: if the HIP library is missing or a
+call returns non-zero this raises (the reference aborts with CHECK/TORCH_CHECK in the same places)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxllm_mi355.so")
+
+vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+ci = C.c_int
+
+_SIGS = {
+    "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_build_block_table_from_paged_kv": ([vp, vp, i32, i32, vp, vp], ci),
+    "xllm_mi355_rms_norm": ([vp, vp, vp, f32, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_fused_add_rms_norm": ([vp, vp, vp, f32, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_rms_norm_static_fp8_quant": ([vp, vp, vp, vp, vp, f32, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_rms_norm_dynamic_int8_quant": ([vp, vp, vp, vp, vp, f32, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_rotary_embedding": ([vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, ci, ci, vp], ci),
+    "xllm_mi355_fused_qk_norm_rope": ([vp, i64, i64, i64, i64, i64, f32, vp, vp, vp, ci, ci, vp, ci, vp], ci),
+    "xllm_mi355_act_and_mul": ([vp, vp, i64, i64, ci, ci, vp], ci),
+    "xllm_mi355_act_and_mul_dynamic_int8_quant": ([vp, vp, vp, i64, i64, ci, ci, vp], ci),
+    "xllm_mi355_scaled_quantize": ([vp, vp, vp, i64, i64, ci, vp], ci),
+    "xllm_mi355_scaled_matmul": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_set_gemm_workspace": ([vp, sz], ci),
+    "xllm_mi355_static_scaled_fp8_quant": ([vp, vp, vp, i64, ci, vp], ci),
+    "xllm_mi355_fp8_scaled_quantize": ([vp, vp, vp, vp, i64, ci, vp], ci),
+    "xllm_mi355_fp8_scaled_matmul": ([vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_matmul": ([vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_prefill_attention": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, i64,
+                                      ci, vp], ci),
+    "xllm_mi355_paged_attention_workspace_bytes": ([i64, i64, i64, i64, i64], sz),
+    "xllm_mi355_paged_attention": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
+                                    i64, f32, ci, i64, ci, vp, sz, vp], ci),
+}
+# entry points declared in the header but implemented in a later build step are bound lazily
+_OPTIONAL = {
+    "xllm_mi355_mla_decode": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, vp, sz, vp], ci),
+    "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
+    "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_group_gemm": ([vp, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),
+}
+
+_lib = None
+
+
+class Mi355Error(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mi355Error(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = args, res
+        for name, (args, res) in _OPTIONAL.items():
+            if hasattr(l, name):
+                fn = getattr(l, name)
+                fn.argtypes, fn.restype = args, res
+        l.xllm_mi355_strerror.argtypes, l.xllm_mi355_strerror.restype = [ci], C.c_char_p
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGS) + list(_OPTIONAL) + ["xllm_mi355_strerror"]
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise Mi355Error(f"{what}: {lib().xllm_mi355_strerror(rc).decode()} (rc={rc})")

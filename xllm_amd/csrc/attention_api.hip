@@ -1,0 +1,125 @@
+// attention_api.hip -- C-ABI entry points for the attention modes (dispatch only; kernels live in
+// attention_decode.hip / attention_prefill.hip / attention_mla.hip).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace xm {
+
+template <typename T, int D>
+int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
+                        const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks, int64_t batch,
+                        int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride, int64_t max_kv_len,
+                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s);
+
+template <typename T, int D, bool PAGED>
+int launch_flash_prefill(const void* q, const void* k, const void* v, void* out, const int32_t* cu_q,
+                         const int32_t* cu_k, const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks,
+                         int64_t batch, int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride,
+                         int64_t k_stride, int64_t v_stride, int64_t max_q_len, float scale, int causal,
+                         int64_t window_left, hipStream_t s);
+
+static int g_split_override = -2;  // -2: env not read yet; -1: no override
+
+// grid-level split-KV count of the decode kernel. Target: >= 512 resident workgroups (2 per CU, all
+// co-resident: one wave of work, no tail), every wave keeping >= 8 tiles of 32 tokens.
+int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len) {
+  if (g_split_override == -2) {
+    const char* e = getenv("XLLM_MI355_DECODE_SPLITS");
+    g_split_override = e ? atoi(e) : -1;
+  }
+  const int nsub = 4 / hpw;
+  const int64_t base = batch * (nkv / hpw);
+  const int64_t tiles = (max_kv_len + 31) / 32;
+  int64_t by_len = tiles / (8 * nsub);
+  if (by_len < 1) by_len = 1;
+  int64_t n;
+  if (g_split_override > 0) n = g_split_override;
+  else {
+    n = (512 + base - 1) / base;
+    if (n > by_len) n = by_len;
+  }
+  if (n > 32) n = 32;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+extern "C" {
+
+size_t xllm_mi355_paged_attention_workspace_bytes(int64_t batch, int64_t n_q_heads, int64_t head_dim_v,
+                                                  int64_t max_q_len, int64_t total_q_tokens) {
+  (void)total_q_tokens;
+  if (max_q_len > 1) return 0;  // chunked prefill needs no workspace
+  return (size_t)batch * n_q_heads * 32 * (head_dim_v + 2) * sizeof(float);  // 32 = max split-KV count
+}
+
+int xllm_mi355_paged_attention(const void* q, const void* k_cache, const void* v_cache, void* out,
+                               const int32_t* cu_q, const int32_t* kv_lens, const int32_t* block_table,
+                               int64_t max_blocks, int64_t batch, int64_t total_q_tokens, int64_t n_q_heads,
+                               int64_t n_kv_heads, int64_t head_dim, int64_t block_size, int64_t n_blocks,
+                               int64_t q_stride, int64_t max_q_len, int64_t max_kv_len, float scale, int causal,
+                               int64_t window_left, int dtype, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  (void)n_blocks;
+  if (!q || !k_cache || !v_cache || !out || !kv_lens || !block_table) return XM_ERR_INVALID;
+  if (batch < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || block_size <= 0 || max_blocks <= 0)
+    return XM_ERR_INVALID;
+  if (batch == 0 || total_q_tokens == 0) return XM_OK;
+  if ((uintptr_t)q % 16 || (uintptr_t)k_cache % 16 || (uintptr_t)v_cache % 16 || q_stride % 8) return XM_ERR_UNSUPPORTED;
+  if (n_q_heads / n_kv_heads > 16) return XM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (max_q_len <= 1) {
+    // decode: one query token per sequence; the causal flag is irrelevant (the token sees all kv_len keys)
+    size_t ws = workspace ? workspace_bytes : 0;
+#define XM_DECODE(T, DD)                                                                                        \
+  return launch_paged_decode<T, DD>(q, k_cache, v_cache, out, cu_q, kv_lens, block_table, max_blocks, batch,    \
+                                    n_q_heads, n_kv_heads, block_size, q_stride, max_kv_len, scale, window_left, \
+                                    workspace, ws, s)
+    if (dtype == XM_BF16 && head_dim == 128) XM_DECODE(bf16_t, 128);
+    if (dtype == XM_BF16 && head_dim == 64) XM_DECODE(bf16_t, 64);
+    if (dtype == XM_F16 && head_dim == 128) XM_DECODE(f16_t, 128);
+    if (dtype == XM_F16 && head_dim == 64) XM_DECODE(f16_t, 64);
+#undef XM_DECODE
+    return XM_ERR_UNSUPPORTED;
+  }
+  if (!cu_q) return XM_ERR_INVALID;
+#define XM_CHUNKED(T, DD)                                                                                         \
+  return launch_flash_prefill<T, DD, true>(q, k_cache, v_cache, out, cu_q, nullptr, kv_lens, block_table,         \
+                                           max_blocks, batch, n_q_heads, n_kv_heads, block_size, q_stride, 0, 0, \
+                                           max_q_len, scale, causal, window_left, s)
+  if (dtype == XM_BF16 && head_dim == 128) XM_CHUNKED(bf16_t, 128);
+  if (dtype == XM_BF16 && head_dim == 64) XM_CHUNKED(bf16_t, 64);
+  if (dtype == XM_F16 && head_dim == 128) XM_CHUNKED(f16_t, 128);
+  if (dtype == XM_F16 && head_dim == 64) XM_CHUNKED(f16_t, 64);
+#undef XM_CHUNKED
+  return XM_ERR_UNSUPPORTED;
+}
+
+int xllm_mi355_prefill_attention(const void* q, const void* k, const void* v, void* out, const int32_t* cu_q,
+                                 const int32_t* cu_k, int64_t batch, int64_t n_q_heads, int64_t n_kv_heads,
+                                 int64_t head_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                 int64_t max_q_len, float scale, int causal, int64_t window_left, int dtype,
+                                 void* stream) {
+  if (!q || !k || !v || !out || !cu_q || !cu_k) return XM_ERR_INVALID;
+  if (batch < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads) return XM_ERR_INVALID;
+  if (batch == 0 || max_q_len == 0) return XM_OK;
+  if ((uintptr_t)q % 16 || (uintptr_t)k % 16 || (uintptr_t)v % 16 || q_stride % 8 || k_stride % 8 || v_stride % 8)
+    return XM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+#define XM_PREFILL(T, DD)                                                                                       \
+  return launch_flash_prefill<T, DD, false>(q, k, v, out, cu_q, cu_k, nullptr, nullptr, 0, batch, n_q_heads,    \
+                                            n_kv_heads, 1, q_stride, k_stride, v_stride, max_q_len, scale, causal, \
+                                            window_left, s)
+  if (dtype == XM_BF16 && head_dim == 128) XM_PREFILL(bf16_t, 128);
+  if (dtype == XM_BF16 && head_dim == 64) XM_PREFILL(bf16_t, 64);
+  if (dtype == XM_F16 && head_dim == 128) XM_PREFILL(f16_t, 128);
+  if (dtype == XM_F16 && head_dim == 64) XM_PREFILL(f16_t, 64);
+#undef XM_PREFILL
+  return XM_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

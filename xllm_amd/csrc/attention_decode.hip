@@ -1,0 +1,357 @@
+// attention_decode.hip -- paged decode attention for gfx950 (the HBM-bound 70%-of-roofline target).
+//
+// Reference semantics: AttentionImpl::paged_forward(is_chunked_prefill=false)
+// (xllm/core/layers/dcu/flash_attention.cpp:220-288) == TorchAttentionImpl decode branch
+// (layers/dcu/torch_attention.cpp:278-337): one query token per sequence, non-causal softmax over the
+// kv_len cached tokens gathered page by page through the block table; GQA by kv_head = h / (nq/nkv).
+//
+// MI355X design (DESIGN.md "paged decode"):
+//  * one WAVE owns (sequence, kv head, token range); the nq/nkv query heads of the GQA group are stacked
+//    as the N dimension of the MFMA so every K/V byte is read from HBM exactly once.
+//  * K is loaded straight from HBM into the MFMA A-fragment layout (16 tokens x 8 contiguous d per lane,
+//    16-byte loads) -- no LDS round trip; S^T = K * Q^T ("swapped QK^T") leaves each lane with the scores
+//    of ONE query head, so the online softmax is lane-local plus two cross-lane maxima per 32 tokens.
+//  * V is loaded with fully coalesced 16-byte row loads, written once to a wave-private LDS tile
+//    (row padded by 32 B -> conflict-free) and read back transposed with ds_read_b64_tr_b16 as the
+//    A operand of O^T = V^T * P^T; the accumulator O^T keeps one query head per lane, so the rescale by
+//    exp2(m_old - m_new) is lane-local too. No workgroup barrier inside the token loop.
+//  * a workgroup = 4 waves = the kv heads of one token range (contiguous 1 KiB rows of the page are
+//    consumed by one CU at about the same time), or 4 token sub-ranges when the rank holds < 4 kv heads
+//    (TP >= 2); grid-level split-KV partials (m, l, O) are merged by a second tiny kernel.
+//  * tile t+1 (16 KiB of K+V per wave) is in flight in registers while tile t is computed:
+//    8 waves/CU x 16-32 KiB = 128-256 KiB outstanding per CU.
+#include "common.h"
+
+namespace xm {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct AttnTraits;
+template <>
+struct AttnTraits<bf16_t> {
+  using x8 = bf16x8_t;
+  using x4 = bf16x4_t;
+  using elem = __bf16;
+  static __device__ __forceinline__ f32x4_t mfma(x8 a, x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 tr_read(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) x4*)lds_ptr);
+  }
+};
+template <>
+struct AttnTraits<f16_t> {
+  using x8 = f16x8_t;
+  using x4 = f16x4_t;
+  using elem = _Float16;
+  static __device__ __forceinline__ f32x4_t mfma(x8 a, x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 tr_read(const void* lds_ptr) {
+    typedef __fp16 hfp16x4 __attribute__((__vector_size__(8)));
+    hfp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hfp16x4*)lds_ptr);
+    x4 o;
+    __builtin_memcpy(&o, &r, 8);
+    return o;
+  }
+};
+
+constexpr int kTile = 32;         // tokens per tile (= K dim of the PV MFMA)
+constexpr float kNegBig = -1e30f;  // finite "-inf" for the running max (log2 domain)
+
+// D = head dim (K and V), UNIFORM: block_size % 32 == 0 so a tile lives in one page
+template <typename T, int D, bool UNIFORM>
+__global__ __launch_bounds__(256, 2) void paged_decode_kernel(
+    const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, T* __restrict__ out,
+    float* __restrict__ part_o, float* __restrict__ part_ml, const int32_t* __restrict__ cu_q,
+    const int32_t* __restrict__ kv_lens, const int32_t* __restrict__ block_table, int max_blocks, int nq,
+    int nkv, int block_size, int64_t q_stride, float scale_log2, int nsplit, int hpw, int window_left) {
+  using TR = AttnTraits<T>;
+  using x8 = typename TR::x8;
+  using x4 = typename TR::x4;
+  using elem = typename TR::elem;
+  constexpr int KK = D / 32;            // MFMA k-steps over the head dim
+  constexpr int CH = D * 2 / 16;        // 16-byte chunks per K/V row
+  constexpr int TPI = 64 / CH;          // V rows fetched per wave-wide load instruction
+  constexpr int NV = kTile / TPI;       // V load instructions per tile
+  constexpr int DB = D / 16;            // 16-wide output d blocks
+  constexpr int RSB = D * 2 + 32;       // padded LDS row stride in bytes
+  constexpr int WAVE_LDS = kTile * RSB; // per-wave LDS bytes (>= 16*D*4 for the epilogue)
+  static_assert(WAVE_LDS >= 16 * D * 4, "epilogue staging must fit");
+
+  __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
+  __shared__ float ml_sh[4][16][2];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p16 = lane & 15, g = lane >> 4;
+  const int nsub = 4 / hpw;
+  const int ngroups = nkv / hpw;
+  int wg = blockIdx.x;
+  const int split = wg % nsplit; wg /= nsplit;
+  const int hg = wg % ngroups;
+  const int b = wg / ngroups;
+  const int hs = wave % hpw, sub = wave / hpw;
+  const int kvh = hg * hpw + hs;
+  const int G = nq / nkv;
+
+  const int kv_len = kv_lens[b];
+  const int t_lo = (window_left >= 0 && kv_len - 1 - window_left > 0) ? kv_len - 1 - window_left : 0;
+  const int tile_lo = t_lo / kTile, tile_hi = (kv_len + kTile - 1) / kTile;
+  const int nslots = nsplit * nsub, slot = split * nsub + sub;
+  const int ntiles = tile_hi - tile_lo > 0 ? tile_hi - tile_lo : 0;
+  const int per = (ntiles + nslots - 1) / nslots;
+  int my_lo = tile_lo + slot * per;
+  int my_hi = my_lo + per < tile_hi ? my_lo + per : tile_hi;
+  my_lo = __builtin_amdgcn_readfirstlane(my_lo);
+  my_hi = __builtin_amdgcn_readfirstlane(my_hi);
+
+  const int32_t* bt_row = block_table + (int64_t)b * max_blocks;
+  const int64_t row_elems = (int64_t)nkv * D;  // elements per token row of the cache
+  char* my_lds = lds + wave * WAVE_LDS;
+
+  // ---- Q as the MFMA B operand: lane (n = q head p16, k group g) holds Q[p16][(kk*4+g)*8 .. +7]
+  x8 qf[KK];
+  {
+    const int64_t qtok = cu_q ? cu_q[b] : b;
+    const T* qp = q + qtok * q_stride + (int64_t)(kvh * G + p16) * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (p16 < G) qf[kk] = *reinterpret_cast<const x8*>(qp + (kk * 4 + g) * 8);
+      else qf[kk] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  f32x4_t acc_o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kNegBig, l_run = 0.0f;
+
+  x8 kreg[2][KK], kreg_n[2][KK];
+  uint4 vreg[NV], vreg_n[NV];
+
+  auto page_of_tile = [&](int tile) -> int {  // UNIFORM only: scalar page id of a tile (clamped)
+    int idx = (tile * kTile) / block_size;
+    const int last = (kv_len - 1) / block_size;
+    idx = idx > last ? last : idx;
+    idx = idx < 0 ? 0 : idx;
+    return bt_row[idx];
+  };
+  auto issue_loads = [&](int tile, int page, x8 (&kr)[2][KK], uint4 (&vr)[NV]) {
+    const int t0 = tile * kTile;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      int tok = t0 + blk * 16 + p16;
+      tok = tok < kv_len ? tok : kv_len - 1;
+      int64_t rowi;
+      if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
+      else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
+      const T* kp = kc + rowi * row_elems + (int64_t)kvh * D + g * 8;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) kr[blk][kk] = *reinterpret_cast<const x8*>(kp + kk * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int tok = t0 + i * TPI + lane / CH;
+      tok = tok < kv_len ? tok : kv_len - 1;
+      int64_t rowi;
+      if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
+      else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
+      vr[i] = *reinterpret_cast<const uint4*>(vc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8);
+    }
+  };
+
+  if (my_lo < my_hi) {
+    int page_b = 0, page_c = 0;
+    if constexpr (UNIFORM) {
+      page_b = page_of_tile(my_lo);
+      issue_loads(my_lo, page_b, kreg_n, vreg_n);
+      page_b = page_of_tile(my_lo + 1);
+    } else {
+      issue_loads(my_lo, 0, kreg_n, vreg_n);
+    }
+    for (int tile = my_lo; tile < my_hi; ++tile) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kreg[blk][kk] = kreg_n[blk][kk];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) vreg[i] = vreg_n[i];
+      if constexpr (UNIFORM) page_c = page_of_tile(tile + 2);
+      if (tile + 1 < my_hi) issue_loads(tile + 1, page_b, kreg_n, vreg_n);
+      page_b = page_c;
+
+      const int t0 = tile * kTile;
+      const bool partial = (t0 + kTile > kv_len) || (t0 < t_lo);
+
+      // ---- V tile -> wave-private LDS (row major, padded rows); invalid rows zeroed (0 * NaN guard)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int r = i * TPI + lane / CH;
+        uint4 v = vreg[i];
+        if (partial && (t0 + r >= kv_len)) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(my_lds + r * RSB + (lane % CH) * 16) = v;
+      }
+
+      // ---- S^T = K * Q^T : lane holds S[q = p16][token = blk*16 + 4g + r]
+      f32x4_t s[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        s[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) s[blk] = TR::mfma(kreg[blk][kk], qf[kk], s[blk]);
+      }
+      // ---- online softmax (log2 domain), lane-local except the 2 cross-group maxima
+      float mx = kNegBig;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[blk][r] * scale_log2;
+          if (partial) {
+            const int tok = t0 + blk * 16 + g * 4 + r;
+            if (tok >= kv_len || tok < t_lo) v = -INFINITY;
+          }
+          s[blk][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.0f;
+      x8 pf;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[blk][r] - m_new);
+          psum += p;
+          pf[blk * 4 + r] = (elem)p;
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
+
+      // ---- O^T += V^T * P^T : A = V^T via transposed LDS reads, k slot (g, j): j<4 -> token 4g+j,
+      //      j>=4 -> token 16+4g+(j-4), matching the P fragment above
+      const char* trb = my_lds + (4 * g + (p16 >> 2)) * RSB + (p16 & 3) * 8;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        x4 lo = TR::tr_read(trb + db * 32);
+        x4 hi = TR::tr_read(trb + 16 * RSB + db * 32);
+        x8 vt;
+        vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
+        vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
+        acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
+      }
+    }
+  }
+
+  // ---- epilogue: stage (m, l, O) of every wave in LDS, merge the sub-ranges of each head
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  {
+    float* o_st = reinterpret_cast<float*>(my_lds);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+      *reinterpret_cast<f32x4_t*>(o_st + p16 * D + db * 16 + g * 4) = acc_o[db];
+    if (g == 0) { ml_sh[wave][p16][0] = m_run; ml_sh[wave][p16][1] = l_run; }
+  }
+  __syncthreads();
+  const int64_t qtok = cu_q ? cu_q[b] : b;
+  for (int e = threadIdx.x; e < hpw * 16 * D; e += 256) {
+    const int h_s = e / (16 * D), qq = (e / D) & 15, d = e % D;
+    if (qq >= G) continue;
+    float m_star = kNegBig;
+    for (int sb = 0; sb < nsub; ++sb) m_star = fmaxf(m_star, ml_sh[sb * hpw + h_s][qq][0]);
+    float o = 0.0f, l = 0.0f;
+    for (int sb = 0; sb < nsub; ++sb) {
+      const int w = sb * hpw + h_s;
+      const float f = exp2f(ml_sh[w][qq][0] - m_star);
+      o += f * reinterpret_cast<const float*>(lds + w * WAVE_LDS)[qq * D + d];
+      l += f * ml_sh[w][qq][1];
+    }
+    const int head = (hg * hpw + h_s) * G + qq;
+    if (nsplit == 1) {
+      out[qtok * (int64_t)nq * D + (int64_t)head * D + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
+    } else {
+      const int64_t pi = ((int64_t)b * nq + head) * nsplit + split;
+      part_o[pi * D + d] = o;
+      if (d == 0) { part_ml[pi * 2] = m_star; part_ml[pi * 2 + 1] = l; }
+    }
+  }
+}
+
+// merge of the grid-level split-KV partials: one workgroup (D threads) per (sequence, head)
+template <typename T, int D>
+__global__ void paged_decode_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                          T* __restrict__ out, const int32_t* __restrict__ cu_q, int nq, int nsplit) {
+  const int b = blockIdx.x / nq, head = blockIdx.x % nq;
+  const int d = threadIdx.x;
+  const int64_t base = ((int64_t)b * nq + head) * nsplit;
+  float m_star = kNegBig;
+  for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
+  float o = 0.0f, l = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float f = exp2f(part_ml[(base + s) * 2] - m_star);
+    o += f * part_o[(base + s) * D + d];
+    l += f * part_ml[(base + s) * 2 + 1];
+  }
+  const int64_t qtok = cu_q ? cu_q[b] : b;
+  out[qtok * (int64_t)nq * D + (int64_t)head * D + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
+}
+
+int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len);
+
+template <typename T, int D>
+int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
+                        const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks, int64_t batch,
+                        int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride, int64_t max_kv_len,
+                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s) {
+  int hpw = nkv >= 4 && nkv % 4 == 0 ? 4 : (nkv % 2 == 0 ? 2 : 1);
+  int nsplit = decode_num_splits(batch, nkv, hpw, max_kv_len);
+  // degrade the split count to what the caller's workspace holds (1 split needs none)
+  const size_t per_split = (size_t)batch * nq * (D + 2) * sizeof(float);
+  if (!workspace) ws_bytes = 0;
+  if ((size_t)nsplit * per_split > ws_bytes) nsplit = (int)(ws_bytes / per_split);
+  if (nsplit < 1) nsplit = 1;
+  float* part_o = reinterpret_cast<float*>(workspace);
+  float* part_ml = part_o ? part_o + (size_t)batch * nq * nsplit * D : nullptr;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  const dim3 grid((unsigned)(batch * (nkv / hpw) * nsplit));
+  const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
+  if (block_size % kTile == 0)
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+  else
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+  if (nsplit > 1)
+    hipLaunchKernelGGL((paged_decode_merge_kernel<T, D>), dim3((unsigned)(batch * nq)), dim3(D), 0, s, part_o,
+                       part_ml, (T*)out, cu_q, (int)nq, nsplit);
+  return hip_check_launch();
+}
+
+template int launch_paged_decode<bf16_t, 128>(const void*, const void*, const void*, void*, const int32_t*,
+                                              const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
+                                              int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+template int launch_paged_decode<bf16_t, 64>(const void*, const void*, const void*, void*, const int32_t*,
+                                             const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
+                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+template int launch_paged_decode<f16_t, 128>(const void*, const void*, const void*, void*, const int32_t*,
+                                             const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
+                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+template int launch_paged_decode<f16_t, 64>(const void*, const void*, const void*, void*, const int32_t*,
+                                            const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
+                                            int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+
+}  // namespace xm

@@ -1,0 +1,119 @@
+// common.h -- device-side helpers shared by the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xllm_mi355.h"
+
+namespace xm {
+
+constexpr int kWave = 64;
+
+struct bf16_t {
+  uint16_t v;
+};
+using f16_t = _Float16;
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {  // RNE, quiet NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T x);
+template <>
+__device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return bf16_bits_to_f32(x.v); }
+template <>
+__device__ __forceinline__ float to_f32<f16_t>(f16_t x) { return (float)x; }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return bf16_t{f32_to_bf16_bits(x)}; }
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)x; }
+
+// round through the tensor dtype (the reference's scalar_t cast point)
+template <typename T>
+__device__ __forceinline__ float r16(float x) { return to_f32<T>(from_f32<T>(x)); }
+
+// OCP e4m3fn, saturating RNE (matches torch .to(float8_e4m3fn) on clamped input)
+__device__ __forceinline__ uint8_t f32_to_e4m3_sat(float f) {
+  // gfx950 has v_cvt_pk_fp8_f32 (OCP); it saturates when the clamp bit is set. We clamp explicitly
+  // and use the hardware conversion (RNE).
+  f = fminf(fmaxf(f, -448.0f), 448.0f);
+  uint32_t r = __builtin_amdgcn_cvt_pk_fp8_f32(f, f, 0, false);
+  return (uint8_t)(r & 0xff);
+}
+
+template <typename T>
+struct Vec16B;  // 16-byte vector of T
+template <>
+struct Vec16B<float> { static constexpr int N = 4; };
+template <>
+struct Vec16B<bf16_t> { static constexpr int N = 8; };
+template <>
+struct Vec16B<f16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// block-wide reductions for blockDim.x <= 1024 (multiple of 64); smem >= 17 floats
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  if (nw == 1) return v;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = (lane < nw) ? smem[lane] : 0.0f;
+  r = wave_sum(r);
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* smem) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_max(v);
+  if (nw == 1) return v;
+  __syncthreads();
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  float r = (lane < nw) ? smem[lane] : -INFINITY;
+  r = wave_max(r);
+  return r;
+}
+
+inline int hip_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? XM_OK : XM_ERR_HIP;
+}
+
+}  // namespace xm
+
+#define XM_DISPATCH_FLOAT(DT, T, ...)                   \
+  switch (DT) {                                         \
+    case XM_F32: { using T = float; __VA_ARGS__; } break;       \
+    case XM_BF16: { using T = xm::bf16_t; __VA_ARGS__; } break; \
+    case XM_F16: { using T = xm::f16_t; __VA_ARGS__; } break;   \
+    default: return XM_ERR_UNSUPPORTED;                 \
+  }
+#define XM_DISPATCH_HALF(DT, T, ...)                    \
+  switch (DT) {                                         \
+    case XM_BF16: { using T = xm::bf16_t; __VA_ARGS__; } break; \
+    case XM_F16: { using T = xm::f16_t; __VA_ARGS__; } break;   \
+    default: return XM_ERR_UNSUPPORTED;                 \
+  }

@@ -1,0 +1,333 @@
+// gemm.hip -- C[M,N] = A[M,K] * W[N,K]^T on the gfx950 matrix cores, with the dequant epilogues of the
+// hot path fused in:
+//   int8 W8A8  (reference: dcu::scaled_matmul, kernels/dcu/scaled_matmul.cpp:103-300)
+//              out = r16( float(int32 acc) * a_scale[m] * w_scale[n] + bias[n] )   v_mfma_i32_32x32x32_i8
+//   fp8 e4m3   (reference: cutlass_scaled_mm, kernels/cuda/cutlass_w8a8/scaled_mm_entry.cu:55-116)
+//              out = r16( a_scale * (w_scale * acc_f32) + bias )                    v_mfma_f32_32x32x16_fp8_fp8
+//   bf16/f16   (reference: dcu::matmul == F::linear, kernels/dcu/matmul.cpp:20-25)
+//              out = r16( acc_f32 + bias )                                          v_mfma_f32_32x32x16_{bf16,f16}
+// Both operands are K-contiguous, so every MFMA fragment is one 16-byte LDS read.
+//
+// Structure (DESIGN.md "quant GEMM"): 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA
+// 32x32 tiles; K step = 128 BYTES of each operand row; global -> registers -> LDS with the next tile's
+// global loads in flight during the MFMAs (issue-early / write-late), LDS rows XOR-swizzled on the
+// 16-byte chunk index by (row>>1)&7 so ds_read_b128 fragment reads are bank-conflict free; one barrier
+// per K step, two LDS buffers. Block ids are remapped so the M-tiles that share a W tile run on the
+// same XCD (same L2) back to back: W is fetched from HBM once.
+// int8 only: optional split-K with exact int32 atomics into a workspace + a tiny dequant epilogue kernel
+// (integer adds commute, so the result stays bit-exact and deterministic).
+#include "common.h"
+
+namespace xm {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 gf16x8_t __attribute__((ext_vector_type(8)));
+
+enum GemmKind { kI8 = 0, kFP8 = 1, kBF16 = 2, kF16 = 3 };
+
+template <int KIND>
+struct MmaTraits;
+template <>
+struct MmaTraits<kI8> {
+  using acc_t = i32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kFP8> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    // 16 fp8 per lane = two K=16 MFMAs (the k permutation is identical on both operands)
+    long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+    long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kBF16> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    gbf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kF16> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    gf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+  }
+};
+
+struct GemmEpi {
+  const float* a_scale;   // int8: [M]; fp8: [1] or [M]
+  int64_t a_scale_n;
+  const float* w_scale;   // int8: [N]; fp8: [1] or [N]
+  int64_t w_scale_n;
+  const void* bias;       // out dtype, [N] or null
+  void* out;              // 16-bit out [M,N] (may be null when only acc_out is wanted)
+  int32_t* acc_out;       // int8: raw accumulators [M,N] (null normally); split-K workspace
+  int out_bf16;           // 1 bf16, 0 f16
+};
+
+__device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {
+  if (out_bf16) reinterpret_cast<uint16_t*>(out)[idx] = f32_to_bf16_bits(v);
+  else reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;
+}
+__device__ __forceinline__ float load16(const void* p, int64_t idx, int is_bf16) {
+  if (is_bf16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[idx]);
+  return (float)reinterpret_cast<const f16_t*>(p)[idx];
+}
+
+constexpr int BM = 128, BN = 128, BKB = 128;  // block tile, K step in bytes
+
+// A [M, Kb bytes per row], W [N, Kb]; grid.x = tiles (XCD-remapped), grid.z = split-K slices
+template <int KIND, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
+                                                      int M, int N, int64_t Kb, int m_tiles, int n_tiles,
+                                                      int ksteps_per_split, GemmEpi epi) {
+  using MT = MmaTraits<KIND>;
+  using acc_t = typename MT::acc_t;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][BM * BKB];  // [buf][A/W][tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile mapping: block b runs on XCD b%8; keep the m-tiles of one n-tile on one XCD
+  int mt, nt;
+  {
+    const int b = blockIdx.x;
+    if (n_tiles % 8 == 0) {
+      const int xcd = b & 7, j = b >> 3;
+      mt = j % m_tiles;
+      nt = (j / m_tiles) * 8 + xcd;
+    } else {
+      mt = b % m_tiles;
+      nt = b / m_tiles;
+    }
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
+  const int ks_begin = blockIdx.z * ksteps_per_split;
+  int ks_end = ks_begin + ksteps_per_split;
+  ks_end = ks_end > total_ksteps ? total_ksteps : ks_end;
+
+  // staging map: thread -> 4 chunks of A and 4 of W per K step; chunk c = tid + i*256: row c/8, col c%8
+  uint4 ra[4], rw[4];
+  auto load_global = [&](int ks) {
+    const int64_t kb0 = (int64_t)ks * BKB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = c & 7;
+      const int64_t kb = kb0 + col * 16;
+      int ar = m0 + row; ar = ar < M ? ar : M - 1;
+      int wr = n0 + row; wr = wr < N ? wr : N - 1;
+      if (kb + 16 <= Kb) {
+        ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)ar * Kb + kb);
+        rw[i] = *reinterpret_cast<const uint4*>(W + (int64_t)wr * Kb + kb);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+        rw[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto write_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = c & 7;
+      const int off = row * BKB + ((col ^ ((row >> 1) & 7)) << 4);
+      *reinterpret_cast<uint4*>(&lds[buf][0][off]) = ra[i];
+      *reinterpret_cast<uint4*>(&lds[buf][1][off]) = rw[i];
+    }
+  };
+
+  acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = MT::zero();
+
+  if (ks_begin < ks_end) {
+    load_global(ks_begin);
+    write_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const bool more = ks + 1 < ks_end;
+      if (more) load_global(ks + 1);
+      const uint8_t* la = lds[cur][0];
+      const uint8_t* lw = lds[cur][1];
+#pragma unroll
+      for (int kk = 0; kk < BKB / 32; ++kk) {
+        uint4 fa[2], fw[2];
+        const int chunk = kk * 2 + (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int rowa = wm * 64 + t * 32 + (lane & 31);
+          fa[t] = *reinterpret_cast<const uint4*>(la + rowa * BKB + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+          const int roww = wn * 64 + t * 32 + (lane & 31);
+          fw[t] = *reinterpret_cast<const uint4*>(lw + roww * BKB + ((chunk ^ ((roww >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = MT::mma(fa[i], fw[j], acc[i][j]);
+      }
+      if (more) write_lds(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // epilogue. C layout of a 32x32 tile: col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (n >= N) continue;
+      float ws = 1.0f, bs = 0.0f;
+      if constexpr (!SPLITK) {
+        if constexpr (KIND == kI8) ws = epi.w_scale[n];
+        if constexpr (KIND == kFP8) ws = epi.w_scale[epi.w_scale_n > 1 ? n : 0];
+        if (epi.bias) bs = load16(epi.bias, n, epi.out_bf16);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        const int64_t idx = (int64_t)m * N + n;
+        if constexpr (KIND == kI8) {
+          const int a = acc[i][j][r];
+          if constexpr (SPLITK) {
+            atomicAdd(epi.acc_out + idx, a);
+          } else {
+            if (epi.acc_out) epi.acc_out[idx] = a;
+            if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
+          }
+        } else if constexpr (KIND == kFP8) {
+          const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
+          store16(epi.out, idx, as * (ws * acc[i][j][r]) + bs, epi.out_bf16);
+        } else {
+          store16(epi.out, idx, acc[i][j][r] + bs, epi.out_bf16);
+        }
+      }
+    }
+}
+
+// dequant epilogue after int8 split-K: reads the int32 sums, applies scales + bias
+__global__ __launch_bounds__(256) void i8_splitk_epilogue_kernel(const int32_t* __restrict__ acc, int64_t M, int64_t N,
+                                                                 GemmEpi epi) {
+  const int64_t total = M * N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / N, n = idx - m * N;
+    float bs = epi.bias ? load16(epi.bias, n, epi.out_bf16) : 0.0f;
+    store16(epi.out, idx, (float)acc[idx] * epi.a_scale[m] * epi.w_scale[n] + bs, epi.out_bf16);
+  }
+}
+
+template <int KIND>
+int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                size_t ws_bytes, hipStream_t s) {
+  if (M == 0 || N == 0) return XM_OK;
+  const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (int)((N + BN - 1) / BN);
+  const int ksteps = (int)((Kb + BKB - 1) / BKB);
+  int splits = 1;
+  if constexpr (KIND == kI8) {
+    // split K until ~2 workgroups per CU are available (small-N decode GEMMs), each slice >= 4 K steps
+    const int64_t tiles = (int64_t)m_tiles * n_tiles;
+    if (workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && tiles < 384) {
+      splits = (int)((512 + tiles - 1) / tiles);
+      const int max_by_k = ksteps / 4 > 0 ? ksteps / 4 : 1;
+      splits = splits > max_by_k ? max_by_k : splits;
+      splits = splits > 16 ? 16 : splits;
+    }
+  }
+  const int per = (ksteps + splits - 1) / splits;
+  splits = (ksteps + per - 1) / per;
+  const dim3 grid((unsigned)(m_tiles * n_tiles), 1, (unsigned)splits);
+  if (splits > 1) {
+    if constexpr (KIND == kI8) {
+      if (hipMemsetAsync(workspace, 0, (size_t)M * N * 4, s) != hipSuccess) return XM_ERR_HIP;
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+      hipLaunchKernelGGL((gemm_kernel<KIND, true>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                         (int)M, (int)N, Kb, m_tiles, n_tiles, per, e2);
+      int64_t blocks = (M * N + 255) / 256;
+      blocks = blocks > 2048 ? 2048 : blocks;
+      hipLaunchKernelGGL(i8_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         (const int32_t*)workspace, M, N, epi);
+    }
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<KIND, false>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
+                       (int)N, Kb, m_tiles, n_tiles, per, epi);
+  }
+  return hip_check_launch();
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+extern "C" {
+
+// workspace for int8 split-K (optional): M*N*4 bytes. Set by xllm_mi355_set_gemm_workspace(); the
+// ops_api-shaped entry point below has no workspace argument because the reference operator has none.
+static void* g_gemm_ws = nullptr;
+static size_t g_gemm_ws_bytes = 0;
+XM_API int xllm_mi355_set_gemm_workspace(void* ws, size_t bytes) {
+  g_gemm_ws = ws;
+  g_gemm_ws_bytes = bytes;
+  return XM_OK;
+}
+
+int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_scale, const float* w_scale,
+                             const void* bias, void* out, int32_t* acc_out, int64_t M, int64_t N, int64_t K,
+                             int out_dtype, void* stream) {
+  if (!a || !w || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (out && (!a_scale || !w_scale)) return XM_ERR_INVALID;
+  if (!out && !acc_out) return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16};
+  return launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
+}
+
+int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale, int64_t a_scale_numel,
+                                 const float* w_scale, int64_t w_scale_numel, const void* bias, void* out, int64_t M,
+                                 int64_t N, int64_t K, int out_dtype, void* stream) {
+  if (!a || !w || !a_scale || !w_scale || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if ((a_scale_numel != 1 && a_scale_numel != M) || (w_scale_numel != 1 && w_scale_numel != N)) return XM_ERR_INVALID;
+  if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16};
+  return launch_gemm<kFP8>(a, w, M, N, K, epi, nullptr, 0, (hipStream_t)stream);
+}
+
+int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                      int dtype, void* stream) {
+  if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (K % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16};
+  if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
+  return launch_gemm<kF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

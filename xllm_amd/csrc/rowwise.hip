@@ -1,0 +1,804 @@
+// rowwise.hip -- HBM-bound row-wise operators of the hot path for gfx950:
+// KV write, block-table build, RMSNorm (+residual, +fp8 / +int8 quant), RoPE, fused QK-norm+RoPE,
+// act_and_mul (+int8 quant), per-token int8 quant, fp8 quant.
+// One workgroup (256 threads = 4 waves) per token row, 16-byte vector IO, the row kept in registers
+// between the reduction pass and the write pass (each HBM byte is read once).
+#include "common.h"
+
+namespace xm {
+
+constexpr int kRowThreads = 256;
+constexpr int kMaxVec = 4;  // 16-B chunks cached per thread -> rows up to 16 KiB
+
+template <typename T>
+struct RowVec {
+  static constexpr int N = Vec16B<T>::N;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    if constexpr (sizeof(T) == 4) {
+      return __uint_as_float((&raw.x)[i]);
+    } else {
+      uint32_t w = (&raw.x)[i >> 1];
+      uint16_t h = (i & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
+      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) return bf16_bits_to_f32(h);
+      else { f16_t x; __builtin_memcpy(&x, &h, 2); return (float)x; }
+    }
+  }
+  __device__ __forceinline__ void set(int i, float f) {
+    if constexpr (sizeof(T) == 4) {
+      (&raw.x)[i] = __float_as_uint(f);
+    } else {
+      uint16_t h;
+      if constexpr (__is_same(T, bf16_t)) h = f32_to_bf16_bits(f);
+      else { f16_t x = (f16_t)f; __builtin_memcpy(&h, &x, 2); }
+      uint32_t& w = (&raw.x)[i >> 1];
+      w = (i & 1) ? ((w & 0x0000ffffu) | ((uint32_t)h << 16)) : ((w & 0xffff0000u) | h);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// KV write (reference: kernels/cuda/reshape_paged_cache.cu:24-63). grid = tokens; 16-B copies when
+// rows are 16-B aligned, else element copies.
+// ------------------------------------------------------------------------------------------------
+template <typename V>
+__global__ __launch_bounds__(256) void reshape_paged_cache_kernel(
+    const int32_t* __restrict__ slot_ids, const V* __restrict__ k, const V* __restrict__ v,
+    V* __restrict__ kc, V* __restrict__ vc, int64_t row_v /* row length in V units */,
+    int64_t k_stride_v, int64_t v_stride_v, int64_t block_size, int64_t n_blocks) {
+  const int64_t t = blockIdx.x;
+  const int64_t slot = slot_ids[t];
+  if (slot < 0) return;
+  if (slot / block_size >= n_blocks) return;
+  // cache row index == slot (block*block_size + offset)
+  const V* ks = k + t * k_stride_v;
+  const V* vs = v + t * v_stride_v;
+  V* kd = kc + slot * row_v;
+  V* vd = vc + slot * row_v;
+  for (int64_t i = threadIdx.x; i < row_v; i += blockDim.x) {
+    kd[i] = ks[i];
+    vd[i] = vs[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void build_block_table_kernel(const int32_t* __restrict__ indptr,
+                                                                const int32_t* __restrict__ indices,
+                                                                int32_t total_pages,
+                                                                int32_t* __restrict__ table) {
+  const int32_t s = blockIdx.x;
+  const int32_t start = indptr[s], n = indptr[s + 1] - start;
+  int32_t* row = table + (int64_t)s * total_pages;
+  for (int32_t j = threadIdx.x; j < total_pages; j += blockDim.x) row[j] = (j < n) ? indices[start + j] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm family (reference: kernels/cuda/norm.cu:45-174, 229-425)
+//   ADD  : residual <- r16(input + residual) first (16-bit add), norm reads the sum
+//   QUANT: 0 -> out dtype T, y = r16(r16(x*inv)*w)
+//          1 -> fp8 e4m3: v = float(r16(x*inv))*float(w); q = sat(clamp(v * (1/scale)))
+//          2 -> int8 per token of y (the 16-bit norm output), scale[t] = amax/127
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool ADD, int QUANT>
+__global__ __launch_bounds__(kRowThreads) void rms_norm_kernel(
+    void* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
+    const T* __restrict__ weight, const float* __restrict__ fp8_scale, float* __restrict__ q_scale,
+    float eps, int hidden, int64_t in_stride, bool write_input) {
+  constexpr int N = RowVec<T>::N;
+  __shared__ float smem[32];
+  const int64_t t = blockIdx.x;
+  const int nvec = hidden / N;
+  T* in_row = input + t * in_stride;
+  T* res_row = ADD ? residual + t * (int64_t)hidden : nullptr;
+  RowVec<T> xv[kMaxVec];
+  float ss = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int c = threadIdx.x + i * kRowThreads;
+    if (c < nvec) {
+      xv[i].raw = reinterpret_cast<const uint4*>(in_row)[c];
+      if constexpr (ADD) {
+        RowVec<T> rv;
+        rv.raw = reinterpret_cast<const uint4*>(res_row)[c];
+#pragma unroll
+        for (int j = 0; j < N; ++j) xv[i].set(j, xv[i].get(j) + rv.get(j));  // r16(x + r)
+        reinterpret_cast<uint4*>(res_row)[c] = xv[i].raw;
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) { float x = xv[i].get(j); ss += x * x; }
+    }
+  }
+  ss = block_sum(ss, smem);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  float amax = 0.0f;
+  [[maybe_unused]] float sinv = 0.0f;
+  if constexpr (QUANT == 1) sinv = 1.0f / fp8_scale[0];
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int c = threadIdx.x + i * kRowThreads;
+    if (c < nvec) {
+      RowVec<T> wv;
+      wv.raw = reinterpret_cast<const uint4*>(weight)[c];
+      if constexpr (QUANT == 1) {
+        uint32_t pk[N / 4];
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float vv = r16<T>(xv[i].get(j + e) * inv) * wv.get(j + e);
+            w |= (uint32_t)f32_to_e4m3_sat(vv * sinv) << (8 * e);
+          }
+          pk[j / 4] = w;
+        }
+        uint8_t* o = reinterpret_cast<uint8_t*>(out) + t * (int64_t)hidden + (int64_t)c * N;
+        if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+        else *reinterpret_cast<uint32_t*>(o) = pk[0];
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float y = r16<T>(r16<T>(xv[i].get(j) * inv) * wv.get(j));
+          xv[i].set(j, y);
+          amax = fmaxf(amax, fabsf(y));
+        }
+        if constexpr (QUANT == 0) {
+          reinterpret_cast<uint4*>(reinterpret_cast<T*>(out) + t * (int64_t)hidden)[c] = xv[i].raw;
+        } else if (write_input) {  // fused_add semantics also return the 16-bit norm in `input`
+          reinterpret_cast<uint4*>(in_row)[c] = xv[i].raw;
+        }
+      }
+    }
+  }
+  if constexpr (QUANT == 2) {
+    amax = block_max(amax, smem);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int c = threadIdx.x + i * kRowThreads;
+      if (c < nvec) {
+        uint32_t pk[N / 4];
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv[i].get(j + e) * qinv)));
+            w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+          }
+          pk[j / 4] = w;
+        }
+        int8_t* o = reinterpret_cast<int8_t*>(out) + t * (int64_t)hidden + (int64_t)c * N;
+        if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+        else *reinterpret_cast<uint32_t*>(o) = pk[0];
+      }
+    }
+    if (threadIdx.x == 0) q_scale[t] = amax / 127.0f;
+  }
+}
+
+// generic fallback (any hidden / alignment): scalar, two passes over global memory
+template <typename T, bool ADD, int QUANT>
+__global__ __launch_bounds__(kRowThreads) void rms_norm_generic_kernel(
+    void* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
+    const T* __restrict__ weight, const float* __restrict__ fp8_scale, float* __restrict__ q_scale,
+    float eps, int hidden, int64_t in_stride, bool write_input) {
+  __shared__ float smem[32];
+  const int64_t t = blockIdx.x;
+  T* in_row = input + t * in_stride;
+  T* res_row = ADD ? residual + t * (int64_t)hidden : nullptr;
+  float ss = 0.0f;
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    float x = to_f32(in_row[i]);
+    if constexpr (ADD) { x = r16<T>(x + to_f32(res_row[i])); res_row[i] = from_f32<T>(x); }
+    ss += x * x;
+  }
+  ss = block_sum(ss, smem);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  const float sinv = (QUANT == 1) ? 1.0f / fp8_scale[0] : 0.0f;
+  const T* src = ADD ? res_row : in_row;
+  float amax = 0.0f;
+  if constexpr (ADD) __syncthreads();
+  for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+    float n = r16<T>(to_f32(src[i]) * inv);
+    if constexpr (QUANT == 1) {
+      reinterpret_cast<uint8_t*>(out)[t * (int64_t)hidden + i] = f32_to_e4m3_sat(n * to_f32(weight[i]) * sinv);
+    } else {
+      float y = r16<T>(n * to_f32(weight[i]));
+      amax = fmaxf(amax, fabsf(y));
+      if constexpr (QUANT == 0) reinterpret_cast<T*>(out)[t * (int64_t)hidden + i] = from_f32<T>(y);
+    }
+  }
+  if constexpr (QUANT == 2) {
+    amax = block_max(amax, smem);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+      float y = r16<T>(r16<T>(to_f32(src[i]) * inv) * to_f32(weight[i]));
+      float qv = fmaxf(-127.0f, fminf(127.0f, rintf(y * qinv)));
+      reinterpret_cast<int8_t*>(out)[t * (int64_t)hidden + i] = (int8_t)qv;
+      if (write_input) in_row[i] = from_f32<T>(y);
+    }
+    if (threadIdx.x == 0) q_scale[t] = amax / 127.0f;
+  }
+}
+
+template <typename T, bool ADD, int QUANT>
+int launch_rms_norm(void* out, void* input, void* residual, const void* weight, const float* fp8_scale,
+                    float* q_scale, float eps, int64_t T_, int64_t H, int64_t in_stride,
+                    bool write_input, hipStream_t s) {
+  if (T_ == 0) return XM_OK;
+  constexpr int N = Vec16B<T>::N;
+  const bool vec_ok = (H % N == 0) && (H / N <= kRowThreads * kMaxVec) && (in_stride % N == 0) &&
+                      ((uintptr_t)input % 16 == 0) && ((uintptr_t)weight % 16 == 0) &&
+                      (!ADD || (uintptr_t)residual % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec_ok)
+    hipLaunchKernelGGL((rms_norm_kernel<T, ADD, QUANT>), dim3(T_), dim3(kRowThreads), 0, s, out, (T*)input,
+                       (T*)residual, (const T*)weight, fp8_scale, q_scale, eps, (int)H, in_stride, write_input);
+  else
+    hipLaunchKernelGGL((rms_norm_generic_kernel<T, ADD, QUANT>), dim3(T_), dim3(kRowThreads), 0, s, out,
+                       (T*)input, (T*)residual, (const T*)weight, fp8_scale, q_scale, eps, (int)H, in_stride,
+                       write_input);
+  return hip_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (reference: kernels/cuda/rope.cu:27-154): all arithmetic in T (each op rounds to 16 bit)
+// one workgroup per token; thread i handles (head, rot_offset) pairs
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool NEOX>
+__global__ __launch_bounds__(256) void rope_kernel(const int64_t* __restrict__ positions, T* __restrict__ q,
+                                                   T* __restrict__ k, const T* __restrict__ cache, int rot_dim,
+                                                   int64_t q_stride, int64_t k_stride, int64_t head_stride,
+                                                   int nq, int nk) {
+  const int64_t t = blockIdx.x;
+  const int half = rot_dim >> 1;
+  const T* cp = cache + positions[t] * rot_dim;
+  const int total = (nq + nk) * half;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int h = i / half, j = i - h * half;
+    T* arr = (h < nq) ? q + t * q_stride + (int64_t)h * head_stride
+                      : k + t * k_stride + (int64_t)(h - nq) * head_stride;
+    const int xi = NEOX ? j : 2 * j, yi = NEOX ? half + j : 2 * j + 1;
+    const float c = to_f32(cp[j]), s = to_f32(cp[half + j]);
+    const float x = to_f32(arr[xi]), y = to_f32(arr[yi]);
+    arr[xi] = from_f32<T>(r16<T>(x * c) - r16<T>(y * s));
+    arr[yi] = from_f32<T>(r16<T>(y * c) + r16<T>(x * s));
+  }
+}
+
+// fused per-head RMSNorm + RoPE inside packed qkv (reference: kernels/cuda/fused_qknorm_rope.cu:88-300)
+// one wave per (token, head); fp32 math, one 16-bit store. head_dim <= 256, multiple of 2.
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void fused_qk_norm_rope_kernel(T* __restrict__ qkv, int64_t n_tokens, int nq,
+                                                                 int nk, int nv, int d, float eps,
+                                                                 const T* __restrict__ qw, const T* __restrict__ kw,
+                                                                 const CT* __restrict__ cache, int interleaved,
+                                                                 const int64_t* __restrict__ positions) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int heads = nq + nk;
+  if (wid >= n_tokens * heads) return;
+  const int64_t t = wid / heads;
+  const int h = (int)(wid - t * heads);
+  T* base = qkv + t * (int64_t)(nq + nk + nv) * d + (int64_t)h * d;
+  const T* w = (h < nq) ? qw : kw;
+  const int half = d >> 1;
+  // each lane owns pairs j = lane, lane+64, ... (x_j, y_j)
+  float xs[2], ys[2];
+  float ss = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j = lane + r * 64;
+    if (j < half) {
+      const int xi = interleaved ? 2 * j : j, yi = interleaved ? 2 * j + 1 : half + j;
+      xs[r] = to_f32(base[xi]);
+      ys[r] = to_f32(base[yi]);
+      ss += xs[r] * xs[r] + ys[r] * ys[r];
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / sqrtf(ss / (float)d + eps);
+  const CT* cp = cache + positions[t] * d;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j = lane + r * 64;
+    if (j < half) {
+      const int xi = interleaved ? 2 * j : j, yi = interleaved ? 2 * j + 1 : half + j;
+      const float x = xs[r] * inv * to_f32(w[xi]), y = ys[r] * inv * to_f32(w[yi]);
+      const float c = to_f32(cp[j]), s = to_f32(cp[half + j]);
+      base[xi] = from_f32<T>(x * c - y * s);
+      base[yi] = from_f32<T>(y * c + x * s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// act_and_mul (reference: kernels/cuda/activation.cu:49-120): out = r16(r16(act(float(x))) * y)
+// QUANT: also per-token int8 quantise the 16-bit result
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ float act_f(float f) {
+  if constexpr (MODE == XM_ACT_SILU) return f / (1.0f + expf(-f));
+  else if constexpr (MODE == XM_ACT_GELU) return f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f));
+  else {
+    const float kBeta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;
+    const float inner = kBeta * (f + 0.044715f * f * f * f);
+    return 0.5f * f * (1.0f + tanhf(inner));
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d,
+                                                          bool vec) {
+  constexpr int N = RowVec<T>::N;
+  const int64_t t = blockIdx.x;
+  const T* x = in + t * 2 * (int64_t)d;
+  const T* y = x + d;
+  T* o = out + t * (int64_t)d;
+  if (vec) {
+    const int nvec = d / N;
+    for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+      RowVec<T> xv, yv;
+      xv.raw = reinterpret_cast<const uint4*>(x)[c];
+      yv.raw = reinterpret_cast<const uint4*>(y)[c];
+#pragma unroll
+      for (int j = 0; j < N; ++j) xv.set(j, r16<T>(act_f<MODE>(xv.get(j))) * yv.get(j));
+      reinterpret_cast<uint4*>(o)[c] = xv.raw;
+    }
+  } else {
+    for (int i = threadIdx.x; i < d; i += blockDim.x)
+      o[i] = from_f32<T>(r16<T>(act_f<MODE>(to_f32(x[i]))) * to_f32(y[i]));
+  }
+}
+
+// fused act_and_mul + per-token int8 quant; d*sizeof(T) may exceed the register cache, so the 16-bit
+// product is staged in LDS (d <= 32768 elements of 2 bytes = 64 KiB).
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
+                                                             const T* __restrict__ in, int d) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  __shared__ float red[32];
+  constexpr int N = RowVec<T>::N;
+  T* stage = reinterpret_cast<T*>(dyn_smem);
+  const int64_t t = blockIdx.x;
+  const T* x = in + t * 2 * (int64_t)d;
+  const T* y = x + d;
+  const int nvec = d / N;
+  float amax = 0.0f;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    RowVec<T> xv, yv;
+    xv.raw = reinterpret_cast<const uint4*>(x)[c];
+    yv.raw = reinterpret_cast<const uint4*>(y)[c];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float r = r16<T>(r16<T>(act_f<MODE>(xv.get(j))) * yv.get(j));
+      xv.set(j, r);
+      amax = fmaxf(amax, fabsf(r));
+    }
+    reinterpret_cast<uint4*>(stage)[c] = xv.raw;
+  }
+  amax = block_max(amax, red);
+  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    RowVec<T> xv;
+    xv.raw = reinterpret_cast<const uint4*>(stage)[c];
+    uint32_t pk[N / 4];
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv.get(j + e) * qinv)));
+        w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+      }
+      pk[j / 4] = w;
+    }
+    int8_t* o = out_q + t * (int64_t)d + (int64_t)c * N;
+    if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+    else *reinterpret_cast<uint32_t*>(o) = pk[0];
+  }
+  if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-token int8 quant (reference: kernels/dcu/scaled_quantize.hip:29-109)
+// the row is read once (register cache up to 16 KiB/row of 16-bit data at 512 threads, else re-read)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void scaled_quantize_i8_kernel(const T* __restrict__ x, int8_t* __restrict__ out,
+                                                                 float* __restrict__ scales, int K, bool vec) {
+  __shared__ float red[32];
+  constexpr int N = RowVec<T>::N;
+  constexpr int kCache = 4;
+  const int64_t m = blockIdx.x;
+  const T* xr = x + m * (int64_t)K;
+  int8_t* orow = out + m * (int64_t)K;
+  float amax = 0.0f;
+  if (vec) {
+    const int nvec = K / N;
+    RowVec<T> xv[kCache];
+#pragma unroll
+    for (int i = 0; i < kCache; ++i) {
+      const int c = threadIdx.x + i * 512;
+      if (c < nvec) {
+        xv[i].raw = reinterpret_cast<const uint4*>(xr)[c];
+#pragma unroll
+        for (int j = 0; j < N; ++j) amax = fmaxf(amax, fabsf(xv[i].get(j)));
+      }
+    }
+    for (int c = threadIdx.x + kCache * 512; c < nvec; c += 512) {
+      RowVec<T> v;
+      v.raw = reinterpret_cast<const uint4*>(xr)[c];
+#pragma unroll
+      for (int j = 0; j < N; ++j) amax = fmaxf(amax, fabsf(v.get(j)));
+    }
+    amax = block_max(amax, red);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+    auto emit = [&](const RowVec<T>& v, int c) {
+      uint32_t pk[N / 4];
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float qv = fmaxf(-127.0f, fminf(127.0f, rintf(v.get(j + e) * qinv)));
+          w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+        }
+        pk[j / 4] = w;
+      }
+      int8_t* o = orow + (int64_t)c * N;
+      if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+      else *reinterpret_cast<uint32_t*>(o) = pk[0];
+    };
+#pragma unroll
+    for (int i = 0; i < kCache; ++i) {
+      const int c = threadIdx.x + i * 512;
+      if (c < nvec) emit(xv[i], c);
+    }
+    for (int c = threadIdx.x + kCache * 512; c < nvec; c += 512) {
+      RowVec<T> v;
+      v.raw = reinterpret_cast<const uint4*>(xr)[c];
+      emit(v, c);
+    }
+  } else {
+    for (int i = threadIdx.x; i < K; i += blockDim.x) amax = fmaxf(amax, fabsf(to_f32(xr[i])));
+    amax = block_max(amax, red);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+    for (int i = threadIdx.x; i < K; i += blockDim.x)
+      orow[i] = (int8_t)fmaxf(-127.0f, fminf(127.0f, rintf(to_f32(xr[i]) * qinv)));
+  }
+  if (threadIdx.x == 0) scales[m] = amax / 127.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp8 static quant + per-tensor amax (reference: kernels/cuda/fp8_quant.cu:79-155,
+// fp8_scaled_quantize.cpp:36-47). grid-stride, 16-B loads.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(uint8_t* __restrict__ out, const T* __restrict__ in,
+                                                        const float* __restrict__ scale, int64_t n, bool vec) {
+  constexpr int N = RowVec<T>::N;
+  const float sinv = 1.0f / scale[0];
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t nvec = n / N;
+    for (int64_t c = tid; c < nvec; c += nthr) {
+      RowVec<T> v;
+      v.raw = reinterpret_cast<const uint4*>(in)[c];
+      uint32_t pk[N / 4];
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (uint32_t)f32_to_e4m3_sat(v.get(j + e) * sinv) << (8 * e);
+        pk[j / 4] = w;
+      }
+      if constexpr (N == 8) reinterpret_cast<uint2*>(out)[c] = make_uint2(pk[0], pk[1]);
+      else reinterpret_cast<uint32_t*>(out)[c] = pk[0];
+    }
+    for (int64_t i = nvec * N + tid; i < n; i += nthr) out[i] = f32_to_e4m3_sat(to_f32(in[i]) * sinv);
+  } else {
+    for (int64_t i = tid; i < n; i += nthr) out[i] = f32_to_e4m3_sat(to_f32(in[i]) * sinv);
+  }
+}
+
+// amax over the tensor -> scale = r16-chain of fp8_scaled_quantize.cpp:39-44 evaluated on a 16-bit
+// 0-dim tensor: s = r16(amax/448); s = r16(max(s, r16(1e-12))). Non-negative floats order like uints,
+// so the cross-block max is an atomicMax on the bit pattern (scale buffer zeroed by the launcher).
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ in, int64_t n, uint32_t* __restrict__ amax_bits) {
+  __shared__ float red[32];
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(to_f32(in[i])));
+  m = block_max(m, red);
+  if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+template <typename T>
+__global__ void fp8_scale_finalize_kernel(float* scale) {
+  float s = r16<T>(scale[0] / 448.0f);
+  s = r16<T>(fmaxf(s, r16<T>(1e-12f)));
+  scale[0] = s;
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* xllm_mi355_strerror(int code) {
+  switch (code) {
+    case XM_OK: return "ok";
+    case XM_ERR_INVALID: return "xllm_mi355: invalid argument";
+    case XM_ERR_UNSUPPORTED: return "xllm_mi355: unsupported shape or dtype";
+    case XM_ERR_HIP: return "xllm_mi355: HIP launch failed";
+    case XM_ERR_WORKSPACE: return "xllm_mi355: workspace too small";
+    default: return "xllm_mi355: unknown error";
+  }
+}
+int xllm_mi355_abi_version(void) { return 1; }
+
+int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const void* v, void* k_cache,
+                                   void* v_cache, int64_t n_tokens, int64_t n_kv_heads, int64_t head_dim,
+                                   int64_t block_size, int64_t n_blocks, int64_t k_stride, int64_t v_stride,
+                                   int elt_bytes, void* stream) {
+  if (!slot_ids || !k || !v || !k_cache || !v_cache || n_tokens < 0 || block_size <= 0) return XM_ERR_INVALID;
+  if (elt_bytes != 2 && elt_bytes != 4 && elt_bytes != 1) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t row_b = n_kv_heads * head_dim * elt_bytes;
+  const int64_t ks_b = k_stride * elt_bytes, vs_b = v_stride * elt_bytes;
+  const bool al16 = (row_b % 16 == 0) && (ks_b % 16 == 0) && (vs_b % 16 == 0) && ((uintptr_t)k % 16 == 0) &&
+                    ((uintptr_t)v % 16 == 0) && ((uintptr_t)k_cache % 16 == 0) && ((uintptr_t)v_cache % 16 == 0);
+  if (al16) {
+    const int64_t rv = row_b / 16;
+    const int thr = (int)(rv >= 256 ? 256 : (rv <= 64 ? 64 : ((rv + 63) / 64) * 64));
+    hipLaunchKernelGGL((reshape_paged_cache_kernel<uint4>), dim3(n_tokens), dim3(thr), 0, s, slot_ids,
+                       (const uint4*)k, (const uint4*)v, (uint4*)k_cache, (uint4*)v_cache, rv, ks_b / 16,
+                       vs_b / 16, block_size, n_blocks);
+  } else if (elt_bytes == 2) {
+    hipLaunchKernelGGL((reshape_paged_cache_kernel<uint16_t>), dim3(n_tokens), dim3(256), 0, s, slot_ids,
+                       (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)k_cache, (uint16_t*)v_cache,
+                       n_kv_heads * head_dim, k_stride, v_stride, block_size, n_blocks);
+  } else if (elt_bytes == 4) {
+    hipLaunchKernelGGL((reshape_paged_cache_kernel<uint32_t>), dim3(n_tokens), dim3(256), 0, s, slot_ids,
+                       (const uint32_t*)k, (const uint32_t*)v, (uint32_t*)k_cache, (uint32_t*)v_cache,
+                       n_kv_heads * head_dim, k_stride, v_stride, block_size, n_blocks);
+  } else {
+    hipLaunchKernelGGL((reshape_paged_cache_kernel<uint8_t>), dim3(n_tokens), dim3(256), 0, s, slot_ids,
+                       (const uint8_t*)k, (const uint8_t*)v, (uint8_t*)k_cache, (uint8_t*)v_cache,
+                       n_kv_heads * head_dim, k_stride, v_stride, block_size, n_blocks);
+  }
+  return hip_check_launch();
+}
+
+int xllm_mi355_build_block_table_from_paged_kv(const int32_t* indptr, const int32_t* indices, int32_t batch,
+                                               int32_t total_pages, int32_t* block_table, void* stream) {
+  if (!indptr || !block_table || batch < 0 || total_pages < 0) return XM_ERR_INVALID;
+  if (batch == 0 || total_pages == 0) return XM_OK;
+  hipLaunchKernelGGL(build_block_table_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, indptr, indices,
+                     total_pages, block_table);
+  return hip_check_launch();
+}
+
+int xllm_mi355_rms_norm(void* out, const void* input, const void* weight, float eps, int64_t n_tokens,
+                        int64_t hidden, int64_t in_stride, int dtype, void* stream) {
+  if (!out || !input || !weight || n_tokens < 0 || hidden <= 0) return XM_ERR_INVALID;
+  XM_DISPATCH_FLOAT(dtype, T, return (launch_rms_norm<T, false, 0>(out, (void*)input, nullptr, weight, nullptr,
+                                                                  nullptr, eps, n_tokens, hidden, in_stride,
+                                                                  false, (hipStream_t)stream)));
+  return XM_OK;
+}
+
+int xllm_mi355_fused_add_rms_norm(void* input, void* residual, const void* weight, float eps, int64_t n_tokens,
+                                  int64_t hidden, int64_t in_stride, int dtype, void* stream) {
+  if (!input || !residual || !weight || n_tokens < 0 || hidden <= 0) return XM_ERR_INVALID;
+  if (in_stride != hidden) {
+    // out == input with a token stride: only the generic kernel handles out-stride != hidden
+    return XM_ERR_UNSUPPORTED;
+  }
+  XM_DISPATCH_FLOAT(dtype, T, return (launch_rms_norm<T, true, 0>(input, input, residual, weight, nullptr, nullptr,
+                                                                 eps, n_tokens, hidden, in_stride, false,
+                                                                 (hipStream_t)stream)));
+  return XM_OK;
+}
+
+int xllm_mi355_rms_norm_static_fp8_quant(uint8_t* out, const void* input, void* residual, const void* weight,
+                                         const float* scale, float eps, int64_t n_tokens, int64_t hidden,
+                                         int64_t in_stride, int dtype, void* stream) {
+  if (!out || !input || !weight || !scale || n_tokens < 0 || hidden <= 0) return XM_ERR_INVALID;
+  if (residual) {
+    XM_DISPATCH_HALF(dtype, T, return (launch_rms_norm<T, true, 1>(out, (void*)input, residual, weight, scale,
+                                                                  nullptr, eps, n_tokens, hidden, in_stride, false,
+                                                                  (hipStream_t)stream)));
+  } else {
+    XM_DISPATCH_HALF(dtype, T, return (launch_rms_norm<T, false, 1>(out, (void*)input, nullptr, weight, scale,
+                                                                   nullptr, eps, n_tokens, hidden, in_stride,
+                                                                   false, (hipStream_t)stream)));
+  }
+  return XM_OK;
+}
+
+int xllm_mi355_rms_norm_dynamic_int8_quant(int8_t* out_q, float* out_scale, const void* input, void* residual,
+                                           const void* weight, float eps, int64_t n_tokens, int64_t hidden,
+                                           int64_t in_stride, int dtype, void* stream) {
+  if (!out_q || !out_scale || !input || !weight || n_tokens < 0 || hidden <= 0) return XM_ERR_INVALID;
+  if (residual) {
+    XM_DISPATCH_HALF(dtype, T, return (launch_rms_norm<T, true, 2>(out_q, (void*)input, residual, weight, nullptr,
+                                                                  out_scale, eps, n_tokens, hidden, in_stride,
+                                                                  false, (hipStream_t)stream)));
+  } else {
+    XM_DISPATCH_HALF(dtype, T, return (launch_rms_norm<T, false, 2>(out_q, (void*)input, nullptr, weight, nullptr,
+                                                                   out_scale, eps, n_tokens, hidden, in_stride,
+                                                                   false, (hipStream_t)stream)));
+  }
+  return XM_OK;
+}
+
+int xllm_mi355_rotary_embedding(const int64_t* positions, void* q, void* k, const void* cos_sin_cache,
+                                int64_t n_tokens, int64_t n_q_heads, int64_t n_k_heads, int64_t head_size,
+                                int64_t rot_dim, int64_t q_stride, int64_t k_stride, int64_t head_stride,
+                                int is_neox, int dtype, void* stream) {
+  if (!positions || !q || !cos_sin_cache || n_tokens < 0 || rot_dim <= 0 || (rot_dim & 1) || rot_dim > head_size)
+    return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  const int nk = k ? (int)n_k_heads : 0;
+  const int work = (int)((n_q_heads + nk) * (rot_dim / 2));
+  const int thr = work >= 256 ? 256 : ((work + 63) / 64) * 64;
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_FLOAT(dtype, T, {
+    if (is_neox)
+      hipLaunchKernelGGL((rope_kernel<T, true>), dim3(n_tokens), dim3(thr), 0, s, positions, (T*)q, (T*)k,
+                         (const T*)cos_sin_cache, (int)rot_dim, q_stride, k_stride, head_stride, (int)n_q_heads, nk);
+    else
+      hipLaunchKernelGGL((rope_kernel<T, false>), dim3(n_tokens), dim3(thr), 0, s, positions, (T*)q, (T*)k,
+                         (const T*)cos_sin_cache, (int)rot_dim, q_stride, k_stride, head_stride, (int)n_q_heads, nk);
+  });
+  return hip_check_launch();
+}
+
+int xllm_mi355_fused_qk_norm_rope(void* qkv, int64_t n_tokens, int64_t n_q, int64_t n_k, int64_t n_v,
+                                  int64_t head_dim, float eps, const void* q_weight, const void* k_weight,
+                                  const void* cos_sin_cache, int cache_dtype, int interleaved,
+                                  const int64_t* positions, int dtype, void* stream) {
+  if (!qkv || !q_weight || !k_weight || !cos_sin_cache || !positions || n_tokens < 0) return XM_ERR_INVALID;
+  if (head_dim > 256 || (head_dim & 1)) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  const int64_t waves = n_tokens * (n_q + n_k);
+  const int64_t blocks = (waves + 3) / 4;
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_HALF(dtype, T, {
+    if (cache_dtype == XM_F32)
+      hipLaunchKernelGGL((fused_qk_norm_rope_kernel<T, float>), dim3(blocks), dim3(256), 0, s, (T*)qkv, n_tokens,
+                         (int)n_q, (int)n_k, (int)n_v, (int)head_dim, eps, (const T*)q_weight, (const T*)k_weight,
+                         (const float*)cos_sin_cache, interleaved, positions);
+    else if (cache_dtype == dtype)
+      hipLaunchKernelGGL((fused_qk_norm_rope_kernel<T, T>), dim3(blocks), dim3(256), 0, s, (T*)qkv, n_tokens,
+                         (int)n_q, (int)n_k, (int)n_v, (int)head_dim, eps, (const T*)q_weight, (const T*)k_weight,
+                         (const T*)cos_sin_cache, interleaved, positions);
+    else
+      return XM_ERR_UNSUPPORTED;
+  });
+  return hip_check_launch();
+}
+
+}  // extern "C" (templates need C++ linkage)
+
+template <typename T>
+static int launch_act(void* out, const void* input, int64_t n_tokens, int64_t d, int act_mode, hipStream_t s) {
+  constexpr int N = Vec16B<T>::N;
+  const bool vec = (d % N == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)input % 16 == 0);
+  switch (act_mode) {
+    case XM_ACT_SILU:
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+                         (const T*)input, (int)d, vec);
+      break;
+    case XM_ACT_GELU:
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+                         (const T*)input, (int)d, vec);
+      break;
+    case XM_ACT_GELU_TANH:
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU_TANH>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+                         (const T*)input, (int)d, vec);
+      break;
+    default: return XM_ERR_UNSUPPORTED;
+  }
+  return hip_check_launch();
+}
+
+template <typename T>
+static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64_t n_tokens, int64_t d,
+                       int act_mode, hipStream_t s) {
+  const size_t lds = (size_t)d * sizeof(T);
+  switch (act_mode) {
+    case XM_ACT_SILU:
+      hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), lds, s, out_q,
+                         out_scale, (const T*)input, (int)d);
+      break;
+    case XM_ACT_GELU:
+      hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_GELU>), dim3(n_tokens), dim3(512), lds, s, out_q,
+                         out_scale, (const T*)input, (int)d);
+      break;
+    case XM_ACT_GELU_TANH:
+      hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_GELU_TANH>), dim3(n_tokens), dim3(512), lds, s, out_q,
+                         out_scale, (const T*)input, (int)d);
+      break;
+    default: return XM_ERR_UNSUPPORTED;
+  }
+  return hip_check_launch();
+}
+
+extern "C" {
+
+int xllm_mi355_act_and_mul(void* out, const void* input, int64_t n_tokens, int64_t d, int act_mode, int dtype,
+                           void* stream) {
+  if (!out || !input || n_tokens < 0 || d <= 0) return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  XM_DISPATCH_FLOAT(dtype, T, return launch_act<T>(out, input, n_tokens, d, act_mode, (hipStream_t)stream));
+  return XM_OK;
+}
+
+int xllm_mi355_act_and_mul_dynamic_int8_quant(int8_t* out_q, float* out_scale, const void* input,
+                                              int64_t n_tokens, int64_t d, int act_mode, int dtype, void* stream) {
+  if (!out_q || !out_scale || !input || n_tokens < 0 || d <= 0) return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  if (d % 8 != 0 || d * 2 > 65536 || (uintptr_t)input % 16 || (uintptr_t)out_q % 8) return XM_ERR_UNSUPPORTED;
+  XM_DISPATCH_HALF(dtype, T,
+                   return launch_actq<T>(out_q, out_scale, input, n_tokens, d, act_mode, (hipStream_t)stream));
+  return XM_OK;
+}
+
+int xllm_mi355_scaled_quantize(const void* x, int8_t* out, float* out_scale, int64_t M, int64_t K, int dtype,
+                               void* stream) {
+  if (!x || !out || !out_scale || M < 0 || K <= 0) return XM_ERR_INVALID;
+  if (M == 0) return XM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_FLOAT(dtype, T, {
+    constexpr int N = Vec16B<T>::N;
+    const bool vec = (K % N == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0);
+    hipLaunchKernelGGL((scaled_quantize_i8_kernel<T>), dim3(M), dim3(512), 0, s, (const T*)x, out, out_scale,
+                       (int)K, vec);
+  });
+  return hip_check_launch();
+}
+
+int xllm_mi355_static_scaled_fp8_quant(uint8_t* out, const void* input, const float* scale, int64_t numel,
+                                       int dtype, void* stream) {
+  if (!out || !input || !scale || numel < 0) return XM_ERR_INVALID;
+  if (numel == 0) return XM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_FLOAT(dtype, T, {
+    constexpr int N = Vec16B<T>::N;
+    const bool vec = ((uintptr_t)input % 16 == 0) && ((uintptr_t)out % 8 == 0);
+    int64_t blocks = (numel / N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((fp8_quant_kernel<T>), dim3(blocks), dim3(256), 0, s, out, (const T*)input, scale, numel, vec);
+  });
+  return hip_check_launch();
+}
+
+int xllm_mi355_fp8_scaled_quantize(uint8_t* out, const void* input, const float* scale_in, float* scale_out,
+                                   int64_t numel, int dtype, void* stream) {
+  if (!out || !input || numel < 0 || (!scale_in && !scale_out)) return XM_ERR_INVALID;
+  if (scale_in) return xllm_mi355_static_scaled_fp8_quant(out, input, scale_in, numel, dtype, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(scale_out, 0, sizeof(float), s) != hipSuccess) return XM_ERR_HIP;
+  if (numel > 0) {
+    XM_DISPATCH_FLOAT(dtype, T, {
+      int64_t blocks = (numel + 256 * 8 - 1) / (256 * 8);
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL((amax_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)input, numel,
+                         (uint32_t*)scale_out);
+      hipLaunchKernelGGL((fp8_scale_finalize_kernel<T>), dim3(1), dim3(1), 0, s, scale_out);
+    });
+  }
+  int rc = hip_check_launch();
+  if (rc) return rc;
+  return xllm_mi355_static_scaled_fp8_quant(out, input, scale_out, numel, dtype, stream);
+}
+
+}  // extern "C"

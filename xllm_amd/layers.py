@@ -1,0 +1,179 @@
+"""The callers of the hot path, in the reference's order, over the xllm_amd operators.
+
+Reference: Qwen2DecoderLayerImpl::forward (xllm/core/layers/qwen2_decoder_layer.cpp:87-110),
+Qwen2AttentionImpl::forward (layers/common/qwen2_attention.cpp:132-193), DenseMLPImpl::forward
+(layers/common/dense_mlp.cpp:97-116), the w8a8-dynamic linear (layers/common/linear.cpp:481-507: scaled_quantize
+then scaled_matmul), Row/Column-parallel sharding (linear.cpp:616-716, 1405-1522) and
+LlmModelImplBase::forward (models/llm/llm_model_base.h:60-125) for the layer loop + final norm + lm_head.
+
+Weights are synthetic (random-init of the architecture): this module is the fixed-shape harness of SURVEY 8d,
+not a checkpoint loader.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops, parallel
+from .attention import AttentionImpl, AttentionMetadata, KVCache
+
+
+@dataclass
+class ModelArgs:
+    hidden_size: int = 3584
+    n_layers: int = 28
+    n_heads: int = 28
+    n_kv_heads: int = 4
+    head_dim: int = 128
+    intermediate_size: int = 18944
+    vocab_size: int = 152064
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_position_embeddings: int = 32768
+
+    @staticmethod
+    def qwen2_7b():  # xllm/models/llm/qwen2.h:89-121
+        return ModelArgs()
+
+    @staticmethod
+    def qwen2_0_5b():
+        return ModelArgs(896, 24, 14, 2, 64, 4864, 151936, 1e-6, 1e6, 32768)
+
+
+def build_cos_sin_cache(args: ModelArgs, dtype, device, max_pos: Optional[int] = None):
+    """layers/common/rotary_embedding_util.cpp:157-192 + rotary_embedding.cpp:46-52: [cos(rot/2) || sin(rot/2)]"""
+    rot = args.head_dim
+    n = max_pos or args.max_position_embeddings
+    inv_freq = 1.0 / torch.pow(torch.tensor(args.rope_theta, dtype=torch.float32),
+                               torch.arange(0, rot, 2, dtype=torch.float32) / rot)
+    fr = torch.outer(torch.arange(n, dtype=torch.float32), inv_freq)
+    return torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(device)
+
+
+class QuantLinear:
+    """Column/Row-parallel linear, w8a8-dynamic (int8) / fp8 / 16-bit, weight [N_local, K_local]."""
+
+    def __init__(self, n: int, k: int, bias: bool, mode: str, dtype, device, gen, row_parallel_pg=None):
+        self.mode, self.dtype, self.pg = mode, dtype, row_parallel_pg
+        if mode == "int8":
+            self.weight = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device, generator=gen)
+            # w_scale = u*0.02+0.01 scaled so outputs stay O(1) (linear_w8a8_dynamic_tests.cpp:73-78 pattern)
+            self.w_scale = (torch.rand(n, device=device, generator=gen) * 0.02 + 0.01) / (73.0 * math.sqrt(k)) * 8
+        elif mode == "fp8":
+            self.weight = (torch.randn(n, k, device=device, generator=gen)).to(torch.float8_e4m3fn)
+            self.w_scale = torch.full((1,), 1.0 / math.sqrt(k), device=device)
+        else:
+            self.weight = (torch.randn(n, k, device=device, generator=gen) / math.sqrt(k)).to(dtype)
+        self.bias = (torch.randn(n, device=device, generator=gen) * 0.1).to(dtype) if bias else None
+
+    def forward(self, x, pre_quant=None):
+        if self.mode == "int8":
+            q, s = pre_quant if pre_quant is not None else ops.scaled_quantize(x)
+            y = ops.scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias)
+        elif self.mode == "fp8":
+            q, s = pre_quant if pre_quant is not None else ops.fp8_scaled_quantize(x)
+            y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias)
+        else:
+            y = ops.matmul(x, self.weight, self.bias)
+        return parallel.reduce(y, self.pg) if self.pg is not None else y
+
+    def weight_bytes(self) -> int:
+        return self.weight.numel() * self.weight.element_size()
+
+
+class Qwen2DecoderLayer:
+    def __init__(self, args: ModelArgs, mode: str, dtype, device, gen, tp: Optional[parallel.ProcessGroup] = None,
+                 fuse: bool = True):
+        tp_size = tp.world_size() if tp else 1
+        assert args.n_heads % tp_size == 0  # qwen2_attention.cpp:54
+        self.nq = args.n_heads // tp_size
+        if args.n_kv_heads >= tp_size:       # qwen2_attention.cpp:57-65
+            assert args.n_kv_heads % tp_size == 0
+            self.nkv = args.n_kv_heads // tp_size
+        else:
+            assert tp_size % args.n_kv_heads == 0
+            self.nkv = 1
+        self.d, self.args, self.mode, self.fuse, self.dtype = args.head_dim, args, mode, fuse and mode == "int8", dtype
+        self.q_size, self.kv_size = self.nq * self.d, self.nkv * self.d
+        H, I = args.hidden_size, args.intermediate_size // tp_size
+        self.I = I
+        w = lambda: (torch.rand(H, device=device, generator=gen) + 0.5).to(dtype)
+        self.input_norm_w, self.post_norm_w = w(), w()
+        self.qkv_proj = QuantLinear(self.q_size + 2 * self.kv_size, H, True, mode, dtype, device, gen)
+        self.o_proj = QuantLinear(H, self.q_size, False, mode, dtype, device, gen, row_parallel_pg=tp)
+        self.gate_up_proj = QuantLinear(2 * I, H, False, mode, dtype, device, gen)
+        self.down_proj = QuantLinear(H, I, False, mode, dtype, device, gen, row_parallel_pg=tp)
+        self.attn = AttentionImpl(self.nq, self.d, math.sqrt(1.0 / self.d), self.nkv)
+
+    def weight_bytes(self) -> int:
+        return sum(l.weight_bytes() for l in (self.qkv_proj, self.o_proj, self.gate_up_proj, self.down_proj))
+
+    def _norm(self, x, residual, w):
+        """apply_norm (qwen2_decoder_layer.cpp:66-85); returns (normed or pre-quantised, residual)"""
+        eps = self.args.rms_norm_eps
+        if self.fuse:  # N1: norm (+add) + per-token int8 quant in one pass
+            if residual is None:
+                return ops.rms_norm_dynamic_int8_quant(x, w, eps), x
+            return ops.rms_norm_dynamic_int8_quant(x, w, eps, residual=residual), residual
+        if residual is None:
+            out = torch.empty_like(x)
+            ops.rms_norm(out, x, w, eps)
+            return out, x
+        ops.fused_add_rms_norm(x, residual, w, eps)
+        return x, residual
+
+    def forward(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin):
+        h, residual = self._norm(x, residual, self.input_norm_w)
+        qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
+        q = qkv[:, :self.q_size]
+        k = qkv[:, self.q_size:self.q_size + self.kv_size]
+        v = qkv[:, self.q_size + self.kv_size:]
+        ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)
+        attn, _ = self.attn.forward(md, q, k, v, kv_cache)
+        x = self.o_proj.forward(attn)
+        h, residual = self._norm(x, residual, self.post_norm_w)
+        gate_up = self.gate_up_proj.forward(None, pre_quant=h) if self.fuse else self.gate_up_proj.forward(h)
+        if self.fuse:  # N1: silu*mul + int8 quant feeding down_proj
+            x = self.down_proj.forward(None, pre_quant=ops.act_and_mul_dynamic_int8_quant(gate_up, "silu"))
+        else:
+            act = torch.empty(gate_up.size(0), self.I, dtype=gate_up.dtype, device=gate_up.device)
+            ops.act_and_mul(act, gate_up, "silu")
+            x = self.down_proj.forward(act)
+        return x, residual
+
+
+class Qwen2Model:
+    """layer loop + final norm + lm_head (llm_model_base.h:60-125, 193-204); lm_head is never quantised
+    (linear.cpp:512-520) and column-parallel with gather_output (linear.cpp:712-714)."""
+
+    def __init__(self, args: ModelArgs, mode: str = "int8", dtype=torch.bfloat16, device="cuda", seed: int = 0,
+                 tp: Optional[parallel.ProcessGroup] = None, fuse: bool = True, n_layers: Optional[int] = None):
+        gen = torch.Generator(device=device).manual_seed(seed + (tp.rank() if tp else 0))
+        self.args, self.tp, self.dtype, self.device = args, tp, dtype, device
+        tp_size = tp.world_size() if tp else 1
+        self.layers = [Qwen2DecoderLayer(args, mode, dtype, device, gen, tp, fuse)
+                       for _ in range(n_layers if n_layers is not None else args.n_layers)]
+        self.norm_w = (torch.rand(args.hidden_size, device=device, generator=gen) + 0.5).to(dtype)
+        self.lm_head = QuantLinear(args.vocab_size // tp_size, args.hidden_size, False, "16bit", dtype, device, gen)
+        self.embed = (torch.randn(args.vocab_size, args.hidden_size, device=device, generator=gen)).to(dtype)
+        self.cos_sin = build_cos_sin_cache(args, dtype, device, 8192)
+
+    def forward(self, tokens, positions, md: AttentionMetadata, kv_caches):
+        x = torch.nn.functional.embedding(tokens, self.embed)  # embed_tokens_ (llm_model_base.h:74)
+        residual = None
+        for layer, kvc in zip(self.layers, kv_caches):
+            x, residual = layer.forward(x, residual, positions, md, kvc, self.cos_sin)
+        if residual is None:
+            out = torch.empty_like(x)
+            ops.rms_norm(out, x, self.norm_w, self.args.rms_norm_eps)
+        else:
+            ops.fused_add_rms_norm(x, residual, self.norm_w, self.args.rms_norm_eps)
+            out = x
+        return out
+
+    def logits(self, hidden):
+        y = self.lm_head.forward(hidden)
+        return parallel.gather(y, self.tp)

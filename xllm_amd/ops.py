@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's operator boundary for the hot path.
+
+Names, argument meaning and error behaviour follow xllm::kernel::* (xllm/core/kernels/ops_api.h:27-287,
+param.h) and the per-backend headers kernels/cuda/cuda_ops_api.h / kernels/dcu/dcu_ops_api.h; each function
+validates like the reference's CHECKs, allocates outputs with torch.empty on the input's device when the
+reference does, and calls ONE C-ABI symbol of include/xllm_mi355.h on torch's current HIP stream.
+PyTorch is only the allocator / stream provider here.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Mi355Error, check
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_ACT = {"silu": 0, "gelu": 1, "gelu_tanh": 2}
+FP8 = torch.float8_e4m3fn
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype not in _DT:
+        raise Mi355Error(f"unsupported dtype {t.dtype}")
+    return _DT[t.dtype]
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise Mi355Error("xllm_amd ops need device tensors (no CPU fallback on the product path)")
+
+
+# ------------------------------------------------------------------------------------------------ KV write
+def reshape_paged_cache(slot_ids, key, value, key_cache, value_cache) -> None:
+    """kernel::reshape_paged_cache(ReshapePagedCacheParams&) (ops_api.h:31, reshape_paged_cache.cu:65-100)."""
+    _need_cuda(slot_ids, key, value, key_cache, value_cache)
+    if not (key.stride(-1) == 1 and key.stride(-2) == key.size(-1) and value.stride(-1) == 1
+            and value.stride(-2) == value.size(-1)):
+        raise Mi355Error("keys/values must be contiguous over (n_kv_heads, head_dim)")  # reference CHECK :73-74
+    if slot_ids.dtype != torch.int32:
+        raise Mi355Error("slot_ids must be int32")
+    n_tokens, n_kv, d = key.shape[-3:]
+    check(_lib.lib().xllm_mi355_reshape_paged_cache(
+        _p(slot_ids), _p(key), _p(value), _p(key_cache), _p(value_cache), n_tokens, n_kv, d,
+        key_cache.size(-3), key_cache.size(0), key.stride(-3), value.stride(-3), key.element_size(), _stream()),
+        "reshape_paged_cache")
+
+
+def build_block_table_from_paged_kv(paged_kv_indptr, paged_kv_indices) -> torch.Tensor:
+    """dcu::build_block_table_from_paged_kv_cuda (dcu_ops_api.h, build_block_table_from_paged_kv.hip:74-110)."""
+    _need_cuda(paged_kv_indptr, paged_kv_indices)
+    B = paged_kv_indptr.numel() - 1
+    total = paged_kv_indices.numel()
+    table = torch.empty(B, total, dtype=torch.int32, device=paged_kv_indptr.device)
+    check(_lib.lib().xllm_mi355_build_block_table_from_paged_kv(_p(paged_kv_indptr), _p(paged_kv_indices), B, total,
+                                                                _p(table), _stream()), "build_block_table")
+    return table
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def rms_norm(output, input, weight, eps: float) -> None:
+    """cuda::rms_norm(out, in, w, eps) (cuda_ops_api.h:146-150, norm.cu:430-464)."""
+    _need_cuda(output, input, weight)
+    H = input.size(-1)
+    x2 = input.view(-1, H) if input.is_contiguous() else input
+    if x2.dim() != 2 or x2.stride(-1) != 1 or not output.is_contiguous():
+        raise Mi355Error("rms_norm: input must be [T, H] with unit inner stride, output contiguous")
+    check(_lib.lib().xllm_mi355_rms_norm(_p(output), _p(x2), _p(weight), eps, x2.size(0), H, x2.stride(0), _dt(input),
+                                        _stream()), "rms_norm")
+
+
+def fused_add_rms_norm(input, residual, weight, eps: float) -> None:
+    """cuda::fused_add_rms_norm(in, residual, w, eps) (norm.cu:466-512): both updated in place."""
+    _need_cuda(input, residual, weight)
+    H = input.size(-1)
+    if not (input.is_contiguous() and residual.is_contiguous()):
+        raise Mi355Error("fused_add_rms_norm: contiguous input/residual required")
+    T = input.numel() // H
+    check(_lib.lib().xllm_mi355_fused_add_rms_norm(_p(input), _p(residual), _p(weight), eps, T, H, H, _dt(input),
+                                                  _stream()), "fused_add_rms_norm")
+
+
+def fused_layernorm(input, weight, eps: float, residual: Optional[torch.Tensor] = None,
+                    output: Optional[torch.Tensor] = None):
+    """kernel::fused_layernorm CUDA/DCU branch (ops_api.cpp:364-372): rms_norm or fused_add_rms_norm."""
+    if residual is not None:
+        fused_add_rms_norm(input, residual, weight, eps)
+        return input, residual
+    out = torch.empty_like(input) if output is None else output
+    rms_norm(out, input, weight, eps)
+    return out, None
+
+
+def rms_norm_static_fp8_quant(output, input, weight, scale, eps: float) -> None:
+    """kernel::rms_norm_static_fp8_quant (ops_api.h:168, norm.cu:517-553)."""
+    _need_cuda(output, input, weight, scale)
+    H = input.size(-1)
+    x2 = input.view(-1, H)
+    check(_lib.lib().xllm_mi355_rms_norm_static_fp8_quant(_p(output), _p(x2), 0, _p(weight), _p(scale), eps, x2.size(0),
+                                                         H, x2.stride(0), _dt(input), _stream()),
+          "rms_norm_static_fp8_quant")
+
+
+def fused_add_rms_norm_static_fp8_quant(output, input, residual, weight, scale, eps: float) -> None:
+    """kernel::fused_add_rms_norm_static_fp8_quant (ops_api.h:172, norm.cu:555-...): residual updated in place."""
+    _need_cuda(output, input, residual, weight, scale)
+    H = input.size(-1)
+    x2 = input.view(-1, H)
+    check(_lib.lib().xllm_mi355_rms_norm_static_fp8_quant(_p(output), _p(x2), _p(residual), _p(weight), _p(scale), eps,
+                                                         x2.size(0), H, x2.stride(0), _dt(input), _stream()),
+          "fused_add_rms_norm_static_fp8_quant")
+
+
+def rms_norm_dynamic_int8_quant(input, weight, eps: float, residual=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """N1 fusion (MLU fused_layernorm(dynamic_quant), param.h:243-277): (int8 [T,H], scale [T])."""
+    _need_cuda(input, weight)
+    H = input.size(-1)
+    x2 = input.view(-1, H)
+    q = torch.empty(x2.shape, dtype=torch.int8, device=input.device)
+    s = torch.empty(x2.size(0), dtype=torch.float32, device=input.device)
+    check(_lib.lib().xllm_mi355_rms_norm_dynamic_int8_quant(_p(q), _p(s), _p(x2), _p(residual), _p(weight), eps,
+                                                           x2.size(0), H, x2.stride(0), _dt(input), _stream()),
+          "rms_norm_dynamic_int8_quant")
+    return q, s
+
+
+# ------------------------------------------------------------------------------------------------ rope / act
+def rotary_embedding(positions, query, key, cos_sin_cache, is_neox: bool = True, head_size: Optional[int] = None):
+    """cuda::rotary_embedding(positions, q, k?, cos_sin_cache, is_neox) (cuda_ops_api.h:31-36, rope.cu:156-250).
+    positions int64 [T]; q/k [T, n*head_size] views with a token stride; in place."""
+    _need_cuda(positions, query, cos_sin_cache)
+    if positions.dtype != torch.int64:
+        raise Mi355Error("positions must be int64 (ops_api.cpp:118-195 converts before the call)")
+    rot = cos_sin_cache.size(-1)
+    hs = head_size if head_size is not None else (query.size(-1) if query.dim() == 3 else rot)
+    T = positions.numel()
+    q2 = query.reshape(T, -1) if query.dim() == 3 and query.is_contiguous() else query
+    nq = q2.size(-1) // hs if q2.dim() == 2 else query.size(-2)
+    nk = 0
+    if key is not None:
+        k2 = key.reshape(T, -1) if key.dim() == 3 and key.is_contiguous() else key
+        nk = k2.size(-1) // hs if k2.dim() == 2 else key.size(-2)
+    check(_lib.lib().xllm_mi355_rotary_embedding(
+        _p(positions), _p(query), _p(key), _p(cos_sin_cache), T, nq, nk, hs, rot, query.stride(0),
+        0 if key is None else key.stride(0), hs, int(is_neox), _dt(query), _stream()), "rotary_embedding")
+
+
+def fused_qk_norm_rope(qkv, num_heads_q, num_heads_k, num_heads_v, head_dim, eps, q_weight, k_weight, cos_sin_cache,
+                       interleaved, position_ids) -> None:
+    """cuda::fused_qk_norm_rope (cuda_ops_api.h:235-249)."""
+    _need_cuda(qkv, q_weight, k_weight, cos_sin_cache, position_ids)
+    check(_lib.lib().xllm_mi355_fused_qk_norm_rope(
+        _p(qkv), qkv.size(0), num_heads_q, num_heads_k, num_heads_v, head_dim, eps, _p(q_weight), _p(k_weight),
+        _p(cos_sin_cache), _dt(cos_sin_cache), int(interleaved), _p(position_ids), _dt(qkv), _stream()),
+        "fused_qk_norm_rope")
+
+
+def act_and_mul(out, input, act_mode: str = "silu") -> None:
+    """cuda::act_and_mul(out, in, mode) (cuda_ops_api.h:38-40, activation.cu:143-185)."""
+    _need_cuda(out, input)
+    if act_mode not in _ACT:
+        raise Mi355Error(f"Unsupported act mode: {act_mode}")  # reference LOG(FATAL) activation.cu:182
+    d = input.size(-1) // 2
+    T = input.numel() // (2 * d)
+    if not (input.is_contiguous() and out.is_contiguous()):
+        raise Mi355Error("act_and_mul: contiguous tensors required")
+    check(_lib.lib().xllm_mi355_act_and_mul(_p(out), _p(input), T, d, _ACT[act_mode], _dt(input), _stream()),
+          "act_and_mul")
+
+
+def act_and_mul_dynamic_int8_quant(input, act_mode: str = "silu"):
+    """N1 fusion (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815)."""
+    _need_cuda(input)
+    d = input.size(-1) // 2
+    T = input.numel() // (2 * d)
+    q = torch.empty(T, d, dtype=torch.int8, device=input.device)
+    s = torch.empty(T, dtype=torch.float32, device=input.device)
+    check(_lib.lib().xllm_mi355_act_and_mul_dynamic_int8_quant(_p(q), _p(s), _p(input), T, d, _ACT[act_mode],
+                                                              _dt(input), _stream()), "act_and_mul_int8")
+    return q, s
+
+
+# ------------------------------------------------------------------------------------------------ int8 W8A8
+def scaled_quantize(x, output=None, output_scale=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """dcu::scaled_quantize(x, smooth=None, ...) -> (int8, fp32 scales) (dcu_ops_api.h, scaled_quantize.hip:411-...)."""
+    _need_cuda(x)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise Mi355Error("scaled_quantize: x must be a contiguous [M, K] tensor")
+    M, K = x.shape
+    q = output if output is not None else torch.empty(M, K, dtype=torch.int8, device=x.device)
+    s = output_scale if output_scale is not None else torch.empty(M, dtype=torch.float32, device=x.device)
+    check(_lib.lib().xllm_mi355_scaled_quantize(_p(x), _p(q), _p(s), M, K, _dt(x), _stream()), "scaled_quantize")
+    return q, s
+
+
+_gemm_ws = {}
+
+
+def _ensure_gemm_workspace(device, nbytes):
+    ws = _gemm_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _gemm_ws[device] = ws
+        check(_lib.lib().xllm_mi355_set_gemm_workspace(ws.data_ptr(), ws.numel()), "set_gemm_workspace")
+
+
+def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, acc_out=None,
+                  quant_bit_size: int = 8, a_quant_bit_size: int = 8):
+    """dcu::scaled_matmul (dcu_ops_api.h, scaled_matmul.cpp:103-300): a [M,K] int8, b [N,K] int8,
+    a_scale [M]/[M,1] f32, b_scale [N]/[N,1] f32, optional bias [N] (output dtype)."""
+    _need_cuda(a, b, a_scale, b_scale)
+    if quant_bit_size != 8 or a_quant_bit_size != 8:
+        raise Mi355Error("scaled_matmul only supports w8a8 quantization")  # scaled_matmul.cpp:120-121
+    if output_dtype not in (torch.bfloat16, torch.float16):
+        raise Mi355Error("output dtype must be half or bfloat16")  # :123-125
+    if a.dim() != 2 or b.dim() != 2 or a.dtype != torch.int8 or b.dtype != torch.int8 or a.size(1) != b.size(1) \
+            or not a.is_contiguous() or not b.is_contiguous():
+        raise Mi355Error("scaled_matmul: a [M,K] int8, b [N,K] int8, contiguous")
+    M, K = a.shape
+    N = b.size(0)
+    out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+    if acc_out is None:
+        _ensure_gemm_workspace(a.device, M * N * 4)
+    check(_lib.lib().xllm_mi355_scaled_matmul(_p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias),
+                                             _p(out), _p(acc_out), M, N, K, _DT[output_dtype], _stream()),
+          "scaled_matmul")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fp8
+def static_scaled_fp8_quant(output, input, scale) -> None:
+    """cuda::static_scaled_fp8_quant(out, in, scale) (cuda_ops_api.h:184-186, fp8_quant.cu:115-155)."""
+    _need_cuda(output, input, scale)
+    check(_lib.lib().xllm_mi355_static_scaled_fp8_quant(_p(output), _p(input.contiguous()), _p(scale), input.numel(),
+                                                       _dt(input), _stream()), "static_scaled_fp8_quant")
+
+
+def fp8_scaled_quantize(input, output=None, scale=None):
+    """cuda::fp8_scaled_quantize(in, out?, scale?) -> (q, scale) (fp8_scaled_quantize.cpp:20-50)."""
+    _need_cuda(input)
+    q = output if output is not None else torch.empty(input.shape, dtype=FP8, device=input.device)
+    x = input.contiguous()
+    if scale is not None:
+        check(_lib.lib().xllm_mi355_fp8_scaled_quantize(_p(q), _p(x), _p(scale), 0, x.numel(), _dt(x), _stream()),
+              "fp8_scaled_quantize")
+        return q, scale
+    s = torch.empty(1, dtype=torch.float32, device=input.device)
+    check(_lib.lib().xllm_mi355_fp8_scaled_quantize(_p(q), _p(x), 0, _p(s), x.numel(), _dt(x), _stream()),
+          "fp8_scaled_quantize")
+    return q, s
+
+
+def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None):
+    """cuda::fp8_scaled_matmul(a, b, a_scale, b_scale, out_dtype, bias?, out?) (fp8_scaled_matmul.cpp:20-47);
+    a [M,K] e4m3fn, b [N,K] e4m3fn (the reference takes the [N,K] weight and forms b.t() itself)."""
+    _need_cuda(a, b, a_scale, b_scale)
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1):
+        raise Mi355Error("fp8_scaled_matmul: a [M,K], b [N,K]")
+    M, K = a.shape
+    N = b.size(0)
+    if a_scale.numel() not in (1, M) or b_scale.numel() not in (1, N):
+        raise Mi355Error("fp8_scaled_matmul: scales must be scalar or per-token / per-channel")
+    out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+    check(_lib.lib().xllm_mi355_fp8_scaled_matmul(_p(a), _p(b), _p(a_scale), a_scale.numel(), _p(b_scale),
+                                                 b_scale.numel(), _p(bias), _p(out), M, N, K, _DT[output_dtype],
+                                                 _stream()), "fp8_scaled_matmul")
+    return out
+
+
+def matmul(a, b, bias=None):
+    """dcu::matmul(a, w, bias) == F::linear (kernels/dcu/matmul.cpp:20-25); a [..., K], w [N, K]."""
+    _need_cuda(a, b)
+    K = a.size(-1)
+    a2 = a.reshape(-1, K)
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    N = b.size(0)
+    out = torch.empty(a2.size(0), N, dtype=a.dtype, device=a.device)
+    check(_lib.lib().xllm_mi355_matmul(_p(a2), _p(b.contiguous()), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
+                                      _stream()), "matmul")
+    return out.view(*a.shape[:-1], N)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+_attn_ws = {}
+
+
+def _attn_workspace(device, nbytes):
+    ws = _attn_ws.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _attn_ws[device] = ws
+    return ws
+
+
+def prefill_attention(q, k, v, cu_seqlens_q, cu_seqlens_k, max_q_len, scale, is_causal=True, window_left=-1, out=None):
+    """prefix_prefill_varlen_fwd argument set (layers/dcu/flash_attention.cpp:45-72, 167-218):
+    q [Tq, nq, d], k/v [Tk, nkv, d] (token-strided views of qkv allowed) -> out [Tq, nq*d]."""
+    _need_cuda(q, k, v, cu_seqlens_q, cu_seqlens_k)
+    Tq, nq, d = q.shape
+    nkv = k.size(1)
+    o = out if out is not None else torch.empty(Tq, nq * d, dtype=q.dtype, device=q.device)
+    check(_lib.lib().xllm_mi355_prefill_attention(
+        _p(q), _p(k), _p(v), _p(o), _p(cu_seqlens_q), _p(cu_seqlens_k), cu_seqlens_q.numel() - 1, nq, nkv, d,
+        q.stride(0), k.stride(0), v.stride(0), max_q_len, scale, int(is_causal), window_left, _dt(q), _stream()),
+        "prefill_attention")
+    return o
+
+
+def paged_attention(q, k_cache, v_cache, cu_seqlens_q, kv_seq_lens, block_table, max_q_len, max_kv_len, scale,
+                    is_causal=False, window_left=-1, out=None):
+    """prefix_decode_varlen_fwd argument set (layers/dcu/flash_attention.cpp:74-94, 220-288):
+    q [Tq, nq, d] packed by cu_seqlens_q (None => one token per sequence); caches [n_blocks, bs, nkv, d]."""
+    _need_cuda(q, k_cache, v_cache, kv_seq_lens, block_table)
+    Tq, nq, d = q.shape
+    n_blocks, bs, nkv, _ = k_cache.shape
+    B = kv_seq_lens.numel()
+    o = out if out is not None else torch.empty(Tq, nq * d, dtype=q.dtype, device=q.device)
+    need = _lib.lib().xllm_mi355_paged_attention_workspace_bytes(B, nq, d, max_q_len, Tq)
+    ws = _attn_workspace(q.device, need)
+    bt = block_table if block_table.is_contiguous() else block_table.contiguous()
+    check(_lib.lib().xllm_mi355_paged_attention(
+        _p(q), _p(k_cache), _p(v_cache), _p(o), _p(cu_seqlens_q), _p(kv_seq_lens), _p(bt), bt.size(1), B, Tq, nq, nkv,
+        d, bs, n_blocks, q.stride(0), max_q_len, max_kv_len, scale, int(is_causal), window_left, _dt(q), _p(ws),
+        ws.numel(), _stream()), "paged_attention")
+    return o
