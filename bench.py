@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--config", default="cfg3", choices=list(CONFIGS))
     p.add_argument("--no-fuse", action="store_true", help="reference op order without the N1 quant fusions")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     return p.parse_args()
 
@@ -205,19 +206,46 @@ def main():
     for _ in range(a.warmup):
         step()
     sync_all()
-    record["on"] = True
+    # decode runs under HIP-graph replay in the reference (runtime/dcu_graph_executor_impl.h): capture one step
+    # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
+    graph = None
+    if not a.no_graph:
+        try:
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap_stream):
+                step()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=cap_stream):
+                    static_out = step()
+            torch.cuda.current_stream().wait_stream(cap_stream)
+            graph = g
+            for _ in range(2):
+                graph.replay()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
+            graph = None
+    run_step = (lambda: graph.replay()) if graph is not None else step
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        run_step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    record["on"] = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
     tok_s = gbatch * a.steps / elapsed
+
+    # roofline leg: per-launch HIP events around the dominant kernel (paged decode attention) on the launch
+    # stream, over eager steps of the same workload (events cannot be read back from inside a replayed graph)
+    record["on"] = True
+    for _ in range(min(a.steps, 3)):
+        step()
+    sync_all()
+    record["on"] = False
 
     attn_ms = sum(e0.elapsed_time(e1) for e0, e1 in attn_events) / max(len(attn_events), 1)
     nq_l = model.layers[0].nq
@@ -246,7 +274,7 @@ def main():
                                    f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
                        "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
-                       "quant_fusion": not a.no_fuse},
+                       "quant_fusion": not a.no_fuse, "hip_graph": graph is not None},
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+split-KV merge)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -88,7 +88,9 @@ def test_rms_norm(dtype, T, H):
     orc.rms_norm(ref, x, w, 1e-6)
     out = torch.empty(T, H, dtype=dtype, device=DEV)
     ops.rms_norm(out, x.to(DEV), w.to(DEV), 1e-6)
-    assert_ulp_close(out, ref, dtype, min_exact=0.98 if dtype != torch.float32 else 0.5)
+    # fp32: the reference's own bar is 1e-5 (dcu/norm_test.cpp:54-65); inv differs by reduction order
+    assert_ulp_close(out, ref, dtype, ulps=1.0 if dtype != torch.float32 else 8.0,
+                     min_exact=0.98 if dtype != torch.float32 else 0.3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -169,8 +171,10 @@ def test_act_and_mul(dtype, mode):
     orc.act_and_mul(ref, x, mode)
     out = torch.empty(T, d, dtype=dtype, device=DEV)
     ops.act_and_mul(out, x.to(DEV), mode)
-    assert_ulp_close(out, ref, dtype, ulps=1.0 if dtype != torch.float32 else 4.0,
-                     min_exact=0.995 if dtype != torch.float32 else 0.5)
+    if dtype == torch.float32:  # device expf/erff/tanhf vs glibc: reference bar 1e-5/1e-6 (dcu/activation_test.cpp:84-85)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+    else:
+        assert_ulp_close(out, ref, dtype, ulps=1.0, min_exact=0.995)
 
 
 def test_fused_qk_norm_rope():
@@ -278,7 +282,7 @@ def test_matmul_16bit(dtype):
     b = torch.randn(N, generator=g).to(dtype)
     ref = orc.matmul(a, w, b)
     out = ops.matmul(a.to(DEV), w.to(DEV), b.to(DEV))
-    assert_ulp_close(out, ref, dtype, ulps=1.0, min_exact=0.95)
+    assert_ulp_close(out, ref, dtype, ulps=2.0, min_exact=0.95)  # MFMA block-sum order vs serial fp32 sum
 
 
 # ------------------------------------------------------------------------------------------- attention
@@ -321,7 +325,7 @@ def test_paged_decode_attention(case, dtype):
     if dtype == torch.bfloat16:
         assert_attn_close(out, ref)
     else:
-        assert_attn_close(out, ref, rel=3e-4)
+        assert_attn_close(out, ref, rel=2e-4)
 
 
 def test_paged_decode_split_kv_and_garbage_tail(monkeypatch):

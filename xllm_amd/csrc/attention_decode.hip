@@ -226,14 +226,18 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
       const float alpha = exp2f(m_run - m_new);
       m_run = m_new;
       float psum = 0.0f;
-      x8 pf;
+      // P is fed to the matrix core as hi + lo 16-bit parts (p = hi + lo to ~2^-17 relative): the PV MFMAs
+      // are idle-cheap in this HBM-bound kernel and the output then matches an fp32-P oracle to rounding.
+      x8 pf, pl;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = exp2f(s[blk][r] - m_new);
           psum += p;
-          pf[blk * 4 + r] = (elem)p;
+          const elem hi = (elem)p;
+          pf[blk * 4 + r] = hi;
+          pl[blk * 4 + r] = (elem)(p - (float)hi);
         }
       l_run = l_run * alpha + psum;
 #pragma unroll
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
         vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
         vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
         acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
+        acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
       }
     }
   }

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
           }
         const bool need_mask = (t0 + kPfTile > kv_len) || (causal && t0 + kPfTile - 1 > wq_lo) ||
                                (window_left >= 0 && t0 < wq_hi - window_left);
-        x8 pf[2];
+        x8 pf[2], pl[2];  // P = hi + lo 16-bit parts (see attention_decode.hip)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int qpos = kvoff + qidx[nb];
@@ -217,7 +217,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
             for (int r = 0; r < 4; ++r) {
               const float p = exp2f(s[nb][blk][r] - m_new);
               psum += p;
-              pf[nb][blk * 4 + r] = (elem)p;
+              const elem hi = (elem)p;
+              pf[nb][blk * 4 + r] = hi;
+              pl[nb][blk * 4 + r] = (elem)(p - (float)hi);
             }
           l_run[nb] = l_run[nb] * alpha + psum;
 #pragma unroll
@@ -232,7 +234,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
           vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
           vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) acc_o[nb][db] = TR::mfma(vt, pf[nb], acc_o[nb][db]);
+          for (int nb = 0; nb < 2; ++nb) {
+            acc_o[nb][db] = TR::mfma(vt, pf[nb], acc_o[nb][db]);
+            acc_o[nb][db] = TR::mfma(vt, pl[nb], acc_o[nb][db]);
+          }
         }
       }
       if (more) write_lds(cur ^ 1, tile + 1);
