@@ -210,7 +210,8 @@ def test_scaled_quantize_bit_exact(dtype, M, K):
     assert torch.equal(q.cpu(), q_ref) and torch.equal(s.cpu(), s_ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 512, 3584), (7, 130, 256), (129, 257, 1024), (256, 4608, 3584), (16, 3584, 18944)])
+@pytest.mark.parametrize("M,N,K", [(256, 512, 3584), (7, 130, 256), (129, 257, 1024), (256, 4608, 3584), (16, 3584, 18944),
+                                   (640, 384, 1024), (1030, 130, 512), (300, 3584, 3584)])
 def test_scaled_matmul_int32_exact_and_epilogue(M, N, K):
     g = torch.Generator().manual_seed(M * N)
     a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8)
@@ -231,6 +232,22 @@ def test_scaled_matmul_int32_exact_and_epilogue(M, N, K):
     # split-K path (workspace registered by ops): same bits as the single-pass epilogue
     out2 = ops.scaled_matmul(a.to(DEV), w.to(DEV), a_s.to(DEV), w_s.to(DEV), torch.bfloat16, bias.to(DEV))
     assert torch.equal(out2, out)
+
+
+def test_splitk_workspace_invariant_across_shapes():
+    """split-K paths (prefill-sized and decode-sized) share one workspace that must be all-zero between calls"""
+    g = torch.Generator().manual_seed(4)
+    shapes = [(640, 384, 1024), (256, 3584, 3584), (16, 512, 18944), (1030, 130, 512), (256, 4608, 3584)]
+    for rep in range(2):
+        for M, N, K in shapes:
+            a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+            w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+            a_s, w_s = torch.rand(M, generator=g).to(DEV), torch.rand(N, generator=g).to(DEV)
+            acc = torch.empty(M, N, dtype=torch.int32, device=DEV)
+            ref = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, acc_out=acc)  # single pass, no split-K
+            out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16)               # planner may split K
+            assert torch.equal(out, ref), (rep, M, N, K)
+            assert torch.equal(acc, (a.double() @ w.double().T).to(torch.int32))
 
 
 def test_w8a8_dynamic_linear_vs_dequantised_matmul():

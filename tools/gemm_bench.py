@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""micro-benchmark of the W8A8 / bf16 GEMM entry points on the decode and prefill shapes of Qwen2-7B.
+Rotates over several weight copies so every launch streams its weights from HBM (not L2 / Infinity Cache)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xllm_amd import ops  # noqa: E402
+
+dev = "cuda"
+shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
+Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
+kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355"))
+for M in Ms:
+    for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
+        copies = max(2, min(8, int(600e6 // (N * K)) + 1))
+        if kind == "int8":
+            ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(copies)]
+            a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+            a_s = torch.rand(M, device=dev)
+            w_s = torch.rand(N, device=dev)
+            fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)
+            bytes_ = N * K + M * K + M * N * 2
+        else:
+            ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(copies)]
+            a = torch.randn(M, K, device=dev).bfloat16()
+            fn = lambda i: ops.matmul(a, ws[i % copies])
+            bytes_ = (N * K + M * K + M * N) * 2
+        for i in range(3):
+            fn(i)
+        n = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        print(f"[gemm {kind}] {tag:40s} M={M:5d} {name:8s} N={N:6d} K={K:6d}  {us:8.1f} us  {bytes_ / us / 1e3:7.1f} GB/s  "
+              f"{2 * M * N * K / us / 1e6:7.1f} TOP/s")
+        del ws

@@ -16,6 +16,10 @@
 // same XCD (same L2) back to back: W is fetched from HBM once.
 // int8 only: optional split-K with exact int32 atomics into a workspace + a tiny dequant epilogue kernel
 // (integer adds commute, so the result stays bit-exact and deterministic).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace xm {
@@ -230,15 +234,304 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
     }
 }
 
-// dequant epilogue after int8 split-K: reads the int32 sums, applies scales + bias
-__global__ __launch_bounds__(256) void i8_splitk_epilogue_kernel(const int32_t* __restrict__ acc, int64_t M, int64_t N,
-                                                                 GemmEpi epi) {
+// ------------------------------------------------------------------------------------------------
+// "skinny" kernel for decode-shaped GEMMs (M <= 256 rows per m-tile): the weight matrix is streamed from
+// HBM exactly once while the small activation matrix is re-read from L2 by every workgroup.
+//   * block tile 256 rows x (NT*32) columns, NT = 1..3 chosen on the host so that the grid is ONE wave of
+//     workgroups (<= 256 CUs, no tail round); 4 waves (one per SIMD, up to 512 VGPRs each), each wave
+//     64 rows x all NT column tiles.
+//   * the dependency chain per workgroup is what bounds a weight-streaming GEMM (one HBM round trip per
+//     K step), so operands are prefetched DEPTH=3 K-steps ahead in registers (issue order == stage order,
+//     so hipcc's counted s_waitcnt vmcnt(N) keeps 2 stages in flight across the LDS write + barrier):
+//     3 x (32 KiB of A + NT*4 KiB of W) outstanding per CU.
+//   * int8: optional split-K (grid.z) with exact int32 atomics when the N tiles alone cannot fill the chip.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_BM = 256;
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int KIND, int NT, bool SPLITK, int WAVES, int DEPTH>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(const uint8_t* __restrict__ A,
+                                                                   const uint8_t* __restrict__ W, int M, int N,
+                                                                   int64_t Kb, int ksteps_per_split, GemmEpi epi) {
+  using MT = MmaTraits<KIND>;
+  using acc_t = typename MT::acc_t;
+  constexpr int BNW = NT * 32;                            // columns per workgroup
+  constexpr int A_BYTES = SK_BM * BKB, W_BYTES = BNW * BKB;
+  constexpr int SK_THREADS = WAVES * 64, MT_PER_WAVE = 8 / WAVES;  // m-tiles (32 rows) per wave
+  constexpr int NLA = A_BYTES / 16 / SK_THREADS;
+  constexpr int NLW = (W_BYTES / 16 + SK_THREADS - 1) / SK_THREADS;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][A_BYTES + W_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * SK_BM;
+  const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
+  const int ks_begin = blockIdx.z * ksteps_per_split;
+  int ks_end = ks_begin + ksteps_per_split;
+  ks_end = ks_end > total_ksteps ? total_ksteps : ks_end;
+  const int nsteps = ks_end - ks_begin;
+  // K-phase stagger: workgroup b walks its K steps starting at a different offset (wrapping around). All
+  // workgroups read the SAME activation slab per K step; with a row stride of K bytes (3584 = 28 lines,
+  // 18944 = 148 lines) the 256 rows of one slab fall on only 4 of the 16 L2 channels, so lock-step readers
+  // serialise on them. Staggering spreads concurrent readers over all slabs (= all channels). Integer
+  // accumulation is order independent; for floating kinds the order is still a fixed function of blockIdx.
+  const int phase = nsteps > 0 ? (int)((blockIdx.x * 5u + blockIdx.z * 3u) % (unsigned)nsteps) : 0;
+
+  // three register stages with compile-time names (never runtime-indexed, never address-taken: they must
+  // stay in VGPRs). NOTE: every load is unconditional (clamped addresses; Kb % BKB == 0 is checked on the
+  // host; tail stages re-load the last K step) -- a branch around a global load makes hipcc fall back to
+  // s_waitcnt vmcnt(0), which collapses the 3-stage pipeline to depth 1.
+  static_assert(DEPTH == 2 || DEPTH == 3, "the main loop is hand-unrolled for 2 or 3 register stages");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // native vector: plain 16-B load/store, no memcpy
+  u32x4 a0[NLA], a1[NLA], a2[NLA], w0[NLW], w1[NLW], w2[NLW];
+  // buffer (SRSRC) addressing: one 32-bit per-lane offset per load, the K offset rides in the scalar soffset
+  // operand -> no 64-bit address arithmetic in VGPRs (the operands are < 4 GiB each, checked on the host)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
+  int a_off[NLA], w_off[NLW];
+  int lds_off_a[NLA], lds_off_w[NLW];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int c = tid + i * SK_THREADS, row = c >> 3, col = c & 7;
+    int ar = m0 + row; ar = ar < M ? ar : M - 1;
+    a_off[i] = (int)((int64_t)ar * Kb + col * 16);
+    lds_off_a[i] = row * BKB + ((col ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NLW; ++i) {
+    int c = tid + i * SK_THREADS;
+    const bool live = c < W_BYTES / 16;  // NT*256 chunks over SK_THREADS threads may not divide evenly
+    c = live ? c : W_BYTES / 16 - 1;
+    const int row = c >> 3, col = c & 7;
+    int wr = n0 + row; wr = wr < N ? wr : N - 1;
+    w_off[i] = (int)((int64_t)wr * Kb + col * 16);
+    lds_off_w[i] = live ? A_BYTES + row * BKB + ((col ^ ((row >> 1) & 7)) << 4) : -1;
+  }
+#define XM_SK_LOAD(KS, AR, WR)                                                                     \
+  {                                                                                                \
+    int ks_ = (KS) + phase;                                                                        \
+    ks_ = ks_begin + (ks_ % nsteps);                                                               \
+    const int kb0_ = ks_ * BKB;                                                                    \
+    static_for<NLA>([&](auto I_) { AR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off[I_], kb0_, 0); }); \
+    static_for<NLW>([&](auto I_) { WR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[I_], kb0_, 0); }); \
+  }
+#define XM_SK_WRITE(BUF, AR, WR)                                                                   \
+  {                                                                                                \
+    static_for<NLA>([&](auto I_) { *reinterpret_cast<u32x4*>(&lds[BUF][lds_off_a[I_]]) = AR[I_]; });               \
+    static_for<NLW>([&](auto I_) { if (lds_off_w[I_] >= 0) *reinterpret_cast<u32x4*>(&lds[BUF][lds_off_w[I_]]) = WR[I_]; }); \
+  }
+
+  acc_t acc[MT_PER_WAVE][NT];
+#pragma unroll
+  for (int t = 0; t < MT_PER_WAVE; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[t][j] = MT::zero();
+
+  auto compute = [&](int buf) {
+    const uint8_t* la = lds[buf];
+    const uint8_t* lw = lds[buf] + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BKB / 32; ++kk) {
+      const int chunk = kk * 2 + (lane >> 5);
+      uint4 fa[MT_PER_WAVE];
+#pragma unroll
+      for (int t = 0; t < MT_PER_WAVE; ++t) {
+        const int rowa = wave * (32 * MT_PER_WAVE) + t * 32 + (lane & 31);
+        fa[t] = *reinterpret_cast<const uint4*>(la + rowa * BKB + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int roww = j * 32 + (lane & 31);
+        const uint4 fw = *reinterpret_cast<const uint4*>(lw + roww * BKB + ((chunk ^ ((roww >> 1) & 7)) << 4));
+#pragma unroll
+        for (int t = 0; t < MT_PER_WAVE; ++t) acc[t][j] = MT::mma(fa[t], fw, acc[t][j]);
+      }
+    }
+  };
+
+  if (nsteps > 0) {
+    // prologue: DEPTH stages in flight; stage 0 -> LDS
+    XM_SK_LOAD(0, a0, w0)
+    XM_SK_LOAD(1, a1, w1)
+    if constexpr (DEPTH == 3) XM_SK_LOAD(2, a2, w2)
+    XM_SK_WRITE(0, a0, w0)
+    __syncthreads();
+    // one K step: refill the register stage that was consumed (stage i+DEPTH), compute stage i from LDS, then
+    // publish stage i+1. Loads are issued in stage order, so waiting for stage i+1 leaves the later ones in flight.
+#define XM_SK_STEP(RA, RW, NA, NW)                          \
+    XM_SK_LOAD(i + DEPTH, RA, RW)                           \
+    compute(i & 1);                                         \
+    if (i + 1 < nsteps) XM_SK_WRITE((i + 1) & 1, NA, NW)    \
+    __syncthreads();                                        \
+    if (++i >= nsteps) break;
+    int i = 0;
+    if constexpr (DEPTH == 3) {
+      while (true) {
+        XM_SK_STEP(a0, w0, a1, w1)
+        XM_SK_STEP(a1, w1, a2, w2)
+        XM_SK_STEP(a2, w2, a0, w0)
+      }
+    } else {
+      while (true) {
+        XM_SK_STEP(a0, w0, a1, w1)
+        XM_SK_STEP(a1, w1, a0, w0)
+      }
+    }
+#undef XM_SK_STEP
+  }
+#undef XM_SK_LOAD
+#undef XM_SK_WRITE
+
+  // epilogue: C tile layout col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    float ws = 1.0f, bs = 0.0f;
+    if constexpr (!SPLITK) {
+      if constexpr (KIND == kI8) ws = epi.w_scale[n];
+      if constexpr (KIND == kFP8) ws = epi.w_scale[epi.w_scale_n > 1 ? n : 0];
+      if (epi.bias) bs = load16(epi.bias, n, epi.out_bf16);
+    }
+#pragma unroll
+    for (int t = 0; t < MT_PER_WAVE; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * (32 * MT_PER_WAVE) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        const int64_t idx = (int64_t)m * N + n;
+        if constexpr (KIND == kI8) {
+          const int a = acc[t][j][r];
+          if constexpr (SPLITK) {
+            atomicAdd(epi.acc_out + idx, a);
+          } else {
+            if (epi.acc_out) epi.acc_out[idx] = a;
+            if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
+          }
+        } else if constexpr (KIND == kFP8) {
+          const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
+          store16(epi.out, idx, as * (ws * acc[t][j][r]) + bs, epi.out_bf16);
+        } else {
+          store16(epi.out, idx, acc[t][j][r] + bs, epi.out_bf16);
+        }
+      }
+  }
+}
+
+// dequant epilogue after int8 split-K: reads the int32 sums, applies scales + bias, and re-zeroes the
+// workspace for the next call (the workspace is zero-filled once when it is registered)
+__global__ __launch_bounds__(256) void i8_splitk_epilogue_zero_kernel(int32_t* __restrict__ acc, int64_t M, int64_t N,
+                                                                      GemmEpi epi) {
   const int64_t total = M * N;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = idx / N, n = idx - m * N;
     float bs = epi.bias ? load16(epi.bias, n, epi.out_bf16) : 0.0f;
-    store16(epi.out, idx, (float)acc[idx] * epi.a_scale[m] * epi.w_scale[n] + bs, epi.out_bf16);
+    const int32_t a = acc[idx];
+    acc[idx] = 0;
+    store16(epi.out, idx, (float)a * epi.a_scale[m] * epi.w_scale[n] + bs, epi.out_bf16);
+  }
+}
+
+struct SkinnyPlan { int nt; int splits; };
+static int g_sk_nt = -2, g_sk_splits = -2, g_sk_disable = -2;
+
+inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) {
+  if (g_sk_nt == -2) {
+    const char* e = getenv("XLLM_MI355_SKINNY_NT");
+    g_sk_nt = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_SKINNY_SPLITS");
+    g_sk_splits = e ? atoi(e) : -1;
+  }
+  const int64_t m_tiles = (M + SK_BM - 1) / SK_BM;
+  const int64_t nt32 = (N + 31) / 32;
+  int nt = (int)((nt32 * m_tiles + 255) / 256);  // smallest NT whose grid fits one round of 256 CUs
+  if (nt == 1 && ksteps >= 64 && can_split) nt = 2;  // long K, few columns: wider tiles + more K slices
+  nt = nt < 1 ? 1 : (nt > 5 ? 5 : nt);
+  if (g_sk_nt > 0) nt = g_sk_nt > 5 ? 5 : g_sk_nt;
+  const int64_t wgs = ((nt32 + nt - 1) / nt) * m_tiles;
+  int splits = 1;
+  if (can_split) {
+    splits = (int)(256 / wgs);
+    const int by_k = ksteps / 6 > 0 ? ksteps / 6 : 1;
+    splits = splits > by_k ? by_k : splits;
+    splits = splits < 1 ? 1 : (splits > 32 ? 32 : splits);
+    if (g_sk_splits > 0) splits = g_sk_splits;
+  }
+  return SkinnyPlan{nt, splits};
+}
+
+static int g_sk_waves = -2, g_sk_depth = -2;
+
+template <int KIND, int NT, int WV, int DP>
+int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int splits,
+                      void* workspace, hipStream_t s) {
+  const int ksteps = (int)((Kb + BKB - 1) / BKB);
+  int per = (ksteps + splits - 1) / splits;
+  splits = (ksteps + per - 1) / per;
+  const dim3 grid((unsigned)((N + NT * 32 - 1) / (NT * 32)), (unsigned)((M + SK_BM - 1) / SK_BM), (unsigned)splits);
+  if (splits > 1) {
+    if constexpr (KIND == kI8) {
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
+      int64_t blocks = (M * N + 255) / 256;
+      blocks = blocks > 1024 ? 1024 : blocks;
+      hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         reinterpret_cast<int32_t*>(workspace), M, N, epi);
+    }
+  } else {
+    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)W, (int)M, (int)N, Kb, per, epi);
+  }
+  return hip_check_launch();
+}
+
+template <int KIND, int NT>
+int launch_skinny_nt(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int splits,
+                     void* workspace, hipStream_t s) {
+  if (g_sk_waves == -2) {
+    const char* e = getenv("XLLM_MI355_SKINNY_WAVES");
+    g_sk_waves = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_SKINNY_DEPTH");
+    g_sk_depth = e ? atoi(e) : -1;
+  }
+  // defaults from the round-1 sweep (tools/gemm_sweep.sh, profiles/r01_gemm_sweep.txt): 8 waves x 32 rows with
+  // 2 register stages wins on every decode shape (two waves per SIMD overlap one wave's MFMAs with the other's
+  // LDS traffic; a third register stage only costs occupancy)
+  int wv = 8, dp = 2;
+  if constexpr (KIND == kI8) {  // tuning overrides are only compiled for the int8 kernels
+    if (g_sk_waves == 4 || g_sk_waves == 8) wv = g_sk_waves;
+    if (g_sk_depth == 2 || g_sk_depth == 3) dp = g_sk_depth;
+    if (NT > 3 && wv == 4) dp = 2;
+    if (wv == 8 && dp == 3) return launch_skinny_cfg<KIND, NT, 8, 3>(A, W, M, N, Kb, epi, splits, workspace, s);
+    if (wv == 8) return launch_skinny_cfg<KIND, NT, 8, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
+    if (dp == 2) return launch_skinny_cfg<KIND, NT, 4, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
+    return launch_skinny_cfg<KIND, NT, 4, 3>(A, W, M, N, Kb, epi, splits, workspace, s);
+  } else {
+    return launch_skinny_cfg<KIND, NT, 8, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
+  }
+}
+
+template <int KIND>
+int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                  size_t ws_bytes, hipStream_t s) {
+  const int ksteps = (int)((Kb + BKB - 1) / BKB);
+  const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
+  const SkinnyPlan p = plan_skinny(M, N, ksteps, can_split);
+  switch (p.nt) {
+    case 1: return launch_skinny_nt<KIND, 1>(A, W, M, N, Kb, epi, p.splits, workspace, s);
+    case 2: return launch_skinny_nt<KIND, 2>(A, W, M, N, Kb, epi, p.splits, workspace, s);
+    case 3: return launch_skinny_nt<KIND, 3>(A, W, M, N, Kb, epi, p.splits, workspace, s);
+    case 4: return launch_skinny_nt<KIND, 4>(A, W, M, N, Kb, epi, p.splits, workspace, s);
+    default: return launch_skinny_nt<KIND, 5>(A, W, M, N, Kb, epi, p.splits, workspace, s);
   }
 }
 
@@ -246,6 +539,12 @@ template <int KIND>
 int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                 size_t ws_bytes, hipStream_t s) {
   if (M == 0 || N == 0) return XM_OK;
+  if (g_sk_disable == -2) {
+    const char* e = getenv("XLLM_MI355_SKINNY_DISABLE");
+    g_sk_disable = e ? atoi(e) : 0;
+  }
+  if (M <= 512 && Kb % BKB == 0 && !g_sk_disable)
+    return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
   const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (int)((N + BN - 1) / BN);
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
   int splits = 1;
@@ -264,15 +563,16 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   const dim3 grid((unsigned)(m_tiles * n_tiles), 1, (unsigned)splits);
   if (splits > 1) {
     if constexpr (KIND == kI8) {
-      if (hipMemsetAsync(workspace, 0, (size_t)M * N * 4, s) != hipSuccess) return XM_ERR_HIP;
+      // invariant: the registered workspace is all-zero between calls (zero-filled at registration, re-zeroed
+      // by the dequant epilogue below), so no memset launch is needed here
       GemmEpi e2 = epi;
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);
       hipLaunchKernelGGL((gemm_kernel<KIND, true>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
                          (int)M, (int)N, Kb, m_tiles, n_tiles, per, e2);
       int64_t blocks = (M * N + 255) / 256;
       blocks = blocks > 2048 ? 2048 : blocks;
-      hipLaunchKernelGGL(i8_splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                         (const int32_t*)workspace, M, N, epi);
+      hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         reinterpret_cast<int32_t*>(workspace), M, N, epi);
     }
   } else {
     hipLaunchKernelGGL((gemm_kernel<KIND, false>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
@@ -294,6 +594,7 @@ static size_t g_gemm_ws_bytes = 0;
 XM_API int xllm_mi355_set_gemm_workspace(void* ws, size_t bytes) {
   g_gemm_ws = ws;
   g_gemm_ws_bytes = bytes;
+  if (ws && bytes && hipMemset(ws, 0, bytes) != hipSuccess) return XM_ERR_HIP;
   return XM_OK;
 }
 
