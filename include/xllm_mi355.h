@@ -194,6 +194,8 @@ XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,
  * kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (kernels/cuda/moe/moe_compute_index.cu:111-160)
  * expert_id [T,topk] int32 -> src_dst[T*topk], dst_src[T*topk], expert_sizes[E]; DETERMINISTIC
  * (stable by expanded row index) unlike the reference's atomics order. workspace >= 4*(E+1)*... see .hip */
+/* scratch for moe_compute_index: >= 4 * ceil(T*topk/1024) * n_experts bytes, registered once */
+XM_API int xllm_mi355_set_moe_workspace(void* workspace, size_t bytes);
 XM_API int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int64_t topk,
                                         int64_t n_experts, int32_t* src_dst, int32_t* dst_src,
                                         int32_t* expert_sizes, void* stream);

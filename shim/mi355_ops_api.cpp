@@ -1,0 +1,282 @@
+// mi355_ops_api.cpp -- see mi355_ops_api.h. Host C++ only: tensor checks, output allocation, stream lookup, and
+// one C-ABI call per operator. No kernels here.
+#include "mi355_ops_api.h"
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include "../include/xllm_mi355.h"
+
+namespace xllm::kernel::mi355 {
+namespace {
+
+void* cur_stream() { return static_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+
+int dt(const torch::Tensor& t) {
+  switch (t.scalar_type()) {
+    case torch::kFloat32: return XM_F32;
+    case torch::kBFloat16: return XM_BF16;
+    case torch::kFloat16: return XM_F16;
+    default: TORCH_CHECK(false, "xllm_mi355: unsupported dtype ", t.scalar_type());
+  }
+}
+int dt(torch::ScalarType s) {
+  TORCH_CHECK(s == torch::kBFloat16 || s == torch::kFloat16, "output dtype must be half or bfloat16");
+  return s == torch::kBFloat16 ? XM_BF16 : XM_F16;
+}
+void check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", xllm_mi355_strerror(rc)); }
+void* p(const torch::Tensor& t) { return t.data_ptr(); }
+void* p(const std::optional<torch::Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
+int act_code(const std::string& m) {
+  if (m == "silu") return XM_ACT_SILU;
+  if (m == "gelu") return XM_ACT_GELU;
+  if (m == "gelu_tanh") return XM_ACT_GELU_TANH;
+  TORCH_CHECK(false, "Unsupported act mode: ", m, ", only support silu, gelu, gelu_tanh");
+}
+
+}  // namespace
+
+void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, std::optional<torch::Tensor> key,
+                      torch::Tensor& cos_sin_cache, bool is_neox) {
+  c10::hip::OptionalHIPGuard guard(query.device());
+  TORCH_CHECK(positions.scalar_type() == torch::kInt64, "positions must be int64");
+  const int64_t T = positions.numel();
+  const int64_t rot = cos_sin_cache.size(-1);
+  // head_size: the reference derives it from the tensor shape (rope.cu:176-200); q is [T, nq*hs] or [T,nq,hs]
+  const int64_t hs = query.dim() == 3 ? query.size(-1) : rot;
+  const int64_t nq = query.numel() / T / hs;
+  const int64_t nk = key.has_value() ? key->numel() / T / hs : 0;
+  check(xllm_mi355_rotary_embedding(positions.data_ptr<int64_t>(), p(query), p(key), p(cos_sin_cache), T, nq, nk, hs,
+                                    rot, query.stride(0), key.has_value() ? key->stride(0) : 0, hs, is_neox ? 1 : 0,
+                                    dt(query), cur_stream()),
+        "rotary_embedding");
+}
+
+void act_and_mul(torch::Tensor out, torch::Tensor input, const std::string& act_mode) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t d = input.size(-1) / 2;
+  check(xllm_mi355_act_and_mul(p(out), p(input), input.numel() / (2 * d), d, act_code(act_mode), dt(input),
+                               cur_stream()),
+        "act_and_mul");
+}
+
+void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tensor values, torch::Tensor key_cache,
+                         torch::Tensor value_cache) {
+  c10::hip::OptionalHIPGuard guard(keys.device());
+  TORCH_CHECK(keys.stride(-1) == 1 && keys.stride(-2) == keys.size(-1));      // reshape_paged_cache.cu:73
+  TORCH_CHECK(values.stride(-1) == 1 && values.stride(-2) == values.size(-1));  // :74
+  check(xllm_mi355_reshape_paged_cache(slot_ids.data_ptr<int32_t>(), p(keys), p(values), p(key_cache), p(value_cache),
+                                       keys.size(-3), keys.size(-2), keys.size(-1), key_cache.size(-3),
+                                       key_cache.size(0), keys.stride(-3), values.stride(-3),
+                                       (int)keys.element_size(), cur_stream()),
+        "reshape_paged_cache");
+}
+
+void rms_norm(torch::Tensor output, torch::Tensor input, torch::Tensor weight, double eps) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t H = input.size(-1);
+  auto x = input.view({-1, H});
+  check(xllm_mi355_rms_norm(p(output), p(x), p(weight), (float)eps, x.size(0), H, x.stride(0), dt(input), cur_stream()),
+        "rms_norm");
+}
+
+void fused_add_rms_norm(torch::Tensor& input, torch::Tensor& residual, torch::Tensor& weight, double epsilon) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t H = input.size(-1);
+  check(xllm_mi355_fused_add_rms_norm(p(input), p(residual), p(weight), (float)epsilon, input.numel() / H, H, H,
+                                      dt(input), cur_stream()),
+        "fused_add_rms_norm");
+}
+
+torch::Tensor matmul(torch::Tensor a, torch::Tensor b, std::optional<torch::Tensor> bias) {
+  c10::hip::OptionalHIPGuard guard(a.device());
+  const int64_t K = a.size(-1), N = b.size(0);
+  auto a2 = a.reshape({-1, K}).contiguous();
+  auto out = torch::empty({a2.size(0), N}, a.options());
+  check(xllm_mi355_matmul(p(a2), p(b.contiguous()), p(bias), p(out), a2.size(0), N, K, dt(a), cur_stream()), "matmul");
+  auto shape = a.sizes().vec();
+  shape.back() = N;
+  return out.view(shape);
+}
+
+void static_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor const& scale) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  check(xllm_mi355_static_scaled_fp8_quant(static_cast<uint8_t*>(p(out)), p(input.contiguous()),
+                                           scale.data_ptr<float>(), input.numel(), dt(input), cur_stream()),
+        "static_scaled_fp8_quant");
+}
+
+std::tuple<torch::Tensor, torch::Tensor> fp8_scaled_quantize(const torch::Tensor& input,
+                                                             const std::optional<torch::Tensor>& output,
+                                                             const std::optional<torch::Tensor>& scale) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  torch::Tensor q = (output.has_value() && output->defined())
+                        ? *output
+                        : torch::empty_like(input, input.options().dtype(torch::kFloat8_e4m3fn));
+  const bool is_static = scale.has_value() && scale->defined();
+  torch::Tensor s = is_static ? *scale : torch::empty({1}, input.options().dtype(torch::kFloat32));
+  auto x = input.contiguous();
+  check(xllm_mi355_fp8_scaled_quantize(static_cast<uint8_t*>(p(q)), p(x), is_static ? s.data_ptr<float>() : nullptr,
+                                       is_static ? nullptr : s.data_ptr<float>(), x.numel(), dt(x), cur_stream()),
+        "fp8_scaled_quantize");
+  return {q, s};
+}
+
+void rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, torch::Tensor& scale,
+                               double epsilon) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t H = input.size(-1);
+  auto x = input.view({-1, H});
+  check(xllm_mi355_rms_norm_static_fp8_quant(static_cast<uint8_t*>(p(out)), p(x), nullptr, p(weight),
+                                             scale.data_ptr<float>(), (float)epsilon, x.size(0), H, x.stride(0),
+                                             dt(input), cur_stream()),
+        "rms_norm_static_fp8_quant");
+}
+
+void fused_add_rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& residual,
+                                         torch::Tensor& weight, torch::Tensor& scale, double epsilon) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t H = input.size(-1);
+  auto x = input.view({-1, H});
+  check(xllm_mi355_rms_norm_static_fp8_quant(static_cast<uint8_t*>(p(out)), p(x), p(residual), p(weight),
+                                             scale.data_ptr<float>(), (float)epsilon, x.size(0), H, x.stride(0),
+                                             dt(input), cur_stream()),
+        "fused_add_rms_norm_static_fp8_quant");
+}
+
+torch::Tensor fp8_scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& a_scale,
+                                const torch::Tensor& b_scale, torch::ScalarType output_dtype,
+                                const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& output) {
+  c10::hip::OptionalHIPGuard guard(a.device());
+  TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "a [M,K], b [N,K]");
+  const int64_t M = a.size(0), K = a.size(1), N = b.size(0);
+  torch::Tensor out = output.has_value() ? *output : torch::empty({M, N}, a.options().dtype(output_dtype));
+  check(xllm_mi355_fp8_scaled_matmul(static_cast<const uint8_t*>(p(a)), static_cast<const uint8_t*>(p(b)),
+                                     a_scale.data_ptr<float>(), a_scale.numel(), b_scale.data_ptr<float>(),
+                                     b_scale.numel(), p(bias), p(out), M, N, K, dt(output_dtype), cur_stream()),
+        "fp8_scaled_matmul");
+  return out;
+}
+
+void fused_qk_norm_rope(torch::Tensor& qkv, int64_t num_heads_q, int64_t num_heads_k, int64_t num_heads_v,
+                        int64_t head_dim, double eps, const torch::Tensor& q_weight, const torch::Tensor& k_weight,
+                        const torch::Tensor& cos_sin_cache, bool interleaved, const torch::Tensor& position_ids) {
+  c10::hip::OptionalHIPGuard guard(qkv.device());
+  check(xllm_mi355_fused_qk_norm_rope(p(qkv), qkv.size(0), num_heads_q, num_heads_k, num_heads_v, head_dim, (float)eps,
+                                      p(q_weight), p(k_weight), p(cos_sin_cache), dt(cos_sin_cache),
+                                      interleaved ? 1 : 0, position_ids.data_ptr<int64_t>(), dt(qkv), cur_stream()),
+        "fused_qk_norm_rope");
+}
+
+std::tuple<torch::Tensor, torch::Tensor> scaled_quantize(
+    const torch::Tensor& x, const torch::Tensor& smooth, const std::optional<torch::Tensor>& zero,
+    const std::optional<torch::Tensor>& token_count, const std::optional<torch::Tensor>& gather_index,
+    const std::optional<torch::Tensor>& gather_index_start_position, const std::optional<torch::Tensor>& output,
+    const std::optional<torch::Tensor>& output_scale, const std::string& act_mode, double /*active_coef*/,
+    bool is_gated, torch::ScalarType quant_type) {
+  c10::hip::OptionalHIPGuard guard(x.device());
+  // same restrictions as the DCU implementation (kernels/dcu/scaled_quantize.hip:411-447)
+  TORCH_CHECK(!smooth.defined() || smooth.numel() == 0, "mi355 scaled_quantize: smooth factor not supported");
+  TORCH_CHECK(!zero.has_value() && !token_count.has_value() && !gather_index.has_value() &&
+                  !gather_index_start_position.has_value(),
+              "mi355 scaled_quantize: only plain per-token int8 quantization is supported");
+  TORCH_CHECK(quant_type == torch::kInt8 || quant_type == torch::kChar, "quant_type must be int8");
+  TORCH_CHECK(x.dim() == 2 && x.is_contiguous(), "x must be a contiguous [M,K] tensor");
+  const int64_t M = x.size(0), K = x.size(1);
+  if (is_gated) {  // N1 fusion: act(gate)*up then quantize (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815)
+    const int64_t d = K / 2;
+    torch::Tensor q = output.has_value() ? *output : torch::empty({M, d}, x.options().dtype(torch::kInt8));
+    torch::Tensor s = output_scale.has_value() ? *output_scale : torch::empty({M}, x.options().dtype(torch::kFloat32));
+    check(xllm_mi355_act_and_mul_dynamic_int8_quant(q.data_ptr<int8_t>(), s.data_ptr<float>(), p(x), M, d,
+                                                    act_code(act_mode), dt(x), cur_stream()),
+          "scaled_quantize(is_gated)");
+    return {q, s};
+  }
+  torch::Tensor q = output.has_value() ? *output : torch::empty({M, K}, x.options().dtype(torch::kInt8));
+  torch::Tensor s = output_scale.has_value() ? *output_scale : torch::empty({M}, x.options().dtype(torch::kFloat32));
+  check(xllm_mi355_scaled_quantize(p(x), q.data_ptr<int8_t>(), s.data_ptr<float>(), M, K, dt(x), cur_stream()),
+        "scaled_quantize");
+  return {q, s};
+}
+
+torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const std::optional<torch::Tensor>& a_scale,
+                            const torch::Tensor& b_scale, torch::ScalarType output_dtype,
+                            const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& /*c*/,
+                            const std::string& /*act_mode*/, int64_t quant_bit_size, double /*alpha*/, double /*beta*/,
+                            bool /*use_hp_active*/, int64_t a_quant_bit_size,
+                            const std::optional<torch::Tensor>& /*a_calib*/,
+                            const std::optional<torch::Tensor>& /*b_calib*/,
+                            const std::optional<torch::Tensor>& output) {
+  c10::hip::OptionalHIPGuard guard(a.device());
+  TORCH_CHECK(quant_bit_size == 8 && a_quant_bit_size == 8, "scaled_matmul only supports w8a8 quantization");
+  TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.scalar_type() == torch::kInt8 && b.scalar_type() == torch::kInt8 &&
+                  a.size(1) == b.size(1) && a.is_contiguous() && b.is_contiguous(),
+              "scaled_matmul: a [M,K] int8, b [N,K] int8, contiguous");
+  TORCH_CHECK(a_scale.has_value() && a_scale->defined(), "a_scale is required for scaled_matmul");
+  const int64_t M = a.size(0), K = a.size(1), N = b.size(0);
+  torch::Tensor out = output.has_value() ? *output : torch::empty({M, N}, a.options().dtype(output_dtype));
+  auto as = a_scale->reshape({-1}).contiguous();
+  auto bs = b_scale.reshape({-1}).contiguous();
+  check(xllm_mi355_scaled_matmul(a.data_ptr<int8_t>(), b.data_ptr<int8_t>(), as.data_ptr<float>(),
+                                 bs.data_ptr<float>(), p(bias), p(out), nullptr, M, N, K, dt(output_dtype),
+                                 cur_stream()),
+        "scaled_matmul");
+  return out;
+}
+
+torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
+                         std::optional<torch::Tensor> output) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  TORCH_CHECK(input.dim() == 2 && weight.dim() == 3 && input.size(1) == weight.size(2), "group_gemm shapes");
+  const int64_t E = weight.size(0), N = weight.size(1), K = weight.size(2);
+  torch::Tensor out = output.has_value() ? *output : torch::empty({input.size(0), N}, input.options());
+  check(xllm_mi355_group_gemm(p(input), p(weight), token_count.data_ptr<int32_t>(), p(out), input.size(0), E, N, K,
+                              dt(input), cur_stream()),
+        "group_gemm");
+  return out;
+}
+
+torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const torch::Tensor& indices) {
+  c10::hip::OptionalHIPGuard guard(indptr.device());
+  const int64_t B = indptr.size(0) - 1, total = indices.size(0);
+  auto table = torch::empty({B, total}, indptr.options().dtype(torch::kInt32));
+  check(xllm_mi355_build_block_table_from_paged_kv(indptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (int32_t)B,
+                                                   (int32_t)total, table.data_ptr<int32_t>(), cur_stream()),
+        "build_block_table_from_paged_kv");
+  return table;
+}
+
+torch::Tensor prefill_attention(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v,
+                                const torch::Tensor& cu_q, const torch::Tensor& cu_k, int64_t max_q_len, double scale,
+                                bool is_causal, int64_t window_left, std::optional<torch::Tensor> out) {
+  c10::hip::OptionalHIPGuard guard(q.device());
+  const int64_t Tq = q.size(0), nq = q.size(1), d = q.size(2), nkv = k.size(1);
+  torch::Tensor o = out.has_value() ? *out : torch::empty({Tq, nq * d}, q.options());
+  check(xllm_mi355_prefill_attention(p(q), p(k), p(v), p(o), cu_q.data_ptr<int32_t>(), cu_k.data_ptr<int32_t>(),
+                                     cu_q.numel() - 1, nq, nkv, d, q.stride(0), k.stride(0), v.stride(0), max_q_len,
+                                     (float)scale, is_causal ? 1 : 0, window_left, dt(q), cur_stream()),
+        "prefill_attention");
+  return o;
+}
+
+torch::Tensor paged_attention(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& v_cache,
+                              const std::optional<torch::Tensor>& cu_q, const torch::Tensor& kv_seq_lens,
+                              const torch::Tensor& block_table, int64_t max_q_len, int64_t max_kv_len, double scale,
+                              bool is_causal, int64_t window_left, std::optional<torch::Tensor> out) {
+  c10::hip::OptionalHIPGuard guard(q.device());
+  const int64_t Tq = q.size(0), nq = q.size(1), d = q.size(2);
+  const int64_t n_blocks = k_cache.size(0), bs = k_cache.size(1), nkv = k_cache.size(2), B = kv_seq_lens.numel();
+  torch::Tensor o = out.has_value() ? *out : torch::empty({Tq, nq * d}, q.options());
+  const size_t ws_bytes = xllm_mi355_paged_attention_workspace_bytes(B, nq, d, max_q_len, Tq);
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, q.options().dtype(torch::kUInt8));
+  auto bt = block_table.contiguous();
+  check(xllm_mi355_paged_attention(p(q), p(k_cache), p(v_cache), p(o),
+                                   cu_q.has_value() ? cu_q->data_ptr<int32_t>() : nullptr,
+                                   kv_seq_lens.data_ptr<int32_t>(), bt.data_ptr<int32_t>(), bt.size(1), B, Tq, nq, nkv,
+                                   d, bs, n_blocks, q.stride(0), max_q_len, max_kv_len, (float)scale,
+                                   is_causal ? 1 : 0, window_left, dt(q), p(ws), ws_bytes, cur_stream()),
+        "paged_attention");
+  return o;
+}
+
+}  // namespace xllm::kernel::mi355

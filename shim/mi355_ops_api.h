@@ -1,0 +1,78 @@
+// mi355_ops_api.h -- xllm::kernel::mi355::*: the per-backend operator header a USE_MI355 build of xLLM includes
+// from xllm/core/kernels/ops_api.cpp, next to kernels/cuda/cuda_ops_api.h and kernels/dcu/dcu_ops_api.h.
+// Argument lists are IDENTICAL to the CUDA/DCU headers (cited per function) so ops_api.cpp gains one
+// `#elif defined(USE_MI355)` line per operator (see INTEGRATION.md / patches/xllm-use-mi355.patch).
+// Every function forwards to one C-ABI symbol of include/xllm_mi355.h on c10::hip::getCurrentHIPStream();
+// outputs the reference allocates with torch::empty are allocated here the same way; a non-zero C return
+// becomes TORCH_CHECK(false, xllm_mi355_strerror(rc)) (reference: CHECK / TORCH_CHECK).
+#pragma once
+#include <torch/torch.h>
+
+#include <optional>
+#include <string>
+#include <tuple>
+
+namespace xllm::kernel::mi355 {
+
+// kernels/cuda/cuda_ops_api.h:31-36
+void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, std::optional<torch::Tensor> key,
+                      torch::Tensor& cos_sin_cache, bool is_neox);
+// cuda_ops_api.h:38-40
+void act_and_mul(torch::Tensor out, torch::Tensor input, const std::string& act_mode);
+// cuda_ops_api.h:42-47
+void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tensor values, torch::Tensor key_cache,
+                         torch::Tensor value_cache);
+// cuda_ops_api.h:146-155
+void rms_norm(torch::Tensor output, torch::Tensor input, torch::Tensor weight, double eps);
+void fused_add_rms_norm(torch::Tensor& input, torch::Tensor& residual, torch::Tensor& weight, double epsilon);
+// cuda_ops_api.h:157-159 == kernels/dcu/dcu_ops_api.h:30-32
+torch::Tensor matmul(torch::Tensor a, torch::Tensor b, std::optional<torch::Tensor> bias);
+// cuda_ops_api.h:184-186, 190-193, 201-216, 220-227
+void static_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor const& scale);
+std::tuple<torch::Tensor, torch::Tensor> fp8_scaled_quantize(const torch::Tensor& input,
+                                                             const std::optional<torch::Tensor>& output = std::nullopt,
+                                                             const std::optional<torch::Tensor>& scale = std::nullopt);
+void rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, torch::Tensor& scale,
+                               double epsilon);
+void fused_add_rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& residual,
+                                         torch::Tensor& weight, torch::Tensor& scale, double epsilon);
+torch::Tensor fp8_scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& a_scale,
+                                const torch::Tensor& b_scale, torch::ScalarType output_dtype,
+                                const std::optional<torch::Tensor>& bias = std::nullopt,
+                                const std::optional<torch::Tensor>& output = std::nullopt);
+// cuda_ops_api.h:235-249
+void fused_qk_norm_rope(torch::Tensor& qkv, int64_t num_heads_q, int64_t num_heads_k, int64_t num_heads_v,
+                        int64_t head_dim, double eps, const torch::Tensor& q_weight, const torch::Tensor& k_weight,
+                        const torch::Tensor& cos_sin_cache, bool interleaved, const torch::Tensor& position_ids);
+// kernels/dcu/dcu_ops_api.h:96-109 (only the no-smooth per-token int8 mode exists on DCU; same here)
+std::tuple<torch::Tensor, torch::Tensor> scaled_quantize(
+    const torch::Tensor& x, const torch::Tensor& smooth, const std::optional<torch::Tensor>& zero,
+    const std::optional<torch::Tensor>& token_count, const std::optional<torch::Tensor>& gather_index,
+    const std::optional<torch::Tensor>& gather_index_start_position, const std::optional<torch::Tensor>& output,
+    const std::optional<torch::Tensor>& output_scale, const std::string& act_mode, double active_coef, bool is_gated,
+    torch::ScalarType quant_type);
+// dcu_ops_api.h:113-129
+torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const std::optional<torch::Tensor>& a_scale,
+                            const torch::Tensor& b_scale, torch::ScalarType output_dtype,
+                            const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& c,
+                            const std::string& act_mode, int64_t quant_bit_size, double alpha, double beta,
+                            bool use_hp_active, int64_t a_quant_bit_size, const std::optional<torch::Tensor>& a_calib,
+                            const std::optional<torch::Tensor>& b_calib, const std::optional<torch::Tensor>& output);
+// dcu_ops_api.h:48-51, 71-73
+torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
+                         std::optional<torch::Tensor> output = std::nullopt);
+torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& paged_kv_indptr,
+                                              const torch::Tensor& paged_kv_indices);
+
+// attention entry points bound by layers/mi355/attention.cpp (arg sets of prefix_prefill_varlen_fwd /
+// prefix_decode_varlen_fwd, layers/dcu/flash_attention.cpp:45-94)
+torch::Tensor prefill_attention(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v,
+                                const torch::Tensor& cu_seqlens_q, const torch::Tensor& cu_seqlens_k, int64_t max_q_len,
+                                double scale, bool is_causal, int64_t window_left,
+                                std::optional<torch::Tensor> out = std::nullopt);
+torch::Tensor paged_attention(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& v_cache,
+                              const std::optional<torch::Tensor>& cu_seqlens_q, const torch::Tensor& kv_seq_lens,
+                              const torch::Tensor& block_table, int64_t max_q_len, int64_t max_kv_len, double scale,
+                              bool is_causal, int64_t window_left, std::optional<torch::Tensor> out = std::nullopt);
+
+}  // namespace xllm::kernel::mi355

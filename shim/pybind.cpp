@@ -1,0 +1,33 @@
+// test-only binding so the pytest suite can call the C++ shim (xllm::kernel::mi355::*) exactly as ops_api.cpp would
+#include <torch/extension.h>
+
+#include "mi355_attention.h"
+#include "mi355_ops_api.h"
+
+namespace k = xllm::kernel::mi355;
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("rms_norm", &k::rms_norm);
+  m.def("fused_add_rms_norm", [](torch::Tensor x, torch::Tensor r, torch::Tensor w, double eps) { k::fused_add_rms_norm(x, r, w, eps); });
+  m.def("act_and_mul", &k::act_and_mul);
+  m.def("reshape_paged_cache", &k::reshape_paged_cache);
+  m.def("rotary_embedding", [](torch::Tensor pos, torch::Tensor q, std::optional<torch::Tensor> kk, torch::Tensor cache, bool neox) { k::rotary_embedding(pos, q, kk, cache, neox); });
+  m.def("matmul", &k::matmul);
+  m.def("scaled_quantize", [](const torch::Tensor& x) {
+    return k::scaled_quantize(x, torch::Tensor(), std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, "none", 1.0, false, torch::kInt8);
+  });
+  m.def("scaled_matmul", [](const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& as, const torch::Tensor& bs, std::optional<torch::Tensor> bias) {
+    return k::scaled_matmul(a, b, as, bs, torch::kBFloat16, bias, std::nullopt, "none", 8, 1.0, 0.0, false, 8, std::nullopt, std::nullopt, std::nullopt);
+  });
+  m.def("fp8_scaled_quantize", [](const torch::Tensor& x) { return k::fp8_scaled_quantize(x); });
+  m.def("paged_attention", [](const torch::Tensor& q, const torch::Tensor& kc, const torch::Tensor& vc, const torch::Tensor& kv_lens, const torch::Tensor& bt, int64_t max_kv, double scale) {
+    return k::paged_attention(q, kc, vc, std::nullopt, kv_lens, bt, 1, max_kv, scale, false, -1);
+  });
+  m.def("attention_forward", [](torch::Tensor q, torch::Tensor kk, torch::Tensor v, torch::Tensor kc, torch::Tensor vc, torch::Tensor slots, torch::Tensor kv_lens, torch::Tensor bt, int64_t nq, int64_t nkv, int64_t d, int64_t max_kv) {
+    xllm::layer::mi355::AttentionImpl attn(nq, d, 1.0f / std::sqrt((float)d), nkv, -1);
+    xllm::layer::mi355::AttentionMetadata md;
+    md.kv_seq_lens = kv_lens; md.block_table = bt; md.slot_mapping = slots; md.max_seq_len = max_kv;
+    xllm::layer::mi355::KVCache cache{kc, vc};
+    return std::get<0>(attn.forward(md, q, kk, v, cache));
+  });
+}

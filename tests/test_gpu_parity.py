@@ -473,3 +473,52 @@ def test_mlu_golden_vectors_through_hip():
                         0.001037598, 0.001083374, 0.000289917, 0.0007820129])
     got = out.flatten()[:10].float().cpu()
     assert (got - exp).norm() / exp.norm() < 3e-2 and (got - exp).abs().max() <= 4e-5
+
+
+# ------------------------------------------------------------------------------------------- MLA / MoE
+@pytest.mark.parametrize("H,bs,kv_lens", [(16, 64, [8192 // 8, 70, 1]), (128, 64, [300, 65]), (5, 16, [100])])
+def test_mla_decode(H, bs, kv_lens):
+    """flash_mla dense decode == softmax(scale q.K) K[:, :512] over the paged latent cache (oracle: the generic
+    paged attention with nkv=1, d=576, dv=512, v_cache aliasing k_cache -- prefill_sdpa's formulation,
+    layers/dcu/deepseek_v2_attention.cpp:212-262)"""
+    B = len(kv_lens)
+    g = torch.Generator().manual_seed(H + bs)
+    pages = [(L + bs - 1) // bs for L in kv_lens]
+    nb = sum(pages) + 2
+    perm = torch.randperm(nb, generator=g).tolist()
+    blocks, used = [], 0
+    for n in pages:
+        blocks.append(perm[used:used + n]); used += n
+    md = orc.build_batch_metadata(kv_lens, [1] * B, blocks, bs)
+    kc = torch.randn(nb, bs, 1, 576, generator=g).bfloat16()
+    q = torch.randn(B, H, 576, generator=g).bfloat16()
+    scale = (192 ** -0.5)
+    ref = orc.paged_attention(q, kc, kc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale, dv=512)
+    out = ops.mla_decode(q.to(DEV), kc.to(DEV), md["kv_seq_lens"].to(DEV), md["block_tables"].to(DEV), 512, scale,
+                         max(kv_lens))
+    assert_attn_close(out.view(B, -1), ref)
+
+
+def test_moe_index_combine_group_gemm():
+    T, topk, E, Hd, N = 301, 8, 128, 256, 384
+    g = torch.Generator().manual_seed(6)
+    logits = torch.randn(T, E, generator=g)
+    w, ids = logits.softmax(-1).topk(topk, -1)
+    ids = ids.to(torch.int32)
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.to(DEV), E)
+    r_src_dst, r_dst_src, r_sizes = orc.moe_compute_index(ids, E)
+    assert torch.equal(sizes.cpu(), r_sizes)            # expert sizes: exact
+    assert torch.equal(src_dst.cpu(), r_src_dst)        # our placement is stable => equals the oracle's order
+    assert torch.equal(dst_src.cpu(), r_dst_src)
+    # grouped GEMM on the sorted rows (bf16, reference DCU path) vs per-expert oracle matmul
+    x = torch.randn(T, Hd, generator=g).bfloat16()
+    xs = x[(dst_src.cpu().long() // topk)]              # expand + sort (index_select in fused_moe.cpp:250-262)
+    we = (torch.randn(E, N, Hd, generator=g) / 16).bfloat16()
+    got = ops.group_gemm(xs.to(DEV), we.to(DEV), sizes)
+    ref = orc.group_gemm(xs, we, r_sizes)
+    assert_ulp_close(got, ref, torch.bfloat16, ulps=2.0, min_exact=0.9)
+    # combine (permutation-invariant result)
+    g2 = torch.randn(T * topk, Hd, generator=g).bfloat16()
+    outc = ops.moe_combine_result(g2.to(DEV), w.to(DEV), T, topk)
+    refc = orc.moe_combine(g2, w.contiguous(), T, topk)
+    assert_ulp_close(outc, refc, torch.bfloat16, ulps=1.0, min_exact=0.99)

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
       m_run = m_new;
       float psum = 0.0f;
       // P is fed to the matrix core as hi + lo 16-bit parts (p = hi + lo to ~2^-17 relative): the PV MFMAs
-      // are idle-cheap in this HBM-bound kernel and the output then matches an fp32-P oracle to rounding.
+      // are idle-cheap in this HBM-bound kernel and the output then matches an fp32-P reference to rounding.
       x8 pf, pl;
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)

@@ -1,0 +1,276 @@
+// attention_mla.hip -- MLA (DeepSeek latent attention) paged decode for gfx950.
+//
+// Reference semantics: flash_mla::dense_decode (xllm/core/kernels/dcu/flash_mla_adapter.cpp:104-160, closed
+// flash_mla.so) as used by DeepseekV2AttentionImpl::decode_flash_mla (layers/dcu/deepseek_v2_attention.cpp:189-210)
+// and specified by its torch twin prefill_sdpa (:212-262): the cache holds ONE latent row per token
+// [c_kv_normed (512) || rope(k_pe) (64)] (kv_cache_shape.cpp:354-364, block 64); the absorbed query is
+// [q_nope*W_kc (512) || rope(q_pe) (64)]; scores run over all 576 dims, values are the first 512 dims of the
+// same row:  out[b,h,:] = softmax(scale * q[b,h,:] . K[:, :]) @ K[:, :512].
+//
+// HBM-bound like GQA decode (every head of the rank shares the one latent row: ~30 flop/B at 16 heads), but the
+// row is 1152 B and the accumulator 16 x 512 fp32, so the tile is shared by the workgroup: K tiles of 32 tokens
+// are staged global -> registers -> LDS once (two buffers, next tile in flight during the MFMAs); each of the
+// 4 waves computes the full 16-head score block (S^T = K Q^T, 36 MFMAs) and softmax redundantly, then owns a
+// 128-wide slice of the 512 output dims (O^T = V^T P^T through ds_read_b64_tr_b16 on the SAME LDS tile).
+#include "common.h"
+
+namespace xm {
+
+typedef __bf16 mbf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 mbf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 mf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 mf16x4_t __attribute__((ext_vector_type(4)));
+typedef float mf32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct MlaTraits;
+template <>
+struct MlaTraits<bf16_t> {
+  using x8 = mbf16x8_t;
+  using x4 = mbf16x4_t;
+  using elem = __bf16;
+  static __device__ __forceinline__ mf32x4_t mfma(x8 a, x8 b, mf32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 tr_read(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) x4*)p);
+  }
+};
+template <>
+struct MlaTraits<f16_t> {
+  using x8 = mf16x8_t;
+  using x4 = mf16x4_t;
+  using elem = _Float16;
+  static __device__ __forceinline__ mf32x4_t mfma(x8 a, x8 b, mf32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ x4 tr_read(const void* p) {
+    typedef __fp16 hfp16x4 __attribute__((__vector_size__(8)));
+    hfp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hfp16x4*)p);
+    x4 o;
+    __builtin_memcpy(&o, &r, 8);
+    return o;
+  }
+};
+
+constexpr int kMlaD = 576, kMlaDV = 512, kMlaTile = 32;
+constexpr float kMlaNegBig = -1e30f;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void mla_decode_kernel(
+    const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
+    float* __restrict__ part_ml, const int32_t* __restrict__ seqlens, const int32_t* __restrict__ block_table,
+    int max_blocks, int n_heads, int block_size, float scale_log2, int nsplit) {
+  using TR = MlaTraits<T>;
+  using x8 = typename TR::x8;
+  using x4 = typename TR::x4;
+  using elem = typename TR::elem;
+  constexpr int KK = kMlaD / 32;                    // 18
+  constexpr int CH = kMlaD * 2 / 16;                // 72 chunks of 16 B per row
+  constexpr int RS = kMlaD * 2 + 16;                // padded LDS row stride
+  constexpr int NLD = kMlaTile * CH / 256;          // 9 chunks per thread per tile
+  constexpr int DBW = (kMlaDV / 4) / 16;            // 8 output blocks of 16 dims per wave
+  __shared__ __attribute__((aligned(16))) char lds[2][kMlaTile * RS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, g = lane >> 4;
+  const int split = blockIdx.x % nsplit;
+  const int hb = (blockIdx.x / nsplit) % ((n_heads + 15) / 16);  // block of 16 heads
+  const int b = blockIdx.x / nsplit / ((n_heads + 15) / 16);
+  const int kv_len = seqlens[b];
+  const int ntiles = (kv_len + kMlaTile - 1) / kMlaTile;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int tile_lo = split * per;
+  const int tile_hi = tile_lo + per < ntiles ? tile_lo + per : ntiles;
+  const int32_t* bt_row = block_table + (int64_t)b * max_blocks;
+  const int head = hb * 16 + p16;
+
+  // Q as the MFMA B operand: lane (n = head p16, k group g)
+  x8 qf[KK];
+  {
+    const T* qp = q + ((int64_t)b * n_heads + (head < n_heads ? head : 0)) * kMlaD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (head < n_heads) qf[kk] = *reinterpret_cast<const x8*>(qp + (kk * 4 + g) * 8);
+      else qf[kk] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  mf32x4_t acc_o[DBW];
+#pragma unroll
+  for (int i = 0; i < DBW; ++i) acc_o[i] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kMlaNegBig, l_run = 0.0f;
+
+  uint4 rk[NLD];
+  auto load_global = [&](int tile) {
+    const int t0 = tile * kMlaTile;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * 256, row = c / CH, col = c % CH;
+      int tok = t0 + row;
+      tok = tok < kv_len ? tok : kv_len - 1;
+      const int64_t rowi = (int64_t)bt_row[tok / block_size] * block_size + tok % block_size;
+      rk[i] = *reinterpret_cast<const uint4*>(kc + rowi * kMlaD + col * 8);
+    }
+  };
+  auto write_lds = [&](int buf, int tile) {
+    const int t0 = tile * kMlaTile;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + i * 256, row = c / CH, col = c % CH;
+      uint4 v = rk[i];
+      if (t0 + row >= kv_len) v = make_uint4(0, 0, 0, 0);  // rows past kv_len: zero (they double as V)
+      *reinterpret_cast<uint4*>(&lds[buf][row * RS + col * 16]) = v;
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    load_global(tile_lo);
+    write_lds(0, tile_lo);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      const bool more = tile + 1 < tile_hi;
+      if (more) load_global(tile + 1);
+      const int t0 = tile * kMlaTile;
+      const char* lk = lds[cur];
+      mf32x4_t s[2] = {mf32x4_t{0.f, 0.f, 0.f, 0.f}, mf32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const x8 ka = *reinterpret_cast<const x8*>(lk + (blk * 16 + p16) * RS + (kk * 4 + g) * 16);
+          s[blk] = TR::mfma(ka, qf[kk], s[blk]);
+        }
+      const bool partial = t0 + kMlaTile > kv_len;
+      float mx = kMlaNegBig;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[blk][r] * scale_log2;
+          if (partial && t0 + blk * 16 + g * 4 + r >= kv_len) v = -INFINITY;
+          s[blk][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.0f;
+      x8 pf, pl;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[blk][r] - m_new);
+          psum += p;
+          const elem hi = (elem)p;
+          pf[blk * 4 + r] = hi;
+          pl[blk * 4 + r] = (elem)(p - (float)hi);
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < DBW; ++i) acc_o[i] *= alpha;
+      // this wave's 128-wide slice of the 512 value dims
+      const char* trb = lk + (4 * g + (p16 >> 2)) * RS + (p16 & 3) * 8 + wave * 256;
+#pragma unroll
+      for (int db = 0; db < DBW; ++db) {
+        const x4 lo = TR::tr_read(trb + db * 32);
+        const x4 hi = TR::tr_read(trb + 16 * RS + db * 32);
+        x8 vt;
+        vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
+        vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
+        acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
+        acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
+      }
+      if (more) write_lds(cur ^ 1, tile + 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (head >= n_heads) return;
+  if (nsplit == 1) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    T* op = out + ((int64_t)b * n_heads + head) * kMlaDV + wave * 128;
+#pragma unroll
+    for (int db = 0; db < DBW; ++db) {
+      uint16_t hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T t = from_f32<T>(acc_o[db][r] * inv);
+        __builtin_memcpy(&hv[r], &t, 2);
+      }
+      *reinterpret_cast<uint2*>(op + db * 16 + g * 4) =
+          make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+    }
+  } else {
+    const int64_t pi = ((int64_t)b * n_heads + head) * nsplit + split;
+    float* po = part_o + pi * kMlaDV + wave * 128;
+#pragma unroll
+    for (int db = 0; db < DBW; ++db) *reinterpret_cast<mf32x4_t*>(po + db * 16 + g * 4) = acc_o[db];
+    if (wave == 0 && g == 0) { part_ml[pi * 2] = m_run; part_ml[pi * 2 + 1] = l_run; }
+  }
+}
+
+template <typename T>
+__global__ void mla_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                 T* __restrict__ out, int nsplit) {
+  const int64_t bh = blockIdx.x;
+  const int d = threadIdx.x;
+  const int64_t base = bh * nsplit;
+  float m_star = kMlaNegBig;
+  for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
+  float o = 0.0f, l = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float f = exp2f(part_ml[(base + s) * 2] - m_star);
+    o += f * part_o[(base + s) * kMlaDV + d];
+    l += f * part_ml[(base + s) * 2 + 1];
+  }
+  out[bh * kMlaDV + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
+}
+
+}  // namespace xm
+
+using namespace xm;
+
+extern "C" int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out, const int32_t* seqlens_k,
+                                     const int32_t* block_table, int64_t max_blocks, int64_t batch, int64_t n_heads,
+                                     int64_t head_dim, int64_t head_dim_v, int64_t block_size, int64_t n_blocks,
+                                     int64_t max_kv_len, float scale, int dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  (void)n_blocks;
+  if (!q || !k_cache || !out || !seqlens_k || !block_table || batch < 0 || n_heads <= 0 || block_size <= 0)
+    return XM_ERR_INVALID;
+  if (head_dim != kMlaD || head_dim_v != kMlaDV) return XM_ERR_UNSUPPORTED;
+  if ((uintptr_t)q % 16 || (uintptr_t)k_cache % 16) return XM_ERR_UNSUPPORTED;
+  if (batch == 0) return XM_OK;
+  const int64_t hblocks = (n_heads + 15) / 16;
+  const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
+  int64_t nsplit = (512 + batch * hblocks - 1) / (batch * hblocks);
+  if (nsplit > tiles / 8) nsplit = tiles / 8;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 32) nsplit = 32;
+  const size_t per_split = (size_t)batch * n_heads * (kMlaDV + 2) * sizeof(float);
+  if (!workspace) workspace_bytes = 0;
+  if ((size_t)nsplit * per_split > workspace_bytes) nsplit = (int64_t)(workspace_bytes / per_split);
+  if (nsplit < 1) nsplit = 1;
+  float* part_o = reinterpret_cast<float*>(workspace);
+  float* part_ml = part_o ? part_o + (size_t)batch * n_heads * nsplit * kMlaDV : nullptr;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)(batch * hblocks * nsplit));
+  XM_DISPATCH_HALF(dtype, T, {
+    hipLaunchKernelGGL((mla_decode_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out, part_o,
+                       part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale_log2,
+                       (int)nsplit);
+    if (nsplit > 1)
+      hipLaunchKernelGGL((mla_merge_kernel<T>), dim3((unsigned)(batch * n_heads)), dim3(kMlaDV), 0, s, part_o, part_ml,
+                         (T*)out, (int)nsplit);
+  });
+  return hip_check_launch();
+}

@@ -87,6 +87,8 @@ struct GemmEpi {
   void* out;              // 16-bit out [M,N] (may be null when only acc_out is wanted)
   int32_t* acc_out;       // int8: raw accumulators [M,N] (null normally); split-K workspace
   int out_bf16;           // 1 bf16, 0 f16
+  const int32_t* group_counts;  // grouped GEMM (MoE): rows per expert, DEVICE array [n_groups]; null otherwise
+  int n_groups;
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
   int mt, nt;
   {
     const int b = blockIdx.x;
-    if (n_tiles % 8 == 0) {
+    if (n_tiles % 8 == 0 && !epi.group_counts) {
       const int xcd = b & 7, j = b >> 3;
       mt = j % m_tiles;
       nt = (j / m_tiles) * 8 + xcd;
@@ -125,7 +127,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
       nt = b / m_tiles;
     }
   }
-  const int m0 = mt * BM, n0 = nt * BN;
+  int m0 = mt * BM;
+  const int n0 = nt * BN;
+  if (epi.group_counts) {
+    // grouped (MoE) mode, reference dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74): rows of A are sorted by
+    // expert, expert e owns rows [off_e, off_e + count_e) and weight W[e]. The m-tile index walks the experts'
+    // tiles in order; counts are read on the DEVICE (no host sync, graph-capturable, unlike group_gemm.cpp:45).
+    int tile = mt, e = 0, off = 0;
+    for (; e < epi.n_groups; ++e) {
+      const int c = epi.group_counts[e];
+      const int t = (c + BM - 1) / BM;
+      if (tile < t) { M = c; break; }
+      tile -= t;
+      off += c;
+    }
+    if (e >= epi.n_groups) return;  // surplus workgroup (grid is sized for the worst case)
+    m0 = tile * BM;
+    A += (int64_t)off * Kb;
+    W += (int64_t)e * N * Kb;
+    epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)off * N * 2;
+  }
   const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
   const int ks_begin = blockIdx.z * ksteps_per_split;
   int ks_end = ks_begin + ksteps_per_split;
@@ -606,7 +627,7 @@ int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_sc
   if (!out && !acc_out) return XM_ERR_INVALID;
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
-  GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16};
+  GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
   return launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
 }
 
@@ -617,7 +638,7 @@ int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if ((a_scale_numel != 1 && a_scale_numel != M) || (w_scale_numel != 1 && w_scale_numel != N)) return XM_ERR_INVALID;
   if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
-  GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16};
+  GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16, nullptr, 0};
   return launch_gemm<kFP8>(a, w, M, N, K, epi, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -626,9 +647,31 @@ int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out,
   if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
-  GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16};
+  GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16, nullptr, 0};
   if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
   return launch_gemm<kF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
+}
+
+int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,
+                          int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream) {
+  if (!a || !w || !token_count || !out || max_rows < 0 || n_experts <= 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (K % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (max_rows == 0) return XM_OK;
+  GemmEpi epi{nullptr, 0, nullptr, 0, nullptr, out, nullptr, dtype == XM_BF16, token_count, (int)n_experts};
+  // worst case number of 128-row tiles over all experts: every expert may waste < 1 tile
+  const int m_tiles = (int)((max_rows + BM - 1) / BM + n_experts);
+  const int n_tiles = (int)((N + BN - 1) / BN);
+  const int ksteps = (int)((K * 2 + BKB - 1) / BKB);
+  const dim3 grid((unsigned)(m_tiles * n_tiles), 1, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == XM_BF16)
+    hipLaunchKernelGGL((gemm_kernel<kBF16, false>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
+                       (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);
+  else
+    hipLaunchKernelGGL((gemm_kernel<kF16, false>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
+                       (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);
+  return hip_check_launch();
 }
 
 }  // extern "C"

@@ -334,3 +334,62 @@ def paged_attention(q, k_cache, v_cache, cu_seqlens_q, kv_seq_lens, block_table,
         d, bs, n_blocks, q.stride(0), max_q_len, max_kv_len, scale, int(is_causal), window_left, _dt(q), _p(ws),
         ws.numel(), _stream()), "paged_attention")
     return o
+
+
+def mla_decode(q, k_cache, seqlens_k, block_table, head_size_v: int, scale: float, max_kv_len: int, out=None):
+    """flash_mla::dense_decode argument set (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] =
+    [q_nope*W_kc || q_pe], k_cache [n_blocks, block, 1, 576]; returns [B, H, head_size_v]."""
+    _need_cuda(q, k_cache, seqlens_k, block_table)
+    B, H, D = q.shape
+    n_blocks, bs = k_cache.shape[0], k_cache.shape[1]
+    o = out if out is not None else torch.empty(B, H, head_size_v, dtype=q.dtype, device=q.device)
+    ws = _attn_workspace(q.device, B * H * 32 * (head_size_v + 2) * 4)
+    bt = block_table if block_table.is_contiguous() else block_table.contiguous()
+    check(_lib.lib().xllm_mi355_mla_decode(_p(q.contiguous()), _p(k_cache), _p(o), _p(seqlens_k), _p(bt), bt.size(1), B, H,
+                                          D, head_size_v, bs, n_blocks, max_kv_len, scale, _dt(q), _p(ws), ws.numel(),
+                                          _stream()), "mla_decode")
+    return o
+
+
+# ------------------------------------------------------------------------------------------------ MoE
+_moe_ws = {}
+
+
+def moe_compute_index(expert_id, num_experts: int):
+    """kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (moe/moe_compute_index.cu:111-160):
+    expert_id [T, topk] int32 -> (src_dst [T*topk], dst_src [T*topk], expert_sizes [E]); stable order."""
+    _need_cuda(expert_id)
+    T, topk = expert_id.shape
+    dev = expert_id.device
+    need = 4 * ((T * topk + 1023) // 1024 + 1) * num_experts
+    ws = _moe_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+        _moe_ws[dev] = ws
+        check(_lib.lib().xllm_mi355_set_moe_workspace(ws.data_ptr(), ws.numel()), "set_moe_workspace")
+    src_dst = torch.empty(T * topk, dtype=torch.int32, device=dev)
+    dst_src = torch.empty(T * topk, dtype=torch.int32, device=dev)
+    sizes = torch.empty(num_experts, dtype=torch.int32, device=dev)
+    check(_lib.lib().xllm_mi355_moe_compute_index(_p(expert_id.contiguous()), T, topk, num_experts, _p(src_dst),
+                                                 _p(dst_src), _p(sizes), _stream()), "moe_compute_index")
+    return src_dst, dst_src, sizes
+
+
+def moe_combine_result(gemm2, weights, n_tokens: int, topk: int):
+    """kernel::moe_combine_result (ops_api.h:77) -> moe/moe_combine.cu:38-62"""
+    _need_cuda(gemm2, weights)
+    H = gemm2.size(-1)
+    out = torch.empty(n_tokens, H, dtype=gemm2.dtype, device=gemm2.device)
+    check(_lib.lib().xllm_mi355_moe_combine(_p(out), _p(gemm2.contiguous()), _p(weights.contiguous()), n_tokens, topk, H,
+                                           _dt(gemm2), _stream()), "moe_combine_result")
+    return out
+
+
+def group_gemm(input, weight, token_count, output=None):
+    """dcu::group_gemm(input [total, K], weight [E, N, K], token_count [E] int32 (device), out?) (dcu_ops_api.h:48-51)"""
+    _need_cuda(input, weight, token_count)
+    E, N, K = weight.shape
+    out = output if output is not None else torch.empty(input.size(0), N, dtype=input.dtype, device=input.device)
+    check(_lib.lib().xllm_mi355_group_gemm(_p(input.contiguous()), _p(weight.contiguous()), _p(token_count), _p(out),
+                                          input.size(0), E, N, K, _dt(input), _stream()), "group_gemm")
+    return out
