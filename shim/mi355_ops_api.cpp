@@ -2,15 +2,17 @@
 // one C-ABI call per operator. No kernels here.
 #include "mi355_ops_api.h"
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// ROCm builds of torch present HIP devices as "cuda": use the masquerading guard / stream accessors
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "../include/xllm_mi355.h"
 
 namespace xllm::kernel::mi355 {
 namespace {
 
-void* cur_stream() { return static_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+void* cur_stream() { return static_cast<void*>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream()); }
+using DeviceGuard = c10::hip::OptionalHIPGuardMasqueradingAsCUDA;
 
 int dt(const torch::Tensor& t) {
   switch (t.scalar_type()) {
@@ -38,7 +40,7 @@ int act_code(const std::string& m) {
 
 void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, std::optional<torch::Tensor> key,
                       torch::Tensor& cos_sin_cache, bool is_neox) {
-  c10::hip::OptionalHIPGuard guard(query.device());
+  DeviceGuard guard(query.device());
   TORCH_CHECK(positions.scalar_type() == torch::kInt64, "positions must be int64");
   const int64_t T = positions.numel();
   const int64_t rot = cos_sin_cache.size(-1);
@@ -53,7 +55,7 @@ void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, std::optio
 }
 
 void act_and_mul(torch::Tensor out, torch::Tensor input, const std::string& act_mode) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const int64_t d = input.size(-1) / 2;
   check(xllm_mi355_act_and_mul(p(out), p(input), input.numel() / (2 * d), d, act_code(act_mode), dt(input),
                                cur_stream()),
@@ -62,7 +64,7 @@ void act_and_mul(torch::Tensor out, torch::Tensor input, const std::string& act_
 
 void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tensor values, torch::Tensor key_cache,
                          torch::Tensor value_cache) {
-  c10::hip::OptionalHIPGuard guard(keys.device());
+  DeviceGuard guard(keys.device());
   TORCH_CHECK(keys.stride(-1) == 1 && keys.stride(-2) == keys.size(-1));      // reshape_paged_cache.cu:73
   TORCH_CHECK(values.stride(-1) == 1 && values.stride(-2) == values.size(-1));  // :74
   check(xllm_mi355_reshape_paged_cache(slot_ids.data_ptr<int32_t>(), p(keys), p(values), p(key_cache), p(value_cache),
@@ -73,7 +75,7 @@ void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tens
 }
 
 void rms_norm(torch::Tensor output, torch::Tensor input, torch::Tensor weight, double eps) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const int64_t H = input.size(-1);
   auto x = input.view({-1, H});
   check(xllm_mi355_rms_norm(p(output), p(x), p(weight), (float)eps, x.size(0), H, x.stride(0), dt(input), cur_stream()),
@@ -81,7 +83,7 @@ void rms_norm(torch::Tensor output, torch::Tensor input, torch::Tensor weight, d
 }
 
 void fused_add_rms_norm(torch::Tensor& input, torch::Tensor& residual, torch::Tensor& weight, double epsilon) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const int64_t H = input.size(-1);
   check(xllm_mi355_fused_add_rms_norm(p(input), p(residual), p(weight), (float)epsilon, input.numel() / H, H, H,
                                       dt(input), cur_stream()),
@@ -89,7 +91,7 @@ void fused_add_rms_norm(torch::Tensor& input, torch::Tensor& residual, torch::Te
 }
 
 torch::Tensor matmul(torch::Tensor a, torch::Tensor b, std::optional<torch::Tensor> bias) {
-  c10::hip::OptionalHIPGuard guard(a.device());
+  DeviceGuard guard(a.device());
   const int64_t K = a.size(-1), N = b.size(0);
   auto a2 = a.reshape({-1, K}).contiguous();
   auto out = torch::empty({a2.size(0), N}, a.options());
@@ -100,7 +102,7 @@ torch::Tensor matmul(torch::Tensor a, torch::Tensor b, std::optional<torch::Tens
 }
 
 void static_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, torch::Tensor const& scale) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   check(xllm_mi355_static_scaled_fp8_quant(static_cast<uint8_t*>(p(out)), p(input.contiguous()),
                                            scale.data_ptr<float>(), input.numel(), dt(input), cur_stream()),
         "static_scaled_fp8_quant");
@@ -109,7 +111,7 @@ void static_scaled_fp8_quant(torch::Tensor& out, torch::Tensor const& input, tor
 std::tuple<torch::Tensor, torch::Tensor> fp8_scaled_quantize(const torch::Tensor& input,
                                                              const std::optional<torch::Tensor>& output,
                                                              const std::optional<torch::Tensor>& scale) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   torch::Tensor q = (output.has_value() && output->defined())
                         ? *output
                         : torch::empty_like(input, input.options().dtype(torch::kFloat8_e4m3fn));
@@ -124,7 +126,7 @@ std::tuple<torch::Tensor, torch::Tensor> fp8_scaled_quantize(const torch::Tensor
 
 void rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& weight, torch::Tensor& scale,
                                double epsilon) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const int64_t H = input.size(-1);
   auto x = input.view({-1, H});
   check(xllm_mi355_rms_norm_static_fp8_quant(static_cast<uint8_t*>(p(out)), p(x), nullptr, p(weight),
@@ -135,7 +137,7 @@ void rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::
 
 void fused_add_rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& input, torch::Tensor& residual,
                                          torch::Tensor& weight, torch::Tensor& scale, double epsilon) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   const int64_t H = input.size(-1);
   auto x = input.view({-1, H});
   check(xllm_mi355_rms_norm_static_fp8_quant(static_cast<uint8_t*>(p(out)), p(x), p(residual), p(weight),
@@ -147,7 +149,7 @@ void fused_add_rms_norm_static_fp8_quant(torch::Tensor& out, torch::Tensor& inpu
 torch::Tensor fp8_scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& a_scale,
                                 const torch::Tensor& b_scale, torch::ScalarType output_dtype,
                                 const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& output) {
-  c10::hip::OptionalHIPGuard guard(a.device());
+  DeviceGuard guard(a.device());
   TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.size(1) == b.size(1), "a [M,K], b [N,K]");
   const int64_t M = a.size(0), K = a.size(1), N = b.size(0);
   torch::Tensor out = output.has_value() ? *output : torch::empty({M, N}, a.options().dtype(output_dtype));
@@ -161,7 +163,7 @@ torch::Tensor fp8_scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, 
 void fused_qk_norm_rope(torch::Tensor& qkv, int64_t num_heads_q, int64_t num_heads_k, int64_t num_heads_v,
                         int64_t head_dim, double eps, const torch::Tensor& q_weight, const torch::Tensor& k_weight,
                         const torch::Tensor& cos_sin_cache, bool interleaved, const torch::Tensor& position_ids) {
-  c10::hip::OptionalHIPGuard guard(qkv.device());
+  DeviceGuard guard(qkv.device());
   check(xllm_mi355_fused_qk_norm_rope(p(qkv), qkv.size(0), num_heads_q, num_heads_k, num_heads_v, head_dim, (float)eps,
                                       p(q_weight), p(k_weight), p(cos_sin_cache), dt(cos_sin_cache),
                                       interleaved ? 1 : 0, position_ids.data_ptr<int64_t>(), dt(qkv), cur_stream()),
@@ -174,7 +176,7 @@ std::tuple<torch::Tensor, torch::Tensor> scaled_quantize(
     const std::optional<torch::Tensor>& gather_index_start_position, const std::optional<torch::Tensor>& output,
     const std::optional<torch::Tensor>& output_scale, const std::string& act_mode, double /*active_coef*/,
     bool is_gated, torch::ScalarType quant_type) {
-  c10::hip::OptionalHIPGuard guard(x.device());
+  DeviceGuard guard(x.device());
   // same restrictions as the DCU implementation (kernels/dcu/scaled_quantize.hip:411-447)
   TORCH_CHECK(!smooth.defined() || smooth.numel() == 0, "mi355 scaled_quantize: smooth factor not supported");
   TORCH_CHECK(!zero.has_value() && !token_count.has_value() && !gather_index.has_value() &&
@@ -207,7 +209,7 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
                             const std::optional<torch::Tensor>& /*a_calib*/,
                             const std::optional<torch::Tensor>& /*b_calib*/,
                             const std::optional<torch::Tensor>& output) {
-  c10::hip::OptionalHIPGuard guard(a.device());
+  DeviceGuard guard(a.device());
   TORCH_CHECK(quant_bit_size == 8 && a_quant_bit_size == 8, "scaled_matmul only supports w8a8 quantization");
   TORCH_CHECK(a.dim() == 2 && b.dim() == 2 && a.scalar_type() == torch::kInt8 && b.scalar_type() == torch::kInt8 &&
                   a.size(1) == b.size(1) && a.is_contiguous() && b.is_contiguous(),
@@ -226,7 +228,7 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
 
 torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
                          std::optional<torch::Tensor> output) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  DeviceGuard guard(input.device());
   TORCH_CHECK(input.dim() == 2 && weight.dim() == 3 && input.size(1) == weight.size(2), "group_gemm shapes");
   const int64_t E = weight.size(0), N = weight.size(1), K = weight.size(2);
   torch::Tensor out = output.has_value() ? *output : torch::empty({input.size(0), N}, input.options());
@@ -237,7 +239,7 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
 }
 
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const torch::Tensor& indices) {
-  c10::hip::OptionalHIPGuard guard(indptr.device());
+  DeviceGuard guard(indptr.device());
   const int64_t B = indptr.size(0) - 1, total = indices.size(0);
   auto table = torch::empty({B, total}, indptr.options().dtype(torch::kInt32));
   check(xllm_mi355_build_block_table_from_paged_kv(indptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (int32_t)B,
@@ -249,7 +251,7 @@ torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const
 torch::Tensor prefill_attention(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v,
                                 const torch::Tensor& cu_q, const torch::Tensor& cu_k, int64_t max_q_len, double scale,
                                 bool is_causal, int64_t window_left, std::optional<torch::Tensor> out) {
-  c10::hip::OptionalHIPGuard guard(q.device());
+  DeviceGuard guard(q.device());
   const int64_t Tq = q.size(0), nq = q.size(1), d = q.size(2), nkv = k.size(1);
   torch::Tensor o = out.has_value() ? *out : torch::empty({Tq, nq * d}, q.options());
   check(xllm_mi355_prefill_attention(p(q), p(k), p(v), p(o), cu_q.data_ptr<int32_t>(), cu_k.data_ptr<int32_t>(),
@@ -263,7 +265,7 @@ torch::Tensor paged_attention(const torch::Tensor& q, const torch::Tensor& k_cac
                               const std::optional<torch::Tensor>& cu_q, const torch::Tensor& kv_seq_lens,
                               const torch::Tensor& block_table, int64_t max_q_len, int64_t max_kv_len, double scale,
                               bool is_causal, int64_t window_left, std::optional<torch::Tensor> out) {
-  c10::hip::OptionalHIPGuard guard(q.device());
+  DeviceGuard guard(q.device());
   const int64_t Tq = q.size(0), nq = q.size(1), d = q.size(2);
   const int64_t n_blocks = k_cache.size(0), bs = k_cache.size(1), nkv = k_cache.size(2), B = kv_seq_lens.numel();
   torch::Tensor o = out.has_value() ? *out : torch::empty({Tq, nq * d}, q.options());

@@ -1,0 +1,113 @@
+"""N>1 path on CPU: world_size-2 gloo process groups (fork-per-rank over a TCP store on 127.0.0.1, the
+reference's own distributed-test pattern, tests/core/layers/mlu/deepseek_v2_attention_multi_device_test.cpp:69-145).
+
+Checks (1) the ProcessGroup mirror's collectives (parallel_state::reduce / gather semantics), (2) the TP/DP rank
+mapping bench.py uses, and (3) that the reference's sharding plan (heads / columns per rank, SUM all-reduce after
+the row-parallel linears, qwen2_attention.cpp:54-103, dense_mlp.cpp:64-94) reproduces the unsharded result --
+per-rank arithmetic done with the CPU oracle, the exchange with xllm_amd.parallel over gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _collectives(rank, world):
+    from xllm_amd import parallel
+    pg, dp_rank = parallel.make_tp_dp_groups(world, rank, world)
+    x = torch.full((3, 4), float(rank + 1))
+    parallel.reduce(x, pg)                                   # in-place SUM all-reduce
+    y = parallel.gather(torch.full((2, 3), float(rank)), pg)  # all-gather + cat on the last dim
+    one = parallel.reduce(torch.ones(2), parallel.ProcessGroup(None, 0, 1))  # world 1: no-op
+    return x.tolist(), y.tolist(), one.tolist(), pg.rank(), pg.world_size(), dp_rank
+
+
+def test_collectives_and_rank_mapping():
+    out = _run(_collectives)
+    for r, (x, y, one, pr, pw, dp) in enumerate(out):
+        assert x == [[3.0] * 4] * 3
+        assert y == [[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]] * 2
+        assert one == [1.0, 1.0] and pr == r and pw == 2 and dp == 0
+
+
+def _dp_mapping(rank, world):
+    from xllm_amd import parallel
+    pg, dp_rank = parallel.make_tp_dp_groups(world, rank, 1)  # TP=1 x DP=2
+    return (pg.world_size(), dp_rank)
+
+
+def test_dp_replicas_need_no_group():
+    assert _run(_dp_mapping) == [(1, 0), (1, 1)]
+
+
+H, NQ, NKV, D, I = 256, 4, 2, 64, 512
+
+
+def _make_weights():
+    g = torch.Generator().manual_seed(42)
+    r = lambda *s: (torch.randn(*s, generator=g) / 16).bfloat16()
+    return dict(q=r(NQ * D, H), k=r(NKV * D, H), v=r(NKV * D, H), o=r(H, NQ * D), gate=r(I, H), up=r(I, H),
+                down=r(H, I), x=torch.randn(5, H, generator=g).bfloat16())
+
+
+def _layer_shard(rank, world):
+    """one attention-less decoder half-layer per rank: column-parallel qkv/gate_up, row-parallel o/down + reduce"""
+    from xllm_amd import parallel
+    pg, _ = parallel.make_tp_dp_groups(world, rank, world)
+    w = _make_weights()
+    nq_l, nkv_l, i_l = NQ // world, max(NKV // world, 1), I // world
+    qs = slice(rank * nq_l * D, (rank + 1) * nq_l * D)
+    q = orc.matmul(w["x"], w["q"][qs].contiguous())                       # column parallel (heads)
+    o = orc.matmul(q, w["o"][:, qs].contiguous()).float()                  # row parallel, partial sums
+    parallel.reduce(o, pg)
+    isl = slice(rank * i_l, (rank + 1) * i_l)
+    gu = torch.cat([orc.matmul(w["x"], w["gate"][isl].contiguous()), orc.matmul(w["x"], w["up"][isl].contiguous())], -1)
+    act = torch.empty(5, i_l, dtype=torch.bfloat16)
+    orc.act_and_mul(act, gu.contiguous(), "silu")
+    dn = orc.matmul(act, w["down"][:, isl].contiguous()).float()
+    parallel.reduce(dn, pg)
+    return o, dn
+
+
+def test_tp_sharded_equals_full():
+    sharded = _run(_layer_shard)
+    w = _make_weights()
+    q = orc.matmul(w["x"], w["q"])
+    o_full = orc.matmul(q, w["o"]).float()
+    gu = torch.cat([orc.matmul(w["x"], w["gate"]), orc.matmul(w["x"], w["up"])], -1)
+    act = torch.empty(5, I, dtype=torch.bfloat16)
+    orc.act_and_mul(act, gu.contiguous(), "silu")
+    dn_full = orc.matmul(act, w["down"]).float()
+    for o, dn in sharded:
+        assert torch.equal(o, sharded[0][0]) and torch.equal(dn, sharded[0][1])  # identical on every rank
+        # partial sums are rounded to bf16 per rank before the SUM (as on the device path): 2 bf16 ulp
+        assert (o - o_full).abs().max() <= 2 * 2.0 ** -8 * o_full.abs().max()
+        assert (dn - dn_full).abs().max() <= 2 * 2.0 ** -8 * dn_full.abs().max()

@@ -104,9 +104,14 @@ constexpr int BM = 128, BN = 128, BKB = 128;  // block tile, K step in bytes
 
 // A [M, Kb bytes per row], W [N, Kb]; grid.x = tiles (XCD-remapped), grid.z = split-K slices
 template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
-                                                      int M, int N, int64_t Kb, int m_tiles, int n_tiles,
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict__ A_, const uint8_t* __restrict__ W_,
+                                                      int M_, int N, int64_t Kb, int m_tiles, int n_tiles,
                                                       int ksteps_per_split, GemmEpi epi) {
+  // grouped mode rebases these per workgroup, so they are locals, not the (read-only) kernel arguments
+  const uint8_t* A = A_;
+  const uint8_t* W = W_;
+  int M = M_;
+  void* out_base = epi.out;
   using MT = MmaTraits<KIND>;
   using acc_t = typename MT::acc_t;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][BM * BKB];  // [buf][A/W][tile]
@@ -133,7 +138,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
     // grouped (MoE) mode, reference dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74): rows of A are sorted by
     // expert, expert e owns rows [off_e, off_e + count_e) and weight W[e]. The m-tile index walks the experts'
     // tiles in order; counts are read on the DEVICE (no host sync, graph-capturable, unlike group_gemm.cpp:45).
-    int tile = mt, e = 0, off = 0;
+    // NOTE: keep the walk on the scalar unit (readfirstlane). With `tile` in a VGPR, hipcc (ROCm 7.2) emitted
+    // v_cmp (-> VCC) followed by s_cselect (reads SCC) for the selects below: a stale-SCC miscompile.
+    int tile = __builtin_amdgcn_readfirstlane(mt), e = 0, off = 0;
     for (; e < epi.n_groups; ++e) {
       const int c = epi.group_counts[e];
       const int t = (c + BM - 1) / BM;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
     m0 = tile * BM;
     A += (int64_t)off * Kb;
     W += (int64_t)e * N * Kb;
-    epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)off * N * 2;
+    out_base = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)off * N * 2;
   }
   const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
   const int ks_begin = blockIdx.z * ksteps_per_split;
@@ -243,13 +250,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
             atomicAdd(epi.acc_out + idx, a);
           } else {
             if (epi.acc_out) epi.acc_out[idx] = a;
-            if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
+            if (out_base) store16(out_base, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
           }
         } else if constexpr (KIND == kFP8) {
           const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
-          store16(epi.out, idx, as * (ws * acc[i][j][r]) + bs, epi.out_bf16);
+          store16(out_base, idx, as * (ws * acc[i][j][r]) + bs, epi.out_bf16);
         } else {
-          store16(epi.out, idx, acc[i][j][r] + bs, epi.out_bf16);
+          store16(out_base, idx, acc[i][j][r] + bs, epi.out_bf16);
         }
       }
     }

@@ -28,7 +28,8 @@ class ProcessGroup:
 
     def allgather(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self._world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+        # list form: supported by both RCCL and gloo (the CPU tests); the views alias `out`, no extra copy
+        dist.all_gather(list(out.unbind(0)), x.contiguous(), group=self.group)
         return out
 
 
