@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
+    p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
+    p.add_argument("--emulate-tp", type=int, default=0,
+                   help="single GPU: run ONE rank's shard of a TP=k job with the collectives stubbed (tuning aid)")
     return p.parse_args()
 
 
@@ -163,6 +166,15 @@ def main():
     B = gbatch // dp_size
     dtype = torch.bfloat16
 
+    if a.emulate_tp > 1 and world == 1:
+        class _StubPG(parallel.ProcessGroup):  # shard shapes of TP=k, no exchange: per-rank compute only
+            def allreduce(self, x):
+                return None
+
+            def allgather(self, x):
+                return x.unsqueeze(0).expand(self._world, *x.shape)
+        tp_pg = _StubPG(None, 0, a.emulate_tp)
+        tp_size = a.emulate_tp
     model = layers.Qwen2Model(margs, mode, dtype, dev, seed=1234, tp=tp_pg, fuse=not a.no_fuse)
     md, n_blocks = build_metadata(B, ctx, block_size, dev, seed=dp_rank)
     nkv_l = model.layers[0].nkv
@@ -255,11 +267,15 @@ def main():
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "decode_attn_pmc.json")
-    if os.path.exists(pmc) and world == 1 and a.config == "cfg3":
+    if os.path.exists(pmc) and world == 1 and tp_size == 1 and a.config == "cfg3":
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+
+    prefill = None
+    if not a.no_prefill and a.config == "cfg3":
+        prefill = prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all)
 
     if a.micro and rank == 0:
         micro(model, md, kv_caches, tokens, positions, B, sys.stderr)
@@ -281,11 +297,58 @@ def main():
                          "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4),
                          "launches_timed": len(attn_events)},
         }
+        if prefill is not None:
+            out["prefill"] = prefill
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all):
+    """prefill TFLOPS (second half of the BASELINE metric): one chunk of 2 x ctx tokens through the
+    full model -- causal varlen flash attention, W8A8 GEMMs at M = 8192, KV written to fresh pages; logits only
+    for the last token of each sequence (llm_model_base.h:193-204). flops = 2*T*sum(N*K) + 2*nq*d*S^2*L per seq."""
+    from xllm_amd.attention import AttentionMetadata
+    nseq = 2
+    T = nseq * ctx
+    pages = ctx // block_size
+    table = torch.arange(nseq * pages, dtype=torch.int32).view(nseq, pages)
+    slots = (table.repeat_interleave(block_size, 1) * block_size + torch.arange(block_size).repeat(pages)).flatten()
+    cu = torch.arange(0, (nseq + 1) * ctx, ctx, dtype=torch.int32, device=dev)
+    md = AttentionMetadata(q_cu_seq_lens=cu, kv_cu_seq_lens=cu, kv_seq_lens=torch.full((nseq,), ctx, dtype=torch.int32, device=dev),
+                           slot_mapping=slots.to(torch.int32).to(dev), block_table=table.to(dev), max_query_len=ctx,
+                           max_seq_len=ctx, is_prefill=True)
+    tokens = torch.randint(0, margs.vocab_size, (T,), device=dev)
+    positions = torch.arange(ctx, device=dev).repeat(nseq)
+    last = torch.arange(ctx - 1, T, ctx, device=dev)
+
+    def chunk():
+        hidden = model.forward(tokens, positions, md, kv_caches)
+        return torch.argmax(model.logits(hidden.index_select(0, last)), dim=-1)
+
+    chunk()
+    sync_all()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        chunk()
+    sync_all()
+    dt = (time.perf_counter() - t0) / n
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    H, I, d = margs.hidden_size, margs.intermediate_size, margs.head_dim
+    w_macs = (margs.n_heads + 2 * margs.n_kv_heads) * d * H + margs.n_heads * d * H + 2 * I * H + I * H
+    flops = margs.n_layers * (2 * T * w_macs + nseq * 2 * margs.n_heads * d * ctx * ctx) + 2 * nseq * H * margs.vocab_size
+    flops *= dp_size  # every DP replica prefills its own chunk
+    peak = 5000.0 * world  # int8 dense MFMA, TOP/s per GPU (BASELINE.md section 2)
+    return {"tflops": round(flops / dt / 1e12, 1), "ms_per_chunk": round(dt * 1e3, 3), "tokens": T * dp_size,
+            "tokens_per_s": round(T * dp_size / dt, 1), "flops_per_chunk": flops, "mfma_peak_tflops": peak,
+            "frac": round(flops / dt / 1e12 / peak, 4), "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else "")}
 
 
 def micro(model, md, kv_caches, tokens, positions, B, fh):

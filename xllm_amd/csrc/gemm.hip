@@ -571,7 +571,11 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
     const char* e = getenv("XLLM_MI355_SKINNY_DISABLE");
     g_sk_disable = e ? atoi(e) : 0;
   }
-  if (M <= 512 && Kb % BKB == 0 && !g_sk_disable)
+  // decode-shaped problems take the skinny kernel (32-bit buffer offsets: operands < 2 GiB); for the 16-bit / fp8
+  // kinds only while the general kernel's 128x128 grid would under-fill the chip (measured at M=256: lm_head
+  // 436 vs 553 us, bf16 gate_up 119 vs 146 us in favour of the general kernel)
+  const bool skinny_pays = KIND == kI8 || ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 256;
+  if (M <= 512 && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && skinny_pays && !g_sk_disable)
     return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
   const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = (int)((N + BN - 1) / BN);
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
