@@ -121,7 +121,8 @@ XM_API int xllm_mi355_scaled_quantize(const void* x, int8_t* out, float* out_sca
                                       int64_t K, int dtype, void* stream);
 /* kernel::scaled_matmul (ops_api.h:98) -> dcu::scaled_matmul (kernels/dcu/scaled_matmul.cpp:103-300):
  * out[m,n] = r16( int32(sum_k a[m,k]*w[n,k]) * a_scale[m] * w_scale[n] + bias[n] ); a [M,K] int8,
- * w [N,K] int8 row-major, bias (out dtype) may be NULL; out dtype XM_BF16 / XM_F16. K % 16 == 0.
+ * w [N,K] int8 row-major, bias (out dtype) may be NULL; out dtype XM_BF16 / XM_F16. K % 128 == 0
+ * (the K step of every GEMM kernel is 128 bytes of each operand row).
  * acc_out (optional, may be NULL): raw int32 accumulators [M,N] (parity tests). */
 XM_API int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_scale,
                                     const float* w_scale, const void* bias, void* out, int32_t* acc_out,
@@ -142,14 +143,14 @@ XM_API int xllm_mi355_fp8_scaled_quantize(uint8_t* out, const void* input, const
                                           float* scale_out, int64_t numel, int dtype, void* stream);
 /* kernel::fp8_scaled_matmul (ops_api.h:156) -> cutlass_scaled_mm (cutlass_w8a8/scaled_mm_entry.cu:55-116):
  * out = r16( a_scale * (w_scale * sum_fp32 a*w) + bias ); a [M,K] e4m3, w [N,K] e4m3 row-major
- * (the reference passes b.t() of it); a_scale numel 1 or M, w_scale numel 1 or N. K % 16 == 0. */
+ * (the reference passes b.t() of it); a_scale numel 1 or M, w_scale numel 1 or N. K % 128 == 0. */
 XM_API int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale,
                                         int64_t a_scale_numel, const float* w_scale,
                                         int64_t w_scale_numel, const void* bias, void* out, int64_t M,
                                         int64_t N, int64_t K, int out_dtype, void* stream);
 
 /* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
- * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 8 == 0. */
+ * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0. */
 XM_API int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M,
                              int64_t N, int64_t K, int dtype, void* stream);
 

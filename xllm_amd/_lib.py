@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxllm_mi355.so")
+# XLLM_MI355_LIB selects an alternative build of the same ABI (A/B experiments); default is the in-tree library
+LIB_PATH = os.environ.get("XLLM_MI355_LIB") or os.path.join(_HERE, "lib", "libxllm_mi355.so")
 
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 ci = C.c_int

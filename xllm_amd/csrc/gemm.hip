@@ -103,8 +103,8 @@ __device__ __forceinline__ float load16(const void* p, int64_t idx, int is_bf16)
 constexpr int BM = 128, BN = 128, BKB = 128;  // block tile, K step in bytes
 
 // A [M, Kb bytes per row], W [N, Kb]; grid.x = tiles (XCD-remapped), grid.z = split-K slices
-template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict__ A_, const uint8_t* __restrict__ W_,
+template <int KIND, bool SPLITK, int KB, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_kernel(const uint8_t* __restrict__ A_, const uint8_t* __restrict__ W_,
                                                       int M_, int N, int64_t Kb, int m_tiles, int n_tiles,
                                                       int ksteps_per_split, GemmEpi epi) {
   // grouped mode rebases these per workgroup, so they are locals, not the (read-only) kernel arguments
@@ -114,19 +114,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
   void* out_base = epi.out;
   using MT = MmaTraits<KIND>;
   using acc_t = typename MT::acc_t;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][BM * BKB];  // [buf][A/W][tile]
+  // KB = K step in bytes (64 or 128); rows of KB bytes = CPR 16-byte chunks, swizzled by SW(row)
+  constexpr int CPR = KB / 16;                      // chunks per row: 4 or 8
+  constexpr int NST = BM * CPR / 256;               // DMA instructions per thread and operand: 2 or 4
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][BM * KB];  // [buf][A/W][tile]
+  auto SW = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile mapping: block b runs on XCD b%8; keep the m-tiles of one n-tile on one XCD
+  // XCD-aware 2-D rasterisation. Block b runs on XCD b%8 and the j = b/8 -th slot of that XCD. Each XCD walks its
+  // own sequence of 8x8-tile super-blocks (64 concurrently resident workgroups = 32 CUs x 2): the 8 m-tiles and
+  // 8 n-tiles of a super-block are each re-used 8 times out of that XCD's L2 while the K loops advance roughly
+  // in step, so both operands leave HBM / Infinity Cache once per super-block instead of once per tile
+  // (round-1 finding: with n-major order the A operand was re-streamed once per n-tile: 8.7 GB per gate_up
+  // launch at M = 8192, i.e. the kernel was HBM-bound at 1.1 POP/s).
   int mt, nt;
   {
     const int b = blockIdx.x;
-    if (n_tiles % 8 == 0 && !epi.group_counts) {
+    if (!epi.group_counts && !SPLITK) {
       const int xcd = b & 7, j = b >> 3;
-      mt = j % m_tiles;
-      nt = (j / m_tiles) * 8 + xcd;
+      const int sb = j >> 6, within = j & 63;
+      const int S = sb * 8 + xcd;                       // global super-block index
+      // super-block = 2^lm x 2^(6-lm) tiles (8x8 when there are >= 8 m-tiles, else all m-tiles x more n-tiles)
+      const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+      const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
+      const int SM = S % n_sb_m, SN = S / n_sb_m;
+      mt = (SM << lm) + (within & ((1 << lm) - 1));
+      nt = (SN << (6 - lm)) + (within >> lm);
+      if (mt >= m_tiles || nt >= n_tiles) return;       // padding of the rasterised grid
     } else {
       mt = b % m_tiles;
       nt = b / m_tiles;
@@ -154,37 +170,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
     W += (int64_t)e * N * Kb;
     out_base = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)off * N * 2;
   }
-  const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
+  const int total_ksteps = (int)((Kb + KB - 1) / KB);
   const int ks_begin = blockIdx.z * ksteps_per_split;
   int ks_end = ks_begin + ksteps_per_split;
   ks_end = ks_end > total_ksteps ? total_ksteps : ks_end;
 
-  // staging map: thread -> 4 chunks of A and 4 of W per K step; chunk c = tid + i*256: row c/8, col c%8
-  uint4 ra[4], rw[4];
-  auto load_global = [&](int ks) {
-    const int64_t kb0 = (int64_t)ks * BKB;
+  // staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write pass.
+  // One wave-instruction moves 64 x 16 B = 8 rows x 128 B into a lane-linear 1-KiB LDS span, so the XOR swizzle
+  // that keeps the ds_read_b128 fragment reads conflict-free is applied to the per-lane GLOBAL source address:
+  // LDS slot (row, s) holds global chunk s ^ ((row >> 1) & 7) of that row (an involution, also used by the reads).
+  // Each thread issues 4 pieces of A and 4 of W per K step (chunk c = tid + i*256: row c/8, slot c%8).
+  const uint8_t* ga[NST];
+  const uint8_t* gw[NST];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 256, row = c >> 3, col = c & 7;
-      const int64_t kb = kb0 + col * 16;
-      int ar = m0 + row; ar = ar < M ? ar : M - 1;
-      int wr = n0 + row; wr = wr < N ? wr : N - 1;
-      if (kb + 16 <= Kb) {
-        ra[i] = *reinterpret_cast<const uint4*>(A + (int64_t)ar * Kb + kb);
-        rw[i] = *reinterpret_cast<const uint4*>(W + (int64_t)wr * Kb + kb);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-        rw[i] = make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  auto write_lds = [&](int buf) {
+  for (int i = 0; i < NST; ++i) {
+    const int c = tid + i * 256, row = c / CPR, slot = c % CPR;
+    const int col = slot ^ SW(row);
+    int ar = m0 + row; ar = ar < M ? ar : M - 1;
+    int wr = n0 + row; wr = wr < N ? wr : N - 1;
+    ga[i] = A + (int64_t)ar * Kb + col * 16;
+    gw[i] = W + (int64_t)wr * Kb + col * 16;
+  }
+  auto stage = [&](int ks, int buf) {
+    const int64_t kb0 = (int64_t)ks * KB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 256, row = c >> 3, col = c & 7;
-      const int off = row * BKB + ((col ^ ((row >> 1) & 7)) << 4);
-      *reinterpret_cast<uint4*>(&lds[buf][0][off]) = ra[i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][off]) = rw[i];
+    for (int i = 0; i < NST; ++i) {
+      // wave-uniform LDS base of this instruction's 1-KiB span: (wave + 4*i) * 1024
+      uint8_t* la = &lds[buf][0][(wave + 4 * i) * 1024];
+      uint8_t* lw = &lds[buf][1][(wave + 4 * i) * 1024];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + kb0),
+                                       (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[i] + kb0),
+                                       (__attribute__((address_space(3))) void*)lw, 16, 0, 0);
     }
   };
 
@@ -195,32 +212,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const uint8_t* __restrict_
     for (int j = 0; j < 2; ++j) acc[i][j] = MT::zero();
 
   if (ks_begin < ks_end) {
-    load_global(ks_begin);
-    write_lds(0);
-    __syncthreads();
+    stage(ks_begin, 0);
+    __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
     int cur = 0;
     for (int ks = ks_begin; ks < ks_end; ++ks) {
       const bool more = ks + 1 < ks_end;
-      if (more) load_global(ks + 1);
+      if (more) stage(ks + 1, cur ^ 1);
       const uint8_t* la = lds[cur][0];
       const uint8_t* lw = lds[cur][1];
+      // all 16 fragment reads of the K step are issued before the first MFMA (the sched_barrier keeps hipcc from
+      // sinking them next to their consumers, which exposes one LDS latency per MFMA pair); the MFMAs then start
+      // on counted lgkmcnt as the fragments land, and the second wave of the SIMD fills the gaps
+      uint4 fa[KB / 32][2], fw[KB / 32][2];
 #pragma unroll
-      for (int kk = 0; kk < BKB / 32; ++kk) {
-        uint4 fa[2], fw[2];
+      for (int kk = 0; kk < KB / 32; ++kk) {
         const int chunk = kk * 2 + (lane >> 5);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int rowa = wm * 64 + t * 32 + (lane & 31);
-          fa[t] = *reinterpret_cast<const uint4*>(la + rowa * BKB + ((chunk ^ ((rowa >> 1) & 7)) << 4));
+          fa[kk][t] = *reinterpret_cast<const uint4*>(la + rowa * KB + ((chunk ^ SW(rowa)) << 4));
           const int roww = wn * 64 + t * 32 + (lane & 31);
-          fw[t] = *reinterpret_cast<const uint4*>(lw + roww * BKB + ((chunk ^ ((roww >> 1) & 7)) << 4));
+          fw[kk][t] = *reinterpret_cast<const uint4*>(lw + roww * KB + ((chunk ^ SW(roww)) << 4));
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < KB / 32; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = MT::mma(fa[i], fw[j], acc[i][j]);
-      }
-      if (more) write_lds(cur ^ 1);
+          for (int j = 0; j < 2; ++j) acc[i][j] = MT::mma(fa[kk][i], fw[kk][j], acc[i][j]);
       __syncthreads();
       cur ^= 1;
     }
@@ -341,6 +362,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
     w_off[i] = (int)((int64_t)wr * Kb + col * 16);
     lds_off_w[i] = live ? A_BYTES + row * BKB + ((col ^ ((row >> 1) & 7)) << 4) : -1;
   }
+#ifdef XM_ABL_NO_LOAD  /* ablation build: no global loads at all */
+#define XM_SK_LOAD(KS, AR, WR)                                                                     \
+  {                                                                                                \
+    static_for<NLA>([&](auto I_) { AR[I_] = u32x4{1u, 2u, 3u, (unsigned)(KS)}; });                 \
+    static_for<NLW>([&](auto I_) { WR[I_] = u32x4{1u, 2u, 3u, (unsigned)(KS)}; });                 \
+  }
+#else
 #define XM_SK_LOAD(KS, AR, WR)                                                                     \
   {                                                                                                \
     int ks_ = (KS) + phase;                                                                        \
@@ -349,6 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
     static_for<NLA>([&](auto I_) { AR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off[I_], kb0_, 0); }); \
     static_for<NLW>([&](auto I_) { WR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[I_], kb0_, 0); }); \
   }
+#endif
 #define XM_SK_WRITE(BUF, AR, WR)                                                                   \
   {                                                                                                \
     static_for<NLA>([&](auto I_) { *reinterpret_cast<u32x4*>(&lds[BUF][lds_off_a[I_]]) = AR[I_]; });               \
@@ -378,7 +407,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
         const int roww = j * 32 + (lane & 31);
         const uint4 fw = *reinterpret_cast<const uint4*>(lw + roww * BKB + ((chunk ^ ((roww >> 1) & 7)) << 4));
 #pragma unroll
-        for (int t = 0; t < MT_PER_WAVE; ++t) acc[t][j] = MT::mma(fa[t], fw, acc[t][j]);
+        for (int t = 0; t < MT_PER_WAVE; ++t) {
+#ifdef XM_ABL_NO_MFMA
+          asm volatile("" ::"v"(fa[t].x), "v"(fw.x));  // ablation build: keep the LDS reads, drop the MFMA
+#else
+          acc[t][j] = MT::mma(fa[t], fw, acc[t][j]);
+#endif
+        }
       }
     }
   };
@@ -563,6 +598,221 @@ int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// "W-direct" kernel: 256 x 256 block tile, 8 waves as 2 (m) x 4 (n), each wave 128 rows x 64 columns.
+// Round-1 ablations of the skinny kernel (profiles/r01_gemm_ablation.txt) showed that with BOTH the global
+// loads and the MFMAs removed it still took 60-85 % of its time: the LDS staging itself (52 KiB written +
+// 192 KiB read + two barriers per K step) was the bound. Here
+//   * only the A operand (activations, L2 resident) goes through LDS: 32 KiB written per K step, three
+//     buffers, ONE barrier per K step;
+//   * the weight rows of a wave stream HBM -> VGPR directly in MFMA B-fragment layout (lane = row, 16
+//     contiguous K bytes), two register stages, issued right after the MFMAs that consumed the old stage:
+//     no LDS traffic, no barrier dependency for the HBM stream;
+//   * a wave computes 4 x 2 MFMA tiles per 32-byte K slice from 4 LDS fragment reads (0.5 LDS reads per
+//     MFMA instead of 1.2), accumulators in AGPRs.
+// grid.x = n tiles (256 columns), grid.y = m tiles (256 rows), grid.z = int8 split-K slices.
+// ------------------------------------------------------------------------------------------------
+constexpr int WD_BM = 256, WD_BN = 256, WD_THREADS = 512, WD_NBUF = 3;
+
+template <int KIND, bool SPLITK>
+__global__ __launch_bounds__(WD_THREADS, 2) void gemm_wdirect_kernel(const uint8_t* __restrict__ A,
+                                                                    const uint8_t* __restrict__ W, int M, int N,
+                                                                    int64_t Kb, int ksteps_per_split, GemmEpi epi) {
+  using MT = MmaTraits<KIND>;
+  using acc_t = typename MT::acc_t;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int A_BYTES = WD_BM * BKB;                 // 32 KiB per K step
+  constexpr int NLA = A_BYTES / 16 / WD_THREADS;        // 4 chunks per thread
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WD_NBUF][A_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int n0 = blockIdx.x * WD_BN, m0 = blockIdx.y * WD_BM;
+  const int total_ksteps = (int)(Kb / BKB);
+  const int ks_begin = blockIdx.z * ksteps_per_split;
+  int ks_end = ks_begin + ksteps_per_split;
+  ks_end = ks_end > total_ksteps ? total_ksteps : ks_end;
+  const int nsteps = ks_end - ks_begin;
+  if (nsteps <= 0) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
+  int a_off[NLA], lds_off_a[NLA];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int c = tid + i * WD_THREADS, row = c >> 3, col = c & 7;
+    int ar = m0 + row; ar = ar < M ? ar : M - 1;
+    a_off[i] = (int)((int64_t)ar * Kb + col * 16);
+    lds_off_a[i] = row * BKB + ((col ^ ((row >> 1) & 7)) << 4);
+  }
+  int w_off[2];  // this lane's two weight rows (one per 32-column tile), + its 16-byte half of a 32-byte K slice
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int wr = n0 + wn * 64 + j * 32 + (lane & 31);
+    wr = wr < N ? wr : N - 1;
+    w_off[j] = (int)((int64_t)wr * Kb + (lane >> 5) * 16);
+  }
+  // LDS fragment offsets of the 4 m-tiles of this wave for the 4 K slices of a step (swizzled, precomputed)
+  int fa_off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) fa_off[t] = (wm * 128 + t * 32 + (lane & 31)) * BKB;
+  const int fa_sw = ((lane & 31) >> 1) & 7;  // (row >> 1) & 7 with row = ...*32 + (lane & 31)
+
+  u32x4 a0[NLA], a1[NLA];     // A register stages (ping-pong by step parity)
+  u32x4 w0[8], w1[8];          // W register stages: [j * 4 + kk]
+  acc_t acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[t][j] = MT::zero();
+
+#define XM_WD_LOAD_A(STEP, AR)                                                                                  \
+  {                                                                                                             \
+    int ks_ = ks_begin + (STEP);                                                                                \
+    ks_ = ks_ < ks_end ? ks_ : ks_end - 1;                                                                      \
+    const int kb0_ = ks_ * BKB;                                                                                 \
+    static_for<NLA>([&](auto I_) { AR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off[I_], kb0_, 0); }); \
+  }
+#define XM_WD_LOAD_W(STEP, WR)                                                                                  \
+  {                                                                                                             \
+    int ks_ = ks_begin + (STEP);                                                                                \
+    ks_ = ks_ < ks_end ? ks_ : ks_end - 1;                                                                      \
+    const int kb0_ = ks_ * BKB;                                                                                 \
+    static_for<8>([&](auto I_) {                                                                                \
+      WR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[I_ / 4], kb0_ + (I_ % 4) * 32, 0);          \
+    });                                                                                                         \
+  }
+#define XM_WD_WRITE_A(BUF, AR) \
+  static_for<NLA>([&](auto I_) { *reinterpret_cast<u32x4*>(&lds[BUF][lds_off_a[I_]]) = AR[I_]; });
+#define XM_WD_COMPUTE(BUF, WR)                                                                                  \
+  {                                                                                                             \
+    const uint8_t* la_ = lds[BUF];                                                                              \
+    static_for<4>([&](auto KK_) {                                                                               \
+      const int chunk_ = ((KK_ * 2 + (lane >> 5)) ^ fa_sw) << 4;                                                \
+      uint4 fa_[4];                                                                                             \
+      static_for<4>([&](auto T_) { fa_[T_] = *reinterpret_cast<const uint4*>(la_ + fa_off[T_] + chunk_); });    \
+      static_for<2>([&](auto J_) {                                                                              \
+        uint4 fw_;                                                                                              \
+        __builtin_memcpy(&fw_, &WR[J_ * 4 + KK_], 16);                                                          \
+        static_for<4>([&](auto T_) { acc[T_][J_] = MT::mma(fa_[T_], fw_, acc[T_][J_]); });                      \
+      });                                                                                                       \
+    });                                                                                                         \
+  }
+
+  // prologue: A(0) -> LDS buf 0, A(1) in a1, W(0) in w0, W(1) in w1
+  XM_WD_LOAD_A(0, a0)
+  XM_WD_LOAD_W(0, w0)
+  XM_WD_LOAD_A(1, a1)
+  XM_WD_LOAD_W(1, w1)
+  XM_WD_WRITE_A(0, a0)
+  __syncthreads();
+  // step i (parity p): refill A regs p with A(i+2); compute stage i (LDS buf i%3, W regs p); refill W regs p
+  // with W(i+2); publish A(i+1) (regs 1-p) into LDS buf (i+1)%3; one barrier.
+  int i = 0, buf = 0;
+  while (true) {
+    {
+      XM_WD_LOAD_A(i + 2, a0)
+      XM_WD_COMPUTE(buf, w0)
+      XM_WD_LOAD_W(i + 2, w0)
+      const int nb = buf == WD_NBUF - 1 ? 0 : buf + 1;
+      if (i + 1 < nsteps) XM_WD_WRITE_A(nb, a1)
+      __syncthreads();
+      buf = nb;
+      if (++i >= nsteps) break;
+    }
+    {
+      XM_WD_LOAD_A(i + 2, a1)
+      XM_WD_COMPUTE(buf, w1)
+      XM_WD_LOAD_W(i + 2, w1)
+      const int nb = buf == WD_NBUF - 1 ? 0 : buf + 1;
+      if (i + 1 < nsteps) XM_WD_WRITE_A(nb, a0)
+      __syncthreads();
+      buf = nb;
+      if (++i >= nsteps) break;
+    }
+  }
+#undef XM_WD_LOAD_A
+#undef XM_WD_LOAD_W
+#undef XM_WD_WRITE_A
+#undef XM_WD_COMPUTE
+
+  // epilogue: C tile layout col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    float ws = 1.0f, bs = 0.0f;
+    if constexpr (!SPLITK) {
+      if constexpr (KIND == kI8) ws = epi.w_scale[n];
+      if constexpr (KIND == kFP8) ws = epi.w_scale[epi.w_scale_n > 1 ? n : 0];
+      if (epi.bias) bs = load16(epi.bias, n, epi.out_bf16);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= M) continue;
+        const int64_t idx = (int64_t)m * N + n;
+        if constexpr (KIND == kI8) {
+          const int a = acc[t][j][r];
+          if constexpr (SPLITK) {
+            atomicAdd(epi.acc_out + idx, a);
+          } else {
+            if (epi.acc_out) epi.acc_out[idx] = a;
+            if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
+          }
+        } else if constexpr (KIND == kFP8) {
+          const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
+          store16(epi.out, idx, as * (ws * acc[t][j][r]) + bs, epi.out_bf16);
+        } else {
+          store16(epi.out, idx, acc[t][j][r] + bs, epi.out_bf16);
+        }
+      }
+  }
+}
+
+static int g_wd_enable = -2, g_wd_splits = -2;
+
+template <int KIND>
+int launch_wdirect(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                   size_t ws_bytes, hipStream_t s) {
+  const int ksteps = (int)(Kb / BKB);
+  const int64_t n_tiles = (N + WD_BN - 1) / WD_BN, m_tiles = (M + WD_BM - 1) / WD_BM;
+  int splits = 1;
+  const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
+  if (can_split) {
+    splits = (int)(256 / (n_tiles * m_tiles));
+    const int by_k = ksteps / 8 > 0 ? ksteps / 8 : 1;
+    splits = splits > by_k ? by_k : splits;
+    splits = splits < 1 ? 1 : (splits > 32 ? 32 : splits);
+    if (g_wd_splits > 0) splits = g_wd_splits;
+  }
+  int per = (ksteps + splits - 1) / splits;
+  splits = (ksteps + per - 1) / per;
+  const dim3 grid((unsigned)n_tiles, (unsigned)m_tiles, (unsigned)splits);
+  if (splits > 1) {
+    if constexpr (KIND == kI8) {
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+      hipLaunchKernelGGL((gemm_wdirect_kernel<KIND, true>), grid, dim3(WD_THREADS), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
+      int64_t blocks = (M * N + 255) / 256;
+      blocks = blocks > 1024 ? 1024 : blocks;
+      hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         reinterpret_cast<int32_t*>(workspace), M, N, epi);
+    }
+  } else {
+    hipLaunchKernelGGL((gemm_wdirect_kernel<KIND, false>), grid, dim3(WD_THREADS), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)W, (int)M, (int)N, Kb, per, epi);
+  }
+  return hip_check_launch();
+}
+
 template <int KIND>
 int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                 size_t ws_bytes, hipStream_t s) {
@@ -574,6 +824,15 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   // decode-shaped problems take the skinny kernel (32-bit buffer offsets: operands < 2 GiB); for the 16-bit / fp8
   // kinds only while the general kernel's 128x128 grid would under-fill the chip (measured at M=256: lm_head
   // 436 vs 553 us, bf16 gate_up 119 vs 146 us in favour of the general kernel)
+  if (g_wd_enable == -2) {
+    const char* e = getenv("XLLM_MI355_WDIRECT");
+    g_wd_enable = e ? atoi(e) : 0;
+    e = getenv("XLLM_MI355_WDIRECT_SPLITS");
+    g_wd_splits = e ? atoi(e) : -1;
+  }
+  if (g_wd_enable && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts &&
+      (g_wd_enable == 2 || N >= 8192 || Kb >= 8192))
+    return launch_wdirect<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
   const bool skinny_pays = KIND == kI8 || ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 256;
   if (M <= 512 && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && skinny_pays && !g_sk_disable)
     return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
@@ -592,14 +851,18 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   }
   const int per = (ksteps + splits - 1) / splits;
   splits = (ksteps + per - 1) / per;
-  const dim3 grid((unsigned)(m_tiles * n_tiles), 1, (unsigned)splits);
+  // rasterised grid (see the kernel): super-blocks of 8x8 tiles, padded to a multiple of 8 super-blocks
+  const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+  const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (6 - lm)) - 1) >> (6 - lm));
+  const unsigned raster_blocks = (unsigned)(((n_sb + 7) / 8) * 8 * 64);
+  const dim3 grid(splits > 1 ? (unsigned)(m_tiles * n_tiles) : raster_blocks, 1, (unsigned)splits);
   if (splits > 1) {
     if constexpr (KIND == kI8) {
       // invariant: the registered workspace is all-zero between calls (zero-filled at registration, re-zeroed
       // by the dequant epilogue below), so no memset launch is needed here
       GemmEpi e2 = epi;
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);
-      hipLaunchKernelGGL((gemm_kernel<KIND, true>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+      hipLaunchKernelGGL((gemm_kernel<KIND, true, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
                          (int)M, (int)N, Kb, m_tiles, n_tiles, per, e2);
       int64_t blocks = (M * N + 255) / 256;
       blocks = blocks > 2048 ? 2048 : blocks;
@@ -607,8 +870,16 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
                          reinterpret_cast<int32_t*>(workspace), M, N, epi);
     }
   } else {
-    hipLaunchKernelGGL((gemm_kernel<KIND, false>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
-                       (int)N, Kb, m_tiles, n_tiles, per, epi);
+    // K step 64 B + 4 workgroups per CU (4 waves/SIMD) measured +17 % over 128 B + 2 workgroups at M = 8192
+    // (profiles/r01_gemm_notes.txt): more independent waves hide the stage -> barrier -> read -> MFMA chain
+    static int kb64 = -2;
+    if (kb64 == -2) { const char* e = getenv("XLLM_MI355_GEMM_KB64"); kb64 = e ? atoi(e) : 1; }
+    if (kb64 && Kb % 64 == 0)
+      hipLaunchKernelGGL((gemm_kernel<KIND, false, 64, 4>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                         (int)M, (int)N, Kb, m_tiles, n_tiles, per * 2, epi);
+    else
+      hipLaunchKernelGGL((gemm_kernel<KIND, false, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                         (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   }
   return hip_check_launch();
 }
@@ -637,7 +908,7 @@ int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_sc
   if (out && (!a_scale || !w_scale)) return XM_ERR_INVALID;
   if (!out && !acc_out) return XM_ERR_INVALID;
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
-  if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
   return launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
 }
@@ -648,7 +919,7 @@ int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float
   if (!a || !w || !a_scale || !w_scale || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if ((a_scale_numel != 1 && a_scale_numel != M) || (w_scale_numel != 1 && w_scale_numel != N)) return XM_ERR_INVALID;
-  if (K % 16 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
   GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16, nullptr, 0};
   return launch_gemm<kFP8>(a, w, M, N, K, epi, nullptr, 0, (hipStream_t)stream);
 }
@@ -657,7 +928,7 @@ int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out,
                       int dtype, void* stream) {
   if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
-  if (K % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (K % 64 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16, nullptr, 0};
   if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
   return launch_gemm<kF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
@@ -667,7 +938,7 @@ int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_cou
                           int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream) {
   if (!a || !w || !token_count || !out || max_rows < 0 || n_experts <= 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
-  if (K % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (K % 64 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
   if (max_rows == 0) return XM_OK;
   GemmEpi epi{nullptr, 0, nullptr, 0, nullptr, out, nullptr, dtype == XM_BF16, token_count, (int)n_experts};
   // worst case number of 128-row tiles over all experts: every expert may waste < 1 tile
@@ -677,10 +948,10 @@ int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_cou
   const dim3 grid((unsigned)(m_tiles * n_tiles), 1, 1);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == XM_BF16)
-    hipLaunchKernelGGL((gemm_kernel<kBF16, false>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
+    hipLaunchKernelGGL((gemm_kernel<kBF16, false, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
                        (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);
   else
-    hipLaunchKernelGGL((gemm_kernel<kF16, false>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
+    hipLaunchKernelGGL((gemm_kernel<kF16, false, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
                        (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);
   return hip_check_launch();
 }
