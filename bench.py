@@ -43,8 +43,13 @@ def parse():
     p.add_argument("--no-fuse", action="store_true", help="reference op order without the N1 quant fusions")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    p.add_argument("--graph", action="store_true",
+                   help="multi-GPU: also capture the RCCL collectives into the HIP graph (default for N>1 is eager "
+                        "launches: a failed capture of a collective cannot be recovered from inside the process)")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
                    help="single GPU: run ONE rank's shard of a TP=k job with the collectives stubbed (tuning aid)")
     return p.parse_args()
@@ -145,12 +150,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % ndev  # gloo self-test: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from xllm_amd import layers, parallel
     from xllm_amd.attention import KVCache
@@ -221,7 +231,8 @@ def main():
     # decode runs under HIP-graph replay in the reference (runtime/dcu_graph_executor_impl.h): capture one step
     # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
     graph = None
-    if not a.no_graph:
+    use_graph = (not a.no_graph) and (world == 1 or a.graph) and a.backend == "nccl"
+    if use_graph:
         try:
             cap_stream = torch.cuda.Stream()
             cap_stream.wait_stream(torch.cuda.current_stream())

@@ -21,8 +21,10 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
 
 static int g_split_override = -2;  // -2: env not read yet; -1: no override
 
-// grid-level split-KV count of the decode kernel. Target: >= 512 resident workgroups (2 per CU, all
-// co-resident: one wave of work, no tail), every wave keeping >= 8 tiles of 32 tokens.
+// grid-level split-KV count of the decode kernel. Target: ~256 workgroups = ONE per CU (4 waves each, 16-32 KiB
+// in flight per wave): the round-1 sweep (tools/attn_bench.py, profiles/r01_attn_split_sweep.txt) shows that
+// fewer, longer token streams beat more resident waves (no split at B*nkv/hpw >= 256: 5.90 TB/s vs 5.62 TB/s
+// with 2 splits; B=64: 4 splits best), every wave keeping >= 8 tiles of 32 tokens.
 int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len) {
   if (g_split_override == -2) {
     const char* e = getenv("XLLM_MI355_DECODE_SPLITS");
@@ -36,12 +38,21 @@ int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len) {
   int64_t n;
   if (g_split_override > 0) n = g_split_override;
   else {
-    n = (512 + base - 1) / base;
+    n = (256 + base - 1) / base;
     if (n > by_len) n = by_len;
   }
   if (n > 32) n = 32;
   if (n < 1) n = 1;
   return (int)n;
+}
+
+static int g_deep = -2;
+bool decode_deep_prefetch() {
+  if (g_deep == -2) {
+    const char* e = getenv("XLLM_MI355_DECODE_DEEP");
+    g_deep = e ? atoi(e) : 0;  // round-1 A/B: 3 stages 5.87 TB/s vs 2 stages 5.93 TB/s (profiles/r01_attn_split_sweep.txt)
+  }
+  return g_deep != 0;
 }
 
 }  // namespace xm

@@ -65,8 +65,8 @@ constexpr int kTile = 32;         // tokens per tile (= K dim of the PV MFMA)
 constexpr float kNegBig = -1e30f;  // finite "-inf" for the running max (log2 domain)
 
 // D = head dim (K and V), UNIFORM: block_size % 32 == 0 so a tile lives in one page
-template <typename T, int D, bool UNIFORM>
-__global__ __launch_bounds__(256, 2) void paged_decode_kernel(
+template <typename T, int D, bool UNIFORM, bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, T* __restrict__ out,
     float* __restrict__ part_o, float* __restrict__ part_ml, const int32_t* __restrict__ cu_q,
     const int32_t* __restrict__ kv_lens, const int32_t* __restrict__ block_table, int max_blocks, int nq,
@@ -132,8 +132,13 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
   for (int i = 0; i < DB; ++i) acc_o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = kNegBig, l_run = 0.0f;
 
-  x8 kreg[2][KK], kreg_n[2][KK];
-  uint4 vreg[NV], vreg_n[NV];
+  // K/V register stages: named (never runtime-indexed) so they stay in VGPRs; native vector types so hipcc
+  // emits plain 16-byte loads/stores (no memcpy allocas). DEEP: three stages = two tiles (32 KiB) in flight per
+  // wave while the third is computed -- with ONE workgroup per CU (the best split count, see attention_api.hip)
+  // a wave may use up to 512 registers.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  x8 k0[2][KK], k1[2][KK], k2[2][KK];
+  u32x4 v0[NV], v1[NV], v2[NV];
 
   auto page_of_tile = [&](int tile) -> int {  // UNIFORM only: scalar page id of a tile (clamped)
     int idx = (tile * kTile) / block_size;
@@ -142,7 +147,10 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
     idx = idx < 0 ? 0 : idx;
     return bt_row[idx];
   };
-  auto issue_loads = [&](int tile, int page, x8 (&kr)[2][KK], uint4 (&vr)[NV]) {
+  // every load is unconditional (tiles past the range re-load the last tile, tokens past kv_len the last token):
+  // a branch around a load would make hipcc fall back to s_waitcnt vmcnt(0) and collapse the prefetch depth
+  auto issue_loads = [&](int tile, int page, x8 (&kr)[2][KK], u32x4 (&vr)[NV]) {
+    tile = tile < my_hi ? tile : my_hi - 1;
     const int t0 = tile * kTile;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -162,99 +170,124 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
       int64_t rowi;
       if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
       else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
-      vr[i] = *reinterpret_cast<const uint4*>(vc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8);
+      vr[i] = *reinterpret_cast<const u32x4*>(vc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8);
+    }
+  };
+  auto page_clamped = [&](int tile) -> int {
+    if constexpr (UNIFORM) return page_of_tile(tile < my_hi ? tile : my_hi - 1);
+    else return 0;
+  };
+
+  auto compute_tile = [&](int tile, const x8 (&kr)[2][KK], const u32x4 (&vr)[NV]) {
+    const int t0 = tile * kTile;
+    const bool partial = (t0 + kTile > kv_len) || (t0 < t_lo);
+
+    // ---- V tile -> wave-private LDS (row major, padded rows); invalid rows zeroed (0 * NaN guard)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int r = i * TPI + lane / CH;
+      u32x4 v = vr[i];
+      if (partial && (t0 + r >= kv_len)) v = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(my_lds + r * RSB + (lane % CH) * 16) = v;
+    }
+
+    // ---- S^T = K * Q^T : lane holds S[q = p16][token = blk*16 + 4g + r]
+    f32x4_t s[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      s[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) s[blk] = TR::mfma(kr[blk][kk], qf[kk], s[blk]);
+    }
+    // ---- online softmax (log2 domain), lane-local except the 2 cross-group maxima
+    float mx = kNegBig;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[blk][r] * scale_log2;
+        if (partial) {
+          const int tok = t0 + blk * 16 + g * 4 + r;
+          if (tok >= kv_len || tok < t_lo) v = -INFINITY;
+        }
+        s[blk][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    // P is fed to the matrix core as hi + lo 16-bit parts (p = hi + lo to ~2^-17 relative): the PV MFMAs
+    // are idle-cheap in this HBM-bound kernel and the output then matches an fp32-P reference to rounding.
+    x8 pf, pl;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s[blk][r] - m_new);
+        psum += p;
+        const elem hi = (elem)p;
+        pf[blk * 4 + r] = hi;
+        pl[blk * 4 + r] = (elem)(p - (float)hi);
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
+
+    // ---- O^T += V^T * P^T : A = V^T via transposed LDS reads, k slot (g, j): j<4 -> token 4g+j,
+    //      j>=4 -> token 16+4g+(j-4), matching the P fragment above
+    const char* trb = my_lds + (4 * g + (p16 >> 2)) * RSB + (p16 & 3) * 8;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      x4 lo = TR::tr_read(trb + db * 32);
+      x4 hi = TR::tr_read(trb + 16 * RSB + db * 32);
+      x8 vt;
+      vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
+      vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
+      acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
+      acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
     }
   };
 
   if (my_lo < my_hi) {
-    int page_b = 0, page_c = 0;
-    if constexpr (UNIFORM) {
-      page_b = page_of_tile(my_lo);
-      issue_loads(my_lo, page_b, kreg_n, vreg_n);
-      page_b = page_of_tile(my_lo + 1);
+    int tile = my_lo;
+    if constexpr (DEEP) {
+      int pg2 = page_clamped(my_lo + 2), pg3;
+      issue_loads(my_lo, page_clamped(my_lo), k0, v0);
+      issue_loads(my_lo + 1, page_clamped(my_lo + 1), k1, v1);
+      while (true) {
+        pg3 = page_clamped(tile + 3);
+        issue_loads(tile + 2, pg2, k2, v2);
+        compute_tile(tile, k0, v0);
+        pg2 = pg3;
+        if (++tile >= my_hi) break;
+        pg3 = page_clamped(tile + 3);
+        issue_loads(tile + 2, pg2, k0, v0);
+        compute_tile(tile, k1, v1);
+        pg2 = pg3;
+        if (++tile >= my_hi) break;
+        pg3 = page_clamped(tile + 3);
+        issue_loads(tile + 2, pg2, k1, v1);
+        compute_tile(tile, k2, v2);
+        pg2 = pg3;
+        if (++tile >= my_hi) break;
+      }
     } else {
-      issue_loads(my_lo, 0, kreg_n, vreg_n);
-    }
-    for (int tile = my_lo; tile < my_hi; ++tile) {
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kreg[blk][kk] = kreg_n[blk][kk];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) vreg[i] = vreg_n[i];
-      if constexpr (UNIFORM) page_c = page_of_tile(tile + 2);
-      if (tile + 1 < my_hi) issue_loads(tile + 1, page_b, kreg_n, vreg_n);
-      page_b = page_c;
-
-      const int t0 = tile * kTile;
-      const bool partial = (t0 + kTile > kv_len) || (t0 < t_lo);
-
-      // ---- V tile -> wave-private LDS (row major, padded rows); invalid rows zeroed (0 * NaN guard)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int r = i * TPI + lane / CH;
-        uint4 v = vreg[i];
-        if (partial && (t0 + r >= kv_len)) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(my_lds + r * RSB + (lane % CH) * 16) = v;
-      }
-
-      // ---- S^T = K * Q^T : lane holds S[q = p16][token = blk*16 + 4g + r]
-      f32x4_t s[2];
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        s[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) s[blk] = TR::mfma(kreg[blk][kk], qf[kk], s[blk]);
-      }
-      // ---- online softmax (log2 domain), lane-local except the 2 cross-group maxima
-      float mx = kNegBig;
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[blk][r] * scale_log2;
-          if (partial) {
-            const int tok = t0 + blk * 16 + g * 4 + r;
-            if (tok >= kv_len || tok < t_lo) v = -INFINITY;
-          }
-          s[blk][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.0f;
-      // P is fed to the matrix core as hi + lo 16-bit parts (p = hi + lo to ~2^-17 relative): the PV MFMAs
-      // are idle-cheap in this HBM-bound kernel and the output then matches an fp32-P reference to rounding.
-      x8 pf, pl;
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[blk][r] - m_new);
-          psum += p;
-          const elem hi = (elem)p;
-          pf[blk * 4 + r] = hi;
-          pl[blk * 4 + r] = (elem)(p - (float)hi);
-        }
-      l_run = l_run * alpha + psum;
-#pragma unroll
-      for (int i = 0; i < DB; ++i) acc_o[i] *= alpha;
-
-      // ---- O^T += V^T * P^T : A = V^T via transposed LDS reads, k slot (g, j): j<4 -> token 4g+j,
-      //      j>=4 -> token 16+4g+(j-4), matching the P fragment above
-      const char* trb = my_lds + (4 * g + (p16 >> 2)) * RSB + (p16 & 3) * 8;
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        x4 lo = TR::tr_read(trb + db * 32);
-        x4 hi = TR::tr_read(trb + 16 * RSB + db * 32);
-        x8 vt;
-        vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
-        vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
-        acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
-        acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
+      int pg1 = page_clamped(my_lo + 1), pg2;
+      issue_loads(my_lo, page_clamped(my_lo), k0, v0);
+      while (true) {
+        pg2 = page_clamped(tile + 2);
+        issue_loads(tile + 1, pg1, k1, v1);
+        compute_tile(tile, k0, v0);
+        pg1 = pg2;
+        if (++tile >= my_hi) break;
+        pg2 = page_clamped(tile + 2);
+        issue_loads(tile + 1, pg1, k0, v0);
+        compute_tile(tile, k1, v1);
+        pg1 = pg2;
+        if (++tile >= my_hi) break;
       }
     }
   }
@@ -314,6 +347,7 @@ __global__ void paged_decode_merge_kernel(const float* __restrict__ part_o, cons
 }
 
 int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len);
+bool decode_deep_prefetch();
 
 template <typename T, int D>
 int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
@@ -332,12 +366,16 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(batch * (nkv / hpw) * nsplit));
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
-  if (block_size % kTile == 0)
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+  if (block_size % kTile == 0 && decode_deep_prefetch())
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+  else if (block_size % kTile == 0)
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
   else
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, false, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
   if (nsplit > 1)
