@@ -214,6 +214,20 @@ def main():
         return out
 
     ops.paged_attention = timed_paged
+    orig_fused = ops.paged_decode_attention_int8
+
+    def timed_fused(*args, **kw):  # the N1-fused decode attention (same kernel, int8 epilogue)
+        if not record["on"]:
+            return orig_fused(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_fused(*args, **kw)
+        e1.record()
+        if out is not None:
+            attn_events.append((e0, e1))
+        return out
+
+    ops.paged_decode_attention_int8 = timed_fused
 
     def step():
         hidden = model.forward(tokens, positions, md, kv_caches)
@@ -302,7 +316,7 @@ def main():
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
                        "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
                        "quant_fusion": not a.no_fuse, "hip_graph": graph is not None},
-            "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+split-KV merge)",
+            "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ split-KV merge when the launch splits)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4),

@@ -182,6 +182,29 @@ XM_API int xllm_mi355_paged_attention(const void* q, const void* k_cache, const 
                                       int64_t q_stride, int64_t max_q_len, int64_t max_kv_len,
                                       float scale, int causal, int64_t window_left, int dtype,
                                       void* workspace, size_t workspace_bytes, void* stream);
+/* N1 fusion (decode): paged attention whose epilogue also emits the per-token int8 quantisation of its 16-bit
+ * output -- the operand of the w8a8-dynamic o_proj (linear.cpp:481-507 would call scaled_quantize next).
+ * out (16-bit, may be NULL), out_q [B, nq*d] int8, out_scale [B] f32; bit-identical to paged_attention followed by
+ * scaled_quantize. Returns XM_ERR_UNSUPPORTED when the launch would need split-KV (small batches): the caller
+ * then uses the two-operator sequence. No workspace. */
+XM_API int xllm_mi355_paged_decode_attention_int8(const void* q, const void* k_cache, const void* v_cache,
+                                                  void* out, int8_t* out_q, float* out_scale,
+                                                  const int32_t* kv_lens, const int32_t* block_table,
+                                                  int64_t max_blocks, int64_t batch, int64_t n_q_heads,
+                                                  int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                                                  int64_t q_stride, int64_t max_kv_len, float scale,
+                                                  int64_t window_left, int dtype, void* stream);
+/* N1 fusion: RoPE (apply_rotary) + KV write (reshape_paged_cache) in one pass over the packed qkv row:
+ * q and k are rotated in place, the rotated k and v are scattered to the caches at slot_ids. Bit-identical to the
+ * two-operator sequence (cf. the MLA fused_mla_kv of param.h:1105-1178). */
+XM_API int xllm_mi355_rotary_embedding_and_cache(const int64_t* positions, void* q, void* k, const void* v,
+                                                 const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache,
+                                                 void* v_cache, int64_t n_tokens, int64_t n_q_heads,
+                                                 int64_t n_kv_heads, int64_t head_size, int64_t rot_dim,
+                                                 int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                                 int64_t block_size, int64_t n_blocks, int is_neox, int dtype,
+                                                 void* stream);
+
 /* flash_mla::dense_decode (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] = [q_nope*W_kc || q_pe],
  * k_cache [n_blocks, block_size, 1, 576]; out [B, H, head_size_v] = softmax(scale q k^T) k[:, :512]. */
 XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,

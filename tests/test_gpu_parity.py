@@ -522,3 +522,57 @@ def test_moe_index_combine_group_gemm():
     outc = ops.moe_combine_result(g2.to(DEV), w.to(DEV), T, topk)
     refc = orc.moe_combine(g2, w.contiguous(), T, topk)
     assert_ulp_close(outc, refc, torch.bfloat16, ulps=1.0, min_exact=0.99)
+
+
+# ------------------------------------------------------------------------------------------- N1 fusions
+@pytest.mark.parametrize("d,mode", [(18944, "silu"), (4864, "silu"), (32000, "silu"), (1024, "gelu")])
+def test_act_and_mul_int8_fusion_equals_two_ops(d, mode):
+    T = 7
+    g = torch.Generator().manual_seed(d)
+    x = (torch.randn(T, 2 * d, generator=g) * 2).bfloat16().to(DEV)
+    act = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    ops.act_and_mul(act, x, mode)
+    q_ref, s_ref = ops.scaled_quantize(act)
+    q, s = ops.act_and_mul_dynamic_int8_quant(x, mode)
+    assert torch.equal(q, q_ref) and torch.equal(s, s_ref)
+
+
+@pytest.mark.parametrize("nq,nkv,bs", [(28, 4, 128), (14, 2, 128), (7, 1, 128), (14, 2, 16)])
+def test_decode_fusions_equal_unfused_ops(nq, nkv, bs):
+    """rotary_embedding_and_cache == rotary_embedding + reshape_paged_cache, and paged_decode_attention_int8 ==
+    paged_attention + scaled_quantize, bit for bit"""
+    B, d = 256, 128
+    kv_lens = [257 + 3 * i for i in range(B)]
+    md, kc, vc, _ = _paged_case(B, nq, nkv, d, bs, kv_lens, [1] * B, torch.bfloat16, seed=nq)
+    g = torch.Generator().manual_seed(nq + 100)
+    qkv = torch.randn(B, (nq + 2 * nkv) * d, generator=g).bfloat16()
+    cache = orc.build_cos_sin_cache(2048, d, 1e6, torch.bfloat16).to(DEV)
+    pos = torch.tensor([L - 1 for L in kv_lens], device=DEV)  # int64
+    slots = md["new_cache_slots"].to(DEV)
+    kv_d, bt = md["kv_seq_lens"].to(DEV), md["block_tables"].to(DEV)
+
+    def split(t):
+        return t[:, :nq * d], t[:, nq * d:(nq + nkv) * d], t[:, (nq + nkv) * d:]
+
+    a = qkv.to(DEV); kc_a, vc_a = kc.to(DEV), vc.to(DEV)
+    qa, ka, va = split(a)
+    ops.rotary_embedding(pos, qa, ka, cache, True, head_size=d)
+    ops.reshape_paged_cache(slots, ka.unflatten(-1, (nkv, d)), va.unflatten(-1, (nkv, d)), kc_a, vc_a)
+    out_a = ops.paged_attention(qa.unflatten(-1, (nq, d)), kc_a, vc_a, None, kv_d, bt, 1, max(kv_lens), d ** -0.5)
+    qa_q, qa_s = ops.scaled_quantize(out_a)
+
+    b = qkv.to(DEV); kc_b, vc_b = kc.to(DEV), vc.to(DEV)
+    qb, kb, vb = split(b)
+    ops.rotary_embedding_and_cache(pos, qb, kb, vb, cache, slots, kc_b, vc_b, d, True)
+    assert torch.equal(a, b) and torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
+    fused = ops.paged_decode_attention_int8(qb.unflatten(-1, (nq, d)), kc_b, vc_b, kv_d, bt, max(kv_lens), d ** -0.5,
+                                            want_16bit=True)
+    assert fused is not None
+    assert torch.equal(fused[2], out_a) and torch.equal(fused[0], qa_q) and torch.equal(fused[1], qa_s)
+
+
+def test_decode_int8_fusion_declines_split_kv_shapes():
+    md, kc, vc, q = _paged_case(2, 28, 4, 128, 128, [4096, 4096], [1, 1], torch.bfloat16, seed=1)
+    r = ops.paged_decode_attention_int8(q.to(DEV), kc.to(DEV), vc.to(DEV), md["kv_seq_lens"].to(DEV),
+                                        md["block_tables"].to(DEV), 4096, 128 ** -0.5)
+    assert r is None  # B=2 wants split-KV: the caller falls back to paged_attention + scaled_quantize

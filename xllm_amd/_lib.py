@@ -33,6 +33,10 @@ _SIGS = {
     "xllm_mi355_matmul": ([vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_prefill_attention": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, i64,
                                       ci, vp], ci),
+    "xllm_mi355_paged_decode_attention_int8": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
+                                                f32, i64, ci, vp], ci),
+    "xllm_mi355_rotary_embedding_and_cache": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
+                                               i64, i64, ci, ci, vp], ci),
     "xllm_mi355_paged_attention_workspace_bytes": ([i64, i64, i64, i64, i64], sz),
     "xllm_mi355_paged_attention": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                                     i64, f32, ci, i64, ci, vp, sz, vp], ci),

@@ -10,7 +10,8 @@ template <typename T, int D>
 int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
                         const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks, int64_t batch,
                         int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride, int64_t max_kv_len,
-                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s);
+                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s,
+                        int8_t* out_q, float* out_scale);
 
 template <typename T, int D, bool PAGED>
 int launch_flash_prefill(const void* q, const void* k, const void* v, void* out, const int32_t* cu_q,
@@ -89,7 +90,7 @@ int xllm_mi355_paged_attention(const void* q, const void* k_cache, const void* v
 #define XM_DECODE(T, DD)                                                                                        \
   return launch_paged_decode<T, DD>(q, k_cache, v_cache, out, cu_q, kv_lens, block_table, max_blocks, batch,    \
                                     n_q_heads, n_kv_heads, block_size, q_stride, max_kv_len, scale, window_left, \
-                                    workspace, ws, s)
+                                    workspace, ws, s, nullptr, nullptr)
     if (dtype == XM_BF16 && head_dim == 128) XM_DECODE(bf16_t, 128);
     if (dtype == XM_BF16 && head_dim == 64) XM_DECODE(bf16_t, 64);
     if (dtype == XM_F16 && head_dim == 128) XM_DECODE(f16_t, 128);
@@ -107,6 +108,31 @@ int xllm_mi355_paged_attention(const void* q, const void* k_cache, const void* v
   if (dtype == XM_F16 && head_dim == 128) XM_CHUNKED(f16_t, 128);
   if (dtype == XM_F16 && head_dim == 64) XM_CHUNKED(f16_t, 64);
 #undef XM_CHUNKED
+  return XM_ERR_UNSUPPORTED;
+}
+
+int xllm_mi355_paged_decode_attention_int8(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                           int8_t* out_q, float* out_scale, const int32_t* kv_lens,
+                                           const int32_t* block_table, int64_t max_blocks, int64_t batch,
+                                           int64_t n_q_heads, int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                                           int64_t q_stride, int64_t max_kv_len, float scale, int64_t window_left,
+                                           int dtype, void* stream) {
+  if (!q || !k_cache || !v_cache || !out_q || !out_scale || !kv_lens || !block_table) return XM_ERR_INVALID;
+  if (batch < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || block_size <= 0 || max_blocks <= 0)
+    return XM_ERR_INVALID;
+  if (batch == 0) return XM_OK;
+  if ((uintptr_t)q % 16 || (uintptr_t)k_cache % 16 || (uintptr_t)v_cache % 16 || q_stride % 8) return XM_ERR_UNSUPPORTED;
+  if (n_q_heads / n_kv_heads > 16) return XM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+#define XM_DECODEQ(T, DD)                                                                                            \
+  return launch_paged_decode<T, DD>(q, k_cache, v_cache, out, nullptr, kv_lens, block_table, max_blocks, batch,      \
+                                    n_q_heads, n_kv_heads, block_size, q_stride, max_kv_len, scale, window_left,     \
+                                    nullptr, 0, s, out_q, out_scale)
+  if (dtype == XM_BF16 && head_dim == 128) XM_DECODEQ(bf16_t, 128);
+  if (dtype == XM_BF16 && head_dim == 64) XM_DECODEQ(bf16_t, 64);
+  if (dtype == XM_F16 && head_dim == 128) XM_DECODEQ(f16_t, 128);
+  if (dtype == XM_F16 && head_dim == 64) XM_DECODEQ(f16_t, 64);
+#undef XM_DECODEQ
   return XM_ERR_UNSUPPORTED;
 }
 

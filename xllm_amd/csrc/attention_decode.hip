@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, T* __restrict__ out,
     float* __restrict__ part_o, float* __restrict__ part_ml, const int32_t* __restrict__ cu_q,
     const int32_t* __restrict__ kv_lens, const int32_t* __restrict__ block_table, int max_blocks, int nq,
-    int nkv, int block_size, int64_t q_stride, float scale_log2, int nsplit, int hpw, int window_left) {
+    int nkv, int block_size, int64_t q_stride, float scale_log2, int nsplit, int hpw, int window_left,
+    int8_t* __restrict__ out_q, float* __restrict__ out_scale) {
   using TR = AttnTraits<T>;
   using x8 = typename TR::x8;
   using x4 = typename TR::x4;
@@ -304,6 +305,46 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
   }
   __syncthreads();
   const int64_t qtok = cu_q ? cu_q[b] : b;
+  if (out_q) {
+    // N1 fusion: the workgroup holds ALL heads of this token (host guarantees nsplit == 1 and one head group),
+    // so the per-token int8 quantisation that feeds o_proj (scaled_quantize of the 16-bit output) is done here:
+    // pass 1 = 16-bit output + |max|, pass 2 = quantise. Bit-identical to paged_attention -> scaled_quantize.
+    __shared__ float red[32];
+    auto value = [&](int e, int& head, int& d) -> float {
+      const int h_s = e / (16 * D), qq = (e / D) & 15;
+      d = e % D;
+      head = h_s * G + qq;
+      if (qq >= G) return 0.0f;
+      float m_star = kNegBig;
+      for (int sb = 0; sb < nsub; ++sb) m_star = fmaxf(m_star, ml_sh[sb * hpw + h_s][qq][0]);
+      float o = 0.0f, l = 0.0f;
+      for (int sb = 0; sb < nsub; ++sb) {
+        const int w = sb * hpw + h_s;
+        const float f = exp2f(ml_sh[w][qq][0] - m_star);
+        o += f * reinterpret_cast<const float*>(lds + w * WAVE_LDS)[qq * D + d];
+        l += f * ml_sh[w][qq][1];
+      }
+      return r16<T>(l > 0.0f ? o / l : 0.0f);
+    };
+    float amax = 0.0f;
+    for (int e = threadIdx.x; e < hpw * 16 * D; e += 256) {
+      int head, d;
+      const float v = value(e, head, d);
+      if (((e / D) & 15) >= G) continue;
+      amax = fmaxf(amax, fabsf(v));
+      if (out) out[qtok * (int64_t)nq * D + (int64_t)head * D + d] = from_f32<T>(v);
+    }
+    amax = block_max(amax, red);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+    for (int e = threadIdx.x; e < hpw * 16 * D; e += 256) {
+      int head, d;
+      const float v = value(e, head, d);
+      if (((e / D) & 15) >= G) continue;
+      out_q[qtok * (int64_t)nq * D + (int64_t)head * D + d] = (int8_t)fmaxf(-127.0f, fminf(127.0f, rintf(v * qinv)));
+    }
+    if (threadIdx.x == 0) out_scale[qtok] = amax / 127.0f;
+    return;
+  }
   for (int e = threadIdx.x; e < hpw * 16 * D; e += 256) {
     const int h_s = e / (16 * D), qq = (e / D) & 15, d = e % D;
     if (qq >= G) continue;
@@ -353,9 +394,13 @@ template <typename T, int D>
 int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
                         const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks, int64_t batch,
                         int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride, int64_t max_kv_len,
-                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s) {
+                        float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s,
+                        int8_t* out_q, float* out_scale) {
   int hpw = nkv >= 4 && nkv % 4 == 0 ? 4 : (nkv % 2 == 0 ? 2 : 1);
   int nsplit = decode_num_splits(batch, nkv, hpw, max_kv_len);
+  // the fused int8 epilogue needs the whole token in one workgroup: decline shapes that want split-KV or have
+  // more than one head group (the caller then runs paged_attention + scaled_quantize)
+  if (out_q && (nsplit != 1 || nkv / hpw != 1)) return XM_ERR_UNSUPPORTED;
   // degrade the split count to what the caller's workspace holds (1 split needs none)
   const size_t per_split = (size_t)batch * nq * (D + 2) * sizeof(float);
   if (!workspace) ws_bytes = 0;
@@ -369,15 +414,15 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   if (block_size % kTile == 0 && decode_deep_prefetch())
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
   else if (block_size % kTile == 0)
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
   else
     hipLaunchKernelGGL((paged_decode_kernel<T, D, false, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl);
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
   if (nsplit > 1)
     hipLaunchKernelGGL((paged_decode_merge_kernel<T, D>), dim3((unsigned)(batch * nq)), dim3(D), 0, s, part_o,
                        part_ml, (T*)out, cu_q, (int)nq, nsplit);
@@ -386,15 +431,15 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
 
 template int launch_paged_decode<bf16_t, 128>(const void*, const void*, const void*, void*, const int32_t*,
                                               const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
-                                              int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+                                              int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t, int8_t*, float*);
 template int launch_paged_decode<bf16_t, 64>(const void*, const void*, const void*, void*, const int32_t*,
                                              const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
-                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t, int8_t*, float*);
 template int launch_paged_decode<f16_t, 128>(const void*, const void*, const void*, void*, const int32_t*,
                                              const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
-                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+                                             int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t, int8_t*, float*);
 template int launch_paged_decode<f16_t, 64>(const void*, const void*, const void*, void*, const int32_t*,
                                             const int32_t*, const int32_t*, int64_t, int64_t, int64_t, int64_t,
-                                            int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t);
+                                            int64_t, int64_t, int64_t, float, int64_t, void*, size_t, hipStream_t, int8_t*, float*);
 
 }  // namespace xm

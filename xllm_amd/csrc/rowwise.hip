@@ -264,6 +264,56 @@ __global__ __launch_bounds__(256) void rope_kernel(const int64_t* __restrict__ p
   }
 }
 
+// N1 fusion: RoPE on q,k (in place) + KV write of the rotated k and of v in one pass (one workgroup per token).
+// Same arithmetic as rope_kernel followed by reshape_paged_cache_kernel: bit-identical results.
+template <typename T, bool NEOX>
+__global__ __launch_bounds__(256) void rope_and_cache_kernel(
+    const int64_t* __restrict__ positions, T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
+    const T* __restrict__ cache, const int32_t* __restrict__ slot_ids, T* __restrict__ kc, T* __restrict__ vc,
+    int rot_dim, int64_t q_stride, int64_t k_stride, int64_t v_stride, int head_size, int nq, int nk,
+    int64_t block_size, int64_t n_blocks) {
+  const int64_t t = blockIdx.x;
+  const int half = rot_dim >> 1;
+  const T* cp = cache + positions[t] * rot_dim;
+  const int64_t slot = slot_ids[t];
+  const bool store = slot >= 0 && slot / block_size < n_blocks;
+  T* kc_row = kc + slot * (int64_t)nk * head_size;
+  T* vc_row = vc + slot * (int64_t)nk * head_size;
+  const int total = (nq + nk) * half;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int h = i / half, j = i - h * half;
+    const bool is_k = h >= nq;
+    T* arr = is_k ? k + t * k_stride + (int64_t)(h - nq) * head_size : q + t * q_stride + (int64_t)h * head_size;
+    const int xi = NEOX ? j : 2 * j, yi = NEOX ? half + j : 2 * j + 1;
+    const float c = to_f32(cp[j]), s = to_f32(cp[half + j]);
+    const float x = to_f32(arr[xi]), y = to_f32(arr[yi]);
+    const T nx = from_f32<T>(r16<T>(x * c) - r16<T>(y * s));
+    const T ny = from_f32<T>(r16<T>(y * c) + r16<T>(x * s));
+    arr[xi] = nx;
+    arr[yi] = ny;
+    if (is_k && store) {
+      kc_row[(h - nq) * head_size + xi] = nx;
+      kc_row[(h - nq) * head_size + yi] = ny;
+    }
+  }
+  if (!store) return;
+  // un-rotated tail of k (rot_dim < head_size) and the whole v row
+  const int tail = head_size - rot_dim;
+  for (int i = threadIdx.x; i < nk * tail; i += blockDim.x) {
+    const int h = i / tail, e = rot_dim + (i - h * tail);
+    kc_row[h * head_size + e] = k[t * k_stride + (int64_t)h * head_size + e];
+  }
+  const int row = nk * head_size;
+  const T* vs = v + t * v_stride;
+  if ((row * sizeof(T)) % 16 == 0 && ((uintptr_t)vs % 16 == 0) && ((uintptr_t)vc_row % 16 == 0)) {
+    const int nv = row * (int)sizeof(T) / 16;
+    for (int i = threadIdx.x; i < nv; i += blockDim.x)
+      reinterpret_cast<uint4*>(vc_row)[i] = reinterpret_cast<const uint4*>(vs)[i];
+  } else {
+    for (int i = threadIdx.x; i < row; i += blockDim.x) vc_row[i] = vs[i];
+  }
+}
+
 // fused per-head RMSNorm + RoPE inside packed qkv (reference: kernels/cuda/fused_qknorm_rope.cu:88-300)
 // one wave per (token, head); fp32 math, one 16-bit store. head_dim <= 256, multiple of 2.
 template <typename T, typename CT>
@@ -395,6 +445,63 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict_
     int8_t* o = out_q + t * (int64_t)d + (int64_t)c * N;
     if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
     else *reinterpret_cast<uint32_t*>(o) = pk[0];
+  }
+  if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
+}
+
+// register-resident variant for d <= 512 * 5 * 8 elements: every 16-byte load of the row is issued before the
+// first use (one HBM latency per row instead of one per loop trip), the 16-bit product stays in registers
+// between the amax reduction and the quantisation, no LDS staging.
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void act_and_mul_i8_reg_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
+                                                                 const T* __restrict__ in, int d) {
+  __shared__ float red[32];
+  constexpr int N = RowVec<T>::N;
+  constexpr int NVR = 5;
+  const int64_t t = blockIdx.x;
+  const T* x = in + t * 2 * (int64_t)d;
+  const T* y = x + d;
+  const int nvec = d / N;
+  RowVec<T> xv[NVR], yv[NVR];
+#pragma unroll
+  for (int i = 0; i < NVR; ++i) {
+    int c = threadIdx.x + i * 512;
+    c = c < nvec ? c : nvec - 1;  // clamped (unconditional) loads keep all of them in flight together
+    xv[i].raw = reinterpret_cast<const uint4*>(x)[c];
+    yv[i].raw = reinterpret_cast<const uint4*>(y)[c];
+  }
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NVR; ++i) {
+    const bool live = threadIdx.x + i * 512 < nvec;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float r = r16<T>(r16<T>(act_f<MODE>(xv[i].get(j))) * yv[i].get(j));
+      xv[i].set(j, r);
+      if (live) amax = fmaxf(amax, fabsf(r));
+    }
+  }
+  amax = block_max(amax, red);
+  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+  for (int i = 0; i < NVR; ++i) {
+    const int c = threadIdx.x + i * 512;
+    if (c < nvec) {
+      uint32_t pk[N / 4];
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv[i].get(j + e) * qinv)));
+          w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+        }
+        pk[j / 4] = w;
+      }
+      int8_t* o = out_q + t * (int64_t)d + (int64_t)c * N;
+      if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
+      else *reinterpret_cast<uint32_t*>(o) = pk[0];
+    }
   }
   if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
 }
@@ -660,6 +767,32 @@ int xllm_mi355_rotary_embedding(const int64_t* positions, void* q, void* k, cons
   return hip_check_launch();
 }
 
+int xllm_mi355_rotary_embedding_and_cache(const int64_t* positions, void* q, void* k, const void* v,
+                                          const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache,
+                                          void* v_cache, int64_t n_tokens, int64_t n_q_heads, int64_t n_kv_heads,
+                                          int64_t head_size, int64_t rot_dim, int64_t q_stride, int64_t k_stride,
+                                          int64_t v_stride, int64_t block_size, int64_t n_blocks, int is_neox,
+                                          int dtype, void* stream) {
+  if (!positions || !q || !k || !v || !cos_sin_cache || !slot_ids || !k_cache || !v_cache || n_tokens < 0 ||
+      rot_dim <= 0 || (rot_dim & 1) || rot_dim > head_size || block_size <= 0)
+    return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_FLOAT(dtype, T, {
+    if (is_neox)
+      hipLaunchKernelGGL((rope_and_cache_kernel<T, true>), dim3(n_tokens), dim3(256), 0, s, positions, (T*)q, (T*)k,
+                         (const T*)v, (const T*)cos_sin_cache, slot_ids, (T*)k_cache, (T*)v_cache, (int)rot_dim,
+                         q_stride, k_stride, v_stride, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                         n_blocks);
+    else
+      hipLaunchKernelGGL((rope_and_cache_kernel<T, false>), dim3(n_tokens), dim3(256), 0, s, positions, (T*)q, (T*)k,
+                         (const T*)v, (const T*)cos_sin_cache, slot_ids, (T*)k_cache, (T*)v_cache, (int)rot_dim,
+                         q_stride, k_stride, v_stride, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                         n_blocks);
+  });
+  return hip_check_launch();
+}
+
 int xllm_mi355_fused_qk_norm_rope(void* qkv, int64_t n_tokens, int64_t n_q, int64_t n_k, int64_t n_v,
                                   int64_t head_dim, float eps, const void* q_weight, const void* k_weight,
                                   const void* cos_sin_cache, int cache_dtype, int interleaved,
@@ -713,6 +846,11 @@ template <typename T>
 static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64_t n_tokens, int64_t d,
                        int act_mode, hipStream_t s) {
   const size_t lds = (size_t)d * sizeof(T);
+  if (act_mode == XM_ACT_SILU && d / RowVec<T>::N <= 512 * 5) {  // the hot configuration: register-resident row
+    hipLaunchKernelGGL((act_and_mul_i8_reg_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), 0, s, out_q, out_scale,
+                       (const T*)input, (int)d);
+    return hip_check_launch();
+  }
   switch (act_mode) {
     case XM_ACT_SILU:
       hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), lds, s, out_q,

@@ -131,9 +131,27 @@ class Qwen2DecoderLayer:
         q = qkv[:, :self.q_size]
         k = qkv[:, self.q_size:self.q_size + self.kv_size]
         v = qkv[:, self.q_size + self.kv_size:]
-        ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)
-        attn, _ = self.attn.forward(md, q, k, v, kv_cache)
-        x = self.o_proj.forward(attn)
+        decode = not (md.is_prefill or md.is_chunked_prefill)
+        fused_attn = None
+        if self.fuse and decode:
+            # N1 fusions on the decode path: RoPE + KV write in one launch, and the attention epilogue emits the
+            # int8 operand of o_proj directly (falls back when the batch is small enough to need split-KV)
+            ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
+                                           kv_cache.v_cache, self.d, True)
+            fused_attn = ops.paged_decode_attention_int8(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache,
+                                                         kv_cache.v_cache, md.kv_seq_lens, md.block_table,
+                                                         md.max_seq_len, self.attn.scale, self.attn.window_left)
+            if fused_attn is None:
+                attn = ops.paged_attention(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache, kv_cache.v_cache, None,
+                                           md.kv_seq_lens, md.block_table, 1, md.max_seq_len, self.attn.scale, False,
+                                           self.attn.window_left)
+        else:
+            ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)
+            attn, _ = self.attn.forward(md, q, k, v, kv_cache)
+        if fused_attn is not None:
+            x = self.o_proj.forward(None, pre_quant=(fused_attn[0], fused_attn[1]))
+        else:
+            x = self.o_proj.forward(attn)
         h, residual = self._norm(x, residual, self.post_norm_w)
         gate_up = self.gate_up_proj.forward(None, pre_quant=h) if self.fuse else self.gate_up_proj.forward(h)
         if self.fuse:  # N1: silu*mul + int8 quant feeding down_proj

@@ -393,3 +393,36 @@ def group_gemm(input, weight, token_count, output=None):
     check(_lib.lib().xllm_mi355_group_gemm(_p(input.contiguous()), _p(weight.contiguous()), _p(token_count), _p(out),
                                           input.size(0), E, N, K, _dt(input), _stream()), "group_gemm")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ N1 fusions
+def rotary_embedding_and_cache(positions, query, key, value, cos_sin_cache, slot_ids, key_cache, value_cache,
+                               head_size: int, is_neox: bool = True) -> None:
+    """apply_rotary + reshape_paged_cache in one launch (bit-identical to the two operators)."""
+    _need_cuda(positions, query, key, value, cos_sin_cache, slot_ids, key_cache, value_cache)
+    T = positions.numel()
+    nq, nk = query.size(-1) // head_size, key.size(-1) // head_size
+    check(_lib.lib().xllm_mi355_rotary_embedding_and_cache(
+        _p(positions), _p(query), _p(key), _p(value), _p(cos_sin_cache), _p(slot_ids), _p(key_cache), _p(value_cache),
+        T, nq, nk, head_size, cos_sin_cache.size(-1), query.stride(0), key.stride(0), value.stride(0),
+        key_cache.size(-3), key_cache.size(0), int(is_neox), _dt(query), _stream()), "rotary_embedding_and_cache")
+
+
+def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, max_kv_len, scale, window_left=-1,
+                                want_16bit: bool = False):
+    """decode attention whose epilogue also emits scaled_quantize of its output: returns (int8 [B, nq*d], scale [B],
+    16-bit out or None), or None when the shape needs split-KV (caller falls back to paged_attention + quant)."""
+    _need_cuda(q, k_cache, v_cache, kv_seq_lens, block_table)
+    B, nq, d = q.shape
+    n_blocks, bs, nkv, _ = k_cache.shape
+    oq = torch.empty(B, nq * d, dtype=torch.int8, device=q.device)
+    os_ = torch.empty(B, dtype=torch.float32, device=q.device)
+    o16 = torch.empty(B, nq * d, dtype=q.dtype, device=q.device) if want_16bit else None
+    bt = block_table if block_table.is_contiguous() else block_table.contiguous()
+    rc = _lib.lib().xllm_mi355_paged_decode_attention_int8(
+        _p(q), _p(k_cache), _p(v_cache), _p(o16), _p(oq), _p(os_), _p(kv_seq_lens), _p(bt), bt.size(1), B, nq, nkv, d,
+        bs, q.stride(0), max_kv_len, scale, window_left, _dt(q), _stream())
+    if rc == -2:  # XM_ERR_UNSUPPORTED: split-KV shape
+        return None
+    check(rc, "paged_decode_attention_int8")
+    return oq, os_, o16
