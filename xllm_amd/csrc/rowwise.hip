@@ -399,8 +399,9 @@ __global__ __launch_bounds__(256) void act_and_mul_kernel(T* __restrict__ out, c
   }
 }
 
-// fused act_and_mul + per-token int8 quant; d*sizeof(T) may exceed the register cache, so the 16-bit
-// product is staged in LDS (d <= 32768 elements of 2 bytes = 64 KiB).
+// fused act_and_mul + per-token int8 quant; the 16-bit product is staged in LDS (d <= 32768 elements of 2 bytes
+// = 64 KiB). A register-resident variant (all loads issued up front, 512 threads x 10 x 16 B) measured 2x SLOWER
+// in the decode step (29.7 vs 14.6 us at d = 18944, round-1 profile) and was dropped.
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
                                                              const T* __restrict__ in, int d) {
@@ -445,63 +446,6 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict_
     int8_t* o = out_q + t * (int64_t)d + (int64_t)c * N;
     if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
     else *reinterpret_cast<uint32_t*>(o) = pk[0];
-  }
-  if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
-}
-
-// register-resident variant for d <= 512 * 5 * 8 elements: every 16-byte load of the row is issued before the
-// first use (one HBM latency per row instead of one per loop trip), the 16-bit product stays in registers
-// between the amax reduction and the quantisation, no LDS staging.
-template <typename T, int MODE>
-__global__ __launch_bounds__(512) void act_and_mul_i8_reg_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
-                                                                 const T* __restrict__ in, int d) {
-  __shared__ float red[32];
-  constexpr int N = RowVec<T>::N;
-  constexpr int NVR = 5;
-  const int64_t t = blockIdx.x;
-  const T* x = in + t * 2 * (int64_t)d;
-  const T* y = x + d;
-  const int nvec = d / N;
-  RowVec<T> xv[NVR], yv[NVR];
-#pragma unroll
-  for (int i = 0; i < NVR; ++i) {
-    int c = threadIdx.x + i * 512;
-    c = c < nvec ? c : nvec - 1;  // clamped (unconditional) loads keep all of them in flight together
-    xv[i].raw = reinterpret_cast<const uint4*>(x)[c];
-    yv[i].raw = reinterpret_cast<const uint4*>(y)[c];
-  }
-  float amax = 0.0f;
-#pragma unroll
-  for (int i = 0; i < NVR; ++i) {
-    const bool live = threadIdx.x + i * 512 < nvec;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const float r = r16<T>(r16<T>(act_f<MODE>(xv[i].get(j))) * yv[i].get(j));
-      xv[i].set(j, r);
-      if (live) amax = fmaxf(amax, fabsf(r));
-    }
-  }
-  amax = block_max(amax, red);
-  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
-#pragma unroll
-  for (int i = 0; i < NVR; ++i) {
-    const int c = threadIdx.x + i * 512;
-    if (c < nvec) {
-      uint32_t pk[N / 4];
-#pragma unroll
-      for (int j = 0; j < N; j += 4) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv[i].get(j + e) * qinv)));
-          w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
-        }
-        pk[j / 4] = w;
-      }
-      int8_t* o = out_q + t * (int64_t)d + (int64_t)c * N;
-      if constexpr (N == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pk[0], pk[1]);
-      else *reinterpret_cast<uint32_t*>(o) = pk[0];
-    }
   }
   if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
 }
@@ -846,11 +790,6 @@ template <typename T>
 static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64_t n_tokens, int64_t d,
                        int act_mode, hipStream_t s) {
   const size_t lds = (size_t)d * sizeof(T);
-  if (act_mode == XM_ACT_SILU && d / RowVec<T>::N <= 512 * 5) {  // the hot configuration: register-resident row
-    hipLaunchKernelGGL((act_and_mul_i8_reg_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), 0, s, out_q, out_scale,
-                       (const T*)input, (int)d);
-    return hip_check_launch();
-  }
   switch (act_mode) {
     case XM_ACT_SILU:
       hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), lds, s, out_q,
