@@ -82,7 +82,7 @@ def cpu_baseline(args_model, mode, ctx, block_size):
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     a = args_model
-    Bs = 8
+    Bs = 64  # bounded sample: ~10-30 s of CPU work on the host cores
     g = torch.Generator().manual_seed(0)
     pages = (ctx + block_size - 1) // block_size
     nb = Bs * pages

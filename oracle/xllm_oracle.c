@@ -590,10 +590,11 @@ ORC_API int orc_paged_attention(const void* q, const void* k_cache, const void* 
     float* qv = (float*)malloc(sizeof(float) * (size_t)d);
     float* ov = (float*)malloc(sizeof(float) * (size_t)dv);
 #pragma omp for schedule(dynamic, 1)
-    for (int64_t b = 0; b < B; ++b) {
+    for (int64_t wi = 0; wi < B * nq; ++wi) { /* one work item per (sequence, q head) */
+      const int64_t b = wi / nq, h = wi % nq;
       int64_t q0 = cu_q[b], ql = cu_q[b + 1] - q0, kl = kv_lens[b];
       for (int64_t i = 0; i < ql; ++i)
-        for (int64_t h = 0; h < nq; ++h) {
+        {
           int64_t kvh = h / grp;
           int64_t iabs = kl - ql + i;
           for (int64_t j = 0; j < kl; ++j) {
