@@ -18,87 +18,9 @@
 // (integer adds commute, so the result stays bit-exact and deterministic).
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "common.h"
+#include "gemm_types.h"
 
 namespace xm {
-
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef int i32x16_t __attribute__((ext_vector_type(16)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 gf16x8_t __attribute__((ext_vector_type(8)));
-
-enum GemmKind { kI8 = 0, kFP8 = 1, kBF16 = 2, kF16 = 3 };
-
-template <int KIND>
-struct MmaTraits;
-template <>
-struct MmaTraits<kI8> {
-  using acc_t = i32x16_t;
-  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
-  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
-    i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
-  }
-};
-template <>
-struct MmaTraits<kFP8> {
-  using acc_t = f32x16_t;
-  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
-  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
-    // 16 fp8 per lane = two K=16 MFMAs (the k permutation is identical on both operands)
-    long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
-    long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, c, 0, 0, 0);
-  }
-};
-template <>
-struct MmaTraits<kBF16> {
-  using acc_t = f32x16_t;
-  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
-  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
-    gbf16x8_t av, bv;
-    __builtin_memcpy(&av, &a, 16);
-    __builtin_memcpy(&bv, &b, 16);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
-  }
-};
-template <>
-struct MmaTraits<kF16> {
-  using acc_t = f32x16_t;
-  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
-  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
-    gf16x8_t av, bv;
-    __builtin_memcpy(&av, &a, 16);
-    __builtin_memcpy(&bv, &b, 16);
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
-  }
-};
-
-struct GemmEpi {
-  const float* a_scale;   // int8: [M]; fp8: [1] or [M]
-  int64_t a_scale_n;
-  const float* w_scale;   // int8: [N]; fp8: [1] or [N]
-  int64_t w_scale_n;
-  const void* bias;       // out dtype, [N] or null
-  void* out;              // 16-bit out [M,N] (may be null when only acc_out is wanted)
-  int32_t* acc_out;       // int8: raw accumulators [M,N] (null normally); split-K workspace
-  int out_bf16;           // 1 bf16, 0 f16
-  const int32_t* group_counts;  // grouped GEMM (MoE): rows per expert, DEVICE array [n_groups]; null otherwise
-  int n_groups;
-};
-
-__device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {
-  if (out_bf16) reinterpret_cast<uint16_t*>(out)[idx] = f32_to_bf16_bits(v);
-  else reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;
-}
-__device__ __forceinline__ float load16(const void* p, int64_t idx, int is_bf16) {
-  if (is_bf16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[idx]);
-  return (float)reinterpret_cast<const f16_t*>(p)[idx];
-}
 
 constexpr int BM = 128, BN = 128, BKB = 128;  // block tile, K step in bytes
 
@@ -296,14 +218,6 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const uint8_t* __restri
 //   * int8: optional split-K (grid.z) with exact int32 atomics when the N tiles alone cannot fill the chip.
 // ------------------------------------------------------------------------------------------------
 constexpr int SK_BM = 256;
-
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
 
 template <int KIND, int NT, bool SPLITK, int WAVES, int DEPTH>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(const uint8_t* __restrict__ A,
@@ -829,6 +743,38 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
     g_wd_enable = e ? atoi(e) : 0;
     e = getenv("XLLM_MI355_WDIRECT_SPLITS");
     g_wd_splits = e ? atoi(e) : -1;
+  }
+  static int p8 = -2, p8_splits = -1;
+  if (p8 == -2) {
+    const char* e = getenv("XLLM_MI355_P8");
+    p8 = e ? atoi(e) : 0;
+    e = getenv("XLLM_MI355_P8_SPLITS");
+    p8_splits = e ? atoi(e) : -1;
+  }
+  if (p8 && Kb % BKB == 0 && (N & 3) == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
+    int splits = 1;
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
+    if (can_split && tiles < 256) {
+      splits = (int)(256 / tiles);
+      const int by_k = (int)(Kb / BKB) / 4 > 0 ? (int)(Kb / BKB) / 4 : 1;
+      splits = splits > by_k ? by_k : splits;
+      if (p8_splits > 0) splits = p8_splits;
+    }
+    if (splits > 1) {
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+      const int rc = launch_gemm_p8<KIND>(A, W, M, N, Kb, e2, workspace, ws_bytes, splits, s);
+      if (rc != XM_OK) return rc;
+      if constexpr (KIND == kI8) {
+        int64_t blocks = (M * N + 255) / 256;
+        blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
+      }
+      return hip_check_launch();
+    }
+    return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
   }
   if (g_wd_enable && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts &&
       (g_wd_enable == 2 || N >= 8192 || Kb >= 8192))

@@ -1,0 +1,359 @@
+// gemm_p8.hip -- C[M,N] = A[M,K] * W[N,K]^T, 256x256 block tile, "8-phase" software pipeline for gfx950.
+//
+// Why a second GEMM structure: the 128x128 kernel of gemm.hip is bound by its stage -> barrier -> read -> MFMA
+// dependency chain (profiles/r01_gemm_notes.txt: matrix pipe 27 % busy, no bank conflicts, not HBM bound; hipcc
+// drains every in-flight LDS-DMA with s_waitcnt vmcnt(0) before the first ds_read of a K step). This kernel removes
+// the drain by hand:
+//   * both operands are staged HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) in 16-KiB HALF-TILES
+//     (128 rows x 128 B), four per K tile, two K tiles of LDS (128 KiB); three half-tiles stay in flight across the
+//     barriers at all times, retired once per K tile by a COUNTED s_waitcnt vmcnt(6) -- never vmcnt(0);
+//   * the fragment reads are inline-asm ds_read_b128 (the compiler's wait-count pass never sees an LDS load, so it
+//     never inserts the drain) retired by explicit lgkmcnt waits that carry the fragment registers as operands;
+//   * 8 waves = 2 groups of 4 (one wave of each group on every SIMD). The groups run one barrier apart: while one
+//     group issues its 8 MFMAs of a phase (256 matrix-pipe cycles) the other issues its LDS reads and DMA requests,
+//     so each SIMD's matrix pipe is fed alternately by its two waves.
+// A K tile (128 bytes of K) is 4 phases, one per 64x32 quadrant of the wave's 128 (m) x 64 (n) output:
+//   P1: read W(nh=0) + A(mh=0), stage, [lgkmcnt(8)] bar, MFMA (0,0), bar
+//   P2: read W(nh=1),           stage,              bar, MFMA (0,1), bar
+//   P3: read A(mh=1),           stage,              bar, MFMA (1,1), bar
+//   P4:                         stage, vmcnt(6),    bar, MFMA (1,0), bar
+// Hazards (two groups one barrier apart): a slot staged in phase q may have been read last in phase q-2, or in
+// phase q-1 if those reads were retired before that phase's first barrier (P1's lgkmcnt(8) retires the W(nh=0)
+// reads, whose slot P2 restages); a slot is read no earlier than the phase after the vmcnt wait that retires it.
+//
+// MFMA operand roles are swapped with respect to gemm.hip: the W fragment is the "row" operand, so a lane's 16
+// accumulator registers are 4 groups of 4 CONSECUTIVE n for one m -> 8-byte stores in the epilogue.
+// int8 results are bit-identical to gemm.hip (exact integer accumulation, same epilogue expression).
+#include <stdlib.h>
+
+#include "gemm_types.h"
+
+namespace xm {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
+constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
+
+template <int KIND>
+__device__ __forceinline__ typename MmaTraits<KIND>::acc_t mma4(const u32x4 a, const u32x4 b,
+                                                                typename MmaTraits<KIND>::acc_t c) {
+  if constexpr (KIND == kI8) {
+    i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+  } else if constexpr (KIND == kFP8) {
+    long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+    long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, c, 0, 0, 0);
+  } else if constexpr (KIND == kBF16) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8_t, a), __builtin_bit_cast(gbf16x8_t, b),
+                                                   c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gf16x8_t, a), __builtin_bit_cast(gf16x8_t, b), c,
+                                                  0, 0, 0);
+  }
+}
+
+// 16-bit output conversion without branches (same bits as f32_to_bf16_bits / the f16 cast of common.h)
+__device__ __forceinline__ unsigned pack16(float v, bool out_bf16) {
+  const unsigned u = __float_as_uint(v);
+  const unsigned rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  const unsigned bf = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : rne;
+  const f16_t hv = (f16_t)v;
+  uint16_t hb;
+  __builtin_memcpy(&hb, &hv, 2);
+  return out_bf16 ? (bf & 0xffffu) : (unsigned)hb;
+}
+
+#define P8_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define P8_WAIT4(F)                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
+#define P8_WAIT8(F)                                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                           \
+               : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]))
+
+template <int KIND, bool SPLITK>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A,
+                                                               const uint8_t* __restrict__ W, int M, int N,
+                                                               int64_t Kb, int m_tiles, int n_tiles,
+                                                               int ktiles_per_split, GemmEpi epi) {
+  using acc_t = typename MmaTraits<KIND>::acc_t;
+  // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: wr is the phase group
+
+  // XCD-aware rasterisation: block b runs on XCD b%8; every XCD walks its own super-blocks of 32 tiles
+  // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
+  // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
+  int mt, nt;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int sb = j >> 5, within = j & 31;
+    const int S = sb * 8 + xcd;
+    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
+    const int SM = S % n_sb_m, SN = S / n_sb_m;
+    mt = (SM << lm) + (within & ((1 << lm) - 1));
+    nt = (SN << (5 - lm)) + (within >> lm);
+    if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
+  }
+  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
+  const int total_kt = (int)(Kb / P8_BK);
+  const int kt_begin = blockIdx.z * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  kt_end = kt_end > total_kt ? total_kt : kt_end;
+  const int nk = kt_end - kt_begin;
+  if (nk <= 0) return;
+
+  // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
+  // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
+  // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
+  int voff_a[2][2], voff_w[2][2];  // [i][half]
+  {
+    const int srow = wave * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
+        int ar = m0 + i * 128 + h * 64 + srow;
+        ar = ar < M ? ar : M - 1;
+        voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
+        // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
+        int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);
+        wrow = wrow < N ? wrow : N - 1;
+        voff_w[i][h] = (int)((int64_t)wrow * Kb) + scol;
+      }
+  }
+  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  // stage one half-tile: (buffer, slot) <- K tile kt (clamped: tail prefetches re-load the last tile, every load
+  // is unconditional so the vmcnt arithmetic is static)
+  auto stage = [&](int buf, int slot, int kt) {
+    kt = kt < kt_end ? kt : kt_end - 1;
+    const int soff = kt * P8_BK;
+    const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
+    const int h = slot >> 1;
+    if (slot & 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, voff_a[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst + 8192, 16, voff_a[1][h], soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, voff_w[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + 8192, 16, voff_w[1][h], soff, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses. MFMA 32x32 fragment: lane l holds row (l & 31), 16 K-bytes at chunk
+  // 2*kk + (l >> 5) of the 128-B row; physical chunk = logical ^ ((row >> 1) & 7). One VGPR per kk and buffer.
+  unsigned rd_w[2][4], rd_a[2][4];
+  {
+    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
+    const int f = ((lane & 31) >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const unsigned o = base + (lane & 31) * P8_BK + (((2 * kk + (lane >> 5)) ^ f) << 4);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        rd_w[b][kk] = o + b * 4 * P8_SLOT + wc * 32 * P8_BK;
+        rd_a[b][kk] = o + b * 4 * P8_SLOT + wr * 64 * P8_BK;
+      }
+    }
+  }
+
+  acc_t acc[4][2];  // [m block of 32][n block of 32]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
+
+  // ---- prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
+  stage(0, 0, kt_begin);
+  stage(0, 1, kt_begin);
+  stage(0, 2, kt_begin);
+  stage(0, 3, kt_begin);
+  stage(1, 0, kt_begin + 1);
+  stage(1, 1, kt_begin + 1);
+  stage(1, 2, kt_begin + 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  u32x4 fw0[4], fw1[4], fa[8];  // W fragments nh=0 / nh=1 [kk]; A fragments [mbl*4 + kk] of the current m half
+
+#define P8_MMA(MB, NB, FW)                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                              \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
+    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
+    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
+  }                                                                                           \
+  __builtin_amdgcn_s_setprio(0);                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto ktile = [&](auto BUF_, int kt) {
+    constexpr int BUF = decltype(BUF_)::value;
+    // ---- P1
+    P8_DSR(fw0[0], rd_w[BUF][0], 0); P8_DSR(fw0[1], rd_w[BUF][1], 0);
+    P8_DSR(fw0[2], rd_w[BUF][2], 0); P8_DSR(fw0[3], rd_w[BUF][3], 0);
+    P8_DSR(fa[0], rd_a[BUF][0], 1 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 1 * P8_SLOT);
+    P8_DSR(fa[2], rd_a[BUF][2], 1 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 1 * P8_SLOT);
+    P8_DSR(fa[4], rd_a[BUF][0], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 1 * P8_SLOT + 32 * P8_BK);
+    P8_DSR(fa[6], rd_a[BUF][2], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 1 * P8_SLOT + 32 * P8_BK);
+    stage(BUF ^ 1, 3, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the W(nh=0) reads are done: P2 may restage slot 0
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw0);
+    P8_WAIT8(fa);
+    P8_MMA(0, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+    // ---- P2
+    P8_DSR(fw1[0], rd_w[BUF][0], 2 * P8_SLOT); P8_DSR(fw1[1], rd_w[BUF][1], 2 * P8_SLOT);
+    P8_DSR(fw1[2], rd_w[BUF][2], 2 * P8_SLOT); P8_DSR(fw1[3], rd_w[BUF][3], 2 * P8_SLOT);
+    stage(BUF, 0, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw1);
+    P8_MMA(0, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P3
+    P8_DSR(fa[0], rd_a[BUF][0], 3 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 3 * P8_SLOT);
+    P8_DSR(fa[2], rd_a[BUF][2], 3 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 3 * P8_SLOT);
+    P8_DSR(fa[4], rd_a[BUF][0], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 3 * P8_SLOT + 32 * P8_BK);
+    P8_DSR(fa[6], rd_a[BUF][2], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 3 * P8_SLOT + 32 * P8_BK);
+    stage(BUF, 1, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT8(fa);
+    P8_MMA(2, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P4
+    stage(BUF, 2, kt + 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K tile kt+1 has landed; 3 half-tiles of kt+2 stay in flight
+    __builtin_amdgcn_s_barrier();
+    P8_MMA(2, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, kt_begin + t);
+    if (t + 1 >= nk) break;
+    ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
+  if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
+#undef P8_MMA
+
+  // ---- epilogue (N % 4 == 0 is checked on the host). Tile acc[mb][nb]: lane & 31 = m within the block, register
+  // r = 4*g + e <-> n within the block = 8*g + 4*(lane >> 5) + e: four consecutive n per g -> one 8-byte store.
+  const int half = lane >> 5;
+  const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
+  const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m = m0 + wr * 128 + mb * 32 + (lane & 31);
+    const bool m_ok = m < M;
+    const int mc = m_ok ? m : M - 1;
+    float as = 1.0f;
+    if constexpr (KIND == kI8 && !SPLITK) as = epi.a_scale ? epi.a_scale[mc] : 1.0f;
+    if constexpr (KIND == kFP8) as = epi.a_scale[epi.a_scale_n > 1 ? mc : 0];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
+        if (!m_ok || n >= N) continue;
+        const int64_t idx = (int64_t)m * N + n;
+        if constexpr (SPLITK) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(epi.acc_out + idx + e, (int)acc[mb][nb][4 * g + e]);
+        } else {
+          float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (has_bias) {
+            const uint2 bw = *reinterpret_cast<const uint2*>(bias16 + n);
+            const uint16_t b16[4] = {(uint16_t)(bw.x & 0xffff), (uint16_t)(bw.x >> 16), (uint16_t)(bw.y & 0xffff),
+                                     (uint16_t)(bw.y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f16_t hv;
+              __builtin_memcpy(&hv, &b16[e], 2);
+              const float as_f16 = (float)hv, as_bf16 = bf16_bits_to_f32(b16[e]);
+              bs[e] = out_bf16 ? as_bf16 : as_f16;
+            }
+          }
+          float v[4];
+          if constexpr (KIND == kI8) {
+            if (epi.acc_out) {
+              i32x4_t raw = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
+              *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = raw;
+            }
+            if (!epi.out) continue;
+            const float4 ws = *reinterpret_cast<const float4*>(epi.w_scale + n);
+            const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][nb][4 * g + e] * as * wsv[e] + bs[e];
+          } else if constexpr (KIND == kFP8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = as * (epi.w_scale[epi.w_scale_n > 1 ? n + e : 0] * acc[mb][nb][4 * g + e]) + bs[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e] + bs[e];
+          }
+          unsigned h16[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h16[e] = pack16(v[e], out_bf16);
+          uint2 pk;
+          pk.x = h16[0] | (h16[1] << 16);
+          pk.y = h16[2] | (h16[3] << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + idx) = pk;
+        }
+      }
+  }
+}
+
+template <int KIND>
+int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                   size_t ws_bytes, int splits, hipStream_t s) {
+  (void)workspace;
+  (void)ws_bytes;
+  if (Kb % P8_BK != 0 || (N & 3) != 0 || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || epi.group_counts) return XM_ERR_UNSUPPORTED;
+  const int m_tiles = (int)((M + P8_BM - 1) / P8_BM), n_tiles = (int)((N + P8_BN - 1) / P8_BN);
+  const int ktiles = (int)(Kb / P8_BK);
+  splits = splits < 1 ? 1 : splits;
+  const int per = (ktiles + splits - 1) / splits;
+  splits = (ktiles + per - 1) / per;
+  const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+  const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
+  const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  if (splits > 1) {
+    if constexpr (KIND == kI8) {
+      if (!epi.acc_out) return XM_ERR_INVALID;  // the caller points acc_out at the zeroed split-K workspace
+      hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+    } else {
+      return XM_ERR_UNSUPPORTED;
+    }
+  } else {
+    hipLaunchKernelGGL((gemm_p8_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+  }
+  return hip_check_launch();
+}
+
+template int launch_gemm_p8<kI8>(const void*, const void*, int64_t, int64_t, int64_t, GemmEpi, void*, size_t, int,
+                                 hipStream_t);
+template int launch_gemm_p8<kFP8>(const void*, const void*, int64_t, int64_t, int64_t, GemmEpi, void*, size_t, int,
+                                  hipStream_t);
+template int launch_gemm_p8<kBF16>(const void*, const void*, int64_t, int64_t, int64_t, GemmEpi, void*, size_t, int,
+                                   hipStream_t);
+template int launch_gemm_p8<kF16>(const void*, const void*, int64_t, int64_t, int64_t, GemmEpi, void*, size_t, int,
+                                  hipStream_t);
+
+}  // namespace xm

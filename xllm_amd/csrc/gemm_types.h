@@ -1,0 +1,99 @@
+// gemm_types.h -- definitions shared by the GEMM translation units (gemm.hip, gemm_p8.hip): MFMA wrappers per operand
+// kind, the fused-epilogue descriptor and small helpers.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace xm {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 gbf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 gf16x8_t __attribute__((ext_vector_type(8)));
+
+enum GemmKind { kI8 = 0, kFP8 = 1, kBF16 = 2, kF16 = 3 };
+
+template <int KIND>
+struct MmaTraits;
+template <>
+struct MmaTraits<kI8> {
+  using acc_t = i32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kFP8> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    // 16 fp8 per lane = two K=16 MFMAs (the k permutation is identical on both operands)
+    long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
+    long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kBF16> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    gbf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+  }
+};
+template <>
+struct MmaTraits<kF16> {
+  using acc_t = f32x16_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0}; }
+  static __device__ __forceinline__ acc_t mma(const uint4& a, const uint4& b, acc_t c) {
+    gf16x8_t av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+  }
+};
+
+struct GemmEpi {
+  const float* a_scale;   // int8: [M]; fp8: [1] or [M]
+  int64_t a_scale_n;
+  const float* w_scale;   // int8: [N]; fp8: [1] or [N]
+  int64_t w_scale_n;
+  const void* bias;       // out dtype, [N] or null
+  void* out;              // 16-bit out [M,N] (may be null when only acc_out is wanted)
+  int32_t* acc_out;       // int8: raw accumulators [M,N] (null normally); split-K workspace
+  int out_bf16;           // 1 bf16, 0 f16
+  const int32_t* group_counts;  // grouped GEMM (MoE): rows per expert, DEVICE array [n_groups]; null otherwise
+  int n_groups;
+};
+
+__device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {
+  if (out_bf16) reinterpret_cast<uint16_t*>(out)[idx] = f32_to_bf16_bits(v);
+  else reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;
+}
+__device__ __forceinline__ float load16(const void* p, int64_t idx, int is_bf16) {
+  if (is_bf16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[idx]);
+  return (float)reinterpret_cast<const f16_t*>(p)[idx];
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// 256x256 8-phase kernel (gemm_p8.hip). Returns XM_ERR_UNSUPPORTED when the shape is outside its envelope.
+template <int KIND>
+int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                   size_t ws_bytes, int splits, hipStream_t s);
+
+}  // namespace xm
