@@ -751,7 +751,7 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
     e = getenv("XLLM_MI355_P8_SPLITS");
     p8_splits = e ? atoi(e) : -1;
   }
-  if (p8 && Kb % BKB == 0 && (N & 3) == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
+  if (p8 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
     int splits = 1;
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;

@@ -139,7 +139,10 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   const lds_ptr_t lds3 = (lds_ptr_t)lds;
   // stage one half-tile: (buffer, slot) <- K tile kt (clamped: tail prefetches re-load the last tile, every load
   // is unconditional so the vmcnt arithmetic is static)
-  auto stage = [&](int buf, int slot, int kt) {
+  auto stage = [&](int buf, int slot, int kt, bool in_loop = true) {
+#ifdef P8_ABL_NOSTAGE  /* ablation build: no DMA inside the K loop (stale LDS is computed on) */
+    if (in_loop) return;
+#endif
     kt = kt < kt_end ? kt : kt_end - 1;
     const int soff = kt * P8_BK;
     const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
@@ -177,19 +180,24 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
 
   // ---- prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
-  stage(0, 0, kt_begin);
-  stage(0, 1, kt_begin);
-  stage(0, 2, kt_begin);
-  stage(0, 3, kt_begin);
-  stage(1, 0, kt_begin + 1);
-  stage(1, 1, kt_begin + 1);
-  stage(1, 2, kt_begin + 1);
+  stage(0, 0, kt_begin, false);
+  stage(0, 1, kt_begin, false);
+  stage(0, 2, kt_begin, false);
+  stage(0, 3, kt_begin, false);
+  stage(1, 0, kt_begin + 1, false);
+  stage(1, 1, kt_begin + 1, false);
+  stage(1, 2, kt_begin + 1, false);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
 
   u32x4 fw0[4], fw1[4], fa[8];  // W fragments nh=0 / nh=1 [kk]; A fragments [mbl*4 + kk] of the current m half
 
+#ifdef P8_ABL_NOMFMA  /* ablation build: keep the fragment reads alive, no matrix work */
+#define P8_MMA(MB, NB, FW)                                                                    \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(FW[kk]), "v"(fa[kk]), "v"(fa[4 + kk])); \
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #define P8_MMA(MB, NB, FW)                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                              \
   _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   }                                                                                           \
   __builtin_amdgcn_s_setprio(0);                                                              \
   __builtin_amdgcn_sched_barrier(0);
+#endif
 
   auto ktile = [&](auto BUF_, int kt) {
     constexpr int BUF = decltype(BUF_)::value;
@@ -250,71 +259,131 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
 #undef P8_MMA
 
-  // ---- epilogue (N % 4 == 0 is checked on the host). Tile acc[mb][nb]: lane & 31 = m within the block, register
+  // ---- epilogue (N % 8 == 0 is checked on the host). Tile acc[mb][nb]: lane & 31 = m within the block, register
   // r = 4*g + e <-> n within the block = 8*g + 4*(lane >> 5) + e: four consecutive n per g -> one 8-byte store.
-  const int half = lane >> 5;
+#ifdef P8_ABL_NOEPI  /* ablation build: one store per lane so the accumulators stay live */
+  if (epi.out) {
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += (int)acc[i][j][r];
+    if (sum == 0x12345) reinterpret_cast<int*>(epi.out)[tid] = sum;
+  }
+  return;
+#endif
+  const int half = lane >> 5, ml = lane & 31;
   const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
   const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+  if constexpr (SPLITK) {
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const int m = m0 + wr * 128 + mb * 32 + (lane & 31);
-    const bool m_ok = m < M;
-    const int mc = m_ok ? m : M - 1;
-    float as = 1.0f;
-    if constexpr (KIND == kI8 && !SPLITK) as = epi.a_scale ? epi.a_scale[mc] : 1.0f;
-    if constexpr (KIND == kFP8) as = epi.a_scale[epi.a_scale_n > 1 ? mc : 0];
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wr * 128 + mb * 32 + ml;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
+          if (m >= M || n >= N) continue;
+          const int64_t idx = (int64_t)m * N + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(epi.acc_out + idx + e, (int)acc[mb][nb][4 * g + e]);
+        }
+    }
+  } else {
+    // dequantise in the accumulator layout (m = lane, n = register), transpose the 16-bit results through a
+    // wave-private 4-KiB LDS block per 32 rows (16-B units XOR-swizzled by row & 7: conflict-free reads, 2-way
+    // writes) and store whole 128-B row segments: 8 lanes x 16 B per row, 8 rows per instruction.
+    __builtin_amdgcn_s_barrier();  // every wave has drained its DMAs and finished its fragment reads
+    float wsv[2][4][4], bsv[2][4][4];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
-        if (!m_ok || n >= N) continue;
-        const int64_t idx = (int64_t)m * N + n;
-        if constexpr (SPLITK) {
+        int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
+        n = n + 3 < N ? n : N - 4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(epi.acc_out + idx + e, (int)acc[mb][nb][4 * g + e]);
-        } else {
-          float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (has_bias) {
-            const uint2 bw = *reinterpret_cast<const uint2*>(bias16 + n);
-            const uint16_t b16[4] = {(uint16_t)(bw.x & 0xffff), (uint16_t)(bw.x >> 16), (uint16_t)(bw.y & 0xffff),
-                                     (uint16_t)(bw.y >> 16)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              f16_t hv;
-              __builtin_memcpy(&hv, &b16[e], 2);
-              const float as_f16 = (float)hv, as_bf16 = bf16_bits_to_f32(b16[e]);
-              bs[e] = out_bf16 ? as_bf16 : as_f16;
-            }
+        for (int e = 0; e < 4; ++e) {
+          wsv[nb][g][e] = 1.0f;
+          bsv[nb][g][e] = 0.0f;
+        }
+        if constexpr (KIND == kI8) {
+          if (epi.out) {
+            const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+            wsv[nb][g][0] = w4.x; wsv[nb][g][1] = w4.y; wsv[nb][g][2] = w4.z; wsv[nb][g][3] = w4.w;
           }
-          float v[4];
-          if constexpr (KIND == kI8) {
-            if (epi.acc_out) {
-              i32x4_t raw = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2], acc[mb][nb][4 * g + 3]};
-              *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = raw;
-            }
-            if (!epi.out) continue;
-            const float4 ws = *reinterpret_cast<const float4*>(epi.w_scale + n);
-            const float wsv[4] = {ws.x, ws.y, ws.z, ws.w};
+        }
+        if constexpr (KIND == kFP8) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][nb][4 * g + e] * as * wsv[e] + bs[e];
-          } else if constexpr (KIND == kFP8) {
+          for (int e = 0; e < 4; ++e) wsv[nb][g][e] = epi.w_scale[epi.w_scale_n > 1 ? n + e : 0];
+        }
+        if (has_bias) {
+          const uint2 bw = *reinterpret_cast<const uint2*>(bias16 + n);
+          const uint16_t b16[4] = {(uint16_t)(bw.x & 0xffff), (uint16_t)(bw.x >> 16), (uint16_t)(bw.y & 0xffff),
+                                   (uint16_t)(bw.y >> 16)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = as * (epi.w_scale[epi.w_scale_n > 1 ? n + e : 0] * acc[mb][nb][4 * g + e]) + bs[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e] + bs[e];
+          for (int e = 0; e < 4; ++e) {
+            f16_t hv;
+            __builtin_memcpy(&hv, &b16[e], 2);
+            const float as_f16 = (float)hv, as_bf16 = bf16_bits_to_f32(b16[e]);
+            bsv[nb][g][e] = out_bf16 ? as_bf16 : as_f16;
           }
-          unsigned h16[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h16[e] = pack16(v[e], out_bf16);
-          uint2 pk;
-          pk.x = h16[0] | (h16[1] << 16);
-          pk.y = h16[2] | (h16[3] << 16);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + idx) = pk;
         }
       }
+    uint8_t* const tbuf = lds + wave * 16384;
+    const int rrow = lane >> 3;                                  // row within an 8-row read group
+    const int rcol = ((lane & 7) ^ (rrow & 7)) << 4;             // swizzled 16-B unit of this lane's 8 columns
+    const int n_st = n0 + wc * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + wr * 128 + mb * 32 + ml;
+      const int mc = m < M ? m : M - 1;
+      float as = 1.0f;
+      if constexpr (KIND == kI8) as = epi.a_scale ? epi.a_scale[mc] : 1.0f;
+      if constexpr (KIND == kFP8) as = epi.a_scale[epi.a_scale_n > 1 ? mc : 0];
+      if constexpr (KIND == kI8) {
+        if (epi.acc_out) {  // raw accumulators requested (tests): direct 16-byte stores
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
+              if (m < M && n < N) {
+                i32x4_t raw = {acc[mb][nb][4 * g], acc[mb][nb][4 * g + 1], acc[mb][nb][4 * g + 2],
+                               acc[mb][nb][4 * g + 3]};
+                *reinterpret_cast<i32x4_t*>(epi.acc_out + (int64_t)m * N + n) = raw;
+              }
+            }
+        }
+      }
+      if (!epi.out) continue;
+      uint8_t* const blk = tbuf + mb * 4096;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (KIND == kI8) v[e] = (float)acc[mb][nb][4 * g + e] * as * wsv[nb][g][e] + bsv[nb][g][e];
+            else if constexpr (KIND == kFP8) v[e] = as * (wsv[nb][g][e] * acc[mb][nb][4 * g + e]) + bsv[nb][g][e];
+            else v[e] = acc[mb][nb][4 * g + e] + bsv[nb][g][e];
+          }
+          uint2 pk;
+          pk.x = pack16(v[0], out_bf16) | (pack16(v[1], out_bf16) << 16);
+          pk.y = pack16(v[2], out_bf16) | (pack16(v[3], out_bf16) << 16);
+          *reinterpret_cast<uint2*>(blk + ml * 128 + (((nb * 4 + g) ^ (ml & 7)) << 4) + 8 * half) = pk;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
+        const int mr = m0 + wr * 128 + mb * 32 + i * 8 + rrow;
+        if (mr < M && n_st < N)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st) = row16;
+      }
+    }
   }
 }
 
@@ -323,7 +392,7 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
                    size_t ws_bytes, int splits, hipStream_t s) {
   (void)workspace;
   (void)ws_bytes;
-  if (Kb % P8_BK != 0 || (N & 3) != 0 || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || epi.group_counts) return XM_ERR_UNSUPPORTED;
+  if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || epi.group_counts) return XM_ERR_UNSUPPORTED;
   const int m_tiles = (int)((M + P8_BM - 1) / P8_BM), n_tiles = (int)((N + P8_BN - 1) / P8_BN);
   const int ktiles = (int)(Kb / P8_BK);
   splits = splits < 1 ? 1 : splits;
