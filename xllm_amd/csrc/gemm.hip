@@ -744,37 +744,47 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
     e = getenv("XLLM_MI355_WDIRECT_SPLITS");
     g_wd_splits = e ? atoi(e) : -1;
   }
-  static int p8 = -2, p8_splits = -1;
+  // 256x256 8-phase kernel (gemm_p8.hip): XLLM_MI355_P8 = 0 off, 1 forced wherever it is legal, unset = the
+  // planner below (round-1 sweep, profiles/r01_gemm_p8.txt): it wins whenever its grid has enough tiles to fill the
+  // chip without split-K; small grids stay on the skinny / 128x128 split-K kernels.
+  static int p8 = -2, p8_splits = -1, p8_min_tiles = 50;
   if (p8 == -2) {
     const char* e = getenv("XLLM_MI355_P8");
-    p8 = e ? atoi(e) : 0;
+    p8 = e ? atoi(e) : -1;
     e = getenv("XLLM_MI355_P8_SPLITS");
     p8_splits = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_P8_MIN_TILES");
+    if (e) p8_min_tiles = atoi(e);
   }
-  if (p8 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
+  if (p8 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 && M * Kb < (1ll << 31) &&
+      N * Kb < (1ll << 31) && !epi.group_counts) {
     int splits = 1;
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
     const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
-    if (can_split && tiles < 256) {
+    if (p8 == 1 && can_split && tiles < 256) {
       splits = (int)(256 / tiles);
       const int by_k = (int)(Kb / BKB) / 4 > 0 ? (int)(Kb / BKB) / 4 : 1;
       splits = splits > by_k ? by_k : splits;
-      if (p8_splits > 0) splits = p8_splits;
     }
-    if (splits > 1) {
-      GemmEpi e2 = epi;
-      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
-      const int rc = launch_gemm_p8<KIND>(A, W, M, N, Kb, e2, workspace, ws_bytes, splits, s);
-      if (rc != XM_OK) return rc;
-      if constexpr (KIND == kI8) {
-        int64_t blocks = (M * N + 255) / 256;
-        blocks = blocks > 2048 ? 2048 : blocks;
-        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
+    if (p8_splits > 0 && can_split) splits = p8_splits;
+    // a long K loop over few tiles (down_proj at M ~ 1024) is better served by the split-K 128x128 kernel
+    const bool long_k_few_tiles = KIND == kI8 && tiles < 100 && Kb >= 8192 && can_split;
+    if (p8 == 1 || (tiles >= p8_min_tiles && !long_k_few_tiles)) {
+      if (splits > 1) {
+        GemmEpi e2 = epi;
+        e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+        const int rc = launch_gemm_p8<KIND>(A, W, M, N, Kb, e2, workspace, ws_bytes, splits, s);
+        if (rc != XM_OK) return rc;
+        if constexpr (KIND == kI8) {
+          int64_t blocks = (M * N + 255) / 256;
+          blocks = blocks > 2048 ? 2048 : blocks;
+          hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                             reinterpret_cast<int32_t*>(workspace), M, N, epi);
+        }
+        return hip_check_launch();
       }
-      return hip_check_launch();
+      return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
     }
-    return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
   }
   if (g_wd_enable && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts &&
       (g_wd_enable == 2 || N >= 8192 || Kb >= 8192))

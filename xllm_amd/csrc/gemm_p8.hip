@@ -278,19 +278,28 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
   const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
   if constexpr (SPLITK) {
+    // split-K partial sums: transpose each 32-row block through a wave-private 8-KiB LDS block ([32][64] int32,
+    // 16-B units XOR-swizzled by row & 15) so that every atomic instruction adds one whole 256-B row segment
+    // (lane = column) instead of 64 scattered dwords.
+    __builtin_amdgcn_s_barrier();  // every wave has drained its DMAs and finished its fragment reads
+    uint8_t* const tbuf = lds + wave * 8192;
+    const int n_at = n0 + wc * 64 + lane;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      const int m = m0 + wr * 128 + mb * 32 + ml;
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wc * 64 + nb * 32 + 8 * g + 4 * half;
-          if (m >= M || n >= N) continue;
-          const int64_t idx = (int64_t)m * N + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(epi.acc_out + idx + e, (int)acc[mb][nb][4 * g + e]);
+          i32x4_t raw = {(int)acc[mb][nb][4 * g], (int)acc[mb][nb][4 * g + 1], (int)acc[mb][nb][4 * g + 2],
+                         (int)acc[mb][nb][4 * g + 3]};
+          *reinterpret_cast<i32x4_t*>(tbuf + ml * 256 + (((nb * 8 + 2 * g + half) ^ (ml & 15)) << 4)) = raw;
         }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int v = *reinterpret_cast<const int*>(tbuf + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
+        const int mr = m0 + wr * 128 + mb * 32 + r;
+        if (mr < M && n_at < N) atomicAdd(epi.acc_out + (int64_t)mr * N + n_at, v);
+      }
     }
   } else {
     // dequantise in the accumulator layout (m = lane, n = register), transpose the 16-bit results through a
