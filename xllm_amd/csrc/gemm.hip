@@ -786,6 +786,45 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
       return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
     }
   }
+  // narrow-tile pipelined kernel (gemm_p8n.hip) for decode-shaped int8 GEMMs whose 256-wide grid would be too small
+  if constexpr (KIND == kI8) {
+    static int pn = -2, pn_nb = -1, pn_splits = -1;
+    if (pn == -2) {
+      const char* e = getenv("XLLM_MI355_P8N");
+      pn = e ? atoi(e) : 0;
+      e = getenv("XLLM_MI355_P8N_NB");
+      pn_nb = e ? atoi(e) : -1;
+      e = getenv("XLLM_MI355_P8N_SPLITS");
+      pn_splits = e ? atoi(e) : -1;
+    }
+    if (pn && M <= 512 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 &&
+        M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
+      const int nb = pn_nb > 0 ? pn_nb : 2;
+      const int64_t tiles = ((N + nb * 32 - 1) / (nb * 32)) * ((M + 255) / 256);
+      const int ktiles = (int)(Kb / BKB);
+      const bool can_split = workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
+      int splits = 1;
+      if (can_split && tiles < 200) {
+        splits = (int)(256 / tiles);
+        const int by_k = ktiles / 6 > 0 ? ktiles / 6 : 1;
+        splits = splits > by_k ? by_k : splits;
+        splits = splits < 1 ? 1 : splits;
+      }
+      if (pn_splits > 0 && can_split) splits = pn_splits;
+      if (splits > 1) {
+        GemmEpi e2 = epi;
+        e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+        const int rc = launch_gemm_p8n<KIND>(A, W, M, N, Kb, e2, nb, splits, s);
+        if (rc != XM_OK) return rc;
+        int64_t blocks = (M * N + 255) / 256;
+        blocks = blocks > 2048 ? 2048 : blocks;
+        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
+        return hip_check_launch();
+      }
+      return launch_gemm_p8n<KIND>(A, W, M, N, Kb, epi, nb, 1, s);
+    }
+  }
   if (g_wd_enable && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts &&
       (g_wd_enable == 2 || N >= 8192 || Kb >= 8192))
     return launch_wdirect<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);

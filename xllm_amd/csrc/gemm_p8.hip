@@ -30,48 +30,8 @@
 
 namespace xm {
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
 constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
-
-template <int KIND>
-__device__ __forceinline__ typename MmaTraits<KIND>::acc_t mma4(const u32x4 a, const u32x4 b,
-                                                                typename MmaTraits<KIND>::acc_t c) {
-  if constexpr (KIND == kI8) {
-    i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
-    return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
-  } else if constexpr (KIND == kFP8) {
-    long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
-    long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, c, 0, 0, 0);
-  } else if constexpr (KIND == kBF16) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8_t, a), __builtin_bit_cast(gbf16x8_t, b),
-                                                   c, 0, 0, 0);
-  } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gf16x8_t, a), __builtin_bit_cast(gf16x8_t, b), c,
-                                                  0, 0, 0);
-  }
-}
-
-// 16-bit output conversion without branches (same bits as f32_to_bf16_bits / the f16 cast of common.h)
-__device__ __forceinline__ unsigned pack16(float v, bool out_bf16) {
-  const unsigned u = __float_as_uint(v);
-  const unsigned rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  const unsigned bf = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : rne;
-  const f16_t hv = (f16_t)v;
-  uint16_t hb;
-  __builtin_memcpy(&hb, &hv, 2);
-  return out_bf16 ? (bf & 0xffffu) : (unsigned)hb;
-}
-
-#define P8_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-#define P8_WAIT4(F)                                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
-#define P8_WAIT8(F)                                                                                             \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                           \
-               : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]))
 
 template <int KIND, bool SPLITK>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A,
