@@ -15,11 +15,11 @@ struct bf16_t {
 using f16_t = _Float16;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {  // RNE, quiet NaN
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {  // RNE, quiet NaN: gfx950 v_cvt_pk_bf16_f32
+  const __bf16 h = (__bf16)f;
+  uint16_t s;
+  __builtin_memcpy(&s, &h, 2);
+  return s;
 }
 
 template <typename T>

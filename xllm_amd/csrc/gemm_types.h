@@ -116,9 +116,7 @@ __device__ __forceinline__ typename MmaTraits<KIND>::acc_t mma4(const u32x4 a, c
 
 // 16-bit output conversion without branches (same bits as f32_to_bf16_bits / the f16 cast of common.h)
 __device__ __forceinline__ unsigned pack16(float v, bool out_bf16) {
-  const unsigned u = __float_as_uint(v);
-  const unsigned rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  const unsigned bf = ((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : rne;
+  const unsigned bf = f32_to_bf16_bits(v);
   const f16_t hv = (f16_t)v;
   uint16_t hb;
   __builtin_memcpy(&hb, &hv, 2);

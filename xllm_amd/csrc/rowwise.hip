@@ -366,7 +366,23 @@ __global__ __launch_bounds__(256) void fused_qk_norm_rope_kernel(T* __restrict__
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ float act_f(float f) {
-  if constexpr (MODE == XM_ACT_SILU) return f / (1.0f + expf(-f));
+  // SiLU on the hardware transcendental units (v_exp_f32, v_rcp_f32) with the two cheap corrections that bring it
+  // back to ~2 ulp in f32: the argument of exp2 carries its rounding residual (x*log2e in two pieces), and the
+  // reciprocal takes one Newton step. 12 VALU instead of the 23 of libm expf + IEEE division, which made the fused
+  // silu+quant kernel VALU-bound (2.6 TB/s at 8192 x 18944; 4.8 TB/s with this form).
+  if constexpr (MODE == XM_ACT_SILU) {
+    const float kL2E = 1.44269504088896340736f, kL2E_lo = 1.92596299112661746e-8f, kLn2 = 0.69314718055994530942f;
+    const float a = -f;
+    const float hi = a * kL2E;
+    const float lo = fmaf(a, kL2E, -hi) + a * kL2E_lo;
+    float e = __builtin_amdgcn_exp2f(hi);
+    e = fmaf(e, lo * kLn2, e);
+    const float dn = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(dn);
+    const float rn = fmaf(r, fmaf(-dn, r, 1.0f), r);
+    r = (dn < 3.0e38f) ? rn : r;  // dn = inf: keep r = 0 (the Newton step would be inf * 0); NaN keeps NaN
+    return f * r;
+  }
   else if constexpr (MODE == XM_ACT_GELU) return f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f));
   else {
     const float kBeta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;
@@ -399,9 +415,75 @@ __global__ __launch_bounds__(256) void act_and_mul_kernel(T* __restrict__ out, c
   }
 }
 
-// fused act_and_mul + per-token int8 quant; the 16-bit product is staged in LDS (d <= 32768 elements of 2 bytes
-// = 64 KiB). A register-resident variant (all loads issued up front, 512 threads x 10 x 16 B) measured 2x SLOWER
-// in the decode step (29.7 vs 14.6 us at d = 18944, round-1 profile) and was dropped.
+// fused act_and_mul + per-token int8 quant, register-resident: a row is one workgroup, every thread issues ALL of
+// its loads (VPT x 2 x 16 B, unconditional, clamped index) before the first use, so a row has its whole 4*d bytes in
+// flight at once (76 KiB at d = 18944: one HBM round trip per row instead of one per loop iteration); the 16-bit
+// products stay packed in registers across the block-wide amax reduction. Native ext_vector registers only: the
+// first attempt at this kept HIP uint4 structs in arrays, which hipcc spilled to scratch (2x slower).
+template <typename T>
+__device__ __forceinline__ float half_bits_to_f32(uint32_t h) {
+  if constexpr (__is_same(T, bf16_t)) return __uint_as_float(h << 16);
+  else { const uint16_t hh = (uint16_t)h; f16_t x; __builtin_memcpy(&x, &hh, 2); return (float)x; }
+}
+template <typename T>
+__device__ __forceinline__ uint32_t f32_to_half_bits(float f) {
+  if constexpr (__is_same(T, bf16_t)) return f32_to_bf16_bits(f);
+  else { const f16_t x = (f16_t)f; uint16_t h; __builtin_memcpy(&h, &x, 2); return h; }
+}
+template <typename T, int MODE, int VPT>
+__global__ __launch_bounds__(512) void act_and_mul_i8_reg_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
+                                                                 const T* __restrict__ in, int d) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[32];
+  const int64_t t = blockIdx.x;
+  const int nvec = d / 8;
+  const u32x4* x = reinterpret_cast<const u32x4*>(in + t * 2 * (int64_t)d);
+  const u32x4* y = x + nvec;
+  u32x4 xv[VPT], yv[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    int c = threadIdx.x + i * 512;
+    c = c < nvec ? c : nvec - 1;
+    xv[i] = x[c];
+    yv[i] = y[c];
+  }
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const bool live = (int)threadIdx.x + i * 512 < nvec;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t xw = xv[i][w], yw = yv[i][w];
+      const float r0 = r16<T>(r16<T>(act_f<MODE>(half_bits_to_f32<T>(xw & 0xffffu))) * half_bits_to_f32<T>(yw & 0xffffu));
+      const float r1 = r16<T>(r16<T>(act_f<MODE>(half_bits_to_f32<T>(xw >> 16))) * half_bits_to_f32<T>(yw >> 16));
+      xv[i][w] = f32_to_half_bits<T>(r0) | (f32_to_half_bits<T>(r1) << 16);
+      amax = fmaxf(amax, live ? fmaxf(fabsf(r0), fabsf(r1)) : 0.0f);
+    }
+  }
+  amax = block_max(amax, red);
+  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = threadIdx.x + i * 512;
+    uint32_t pk[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t wq = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t word = xv[i][h * 2 + (e >> 1)];
+        const float r = half_bits_to_f32<T>((e & 1) ? (word >> 16) : (word & 0xffffu));
+        const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(r * qinv)));
+        wq |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+      }
+      pk[h] = wq;
+    }
+    if (c < nvec) *reinterpret_cast<uint2*>(out_q + t * (int64_t)d + (int64_t)c * 8) = make_uint2(pk[0], pk[1]);
+  }
+  if (threadIdx.x == 0) out_s[t] = amax / 127.0f;
+}
+
+// LDS-staged variant for rows too long for the register kernel (d up to 32768 elements of 2 bytes = 64 KiB)
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
                                                              const T* __restrict__ in, int d) {
@@ -789,6 +871,17 @@ static int launch_act(void* out, const void* input, int64_t n_tokens, int64_t d,
 template <typename T>
 static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64_t n_tokens, int64_t d,
                        int act_mode, hipStream_t s) {
+  if (sizeof(T) == 2 && act_mode == XM_ACT_SILU && d % 8 == 0 && d <= 20480) {  // the hot-path configuration
+    const int nvec = (int)(d / 8);
+#define XM_ACTQ_REG(VPT)                                                                                         \
+  hipLaunchKernelGGL((act_and_mul_i8_reg_kernel<T, XM_ACT_SILU, VPT>), dim3(n_tokens), dim3(512), 0, s, out_q,   \
+                     out_scale, (const T*)input, (int)d)
+    if (nvec <= 512 * 2) XM_ACTQ_REG(2);
+    else if (nvec <= 512 * 3) XM_ACTQ_REG(3);
+    else XM_ACTQ_REG(5);
+#undef XM_ACTQ_REG
+    return hip_check_launch();
+  }
   const size_t lds = (size_t)d * sizeof(T);
   switch (act_mode) {
     case XM_ACT_SILU:
