@@ -63,6 +63,45 @@ XM_API int xllm_mi355_build_block_table_from_paged_kv(const int32_t* indptr, con
                                                       int32_t batch, int32_t total_pages,
                                                       int32_t* block_table, void* stream);
 
+/* N2: device-side refresh of the persistent decode metadata a replayed HIP graph reads.
+ * cuda::update_llm_decode_metadata (kernels/cuda/llm_decode_metadata_update.cu:27-60, params struct
+ * llm_decode_metadata_update.h:34-54; caller runtime/cuda_graph_executor_impl.cpp:218-258): copies tokens /
+ * positions / new cache slots (tokens and slots of the padded tail are zeroed, positions are left alone),
+ * kv_seq_lens and paged_kv_indptr (B+1 entries, cumulative form), kv_seq_lens_delta[b] = kv_seq_lens[b+1] -
+ * kv_seq_lens[b], paged_kv_last_page_len and paged_kv_indices from the step's staging buffers into the
+ * persistent ones.  MI355X extension, same launch: when dst_block_table is non-null the dense 0-padded block
+ * table [actual_batch_size, max_blocks_per_seq] that xllm_mi355_paged_attention reads is rebuilt from the CSR
+ * arrays (the DCU path needs a second kernel for that, build_block_table_from_paged_kv.hip), rows of the
+ * padded batch tail [actual_batch_size, padded_batch_size) are zeroed and dst_kv_lens (per-sequence lengths
+ * = the deltas, 0 for the padded tail) is written.  Any pointer pair may be null (skipped). */
+typedef struct xllm_mi355_decode_metadata {
+  const int32_t* src_tokens;
+  const int32_t* src_positions;
+  const int32_t* src_new_cache_slots;
+  const int32_t* src_kv_seq_lens;
+  const int32_t* src_paged_kv_indptr;
+  const int32_t* src_paged_kv_indices;
+  const int32_t* src_paged_kv_last_page_len;
+  int32_t* dst_tokens;
+  int32_t* dst_positions;
+  int32_t* dst_new_cache_slots;
+  int32_t* dst_kv_seq_lens;
+  int32_t* dst_kv_seq_lens_delta;
+  int32_t* dst_paged_kv_indptr;
+  int32_t* dst_paged_kv_indices;
+  int32_t* dst_paged_kv_last_page_len;
+  int64_t actual_num_tokens;
+  int64_t padded_num_tokens;
+  int64_t actual_batch_size;
+  int64_t actual_indices_size;
+  /* MI355X extension (all optional) */
+  int32_t* dst_block_table;
+  int32_t* dst_kv_lens;
+  int64_t max_blocks_per_seq;
+  int64_t padded_batch_size;
+} xllm_mi355_decode_metadata_t;
+XM_API int xllm_mi355_decode_metadata_update(const xllm_mi355_decode_metadata_t* params, void* stream);
+
 /* ---- RMSNorm family ------------------------------------------------------------------------
  * kernel::fused_layernorm (ops_api.h:43) -> cuda::rms_norm / cuda::fused_add_rms_norm
  * (kernels/cuda/norm.cu:430-512).  in_stride = token stride of `input` in elements. */

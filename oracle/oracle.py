@@ -128,6 +128,22 @@ def build_block_table_from_paged_kv(indptr, indices):
     return table
 
 
+def decode_metadata_update(src: dict, dst: dict, n_tok, n_tok_padded, B, n_idx, B_padded=0):
+    """CPU restatement of the N2 metadata refresh (same dict keys as xllm_amd.ops.decode_metadata_update)."""
+    sk = ("tokens", "positions", "new_cache_slots", "kv_seq_lens", "paged_kv_indptr", "paged_kv_indices",
+          "paged_kv_last_page_len")
+    dk = ("tokens", "positions", "new_cache_slots", "kv_seq_lens", "kv_seq_lens_delta", "paged_kv_indptr",
+          "paged_kv_indices", "paged_kv_last_page_len")
+    bt = dst.get("block_table")
+    args = [_p(src.get(k)) if src.get(k) is not None else None for k in sk]
+    args += [_p(dst.get(k)) if dst.get(k) is not None else None for k in dk]
+    args += [C.c_int64(n_tok), C.c_int64(n_tok_padded), C.c_int64(B), C.c_int64(n_idx)]
+    args += [_p(bt) if bt is not None else None, _p(dst["kv_lens"]) if dst.get("kv_lens") is not None else None,
+             C.c_int64(bt.size(1) if bt is not None else 0),
+             C.c_int64(B_padded or (bt.size(0) if bt is not None else B))]
+    lib().orc_decode_metadata_update(*args)
+
+
 # --------------------------------------------------------------------------- operators
 def reshape_paged_cache(slot_ids, k, v, k_cache, v_cache):
     T, nkv, d = k.shape[-3:]

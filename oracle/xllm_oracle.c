@@ -206,6 +206,47 @@ ORC_API void orc_build_block_table(const int32_t* indptr, const int32_t* indices
       table[(int64_t)s * total_pages + (j - indptr[s])] = indices[j];
 }
 
+/* N2 decode metadata refresh: kernels/cuda/llm_decode_metadata_update.cu:27-60 restated as plain loops (the copies,
+ * the zeroed padded tail of tokens / slots, kv_seq_lens_delta), plus the dense 0-padded block table and per-sequence
+ * lengths the MI355X entry point derives in the same pass (block table rule: batch_input_builder.cpp:904-938). */
+ORC_API void orc_decode_metadata_update(
+    const int32_t* src_tokens, const int32_t* src_positions, const int32_t* src_slots, const int32_t* src_kv_seq_lens,
+    const int32_t* src_indptr, const int32_t* src_indices, const int32_t* src_last_page_len, int32_t* dst_tokens,
+    int32_t* dst_positions, int32_t* dst_slots, int32_t* dst_kv_seq_lens, int32_t* dst_delta, int32_t* dst_indptr,
+    int32_t* dst_indices, int32_t* dst_last_page_len, int64_t n_tok, int64_t n_tok_padded, int64_t B, int64_t n_idx,
+    int32_t* dst_block_table, int32_t* dst_kv_lens, int64_t max_blocks, int64_t B_padded) {
+  for (int64_t i = 0; i < n_tok; ++i) {
+    if (dst_tokens) dst_tokens[i] = src_tokens[i];
+    if (dst_positions) dst_positions[i] = src_positions[i];
+    if (dst_slots) dst_slots[i] = src_slots[i];
+  }
+  for (int64_t i = n_tok; i < n_tok_padded; ++i) {
+    if (dst_tokens) dst_tokens[i] = 0;
+    if (dst_slots) dst_slots[i] = 0;
+  }
+  for (int64_t i = 0; i < B + 1; ++i) {
+    if (dst_kv_seq_lens) dst_kv_seq_lens[i] = src_kv_seq_lens[i];
+    if (dst_indptr) dst_indptr[i] = src_indptr[i];
+  }
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t len = src_kv_seq_lens[b + 1] - src_kv_seq_lens[b];
+    if (dst_delta) dst_delta[b] = len;
+    if (dst_kv_lens) dst_kv_lens[b] = len;
+    if (dst_last_page_len) dst_last_page_len[b] = src_last_page_len[b];
+  }
+  if (B_padded < B) B_padded = B;
+  for (int64_t b = B; b < B_padded; ++b)
+    if (dst_kv_lens) dst_kv_lens[b] = 0;
+  for (int64_t i = 0; i < n_idx; ++i)
+    if (dst_indices) dst_indices[i] = src_indices[i];
+  if (dst_block_table) {
+    for (int64_t i = 0; i < B_padded * max_blocks; ++i) dst_block_table[i] = 0;
+    for (int64_t b = 0; b < B; ++b)
+      for (int32_t j = src_indptr[b]; j < src_indptr[b + 1] && j - src_indptr[b] < max_blocks; ++j)
+        dst_block_table[b * max_blocks + (j - src_indptr[b])] = src_indices[j];
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* RMSNorm family: kernels/cuda/norm.cu:45-174, 229-270                      */
 /* ------------------------------------------------------------------------- */

@@ -248,6 +248,10 @@ torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const
   return table;
 }
 
+void update_llm_decode_metadata(const LlmDecodeMetadataUpdateParams& params, void* stream) {
+  check(xllm_mi355_decode_metadata_update(&params, stream), "update_llm_decode_metadata");
+}
+
 torch::Tensor prefill_attention(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v,
                                 const torch::Tensor& cu_q, const torch::Tensor& cu_k, int64_t max_q_len, double scale,
                                 bool is_causal, int64_t window_left, std::optional<torch::Tensor> out) {

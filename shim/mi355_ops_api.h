@@ -64,6 +64,12 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& paged_kv_indptr,
                                               const torch::Tensor& paged_kv_indices);
 
+// graph-mode decode: kernels/cuda/llm_decode_metadata_update.h:34-57 (same field names; the struct IS the C-ABI one,
+// whose first 19 members are the reference's LlmDecodeMetadataUpdateParams in order, followed by the optional
+// dense-block-table extension)
+using LlmDecodeMetadataUpdateParams = xllm_mi355_decode_metadata_t;
+void update_llm_decode_metadata(const LlmDecodeMetadataUpdateParams& params, void* stream);
+
 // attention entry points bound by layers/mi355/attention.cpp (arg sets of prefix_prefill_varlen_fwd /
 // prefix_decode_varlen_fwd, layers/dcu/flash_attention.cpp:45-94)
 torch::Tensor prefill_attention(const torch::Tensor& q, const torch::Tensor& k, const torch::Tensor& v,

@@ -72,6 +72,19 @@ def test_reshape_paged_cache_bit_exact(nkv, d, bs, dtype):
     assert torch.equal(kc_d.cpu(), kc_ref) and torch.equal(vc_d.cpu(), vc_ref)
 
 
+def test_decode_metadata_update_bit_exact():
+    """N2: device-side metadata refresh == the oracle on the same staging buffers, incl. the dense block table"""
+    from tests.test_oracle_ops import _decode_metadata_case
+    for B, Bp in [(5, 8), (256, 256), (1, 4)]:
+        src, dst, seq_lens, blocks, md = _decode_metadata_case(seed=B, B=B, B_padded=Bp)
+        n_idx = md["paged_kv_indices"].numel()
+        dst_dev = {k: v.clone().to(DEV) for k, v in dst.items()}
+        orc.decode_metadata_update(src, dst, B, Bp, B, n_idx, Bp)
+        ops.decode_metadata_update({k: v.to(DEV) for k, v in src.items()}, dst_dev, B, Bp, B, n_idx, Bp)
+        for k in dst:
+            assert torch.equal(dst_dev[k].cpu(), dst[k]), (B, k)
+
+
 def test_build_block_table_bit_exact():
     md = orc.build_batch_metadata([33, 16, 1, 40], [1, 16, 1, 8], [[5, 0, 9], [7], [3], [2, 11, 4]], 16)
     ref = orc.build_block_table_from_paged_kv(md["paged_kv_indptr"], md["paged_kv_indices"])

@@ -187,6 +187,53 @@ def test_batch_metadata_builder():
     assert table.shape == (4, 8) and table[1].tolist() == [7] + [-1] * 7
 
 
+def _decode_metadata_case(seed=3, B=5, B_padded=8, block_size=16):
+    """a decode step's staging metadata (BatchInputBuilder rules) + poisoned persistent buffers"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    seq_lens = [int(x) for x in rng.integers(1, 70, B)]
+    blocks, nxt = [], 1
+    for s in seq_lens:
+        n = (s + block_size - 1) // block_size
+        blocks.append(list(range(nxt, nxt + n)))
+        nxt += n
+    md = orc.build_batch_metadata(seq_lens, [1] * B, blocks, block_size)
+    i32 = lambda x: torch.tensor(np.asarray(x, dtype=np.int32))
+    src = dict(tokens=i32(rng.integers(0, 1000, B)), positions=i32([s - 1 for s in seq_lens]),
+               new_cache_slots=md["new_cache_slots"], kv_seq_lens=md["kv_cu_seq_lens"],
+               paged_kv_indptr=md["paged_kv_indptr"], paged_kv_indices=md["paged_kv_indices"],
+               paged_kv_last_page_len=md["paged_kv_last_page_len"])
+    max_blocks = max(len(b) for b in blocks) + 2
+    poison = lambda *shape: torch.full(shape, -7, dtype=torch.int32)
+    dst = dict(tokens=poison(B_padded), positions=poison(B_padded), new_cache_slots=poison(B_padded),
+               kv_seq_lens=poison(B_padded + 1), kv_seq_lens_delta=poison(B_padded), paged_kv_indptr=poison(B_padded + 1),
+               paged_kv_indices=poison(md["paged_kv_indices"].numel() + 4), paged_kv_last_page_len=poison(B_padded),
+               block_table=poison(B_padded, max_blocks), kv_lens=poison(B_padded))
+    return src, dst, seq_lens, blocks, md
+
+
+def test_decode_metadata_update_matches_reference_rules():
+    """llm_decode_metadata_update.cu:27-60 restated + the dense block table of batch_input_builder.cpp:904-938"""
+    B, Bp = 5, 8
+    src, dst, seq_lens, blocks, md = _decode_metadata_case(B=B, B_padded=Bp)
+    n_idx = md["paged_kv_indices"].numel()
+    orc.decode_metadata_update(src, dst, B, Bp, B, n_idx, Bp)
+    assert dst["tokens"].tolist() == src["tokens"].tolist() + [0] * (Bp - B)
+    assert dst["new_cache_slots"].tolist() == src["new_cache_slots"].tolist() + [0] * (Bp - B)
+    assert dst["positions"].tolist() == src["positions"].tolist() + [-7] * (Bp - B)   # padded tail left alone
+    assert dst["kv_seq_lens"][:B + 1].tolist() == md["kv_cu_seq_lens"].tolist()
+    assert dst["kv_seq_lens"][B + 1:].tolist() == [-7] * (Bp - B)
+    assert dst["kv_seq_lens_delta"][:B].tolist() == seq_lens
+    assert dst["paged_kv_indptr"][:B + 1].tolist() == md["paged_kv_indptr"].tolist()
+    assert dst["paged_kv_indices"][:n_idx].tolist() == md["paged_kv_indices"].tolist()
+    assert dst["paged_kv_indices"][n_idx:].tolist() == [-7] * 4
+    assert dst["paged_kv_last_page_len"][:B].tolist() == md["paged_kv_last_page_len"].tolist()
+    assert dst["kv_lens"].tolist() == seq_lens + [0] * (Bp - B)
+    width = md["block_tables"].size(1)
+    assert torch.equal(dst["block_table"][:B, :width], md["block_tables"])          # same 0-padded table
+    assert int(dst["block_table"][:, width:].abs().sum()) == 0 and int(dst["block_table"][B:].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_int8_quant_closed_form(dtype):
     M, K = 16, 3584

@@ -12,8 +12,22 @@ LIB_PATH = os.environ.get("XLLM_MI355_LIB") or os.path.join(_HERE, "lib", "libxl
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 ci = C.c_int
 
+
+
+class DecodeMetadata(C.Structure):
+    """xllm_mi355_decode_metadata_t (include/xllm_mi355.h)"""
+    _fields_ = ([(n, vp) for n in (
+        "src_tokens", "src_positions", "src_new_cache_slots", "src_kv_seq_lens", "src_paged_kv_indptr",
+        "src_paged_kv_indices", "src_paged_kv_last_page_len", "dst_tokens", "dst_positions", "dst_new_cache_slots",
+        "dst_kv_seq_lens", "dst_kv_seq_lens_delta", "dst_paged_kv_indptr", "dst_paged_kv_indices",
+        "dst_paged_kv_last_page_len")] +
+        [(n, i64) for n in ("actual_num_tokens", "padded_num_tokens", "actual_batch_size", "actual_indices_size")] +
+        [("dst_block_table", vp), ("dst_kv_lens", vp), ("max_blocks_per_seq", i64), ("padded_batch_size", i64)])
+
+
 _SIGS = {
     "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_decode_metadata_update": ([C.POINTER(DecodeMetadata), vp], ci),
     "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_build_block_table_from_paged_kv": ([vp, vp, i32, i32, vp, vp], ci),
     "xllm_mi355_rms_norm": ([vp, vp, vp, f32, i64, i64, i64, ci, vp], ci),

@@ -660,7 +660,74 @@ using namespace xm;
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// N2: decode metadata refresh for graph replay (reference: llm_decode_metadata_update.cu:27-60) + dense block table
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_metadata_update_kernel(xllm_mi355_decode_metadata_t p, int64_t work) {
+  const int64_t step = (int64_t)blockDim.x * gridDim.x;
+  const int64_t nt = p.actual_num_tokens, B = p.actual_batch_size;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < work; idx += step) {
+    if (idx < nt) {
+      if (p.dst_tokens) p.dst_tokens[idx] = p.src_tokens[idx];
+      if (p.dst_positions) p.dst_positions[idx] = p.src_positions[idx];
+      if (p.dst_new_cache_slots) p.dst_new_cache_slots[idx] = p.src_new_cache_slots[idx];
+    } else if (idx < p.padded_num_tokens) {
+      if (p.dst_tokens) p.dst_tokens[idx] = 0;
+      if (p.dst_new_cache_slots) p.dst_new_cache_slots[idx] = 0;
+    }
+    if (idx < B + 1) {
+      if (p.dst_kv_seq_lens) p.dst_kv_seq_lens[idx] = p.src_kv_seq_lens[idx];
+      if (p.dst_paged_kv_indptr) p.dst_paged_kv_indptr[idx] = p.src_paged_kv_indptr[idx];
+    }
+    if (idx < B) {
+      const int32_t len = p.src_kv_seq_lens ? p.src_kv_seq_lens[idx + 1] - p.src_kv_seq_lens[idx] : 0;
+      if (p.dst_kv_seq_lens_delta) p.dst_kv_seq_lens_delta[idx] = len;
+      if (p.dst_kv_lens) p.dst_kv_lens[idx] = len;
+      if (p.dst_paged_kv_last_page_len) p.dst_paged_kv_last_page_len[idx] = p.src_paged_kv_last_page_len[idx];
+    } else if (idx < p.padded_batch_size) {
+      if (p.dst_kv_lens) p.dst_kv_lens[idx] = 0;
+    }
+    if (idx < p.actual_indices_size && p.dst_paged_kv_indices) p.dst_paged_kv_indices[idx] = p.src_paged_kv_indices[idx];
+    if (p.dst_block_table && idx < p.padded_batch_size * p.max_blocks_per_seq) {
+      const int64_t b = idx / p.max_blocks_per_seq, j = idx - b * p.max_blocks_per_seq;
+      int32_t v = 0;
+      if (b < B) {
+        const int32_t beg = p.src_paged_kv_indptr[b], end = p.src_paged_kv_indptr[b + 1];
+        if (j < end - beg) v = p.src_paged_kv_indices[beg + j];
+      }
+      p.dst_block_table[idx] = v;
+    }
+  }
+}
+
 extern "C" {
+
+int xllm_mi355_decode_metadata_update(const xllm_mi355_decode_metadata_t* params, void* stream) {
+  if (!params) return XM_ERR_INVALID;
+  xllm_mi355_decode_metadata_t p = *params;
+  if (p.actual_num_tokens < 0 || p.actual_batch_size < 0 || p.actual_indices_size < 0) return XM_ERR_INVALID;
+  if ((p.dst_tokens && !p.src_tokens) || (p.dst_positions && !p.src_positions) ||
+      (p.dst_new_cache_slots && !p.src_new_cache_slots) || (p.dst_paged_kv_indices && !p.src_paged_kv_indices) ||
+      (p.dst_paged_kv_indptr && !p.src_paged_kv_indptr) ||
+      (p.dst_paged_kv_last_page_len && !p.src_paged_kv_last_page_len) ||
+      ((p.dst_kv_seq_lens || p.dst_kv_seq_lens_delta || p.dst_kv_lens) && !p.src_kv_seq_lens))
+    return XM_ERR_INVALID;
+  if (p.dst_block_table && (!p.src_paged_kv_indptr || !p.src_paged_kv_indices || p.max_blocks_per_seq <= 0))
+    return XM_ERR_INVALID;
+  if (p.padded_batch_size < p.actual_batch_size) p.padded_batch_size = p.actual_batch_size;
+  if (p.padded_num_tokens < p.actual_num_tokens) p.padded_num_tokens = p.actual_num_tokens;
+  int64_t work = p.padded_num_tokens;
+  if (p.actual_batch_size + 1 > work) work = p.actual_batch_size + 1;
+  if (p.padded_batch_size > work) work = p.padded_batch_size;
+  if (p.actual_indices_size > work) work = p.actual_indices_size;
+  if (p.dst_block_table && p.padded_batch_size * p.max_blocks_per_seq > work) work = p.padded_batch_size * p.max_blocks_per_seq;
+  if (work <= 0) return XM_OK;
+  int64_t blocks = (work + 255) / 256;
+  blocks = blocks > 4096 ? 4096 : blocks;
+  hipLaunchKernelGGL(decode_metadata_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, work);
+  return hip_check_launch();
+}
+
 
 const char* xllm_mi355_strerror(int code) {
   switch (code) {

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -426,3 +428,33 @@ def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, m
         return None
     check(rc, "paged_decode_attention_int8")
     return oq, os_, o16
+
+
+def decode_metadata_update(src: dict, dst: dict, actual_num_tokens: int, padded_num_tokens: int,
+                           actual_batch_size: int, actual_indices_size: int, padded_batch_size: int = 0) -> None:
+    """N2: refresh the persistent decode metadata of a captured graph on the device
+    (cuda::update_llm_decode_metadata, kernels/cuda/llm_decode_metadata_update.cu:27-60) and, when dst holds
+    "block_table" / "kv_lens", rebuild the dense 0-padded block table + per-sequence lengths in the same launch.
+    src keys: tokens positions new_cache_slots kv_seq_lens paged_kv_indptr paged_kv_indices paged_kv_last_page_len;
+    dst keys: the same + kv_seq_lens_delta, block_table [padded_B, max_blocks], kv_lens [padded_B]."""
+    md = _lib.DecodeMetadata()
+    for k in ("tokens", "positions", "new_cache_slots", "kv_seq_lens", "paged_kv_indptr", "paged_kv_indices",
+              "paged_kv_last_page_len"):
+        t = src.get(k)
+        if t is not None:
+            _need_cuda(t)
+            assert t.dtype == torch.int32 and t.is_contiguous()
+        setattr(md, "src_" + k, _p(t) or None)
+    for k in ("tokens", "positions", "new_cache_slots", "kv_seq_lens", "kv_seq_lens_delta", "paged_kv_indptr",
+              "paged_kv_indices", "paged_kv_last_page_len", "block_table", "kv_lens"):
+        t = dst.get(k)
+        if t is not None:
+            _need_cuda(t)
+            assert t.dtype == torch.int32 and t.is_contiguous()
+        setattr(md, "dst_" + k, _p(t) or None)
+    md.actual_num_tokens, md.padded_num_tokens = actual_num_tokens, padded_num_tokens
+    md.actual_batch_size, md.actual_indices_size = actual_batch_size, actual_indices_size
+    bt = dst.get("block_table")
+    md.max_blocks_per_seq = bt.size(1) if bt is not None else 0
+    md.padded_batch_size = padded_batch_size or (bt.size(0) if bt is not None else actual_batch_size)
+    check(_lib.lib().xllm_mi355_decode_metadata_update(C.byref(md), _stream()), "decode_metadata_update")
