@@ -8,6 +8,8 @@
 #pragma once
 #include <torch/torch.h>
 
+#include "../include/xllm_mi355.h"
+
 #include <optional>
 #include <string>
 #include <tuple>
