@@ -49,7 +49,8 @@ XM_API int xllm_mi355_abi_version(void);
 /* ---- KV write ------------------------------------------------------------------------------
  * kernel::reshape_paged_cache (ops_api.h:31) -> cuda::reshape_paged_cache
  * (kernels/cuda/reshape_paged_cache.cu:65-100).  k/v [T, nkv, d] with token strides (elements),
- * caches [n_blocks, block_size, nkv, d]; slot<0 skipped; slot/block_size >= n_blocks is silently
+ * caches [n_blocks, block_size, nkv, d]; v and v_cache may both be NULL (K-only cache: the MLA latent cache,
+ * DeepseekV2AttentionImpl::store_latent_cache, layers/dcu/deepseek_v2_attention.cpp:170-178); slot<0 skipped; slot/block_size >= n_blocks is silently
  * skipped as out of range (the reference would write out of bounds).  elt_bytes 2 or 4. */
 XM_API int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const void* v,
                                           void* k_cache, void* v_cache, int64_t n_tokens,
@@ -252,6 +253,21 @@ XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,
                                  int64_t head_dim_v, int64_t block_size, int64_t n_blocks,
                                  int64_t max_kv_len, float scale, int dtype, void* workspace,
                                  size_t workspace_bytes, void* stream);
+
+/* MLA prefill / chunked prefill: DeepseekV2AttentionImpl::prefill_sdpa (layers/dcu/deepseek_v2_attention.cpp:212-262;
+ * the reference loops over sequences on the HOST and calls torch SDPA per sequence) in the same absorbed form as the
+ * decode: q [T, H, 576] = [q_nope*W_kc || q_pe] of a ragged batch (cu_q [B+1]), keys = the paged latent cache rows
+ * of each sequence (kv_lens [B], block_table [B, max_blocks]) -- call xllm_mi355_reshape_paged_cache with v = NULL
+ * (store_latent_cache, :170-178) first -- out [T, H, 512].  causal != 0: query i of a sequence sees its first
+ * kv_len - (q_len - 1 - i) keys (bottom-right alignment; identical to torch's is_causal when q_len == kv_len).
+ * First version: every query token streams its keys like a decode entry (HBM/L2 traffic T*L/2 rows; the H heads of
+ * a token share the stream).  workspace >= 8*T bytes (+ split-KV partials, see _mla_decode). */
+XM_API int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out, const int32_t* cu_q,
+                                  const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks,
+                                  int64_t batch, int64_t total_q_tokens, int64_t n_heads, int64_t head_dim,
+                                  int64_t head_dim_v, int64_t block_size, int64_t n_blocks, int64_t max_kv_len,
+                                  float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ---- MoE -----------------------------------------------------------------------------------
  * kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (kernels/cuda/moe/moe_compute_index.cu:111-160)

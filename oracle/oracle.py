@@ -146,12 +146,16 @@ def decode_metadata_update(src: dict, dst: dict, n_tok, n_tok_padded, B, n_idx, 
 
 # --------------------------------------------------------------------------- operators
 def reshape_paged_cache(slot_ids, k, v, k_cache, v_cache):
+    """v / v_cache may both be None: K-only caches (MLA store_latent_cache, deepseek_v2_attention.cpp:170-178)"""
     T, nkv, d = k.shape[-3:]
-    assert k.stride(-1) == 1 and k.stride(-2) == d and v.stride(-1) == 1 and v.stride(-2) == d
+    assert k.stride(-1) == 1 and k.stride(-2) == d
+    assert (v is None) == (v_cache is None)
+    if v is not None:
+        assert v.stride(-1) == 1 and v.stride(-2) == d
     rc = lib().orc_reshape_paged_cache(
         _p(slot_ids), _p(k), _p(v), _p(k_cache), _p(v_cache), _i64(T), _i64(nkv), _i64(d),
-        _i64(k_cache.shape[-3]), _i64(k_cache.shape[0]), _i64(k.stride(-3)), _i64(v.stride(-3)),
-        C.c_int(k.element_size()))
+        _i64(k_cache.shape[-3]), _i64(k_cache.shape[0]), _i64(k.stride(-3)),
+        _i64(v.stride(-3) if v is not None else 0), C.c_int(k.element_size()))
     if rc:
         raise ValueError("slot out of range")
 

@@ -191,7 +191,8 @@ ORC_API int orc_reshape_paged_cache(const int32_t* slot_ids, const void* k, cons
     if (blk >= n_blocks) return -1;
     int64_t dst = (blk * block_size + off) * row;
     memcpy((char*)k_cache + dst * elt_bytes, (const char*)k + t * k_stride * elt_bytes, row * elt_bytes);
-    memcpy((char*)v_cache + dst * elt_bytes, (const char*)v + t * v_stride * elt_bytes, row * elt_bytes);
+    if (v) /* K-only = MLA store_latent_cache, layers/dcu/deepseek_v2_attention.cpp:170-178 */
+      memcpy((char*)v_cache + dst * elt_bytes, (const char*)v + t * v_stride * elt_bytes, row * elt_bytes);
   }
   return 0;
 }

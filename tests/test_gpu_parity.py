@@ -512,6 +512,42 @@ def test_mla_decode(H, bs, kv_lens):
     assert_attn_close(out.view(B, -1), ref)
 
 
+@pytest.mark.parametrize("H,bs,lens", [(16, 64, [(40, 40), (1, 1), (97, 97)]), (8, 64, [(17, 300), (64, 64), (5, 133)]),
+                                       (128, 16, [(33, 33)])])
+def test_mla_prefill_and_latent_store(H, bs, lens):
+    """a6: store_latent_cache (K-only cache write, bit-exact) then prefill / chunked prefill over the paged latent
+    cache == softmax(scale q.K^T) K[:, :512] with the bottom-right causal mask (prefill_sdpa's formulation,
+    layers/dcu/deepseek_v2_attention.cpp:212-262; oracle = generic paged attention, nkv=1, d=576, dv=512)"""
+    q_lens, kv_lens = [a for a, _ in lens], [b for _, b in lens]
+    B, T = len(lens), sum(q_lens)
+    g = torch.Generator().manual_seed(H * 7 + bs)
+    pages = [(L + bs - 1) // bs for L in kv_lens]
+    nb = sum(pages) + 3
+    perm = torch.randperm(nb, generator=g).tolist()
+    blocks, used = [], 0
+    for n in pages:
+        blocks.append(perm[used:used + n]); used += n
+    md = orc.build_batch_metadata(kv_lens, q_lens, blocks, bs)
+    kc = torch.randn(nb, bs, 1, 576, generator=g).bfloat16()          # cached prefix (+ garbage elsewhere)
+    latent = torch.randn(T, 576, generator=g).bfloat16()               # this step's [c_kv_normed || k_pe] rows
+    kc_ref = kc.clone()
+    orc.reshape_paged_cache(md["new_cache_slots"], latent.view(T, 1, 576), None, kc_ref, None)
+    kc_dev = kc.to(DEV)
+    ops.store_latent_cache(latent.to(DEV), md["new_cache_slots"].to(DEV), kc_dev)
+    assert torch.equal(kc_dev.cpu().view(torch.int16), kc_ref.view(torch.int16))
+    q = torch.randn(T, H, 576, generator=g).bfloat16()
+    scale = 192 ** -0.5
+    ref = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
+                              causal=True, dv=512)
+    out = ops.mla_prefill(q.to(DEV), kc_dev, md["q_cu_seq_lens"].to(DEV), md["kv_seq_lens"].to(DEV),
+                          md["block_tables"].to(DEV), 512, scale, max(kv_lens), is_causal=True)
+    assert_attn_close(out.view(T, -1), ref)
+    # decode through the same cache agrees with the last query row of every sequence
+    dec = ops.mla_decode(q[md["q_cu_seq_lens"][1:].long() - 1].contiguous().to(DEV), kc_dev, md["kv_seq_lens"].to(DEV),
+                         md["block_tables"].to(DEV), 512, scale, max(kv_lens))
+    assert torch.equal(dec.cpu(), out.cpu()[md["q_cu_seq_lens"][1:].long() - 1])
+
+
 def test_moe_index_combine_group_gemm():
     T, topk, E, Hd, N = 301, 8, 128, 256, 384
     g = torch.Generator().manual_seed(6)

@@ -187,6 +187,19 @@ def test_batch_metadata_builder():
     assert table.shape == (4, 8) and table[1].tolist() == [7] + [-1] * 7
 
 
+def test_latent_cache_store_is_index_copy():
+    """K-only reshape_paged_cache == k_cache.view(-1, dim).index_copy_(0, slots, latent)
+    (DeepseekV2AttentionImpl::store_latent_cache, layers/dcu/deepseek_v2_attention.cpp:170-178)"""
+    g = torch.Generator().manual_seed(5)
+    kc = torch.randn(6, 64, 1, 576, generator=g).bfloat16()
+    latent = torch.randn(50, 576, generator=g).bfloat16()
+    slots = torch.randperm(6 * 64, generator=g)[:50].to(torch.int32)
+    ref = kc.clone()
+    ref.view(-1, 576).index_copy_(0, slots.long(), latent)
+    orc.reshape_paged_cache(slots, latent.view(50, 1, 576), None, kc, None)
+    assert torch.equal(kc.view(torch.int16), ref.view(torch.int16))
+
+
 def _decode_metadata_case(seed=3, B=5, B_padded=8, block_size=16):
     """a decode step's staging metadata (BatchInputBuilder rules) + poisoned persistent buffers"""
     import numpy as np

@@ -58,6 +58,8 @@ _SIGS = {
 # entry points declared in the header but implemented in a later build step are bound lazily
 _OPTIONAL = {
     "xllm_mi355_mla_decode": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, vp, sz, vp], ci),
+    "xllm_mi355_mla_prefill": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, ci, vp, sz,
+                                vp], ci),
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),
     "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),

@@ -60,7 +60,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_ml, const int32_t* __restrict__ seqlens, const int32_t* __restrict__ block_table,
-    int max_blocks, int n_heads, int block_size, float scale_log2, int nsplit) {
+    int max_blocks, int n_heads, int block_size, float scale_log2, int nsplit,
+    const int32_t* __restrict__ q_seq, const int32_t* __restrict__ q_kvlen) {
   using TR = MlaTraits<T>;
   using x8 = typename TR::x8;
   using x4 = typename TR::x4;
@@ -78,12 +79,15 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   const int split = blockIdx.x % nsplit;
   const int hb = (blockIdx.x / nsplit) % ((n_heads + 15) / 16);  // block of 16 heads
   const int b = blockIdx.x / nsplit / ((n_heads + 15) / 16);
-  const int kv_len = seqlens[b];
+  // prefill / chunked prefill drive the same kernel with one "batch entry" per QUERY TOKEN: q_seq maps the token to
+  // its sequence (block-table row) and q_kvlen is its causal key count; decode passes null (entry = sequence)
+  const int seq = q_seq ? q_seq[b] : b;
+  const int kv_len = q_kvlen ? q_kvlen[b] : seqlens[seq];
   const int ntiles = (kv_len + kMlaTile - 1) / kMlaTile;
   const int per = (ntiles + nsplit - 1) / nsplit;
   const int tile_lo = split * per;
   const int tile_hi = tile_lo + per < ntiles ? tile_lo + per : ntiles;
-  const int32_t* bt_row = block_table + (int64_t)b * max_blocks;
+  const int32_t* bt_row = block_table + (int64_t)seq * max_blocks;
   const int head = hb * 16 + p16;
 
   // Q as the MFMA B operand: lane (n = head p16, k group g)
@@ -234,6 +238,49 @@ __global__ void mla_merge_kernel(const float* __restrict__ part_o, const float* 
   out[bh * kMlaDV + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
 }
 
+// one entry per query token of a ragged batch: its sequence and its (bottom-right aligned) causal key count
+__global__ __launch_bounds__(256) void mla_expand_queries_kernel(const int32_t* __restrict__ cu_q,
+                                                                 const int32_t* __restrict__ kv_lens, int causal,
+                                                                 int32_t* __restrict__ q_seq,
+                                                                 int32_t* __restrict__ q_kvlen) {
+  const int b = blockIdx.x;
+  const int q0 = cu_q[b], ql = cu_q[b + 1] - q0, L = kv_lens[b];
+  for (int i = threadIdx.x; i < ql; i += blockDim.x) {
+    const int len = causal ? L - (ql - 1 - i) : L;
+    q_seq[q0 + i] = b;
+    q_kvlen[q0 + i] = len > 0 ? len : 0;
+  }
+}
+
+static int launch_mla(const void* q, const void* k_cache, void* out, const int32_t* seqlens_k, const int32_t* q_seq,
+                      const int32_t* q_kvlen, const int32_t* block_table, int64_t max_blocks, int64_t entries,
+                      int64_t n_heads, int64_t block_size, int64_t max_kv_len, float scale, int dtype, void* workspace,
+                      size_t workspace_bytes, hipStream_t s) {
+  const int64_t hblocks = (n_heads + 15) / 16;
+  const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
+  int64_t nsplit = (512 + entries * hblocks - 1) / (entries * hblocks);
+  if (nsplit > tiles / 8) nsplit = tiles / 8;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 32) nsplit = 32;
+  const size_t per_split = (size_t)entries * n_heads * (kMlaDV + 2) * sizeof(float);
+  if (!workspace) workspace_bytes = 0;
+  if ((size_t)nsplit * per_split > workspace_bytes) nsplit = (int64_t)(workspace_bytes / per_split);
+  if (nsplit < 1) nsplit = 1;
+  float* part_o = reinterpret_cast<float*>(workspace);
+  float* part_ml = part_o ? part_o + (size_t)entries * n_heads * nsplit * kMlaDV : nullptr;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  const dim3 grid((unsigned)(entries * hblocks * nsplit));
+  XM_DISPATCH_HALF(dtype, T, {
+    hipLaunchKernelGGL((mla_decode_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out, part_o,
+                       part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale_log2,
+                       (int)nsplit, q_seq, q_kvlen);
+    if (nsplit > 1)
+      hipLaunchKernelGGL((mla_merge_kernel<T>), dim3((unsigned)(entries * n_heads)), dim3(kMlaDV), 0, s, part_o, part_ml,
+                         (T*)out, (int)nsplit);
+  });
+  return hip_check_launch();
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -249,28 +296,31 @@ extern "C" int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* o
   if (head_dim != kMlaD || head_dim_v != kMlaDV) return XM_ERR_UNSUPPORTED;
   if ((uintptr_t)q % 16 || (uintptr_t)k_cache % 16) return XM_ERR_UNSUPPORTED;
   if (batch == 0) return XM_OK;
-  const int64_t hblocks = (n_heads + 15) / 16;
-  const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
-  int64_t nsplit = (512 + batch * hblocks - 1) / (batch * hblocks);
-  if (nsplit > tiles / 8) nsplit = tiles / 8;
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > 32) nsplit = 32;
-  const size_t per_split = (size_t)batch * n_heads * (kMlaDV + 2) * sizeof(float);
-  if (!workspace) workspace_bytes = 0;
-  if ((size_t)nsplit * per_split > workspace_bytes) nsplit = (int64_t)(workspace_bytes / per_split);
-  if (nsplit < 1) nsplit = 1;
-  float* part_o = reinterpret_cast<float*>(workspace);
-  float* part_ml = part_o ? part_o + (size_t)batch * n_heads * nsplit * kMlaDV : nullptr;
-  const float scale_log2 = scale * 1.4426950408889634f;
+  return launch_mla(q, k_cache, out, seqlens_k, nullptr, nullptr, block_table, max_blocks, batch, n_heads, block_size,
+                    max_kv_len, scale, dtype, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out, const int32_t* cu_q,
+                                      const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks,
+                                      int64_t batch, int64_t total_q_tokens, int64_t n_heads, int64_t head_dim,
+                                      int64_t head_dim_v, int64_t block_size, int64_t n_blocks, int64_t max_kv_len,
+                                      float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  (void)n_blocks;
+  if (!q || !k_cache || !out || !cu_q || !kv_lens || !block_table || batch < 0 || total_q_tokens < 0 || n_heads <= 0 ||
+      block_size <= 0)
+    return XM_ERR_INVALID;
+  if (head_dim != kMlaD || head_dim_v != kMlaDV) return XM_ERR_UNSUPPORTED;
+  if ((uintptr_t)q % 16 || (uintptr_t)k_cache % 16) return XM_ERR_UNSUPPORTED;
+  if (batch == 0 || total_q_tokens == 0) return XM_OK;
+  const size_t idx_bytes = (((size_t)total_q_tokens * 2 * sizeof(int32_t)) + 255) & ~(size_t)255;
+  if (!workspace || workspace_bytes < idx_bytes) return XM_ERR_WORKSPACE;
+  int32_t* q_seq = reinterpret_cast<int32_t*>(workspace);
+  int32_t* q_kvlen = q_seq + total_q_tokens;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)(batch * hblocks * nsplit));
-  XM_DISPATCH_HALF(dtype, T, {
-    hipLaunchKernelGGL((mla_decode_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out, part_o,
-                       part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale_log2,
-                       (int)nsplit);
-    if (nsplit > 1)
-      hipLaunchKernelGGL((mla_merge_kernel<T>), dim3((unsigned)(batch * n_heads)), dim3(kMlaDV), 0, s, part_o, part_ml,
-                         (T*)out, (int)nsplit);
-  });
-  return hip_check_launch();
+  hipLaunchKernelGGL(mla_expand_queries_kernel, dim3((unsigned)batch), dim3(256), 0, s, cu_q, kv_lens, causal, q_seq,
+                     q_kvlen);
+  return launch_mla(q, k_cache, out, kv_lens, q_seq, q_kvlen, block_table, max_blocks, total_q_tokens, n_heads,
+                    block_size, max_kv_len, scale, dtype, reinterpret_cast<uint8_t*>(workspace) + idx_bytes,
+                    workspace_bytes - idx_bytes, s);
 }

@@ -52,12 +52,16 @@ __global__ __launch_bounds__(256) void reshape_paged_cache_kernel(
   if (slot / block_size >= n_blocks) return;
   // cache row index == slot (block*block_size + offset)
   const V* ks = k + t * k_stride_v;
-  const V* vs = v + t * v_stride_v;
   V* kd = kc + slot * row_v;
-  V* vd = vc + slot * row_v;
-  for (int64_t i = threadIdx.x; i < row_v; i += blockDim.x) {
-    kd[i] = ks[i];
-    vd[i] = vs[i];
+  if (v) {
+    const V* vs = v + t * v_stride_v;
+    V* vd = vc + slot * row_v;
+    for (int64_t i = threadIdx.x; i < row_v; i += blockDim.x) {
+      kd[i] = ks[i];
+      vd[i] = vs[i];
+    }
+  } else {  // K-only caches: the MLA latent cache (store_latent_cache, deepseek_v2_attention.cpp:170-178)
+    for (int64_t i = threadIdx.x; i < row_v; i += blockDim.x) kd[i] = ks[i];
   }
 }
 
@@ -745,7 +749,8 @@ int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const
                                    void* v_cache, int64_t n_tokens, int64_t n_kv_heads, int64_t head_dim,
                                    int64_t block_size, int64_t n_blocks, int64_t k_stride, int64_t v_stride,
                                    int elt_bytes, void* stream) {
-  if (!slot_ids || !k || !v || !k_cache || !v_cache || n_tokens < 0 || block_size <= 0) return XM_ERR_INVALID;
+  if (!slot_ids || !k || !k_cache || n_tokens < 0 || block_size <= 0) return XM_ERR_INVALID;
+  if ((v == nullptr) != (v_cache == nullptr)) return XM_ERR_INVALID;  // K-only (MLA latent cache) needs both null
   if (elt_bytes != 2 && elt_bytes != 4 && elt_bytes != 1) return XM_ERR_UNSUPPORTED;
   if (n_tokens == 0) return XM_OK;
   hipStream_t s = (hipStream_t)stream;

@@ -45,17 +45,26 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------ KV write
 def reshape_paged_cache(slot_ids, key, value, key_cache, value_cache) -> None:
     """kernel::reshape_paged_cache(ReshapePagedCacheParams&) (ops_api.h:31, reshape_paged_cache.cu:65-100)."""
-    _need_cuda(slot_ids, key, value, key_cache, value_cache)
-    if not (key.stride(-1) == 1 and key.stride(-2) == key.size(-1) and value.stride(-1) == 1
-            and value.stride(-2) == value.size(-1)):
+    if (value is None) != (value_cache is None):
+        raise Mi355Error("value and value_cache must both be given or both be None (K-only cache)")
+    _need_cuda(*[t for t in (slot_ids, key, value, key_cache, value_cache) if t is not None])
+    if not (key.stride(-1) == 1 and key.stride(-2) == key.size(-1)) or (
+            value is not None and not (value.stride(-1) == 1 and value.stride(-2) == value.size(-1))):
         raise Mi355Error("keys/values must be contiguous over (n_kv_heads, head_dim)")  # reference CHECK :73-74
     if slot_ids.dtype != torch.int32:
         raise Mi355Error("slot_ids must be int32")
     n_tokens, n_kv, d = key.shape[-3:]
     check(_lib.lib().xllm_mi355_reshape_paged_cache(
         _p(slot_ids), _p(key), _p(value), _p(key_cache), _p(value_cache), n_tokens, n_kv, d,
-        key_cache.size(-3), key_cache.size(0), key.stride(-3), value.stride(-3), key.element_size(), _stream()),
-        "reshape_paged_cache")
+        key_cache.size(-3), key_cache.size(0), key.stride(-3), value.stride(-3) if value is not None else 0,
+        key.element_size(), _stream()), "reshape_paged_cache")
+
+
+def store_latent_cache(latent_cache, slot_mapping, k_cache) -> None:
+    """DeepseekV2AttentionImpl::store_latent_cache (layers/dcu/deepseek_v2_attention.cpp:170-178):
+    k_cache.view(-1, 576).index_copy_(0, slot_mapping, latent_cache) -- the K-only form of reshape_paged_cache."""
+    reshape_paged_cache(slot_mapping, latent_cache.view(latent_cache.size(0), 1, latent_cache.size(-1)), None, k_cache,
+                        None)
 
 
 def build_block_table_from_paged_kv(paged_kv_indptr, paged_kv_indices) -> torch.Tensor:
@@ -355,6 +364,24 @@ def mla_decode(q, k_cache, seqlens_k, block_table, head_size_v: int, scale: floa
 
 # ------------------------------------------------------------------------------------------------ MoE
 _moe_ws = {}
+
+
+def mla_prefill(q, k_cache, cu_seqlens_q, kv_seq_lens, block_table, head_size_v: int, scale: float, max_kv_len: int,
+                is_causal: bool = True, out=None):
+    """DeepseekV2AttentionImpl::prefill_sdpa (layers/dcu/deepseek_v2_attention.cpp:212-262) over the paged latent
+    cache: q [T, H, 576], out [T, H, head_size_v]; bottom-right causal alignment."""
+    _need_cuda(q, k_cache, cu_seqlens_q, kv_seq_lens, block_table)
+    T, H, D = q.shape
+    if not q.is_contiguous() or not block_table.is_contiguous():
+        raise Mi355Error("q and block_table must be contiguous")
+    out = out if out is not None else torch.empty(T, H, head_size_v, dtype=q.dtype, device=q.device)
+    ws_bytes = ((T * 8 + 255) // 256) * 256 + 8 * T * H * (head_size_v + 2) * 4
+    ws = _attn_workspace(q.device, ws_bytes)
+    check(_lib.lib().xllm_mi355_mla_prefill(
+        _p(q), _p(k_cache), _p(out), _p(cu_seqlens_q), _p(kv_seq_lens), _p(block_table), block_table.size(1),
+        kv_seq_lens.numel(), T, H, D, head_size_v, k_cache.size(1), k_cache.size(0), max_kv_len, scale,
+        int(is_causal), _dt(q), _p(ws), ws.numel() * ws.element_size(), _stream()), "mla_prefill")
+    return out
 
 
 def moe_compute_index(expert_id, num_experts: int):
