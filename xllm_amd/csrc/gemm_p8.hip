@@ -33,192 +33,12 @@ namespace xm {
 constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
 constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
 
+// Shared epilogue of the 256x256 kernels. On entry every wave has drained its DMAs (vmcnt(0)); the function
+// synchronises the workgroup before it reuses the LDS.
 template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A,
-                                                               const uint8_t* __restrict__ W, int M, int N,
-                                                               int64_t Kb, int m_tiles, int n_tiles,
-                                                               int ktiles_per_split, GemmEpi epi) {
-  using acc_t = typename MmaTraits<KIND>::acc_t;
-  // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: wr is the phase group
-
-  // XCD-aware rasterisation: block b runs on XCD b%8; every XCD walks its own super-blocks of 32 tiles
-  // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
-  // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
-  int mt, nt;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int sb = j >> 5, within = j & 31;
-    const int S = sb * 8 + xcd;
-    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
-    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
-    const int SM = S % n_sb_m, SN = S / n_sb_m;
-    mt = (SM << lm) + (within & ((1 << lm) - 1));
-    nt = (SN << (5 - lm)) + (within >> lm);
-    if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
-  }
-  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
-  const int total_kt = (int)(Kb / P8_BK);
-  const int kt_begin = blockIdx.z * ktiles_per_split;
-  int kt_end = kt_begin + ktiles_per_split;
-  kt_end = kt_end > total_kt ? total_kt : kt_end;
-  const int nk = kt_end - kt_begin;
-  if (nk <= 0) return;
-
-  // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
-  // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
-  // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
-  int voff_a[2][2], voff_w[2][2];  // [i][half]
-  {
-    const int srow = wave * 8 + (lane >> 3);
-    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
-        int ar = m0 + i * 128 + h * 64 + srow;
-        ar = ar < M ? ar : M - 1;
-        voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
-        // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
-        int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);
-        wrow = wrow < N ? wrow : N - 1;
-        voff_w[i][h] = (int)((int64_t)wrow * Kb) + scol;
-      }
-  }
-  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
-  const lds_ptr_t lds3 = (lds_ptr_t)lds;
-  // stage one half-tile: (buffer, slot) <- K tile kt (clamped: tail prefetches re-load the last tile, every load
-  // is unconditional so the vmcnt arithmetic is static)
-  auto stage = [&](int buf, int slot, int kt, bool in_loop = true) {
-#ifdef P8_ABL_NOSTAGE  /* ablation build: no DMA inside the K loop (stale LDS is computed on) */
-    if (in_loop) return;
-#endif
-    kt = kt < kt_end ? kt : kt_end - 1;
-    const int soff = kt * P8_BK;
-    const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
-    const int h = slot >> 1;
-    if (slot & 1) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, voff_a[0][h], soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst + 8192, 16, voff_a[1][h], soff, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, voff_w[0][h], soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + 8192, 16, voff_w[1][h], soff, 0, 0);
-    }
-  };
-
-  // ---- fragment read addresses. MFMA 32x32 fragment: lane l holds row (l & 31), 16 K-bytes at chunk
-  // 2*kk + (l >> 5) of the 128-B row; physical chunk = logical ^ ((row >> 1) & 7). One VGPR per kk and buffer.
-  unsigned rd_w[2][4], rd_a[2][4];
-  {
-    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
-    const int f = ((lane & 31) >> 1) & 7;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const unsigned o = base + (lane & 31) * P8_BK + (((2 * kk + (lane >> 5)) ^ f) << 4);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        rd_w[b][kk] = o + b * 4 * P8_SLOT + wc * 32 * P8_BK;
-        rd_a[b][kk] = o + b * 4 * P8_SLOT + wr * 64 * P8_BK;
-      }
-    }
-  }
-
-  acc_t acc[4][2];  // [m block of 32][n block of 32]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
-
-  // ---- prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
-  stage(0, 0, kt_begin, false);
-  stage(0, 1, kt_begin, false);
-  stage(0, 2, kt_begin, false);
-  stage(0, 3, kt_begin, false);
-  stage(1, 0, kt_begin + 1, false);
-  stage(1, 1, kt_begin + 1, false);
-  stage(1, 2, kt_begin + 1, false);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-
-  u32x4 fw0[4], fw1[4], fa[8];  // W fragments nh=0 / nh=1 [kk]; A fragments [mbl*4 + kk] of the current m half
-
-#ifdef P8_ABL_NOMFMA  /* ablation build: keep the fragment reads alive, no matrix work */
-#define P8_MMA(MB, NB, FW)                                                                    \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(FW[kk]), "v"(fa[kk]), "v"(fa[4 + kk])); \
-  __builtin_amdgcn_sched_barrier(0);
-#else
-#define P8_MMA(MB, NB, FW)                                                                    \
-  __builtin_amdgcn_s_setprio(1);                                                              \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
-    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
-    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
-  }                                                                                           \
-  __builtin_amdgcn_s_setprio(0);                                                              \
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-
-  auto ktile = [&](auto BUF_, int kt) {
-    constexpr int BUF = decltype(BUF_)::value;
-    // ---- P1
-    P8_DSR(fw0[0], rd_w[BUF][0], 0); P8_DSR(fw0[1], rd_w[BUF][1], 0);
-    P8_DSR(fw0[2], rd_w[BUF][2], 0); P8_DSR(fw0[3], rd_w[BUF][3], 0);
-    P8_DSR(fa[0], rd_a[BUF][0], 1 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 1 * P8_SLOT);
-    P8_DSR(fa[2], rd_a[BUF][2], 1 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 1 * P8_SLOT);
-    P8_DSR(fa[4], rd_a[BUF][0], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 1 * P8_SLOT + 32 * P8_BK);
-    P8_DSR(fa[6], rd_a[BUF][2], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 1 * P8_SLOT + 32 * P8_BK);
-    stage(BUF ^ 1, 3, kt + 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the W(nh=0) reads are done: P2 may restage slot 0
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT4(fw0);
-    P8_WAIT8(fa);
-    P8_MMA(0, 0, fw0)
-    __builtin_amdgcn_s_barrier();
-    // ---- P2
-    P8_DSR(fw1[0], rd_w[BUF][0], 2 * P8_SLOT); P8_DSR(fw1[1], rd_w[BUF][1], 2 * P8_SLOT);
-    P8_DSR(fw1[2], rd_w[BUF][2], 2 * P8_SLOT); P8_DSR(fw1[3], rd_w[BUF][3], 2 * P8_SLOT);
-    stage(BUF, 0, kt + 2);
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT4(fw1);
-    P8_MMA(0, 1, fw1)
-    __builtin_amdgcn_s_barrier();
-    // ---- P3
-    P8_DSR(fa[0], rd_a[BUF][0], 3 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 3 * P8_SLOT);
-    P8_DSR(fa[2], rd_a[BUF][2], 3 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 3 * P8_SLOT);
-    P8_DSR(fa[4], rd_a[BUF][0], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 3 * P8_SLOT + 32 * P8_BK);
-    P8_DSR(fa[6], rd_a[BUF][2], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 3 * P8_SLOT + 32 * P8_BK);
-    stage(BUF, 1, kt + 2);
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT8(fa);
-    P8_MMA(2, 1, fw1)
-    __builtin_amdgcn_s_barrier();
-    // ---- P4
-    stage(BUF, 2, kt + 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K tile kt+1 has landed; 3 half-tiles of kt+2 stay in flight
-    __builtin_amdgcn_s_barrier();
-    P8_MMA(2, 0, fw0)
-    __builtin_amdgcn_s_barrier();
-  };
-
-  for (int t = 0; t < nk; t += 2) {
-    ktile(std::integral_constant<int, 0>{}, kt_begin + t);
-    if (t + 1 >= nk) break;
-    ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
-  if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
-#undef P8_MMA
-
+__device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&acc)[4][2], uint8_t* lds, int M, int N,
+                                            int m0, int n0, int wr, int wc, int wave, int lane, int tid,
+                                            const GemmEpi& epi) {
   // ---- epilogue (N % 8 == 0 is checked on the host). Tile acc[mb][nb]: lane & 31 = m within the block, register
   // r = 4*g + e <-> n within the block = 8*g + 4*(lane >> 5) + e: four consecutive n per g -> one 8-byte store.
 #ifdef P8_ABL_NOEPI  /* ablation build: one store per lane so the accumulators stay live */
@@ -356,6 +176,415 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   }
 }
 
+template <int KIND, bool SPLITK>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A,
+                                                               const uint8_t* __restrict__ W, int M, int N,
+                                                               int64_t Kb, int m_tiles, int n_tiles,
+                                                               int ktiles_per_split, GemmEpi epi) {
+  using acc_t = typename MmaTraits<KIND>::acc_t;
+  // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: wr is the phase group
+
+  // XCD-aware rasterisation: block b runs on XCD b%8; every XCD walks its own super-blocks of 32 tiles
+  // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
+  // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
+  int mt, nt;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int sb = j >> 5, within = j & 31;
+    const int S = sb * 8 + xcd;
+    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
+    const int SM = S % n_sb_m, SN = S / n_sb_m;
+    mt = (SM << lm) + (within & ((1 << lm) - 1));
+    nt = (SN << (5 - lm)) + (within >> lm);
+    if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
+  }
+  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
+  const int total_kt = (int)(Kb / P8_BK);
+  const int kt_begin = blockIdx.z * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  kt_end = kt_end > total_kt ? total_kt : kt_end;
+  const int nk = kt_end - kt_begin;
+  if (nk <= 0) return;
+
+  // K walk: every workgroup walks K in the same order (steps past the end re-load the last tile: every DMA is
+  // unconditional, so the vmcnt arithmetic is static). Starting each workgroup at a different K tile (to spread the
+  // readers of a shared operand panel over more L2 channels) was measured and is WORSE: 1033 -> 1272 us on
+  // gate_up at M = 8192 -- the workgroups of a super-block re-use each other's L2 lines only while they move in step.
+  auto kwalk = [&](int kt) { return kt < kt_end ? kt : kt_end - 1; };
+  // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
+  // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
+  // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
+  int voff_a[2][2], voff_w[2][2];  // [i][half]
+  {
+    const int srow = wave * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
+        int ar = m0 + i * 128 + h * 64 + srow;
+        ar = ar < M ? ar : M - 1;
+        voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
+        // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
+        int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);
+        wrow = wrow < N ? wrow : N - 1;
+        voff_w[i][h] = (int)((int64_t)wrow * Kb) + scol;
+      }
+  }
+  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  // stage one half-tile: (buffer, slot) <- K tile kt (clamped: tail prefetches re-load the last tile, every load
+  // is unconditional so the vmcnt arithmetic is static)
+  auto stage = [&](int buf, int slot, int kt, bool in_loop = true) {
+#ifdef P8_ABL_NOSTAGE  /* ablation build: no DMA inside the K loop (stale LDS is computed on) */
+    if (in_loop) return;
+#endif
+    const int soff = kwalk(kt) * P8_BK;
+    const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
+    const int h = slot >> 1;
+    if (slot & 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, voff_a[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst + 8192, 16, voff_a[1][h], soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, voff_w[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + 8192, 16, voff_w[1][h], soff, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses. MFMA 32x32 fragment: lane l holds row (l & 31), 16 K-bytes at chunk
+  // 2*kk + (l >> 5) of the 128-B row; physical chunk = logical ^ ((row >> 1) & 7). One VGPR per kk and buffer.
+  unsigned rd_w[2][4], rd_a[2][4];
+  {
+    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
+    const int f = ((lane & 31) >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const unsigned o = base + (lane & 31) * P8_BK + (((2 * kk + (lane >> 5)) ^ f) << 4);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        rd_w[b][kk] = o + b * 4 * P8_SLOT + wc * 32 * P8_BK;
+        rd_a[b][kk] = o + b * 4 * P8_SLOT + wr * 64 * P8_BK;
+      }
+    }
+  }
+
+  acc_t acc[4][2];  // [m block of 32][n block of 32]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
+
+  // ---- prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
+  stage(0, 0, kt_begin, false);
+  stage(0, 1, kt_begin, false);
+  stage(0, 2, kt_begin, false);
+  stage(0, 3, kt_begin, false);
+  stage(1, 0, kt_begin + 1, false);
+  stage(1, 1, kt_begin + 1, false);
+  stage(1, 2, kt_begin + 1, false);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  u32x4 fw0[4], fw1[4], fa[8];  // W fragments nh=0 / nh=1 [kk]; A fragments [mbl*4 + kk] of the current m half
+
+#ifdef P8_ABL_NOMFMA  /* ablation build: keep the fragment reads alive, no matrix work */
+#define P8_MMA(MB, NB, FW)                                                                    \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(FW[kk]), "v"(fa[kk]), "v"(fa[4 + kk])); \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define P8_MMA(MB, NB, FW)                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                              \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
+    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
+    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
+  }                                                                                           \
+  __builtin_amdgcn_s_setprio(0);                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+
+  auto ktile = [&](auto BUF_, int kt) {
+    constexpr int BUF = decltype(BUF_)::value;
+    // ---- P1
+    P8_DSR(fw0[0], rd_w[BUF][0], 0); P8_DSR(fw0[1], rd_w[BUF][1], 0);
+    P8_DSR(fw0[2], rd_w[BUF][2], 0); P8_DSR(fw0[3], rd_w[BUF][3], 0);
+    P8_DSR(fa[0], rd_a[BUF][0], 1 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 1 * P8_SLOT);
+    P8_DSR(fa[2], rd_a[BUF][2], 1 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 1 * P8_SLOT);
+    P8_DSR(fa[4], rd_a[BUF][0], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 1 * P8_SLOT + 32 * P8_BK);
+    P8_DSR(fa[6], rd_a[BUF][2], 1 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 1 * P8_SLOT + 32 * P8_BK);
+    stage(BUF ^ 1, 3, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the W(nh=0) reads are done: P2 may restage slot 0
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw0);
+    P8_WAIT8(fa);
+    P8_MMA(0, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+    // ---- P2
+    P8_DSR(fw1[0], rd_w[BUF][0], 2 * P8_SLOT); P8_DSR(fw1[1], rd_w[BUF][1], 2 * P8_SLOT);
+    P8_DSR(fw1[2], rd_w[BUF][2], 2 * P8_SLOT); P8_DSR(fw1[3], rd_w[BUF][3], 2 * P8_SLOT);
+    stage(BUF, 0, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw1);
+    P8_MMA(0, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P3
+    P8_DSR(fa[0], rd_a[BUF][0], 3 * P8_SLOT); P8_DSR(fa[1], rd_a[BUF][1], 3 * P8_SLOT);
+    P8_DSR(fa[2], rd_a[BUF][2], 3 * P8_SLOT); P8_DSR(fa[3], rd_a[BUF][3], 3 * P8_SLOT);
+    P8_DSR(fa[4], rd_a[BUF][0], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], 3 * P8_SLOT + 32 * P8_BK);
+    P8_DSR(fa[6], rd_a[BUF][2], 3 * P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], rd_a[BUF][3], 3 * P8_SLOT + 32 * P8_BK);
+    stage(BUF, 1, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT8(fa);
+    P8_MMA(2, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P4
+    stage(BUF, 2, kt + 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K tile kt+1 has landed; 3 half-tiles of kt+2 stay in flight
+    __builtin_amdgcn_s_barrier();
+    P8_MMA(2, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, kt_begin + t);
+    if (t + 1 >= nk) break;
+    ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
+  if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
+#undef P8_MMA
+
+  p8_epilogue<KIND, SPLITK>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant "r" (role split, 3-deep weight ring). Same tile, phases and fragment schedule as gemm_p8_kernel, but
+//   * the activation stream is issued by waves 0-3 and the weight stream by waves 4-7 (4 DMA instructions of 1 KiB
+//     per half-tile and wave, 2 per phase as before). s_waitcnt vmcnt retires in order per wave, so with one wave
+//     issuing both streams a deeper weight prefetch would be waited for every time the next activation tile is
+//     needed; split by role each wave counts only its own stream: vmcnt(4) (activations, L2 latency) / vmcnt(14)
+//     (weights, HBM latency);
+//   * LDS = activations 2 K tiles (64 KiB) + weights 3 K tiles (96 KiB) = all 160 KiB: 14 weight DMA instructions
+//     per wave = 56 KiB of weights in flight per CU (24 KiB before) -- what a weight-streaming decode GEMM
+//     (M = 256, one m tile, 148 workgroups at gate_up) needs to cover the ~2 us HBM latency.
+// Stage schedule of K tile t (slot reuse rules as in the header comment):
+//   activations: P1,P2 <- A(mh=1) of tile t+1;  P3,P4 <- A(mh=0) of tile t+2        (buffer = tile & 1)
+//   weights:     P1 <- 2nd half of W(nh=1) of t+2;  P2,P3 <- W(nh=0) of t+3;  P4 <- 1st half of W(nh=1) of t+3
+//                (ring slot = tile % 3)
+// ------------------------------------------------------------------------------------------------
+template <int KIND, bool SPLITK>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8r_kernel(const uint8_t* __restrict__ A,
+                                                                const uint8_t* __restrict__ W, int M, int N,
+                                                                int64_t Kb, int m_tiles, int n_tiles,
+                                                                int ktiles_per_split, GemmEpi epi) {
+  using acc_t = typename MmaTraits<KIND>::acc_t;
+  constexpr int A_BYTES = 2 * 2 * P8_SLOT;  // [buffer 2][mh 2][16 KiB]
+  constexpr int W_BYTES = 3 * 2 * P8_SLOT;  // [ring 3][nh 2][16 KiB]
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[A_BYTES + W_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // wr: phase group AND DMA role (0 = activations, 1 = weights)
+  int mt, nt;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int sb = j >> 5, within = j & 31;
+    const int S = sb * 8 + xcd;
+    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
+    const int SM = S % n_sb_m, SN = S / n_sb_m;
+    mt = (SM << lm) + (within & ((1 << lm) - 1));
+    nt = (SN << (5 - lm)) + (within >> lm);
+    if (mt >= m_tiles || nt >= n_tiles) return;
+  }
+  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
+  const int total_kt = (int)(Kb / P8_BK);
+  const int kt_begin = blockIdx.z * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  kt_end = kt_end > total_kt ? total_kt : kt_end;
+  const int nk = kt_end - kt_begin;
+  if (nk <= 0) return;
+
+  // K walk: every workgroup walks K in the same order (steps past the end re-load the last tile: every DMA is
+  // unconditional, so the vmcnt arithmetic is static). Starting each workgroup at a different K tile (to spread the
+  // readers of a shared operand panel over more L2 channels) was measured and is WORSE: 1033 -> 1272 us on
+  // gate_up at M = 8192 -- the workgroups of a super-block re-use each other's L2 lines only while they move in step.
+  auto kwalk = [&](int kt) { return kt < kt_end ? kt : kt_end - 1; };
+  // ---- DMA offsets of this wave's stream. A half-tile (128 LDS rows) = 16 instructions = 4 pieces per wave; piece j
+  // of wave wc covers LDS rows j*32 + wc*8 + lane/8.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(wr == 0 ? A : W), 0, (int)((int64_t)(wr == 0 ? M : N) * Kb), 0x00020000);
+  int voff[4][2];  // [piece][half]
+  {
+    const int srow = wc * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = j * 32 + srow;  // LDS row of the half-tile
+        int g;
+        if (wr == 0) {  // activation half mh = h: LDS rows 0-63 = reading group 0, 64-127 = group 1
+          g = m0 + (row >> 6) * 128 + h * 64 + (row & 63);
+          g = g < M ? g : M - 1;
+        } else {        // weight half nh = h: LDS row wc'*32 + c  <->  W row n0 + wc'*64 + h*32 + c
+          g = n0 + (row >> 5) * 64 + h * 32 + (row & 31);
+          g = g < N ? g : N - 1;
+        }
+        voff[j][h] = (int)((int64_t)g * Kb) + scol;
+      }
+  }
+  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  // two DMA instructions: pieces (2*pp, 2*pp+1) of half-tile `h` of K tile kt into LDS byte offset `slot_off`
+  auto stage2 = [&](int slot_off, int h, int pp, int kt, bool in_loop = true) {
+#ifdef P8_ABL_NOSTAGE
+    if (in_loop) return;
+#endif
+    const int soff = kwalk(kt) * P8_BK;
+    const lds_ptr_t dst = lds3 + slot_off + (pp * 2) * 4096 + wc * 1024;
+    if (h == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, pp ? voff[2][0] : voff[0][0], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + 4096, 16, pp ? voff[3][0] : voff[1][0], soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, pp ? voff[2][1] : voff[0][1], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + 4096, 16, pp ? voff[3][1] : voff[1][1], soff, 0, 0);
+    }
+  };
+  // LDS byte offsets: activations [buf][mh], weights [ring][nh]
+  auto a_slot = [&](int buf, int mh) { return (buf * 2 + mh) * P8_SLOT; };
+  auto w_slot = [&](int ring, int nh) { return A_BYTES + (ring * 2 + nh) * P8_SLOT; };
+
+  unsigned rd_w[4], rd_a[4];
+  {
+    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
+    const int f = ((lane & 31) >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const unsigned o = base + (lane & 31) * P8_BK + (((2 * kk + (lane >> 5)) ^ f) << 4);
+      rd_w[kk] = o + A_BYTES + wc * 32 * P8_BK;
+      rd_a[kk] = o + wr * 64 * P8_BK;
+    }
+  }
+
+  acc_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
+
+  // ---- prologue = the state the loop maintains at the top of K tile t0 (see the stage schedule)
+  if (wr == 0) {
+    stage2(a_slot(0, 0), 0, 0, kt_begin, false); stage2(a_slot(0, 0), 0, 1, kt_begin, false);
+    stage2(a_slot(0, 1), 1, 0, kt_begin, false); stage2(a_slot(0, 1), 1, 1, kt_begin, false);
+    stage2(a_slot(1, 0), 0, 0, kt_begin + 1, false); stage2(a_slot(1, 0), 0, 1, kt_begin + 1, false);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      stage2(w_slot(d, 0), 0, 0, kt_begin + d, false); stage2(w_slot(d, 0), 0, 1, kt_begin + d, false);
+      stage2(w_slot(d, 1), 1, 0, kt_begin + d, false);
+      if (d < 2) stage2(w_slot(d, 1), 1, 1, kt_begin + d, false);
+    }
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  u32x4 fw0[4], fw1[4], fa[8];
+#ifdef P8_ABL_NOMFMA
+#define P8_MMA(MB, NB, FW)                                                                    \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(FW[kk]), "v"(fa[kk]), "v"(fa[4 + kk])); \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define P8_MMA(MB, NB, FW)                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                              \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
+    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
+    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
+  }                                                                                           \
+  __builtin_amdgcn_s_setprio(0);                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+
+  int abuf = 0, wring = 0;  // buffer / ring slot of the K tile being computed
+  for (int t = 0; t < nk; ++t) {
+    const int kt = kt_begin + t;
+    const int wnext = wring == 2 ? 0 : wring + 1;   // ring slot of tile t+1 == slot of tile t+... (t+2)%3 = wprev
+    const int wprev = wring == 0 ? 2 : wring - 1;   // (t+2) % 3
+    unsigned va[4], vw[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      va[kk] = rd_a[kk] + abuf * 2 * P8_SLOT;
+      vw[kk] = rd_w[kk] + wring * 2 * P8_SLOT;
+    }
+    (void)wnext;
+    // ---- P1: W(nh=0) + A(mh=0)
+    P8_DSR(fw0[0], vw[0], 0); P8_DSR(fw0[1], vw[1], 0); P8_DSR(fw0[2], vw[2], 0); P8_DSR(fw0[3], vw[3], 0);
+    P8_DSR(fa[0], va[0], 0); P8_DSR(fa[1], va[1], 0); P8_DSR(fa[2], va[2], 0); P8_DSR(fa[3], va[3], 0);
+    P8_DSR(fa[4], va[0], 32 * P8_BK); P8_DSR(fa[5], va[1], 32 * P8_BK);
+    P8_DSR(fa[6], va[2], 32 * P8_BK); P8_DSR(fa[7], va[3], 32 * P8_BK);
+    if (wr == 0) stage2(a_slot(abuf ^ 1, 1), 1, 0, kt + 1);
+    else stage2(w_slot(wprev, 1), 1, 1, kt + 2);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the W(nh=0) reads are done: P2 may restage that slot
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw0);
+    P8_WAIT8(fa);
+    P8_MMA(0, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+    // ---- P2: W(nh=1)
+    P8_DSR(fw1[0], vw[0], P8_SLOT); P8_DSR(fw1[1], vw[1], P8_SLOT);
+    P8_DSR(fw1[2], vw[2], P8_SLOT); P8_DSR(fw1[3], vw[3], P8_SLOT);
+    if (wr == 0) stage2(a_slot(abuf ^ 1, 1), 1, 1, kt + 1);
+    else stage2(w_slot(wring, 0), 0, 0, kt + 3);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw1);
+    P8_MMA(0, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P3: A(mh=1)
+    P8_DSR(fa[0], va[0], P8_SLOT); P8_DSR(fa[1], va[1], P8_SLOT);
+    P8_DSR(fa[2], va[2], P8_SLOT); P8_DSR(fa[3], va[3], P8_SLOT);
+    P8_DSR(fa[4], va[0], P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], va[1], P8_SLOT + 32 * P8_BK);
+    P8_DSR(fa[6], va[2], P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], va[3], P8_SLOT + 32 * P8_BK);
+    if (wr == 0) stage2(a_slot(abuf, 0), 0, 0, kt + 2);
+    else stage2(w_slot(wring, 0), 0, 1, kt + 3);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT8(fa);
+    P8_MMA(2, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P4
+    if (wr == 0) {
+      stage2(a_slot(abuf, 0), 0, 1, kt + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A of tile t+1 has landed; A(mh=0) of t+2 in flight
+    } else {
+      stage2(w_slot(wring, 1), 1, 0, kt + 3);
+      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // W of tile t+1 has landed; 14 DMAs of t+2, t+3 in flight
+    }
+    __builtin_amdgcn_s_barrier();
+    P8_MMA(2, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+    abuf ^= 1;
+    wring = wring == 2 ? 0 : wring + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef P8_MMA
+  p8_epilogue<KIND, SPLITK>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
+}
+
 template <int KIND>
 int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                    size_t ws_bytes, int splits, hipStream_t s) {
@@ -370,14 +599,26 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
   const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  static int ring = -2;  // XLLM_MI355_P8_RING: 1 = role-split kernel with the 3-deep weight ring, 0 = first version
+  if (ring == -2) {
+    const char* e = getenv("XLLM_MI355_P8_RING");
+    ring = e ? atoi(e) : 0;  // measured: the deeper weight ring is 2-4 % slower at M = 8192 and no faster at M = 256
+  }
   if (splits > 1) {
     if constexpr (KIND == kI8) {
       if (!epi.acc_out) return XM_ERR_INVALID;  // the caller points acc_out at the zeroed split-K workspace
-      hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
-                         (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+      if (ring)
+        hipLaunchKernelGGL((gemm_p8r_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                           (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+      else
+        hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                           (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
     } else {
       return XM_ERR_UNSUPPORTED;
     }
+  } else if (ring) {
+    hipLaunchKernelGGL((gemm_p8r_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   } else {
     hipLaunchKernelGGL((gemm_p8_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
