@@ -44,8 +44,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     p.add_argument("--graph", action="store_true",
-                   help="multi-GPU: also capture the RCCL collectives into the HIP graph (default for N>1 is eager "
-                        "launches: a failed capture of a collective cannot be recovered from inside the process)")
+                   help="multi-GPU: capture the RCCL collectives INTO one HIP graph (default for N>1 is the piecewise "
+                        "replay of xllm_amd.parallel.PiecewiseGraph: kernels between collectives are graphs, the "
+                        "collectives stay eager -- a failed capture of a collective cannot be recovered in-process)")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -246,6 +247,20 @@ def main():
     # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
     graph = None
     use_graph = (not a.no_graph) and (world == 1 or a.graph) and a.backend == "nccl"
+    piecewise = (not a.no_graph) and world > 1 and not use_graph
+    if piecewise:
+        # TP > 1: one graph per run of kernels between two collectives, collectives eager in between
+        # (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo never run inside a capture
+        try:
+            step()
+            pw = parallel.PiecewiseGraph()
+            static_out = pw.capture(step)
+            graph = pw
+            for _ in range(2):
+                graph.replay()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] piecewise graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
+            graph = None
     if use_graph:
         try:
             cap_stream = torch.cuda.Stream()
@@ -315,7 +330,8 @@ def main():
                                    f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
                        "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
-                       "quant_fusion": not a.no_fuse, "hip_graph": graph is not None},
+                       "quant_fusion": not a.no_fuse,
+                       "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ split-KV merge when the launch splits)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

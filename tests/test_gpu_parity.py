@@ -625,3 +625,63 @@ def test_decode_int8_fusion_declines_split_kv_shapes():
     r = ops.paged_decode_attention_int8(q.to(DEV), kc.to(DEV), vc.to(DEV), md["kv_seq_lens"].to(DEV),
                                         md["block_tables"].to(DEV), 4096, 128 ** -0.5)
     assert r is None  # B=2 wants split-KV: the caller falls back to paged_attention + scaled_quantize
+
+
+def test_piecewise_graph_replay_equals_eager():
+    """N2: a TP step replayed as [graph | collective | graph | ...] (xllm_amd.parallel.PiecewiseGraph) produces the
+    bits of the eager step. The "collective" here is a local stand-in with a visible effect (the real RCCL / gloo
+    exchange runs outside every capture exactly like this callable does)."""
+    import bench
+    from xllm_amd import layers, parallel
+    from xllm_amd.attention import KVCache
+
+    calls = {"n": 0}
+
+    class FakeTP(parallel.ProcessGroup):
+        def allreduce(self, x):
+            def fn():
+                calls["n"] += 1
+                x.mul_(2.0)          # what a 2-rank SUM of identical shards would do
+            parallel._run_collective(fn)
+
+        def allgather(self, x):
+            out = torch.empty((2,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+            xc = x.contiguous()
+
+            def fn():
+                calls["n"] += 1
+                out[0].copy_(xc)
+                out[1].copy_(xc)
+            parallel._run_collective(fn)
+            return out
+
+    args = layers.ModelArgs(1024, 3, 16, 4, 64, 2048, 4096, 1e-6, 1e6, 4096)  # every sharded K stays a multiple of 128
+    B, ctx, bs = 32, 300, 128
+    model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=3, tp=FakeTP(None, 0, 2), n_layers=3)
+    md, n_blocks = bench.build_metadata(B, ctx, bs, torch.device(DEV), seed=1)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    caches = [KVCache(torch.randn(n_blocks, bs, model.layers[0].nkv, args.head_dim, device=DEV, generator=g).bfloat16(),
+                      torch.randn(n_blocks, bs, model.layers[0].nkv, args.head_dim, device=DEV, generator=g).bfloat16())
+              for _ in model.layers]
+    tokens = torch.randint(0, args.vocab_size, (B,), device=DEV, generator=g)
+    positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
+
+    def step():
+        return model.logits(model.forward(tokens, positions, md, caches))
+
+    ref = step().clone()
+    n_eager = calls["n"]
+    assert n_eager == 2 * 3 + 1                      # two all-reduces per layer + the logits gather
+    step()
+    pw = parallel.PiecewiseGraph()
+    static_out = pw.capture(step)
+    assert sum(isinstance(it, torch.cuda.CUDAGraph) for it in pw.items) == n_eager + 1
+    static_out.zero_()
+    pw.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref)
+    tokens.copy_(torch.randint(0, args.vocab_size, (B,), device=DEV, generator=g))   # new inputs, same buffers
+    ref2 = step().clone()
+    pw.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref2) and not torch.equal(ref2, ref)
