@@ -64,6 +64,21 @@ XM_API int xllm_mi355_build_block_table_from_paged_kv(const int32_t* indptr, con
                                                       int32_t batch, int32_t total_pages,
                                                       int32_t* block_table, void* stream);
 
+/* N1 fusion across the GEMM boundary (decode shapes, M <= 512): the row-parallel W8A8 linear followed by the
+ * residual add + RMSNorm (+ per-token int8 quant) of the next half-layer -- kernel::scaled_matmul (ops_api.h:98) then
+ * kernel::fused_layernorm with residual (ops_api.h:43; MLU's fused_layernorm(dynamic_quant) for the quantised form) --
+ * in two launches instead of four: the GEMM leaves exact int32 sums in the registered workspace
+ * (xllm_mi355_set_gemm_workspace, >= 4*M*N bytes, XM_ERR_WORKSPACE otherwise) and one row kernel dequantises them
+ * (r16(acc*a_scale[m]*w_scale[n] + bias[n])), adds `residual` in place (residual <- r16(y + residual)), normalises and
+ * writes either the 16-bit norm (out_norm) or its int8 quantisation (out_q, out_q_scale) -- exactly one of the two.
+ * Bit-identical to xllm_mi355_scaled_matmul -> xllm_mi355_fused_add_rms_norm / _rms_norm_dynamic_int8_quant.
+ * Not applicable when a TP all-reduce sits between the linear and the norm. */
+XM_API int xllm_mi355_scaled_matmul_add_rms_norm(const int8_t* a, const int8_t* w, const float* a_scale,
+                                                 const float* w_scale, const void* bias, void* residual,
+                                                 const void* norm_weight, float eps, void* out_norm,
+                                                 int8_t* out_q, float* out_q_scale, int64_t M, int64_t N,
+                                                 int64_t K, int dtype, void* stream);
+
 /* N2: device-side refresh of the persistent decode metadata a replayed HIP graph reads.
  * cuda::update_llm_decode_metadata (kernels/cuda/llm_decode_metadata_update.cu:27-60, params struct
  * llm_decode_metadata_update.h:34-54; caller runtime/cuda_graph_executor_impl.cpp:218-258): copies tokens /

@@ -685,3 +685,56 @@ def test_piecewise_graph_replay_equals_eager():
     pw.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, ref2) and not torch.equal(ref2, ref)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(256, 3584, 3584, False), (256, 3584, 18944, False), (37, 512, 1024, True),
+                                        (300, 1024, 256, True)])
+def test_gemm_add_norm_fusion_equals_separate_ops(M, N, K, bias):
+    """N1 across the GEMM boundary: scaled_matmul_add_rms_norm == scaled_matmul -> fused_add_rms_norm (-> int8 quant),
+    bit for bit, and it leaves the split-K workspace zeroed (the next plain GEMM is still exact)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.02 + 0.001).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.02 + 0.001).to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV) if bias else None
+    res0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    nw = (torch.rand(N, generator=g) + 0.5).bfloat16().to(DEV)
+    # separate operators
+    y = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, b)
+    res_ref = res0.clone()
+    q_ref, s_ref = ops.rms_norm_dynamic_int8_quant(y.clone(), nw, 1e-6, residual=res_ref)
+    res_ref2 = res0.clone()
+    y2 = y.clone()
+    ops.fused_add_rms_norm(y2, res_ref2, nw, 1e-6)      # y2 <- norm, res_ref2 <- y + residual
+    # fused
+    res_a = res0.clone()
+    q, qs = ops.scaled_matmul_add_rms_norm(a, w, a_s, w_s, res_a, nw, 1e-6, b, quantize=True)
+    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref) and torch.equal(res_a, res_ref)
+    res_b = res0.clone()
+    n16 = ops.scaled_matmul_add_rms_norm(a, w, a_s, w_s, res_b, nw, 1e-6, b, quantize=False)
+    assert torch.equal(n16, y2) and torch.equal(res_b, res_ref2)
+    # workspace invariant: a following split-K GEMM is exact
+    acc = torch.empty(M, N, dtype=torch.int32, device=DEV)
+    ref = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, b, acc_out=acc)
+    assert torch.equal(ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, b), ref)
+
+
+def test_model_step_fused_equals_reference_operator_order():
+    """every N1 fusion is bit-identical to the operators it replaces, so the whole decode step is too"""
+    import bench
+    from xllm_amd import layers
+    from xllm_amd.attention import KVCache
+    args = layers.ModelArgs(1024, 3, 16, 4, 128, 2048, 4096, 1e-6, 1e6, 4096)
+    B, ctx, bs = 256, 300, 128
+    outs = []
+    for fuse in (True, False):
+        model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=11, fuse=fuse, n_layers=3)
+        md, n_blocks = bench.build_metadata(B, ctx, bs, torch.device(DEV), seed=2)
+        g = torch.Generator(device=DEV).manual_seed(7)
+        caches = [KVCache(torch.randn(n_blocks, bs, 4, 128, device=DEV, generator=g).bfloat16(),
+                          torch.randn(n_blocks, bs, 4, 128, device=DEV, generator=g).bfloat16()) for _ in model.layers]
+        tokens = torch.randint(0, args.vocab_size, (B,), device=DEV, generator=g)
+        positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
+        outs.append(model.logits(model.forward(tokens, positions, md, caches)).clone())
+    assert torch.equal(outs[0], outs[1])

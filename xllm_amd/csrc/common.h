@@ -102,6 +102,11 @@ inline int hip_check_launch() {
   return e == hipSuccess ? XM_OK : XM_ERR_HIP;
 }
 
+// rowwise.hip: consumes (and re-zeroes) int32 GEMM sums: dequant + residual add + RMSNorm (+ int8 quant)
+int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
+                            const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
+                            int dtype, int quant, hipStream_t s);
+
 }  // namespace xm
 
 #define XM_DISPATCH_FLOAT(DT, T, ...)                   \

@@ -459,11 +459,19 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);
       hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                          (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
-      int64_t blocks = (M * N + 255) / 256;
-      blocks = blocks > 1024 ? 1024 : blocks;
-      hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                         reinterpret_cast<int32_t*>(workspace), M, N, epi);
+      if (!epi.defer) {
+        int64_t blocks = (M * N + 255) / 256;
+        blocks = blocks > 1024 ? 1024 : blocks;
+        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
+      }
     }
+  } else if (epi.defer) {
+    GemmEpi e2 = epi;  // single pass: plain int32 stores into the workspace, nothing else
+    e2.acc_out = reinterpret_cast<int32_t*>(workspace);
+    e2.out = nullptr;
+    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
   } else {
     hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, per, epi);
@@ -501,7 +509,8 @@ template <int KIND>
 int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                   size_t ws_bytes, hipStream_t s) {
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
-  const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
+  const bool can_split =
+      KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
   const SkinnyPlan p = plan_skinny(M, N, ksteps, can_split);
   switch (p.nt) {
     case 1: return launch_skinny_nt<KIND, 1>(A, W, M, N, Kb, epi, p.splits, workspace, s);
@@ -731,6 +740,12 @@ template <int KIND>
 int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                 size_t ws_bytes, hipStream_t s) {
   if (M == 0 || N == 0) return XM_OK;
+  if (epi.defer) {  // deferred dequant (see xllm_mi355_scaled_matmul_add_rms_norm): decode-shaped int8 problems only
+    if (KIND != kI8 || M > 512 || Kb % BKB != 0 || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || !workspace ||
+        ws_bytes < (size_t)M * N * 4)
+      return XM_ERR_UNSUPPORTED;
+    return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
+  }
   if (g_sk_disable == -2) {
     const char* e = getenv("XLLM_MI355_SKINNY_DISABLE");
     g_sk_disable = e ? atoi(e) : 0;
@@ -906,6 +921,25 @@ int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_sc
   if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
   return launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
+}
+
+int xllm_mi355_scaled_matmul_add_rms_norm(const int8_t* a, const int8_t* w, const float* a_scale,
+                                          const float* w_scale, const void* bias, void* residual,
+                                          const void* norm_weight, float eps, void* out_norm, int8_t* out_q,
+                                          float* out_q_scale, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  if (!a || !w || !a_scale || !w_scale || !residual || !norm_weight || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if ((out_q != nullptr) == (out_norm != nullptr)) return XM_ERR_INVALID;  // exactly one output form
+  if (out_q && !out_q_scale) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  if (!g_gemm_ws || g_gemm_ws_bytes < (size_t)M * N * 4) return XM_ERR_WORKSPACE;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0, 1};
+  const int rc = launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
+  if (rc != XM_OK) return rc;
+  return launch_acc_add_rms_norm(out_q ? (void*)out_q : out_norm, out_q_scale, reinterpret_cast<int32_t*>(g_gemm_ws),
+                                 a_scale, w_scale, bias, residual, norm_weight, eps, M, N, dtype, out_q != nullptr,
+                                 (hipStream_t)stream);
 }
 
 int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale, int64_t a_scale_numel,

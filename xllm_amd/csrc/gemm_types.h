@@ -72,6 +72,7 @@ struct GemmEpi {
   int out_bf16;           // 1 bf16, 0 f16
   const int32_t* group_counts;  // grouped GEMM (MoE): rows per expert, DEVICE array [n_groups]; null otherwise
   int n_groups;
+  int defer;  // int8: leave the exact int32 sums in the (zeroed) split-K workspace, no dequant epilogue launch
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {

@@ -179,6 +179,113 @@ __global__ __launch_bounds__(kRowThreads) void rms_norm_kernel(
   }
 }
 
+// N1 fusion across the GEMM boundary: the row-parallel int8 GEMMs of a decode step (o_proj, down_proj) run split-K and
+// leave exact int32 sums in the GEMM workspace; instead of a dequant kernel that writes the 16-bit output and a
+// fused_add_rms_norm(+quant) kernel that reads it back, this kernel dequantises the sums in registers (same
+// expression and rounding as the split-K epilogue: r16(float(acc)*a_s[m]*w_s[n] + bias[n])), re-zeroes the workspace
+// (its invariant), adds the residual, normalises and quantises exactly like rms_norm_kernel<T, true, QUANT>.
+// Bit-identical to scaled_matmul -> fused_add_rms_norm(-> scaled_quantize). QUANT: 0 = 16-bit norm out, 2 = int8.
+template <typename T, int QUANT>
+__global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
+    void* __restrict__ out, float* __restrict__ q_scale, int32_t* __restrict__ acc, const float* __restrict__ a_scale,
+    const float* __restrict__ w_scale, const T* __restrict__ bias, T* __restrict__ residual,
+    const T* __restrict__ weight, float eps, int hidden) {
+  static_assert(sizeof(T) == 2, "16-bit activations");
+  constexpr int N = 8;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  __shared__ float smem[32];
+  const int64_t t = blockIdx.x;
+  const int nvec = hidden / N;
+  int32_t* acc_row = acc + t * (int64_t)hidden;
+  T* res_row = residual + t * (int64_t)hidden;
+  const float as = a_scale[t];
+  RowVec<T> xv[kMaxVec];
+  float ss = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int c = threadIdx.x + i * kRowThreads;
+    if (c < nvec) {
+      const i32x4 a0 = reinterpret_cast<const i32x4*>(acc_row)[2 * c], a1 = reinterpret_cast<const i32x4*>(acc_row)[2 * c + 1];
+      reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
+      reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
+      const float4 w0 = reinterpret_cast<const float4*>(w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
+      const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      RowVec<T> bv, rv;
+      bv.raw = bias ? reinterpret_cast<const uint4*>(bias)[c] : make_uint4(0, 0, 0, 0);
+      rv.raw = reinterpret_cast<const uint4*>(res_row)[c];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float y = r16<T>((float)av[j] * as * wv[j] + (bias ? bv.get(j) : 0.0f));  // the GEMM's 16-bit output
+        xv[i].set(j, y + rv.get(j));                                                      // r16(y + residual)
+      }
+      reinterpret_cast<uint4*>(res_row)[c] = xv[i].raw;
+#pragma unroll
+      for (int j = 0; j < N; ++j) { float x = xv[i].get(j); ss += x * x; }
+    }
+  }
+  ss = block_sum(ss, smem);
+  const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxVec; ++i) {
+    const int c = threadIdx.x + i * kRowThreads;
+    if (c < nvec) {
+      RowVec<T> wv;
+      wv.raw = reinterpret_cast<const uint4*>(weight)[c];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float y = r16<T>(r16<T>(xv[i].get(j) * inv) * wv.get(j));
+        xv[i].set(j, y);
+        amax = fmaxf(amax, fabsf(y));
+      }
+      if constexpr (QUANT == 0) reinterpret_cast<uint4*>(reinterpret_cast<T*>(out) + t * (int64_t)hidden)[c] = xv[i].raw;
+    }
+  }
+  if constexpr (QUANT == 2) {
+    amax = block_max(amax, smem);
+    const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+      const int c = threadIdx.x + i * kRowThreads;
+      if (c < nvec) {
+        uint32_t pk[2];
+#pragma unroll
+        for (int j = 0; j < N; j += 4) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv[i].get(j + e) * qinv)));
+            w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+          }
+          pk[j / 4] = w;
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(out) + t * (int64_t)hidden + (int64_t)c * N) =
+            make_uint2(pk[0], pk[1]);
+      }
+    }
+    if (threadIdx.x == 0) q_scale[t] = amax / 127.0f;
+  }
+}
+
+// launcher used by gemm.hip (declared in common.h)
+int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
+                            const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
+                            int dtype, int quant, hipStream_t s) {
+  if (N % 8 != 0 || N > (int64_t)kRowThreads * kMaxVec * 8) return XM_ERR_UNSUPPORTED;
+  if (((uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)w_scale | (uintptr_t)acc) % 16)
+    return XM_ERR_UNSUPPORTED;
+  XM_DISPATCH_HALF(dtype, T, {
+    if (quant)
+      hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 2>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
+                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N);
+    else
+      hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 0>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
+                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N);
+  });
+  return hip_check_launch();
+}
+
 // generic fallback (any hidden / alignment): scalar, two passes over global memory
 template <typename T, bool ADD, int QUANT>
 __global__ __launch_bounds__(kRowThreads) void rms_norm_generic_kernel(

@@ -125,8 +125,22 @@ class Qwen2DecoderLayer:
         ops.fused_add_rms_norm(x, residual, w, eps)
         return x, residual
 
-    def forward(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin):
-        h, residual = self._norm(x, residual, self.input_norm_w)
+    def _fused_linear_norm(self, lin: "QuantLinear", pre_quant, residual, norm_w, quantize=True):
+        """N1 across the GEMM boundary: row-parallel W8A8 linear + residual add + RMSNorm (+ int8 quant) in two launches
+        (ops.scaled_matmul_add_rms_norm). Only without a TP all-reduce in between; None = not applicable."""
+        if not self.fuse or lin.pg is not None or lin.mode != "int8" or residual is None or norm_w is None:
+            return None
+        return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
+                                              self.args.rms_norm_eps, lin.bias, quantize=quantize)
+
+    def forward(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin, h_in=None,
+                next_norm_w=None, next_quant=True):
+        """returns (x, residual, h_next): h_next is the NEXT layer's (or the model's final) norm output when this
+        layer's down_proj was fused with it (then x is None), else None."""
+        if h_in is not None:
+            h = h_in                      # the previous layer already ran this layer's input norm (fused)
+        else:
+            h, residual = self._norm(x, residual, self.input_norm_w)
         qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
         q = qkv[:, :self.q_size]
         k = qkv[:, self.q_size:self.q_size + self.kv_size]
@@ -148,19 +162,31 @@ class Qwen2DecoderLayer:
         else:
             ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)
             attn, _ = self.attn.forward(md, q, k, v, kv_cache)
-        if fused_attn is not None:
+        h = None
+        if self.fuse and decode:
+            o_in = (fused_attn[0], fused_attn[1]) if fused_attn is not None else ops.scaled_quantize(attn)
+            h = self._fused_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)   # residual updated in place
+            if h is None:
+                x = self.o_proj.forward(None, pre_quant=o_in)
+        elif fused_attn is not None:
             x = self.o_proj.forward(None, pre_quant=(fused_attn[0], fused_attn[1]))
         else:
             x = self.o_proj.forward(attn)
-        h, residual = self._norm(x, residual, self.post_norm_w)
+        if h is None:
+            h, residual = self._norm(x, residual, self.post_norm_w)
         gate_up = self.gate_up_proj.forward(None, pre_quant=h) if self.fuse else self.gate_up_proj.forward(h)
         if self.fuse:  # N1: silu*mul + int8 quant feeding down_proj
-            x = self.down_proj.forward(None, pre_quant=ops.act_and_mul_dynamic_int8_quant(gate_up, "silu"))
+            act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+            if decode:
+                h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
+                if h_next is not None:
+                    return None, residual, h_next
+            x = self.down_proj.forward(None, pre_quant=act_q)
         else:
             act = torch.empty(gate_up.size(0), self.I, dtype=gate_up.dtype, device=gate_up.device)
             ops.act_and_mul(act, gate_up, "silu")
             x = self.down_proj.forward(act)
-        return x, residual
+        return x, residual, None
 
 
 class Qwen2Model:
@@ -181,9 +207,15 @@ class Qwen2Model:
 
     def forward(self, tokens, positions, md: AttentionMetadata, kv_caches):
         x = torch.nn.functional.embedding(tokens, self.embed)  # embed_tokens_ (llm_model_base.h:74)
-        residual = None
-        for layer, kvc in zip(self.layers, kv_caches):
-            x, residual = layer.forward(x, residual, positions, md, kvc, self.cos_sin)
+        residual, h_in = None, None
+        n = len(self.layers)
+        for i, (layer, kvc) in enumerate(zip(self.layers, kv_caches)):
+            last = i + 1 == n
+            nxt = self.norm_w if last else self.layers[i + 1].input_norm_w
+            x, residual, h_in = layer.forward(x, residual, positions, md, kvc, self.cos_sin, h_in=h_in, next_norm_w=nxt,
+                                              next_quant=not last)
+        if h_in is not None:
+            return h_in      # the last layer's down_proj already produced the final norm (16-bit)
         if residual is None:
             out = torch.empty_like(x)
             ops.rms_norm(out, x, self.norm_w, self.args.rms_norm_eps)

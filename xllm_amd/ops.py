@@ -249,6 +249,34 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
 
 
 # ------------------------------------------------------------------------------------------------ fp8
+def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, eps: float, bias=None,
+                               quantize: bool = True):
+    """N1 fusion across the GEMM boundary: scaled_matmul (dcu::scaled_matmul) -> residual add + RMSNorm
+    (kernel::fused_layernorm) [-> scaled_quantize]. `residual` [M, N] is updated in place to r16(y + residual);
+    returns (q int8 [M, N], scale [M]) when `quantize`, else the 16-bit norm [M, N]. Bit-identical to the separate
+    operators; returns None when the shape is outside the fused path's envelope (caller falls back)."""
+    _need_cuda(a, b, a_scale, b_scale, residual, norm_weight)
+    M, K = a.shape
+    N = b.size(0)
+    if not (a.is_contiguous() and b.is_contiguous() and residual.is_contiguous() and residual.shape == (M, N)):
+        raise Mi355Error("scaled_matmul_add_rms_norm: contiguous a [M,K], b [N,K], residual [M,N]")
+    _ensure_gemm_workspace(a.device, M * N * 4)
+    if quantize:
+        q = torch.empty(M, N, dtype=torch.int8, device=a.device)
+        qs = torch.empty(M, dtype=torch.float32, device=a.device)
+        out = None
+    else:
+        q = qs = None
+        out = torch.empty(M, N, dtype=residual.dtype, device=a.device)
+    rc = _lib.lib().xllm_mi355_scaled_matmul_add_rms_norm(
+        _p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias), _p(residual), _p(norm_weight), eps,
+        _p(out), _p(q), _p(qs), M, N, K, _dt(residual), _stream())
+    if rc == -2:  # XM_ERR_UNSUPPORTED: not a decode-shaped problem
+        return None
+    check(rc, "scaled_matmul_add_rms_norm")
+    return (q, qs) if quantize else out
+
+
 def static_scaled_fp8_quant(output, input, scale) -> None:
     """cuda::static_scaled_fp8_quant(out, in, scale) (cuda_ops_api.h:184-186, fp8_quant.cu:115-155)."""
     _need_cuda(output, input, scale)
