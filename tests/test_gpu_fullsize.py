@@ -1,0 +1,167 @@
+"""GPU parity at BASELINE.json's FULL sizes (cfg3: Qwen2-7B, batch 256, ctx 4096; prefill chunks of 4096 tokens).
+
+The oracle cannot finish these shapes in seconds, so every test combines
+  * an oracle check on a SAMPLE of the units (sequences / rows / queries) of the full-size launch, and
+  * size-independent properties of the whole output: physical-page permutation invariance, independence of the
+    sequences of a batch, causality (future keys cannot change past outputs), exact integer checksums of the int32
+    accumulators (a checksum of checksums), scatter -> gather round trips.
+Bars as in test_gpu_parity.py (bit-exact for integer / index work, <= 1e-3 relative L2 for bf16 attention).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from xllm_amd import ops
+DEV = "cuda"
+NQ, NKV, D, H, I = 28, 4, 128, 3584, 18944
+B, CTX, BS = 256, 4096, 128
+
+
+def rel_l2(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+
+
+def _paged_cache(gen, n_seqs, ctx, extra=7):
+    pages = (ctx + BS - 1) // BS
+    n_blocks = n_seqs * pages + extra
+    perm = torch.randperm(n_blocks, generator=gen)[: n_seqs * pages].to(torch.int32).view(n_seqs, pages)
+    return n_blocks, perm
+
+
+def test_paged_decode_full_size_sample_and_properties():
+    g = torch.Generator().manual_seed(100)
+    gd = torch.Generator(device=DEV).manual_seed(100)
+    n_blocks, table = _paged_cache(g, B, CTX)
+    kc = torch.empty(n_blocks, BS, NKV, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    vc = torch.empty(n_blocks, BS, NKV, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    q = torch.empty(B, NQ, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    kv_lens = torch.full((B,), CTX, dtype=torch.int32)
+    kv_lens[5], kv_lens[77], kv_lens[200] = CTX - 1, 1, 2049          # ragged tails inside the full-size batch
+    scale = 1.0 / math.sqrt(D)
+    tbl_d, len_d = table.to(DEV), kv_lens.to(DEV)
+    out = ops.paged_attention(q, kc, vc, None, len_d, tbl_d, 1, CTX, scale)
+    assert torch.isfinite(out.float()).all()
+    # (1) oracle on a sample of sequences (their pages gathered into a compact cache)
+    sample = [0, 5, 77, 200, 255]
+    pages = table.size(1)
+    ids = table[sample].reshape(-1).long()
+    kc_s, vc_s = kc[ids.to(DEV)].cpu(), vc[ids.to(DEV)].cpu()
+    tbl_s = torch.arange(len(sample) * pages, dtype=torch.int32).view(len(sample), pages)
+    ref = orc.paged_attention(q[sample].cpu(), kc_s, vc_s, torch.arange(len(sample) + 1, dtype=torch.int32),
+                              kv_lens[sample], tbl_s, scale)
+    assert rel_l2(out[sample], ref) <= 1e-3
+    # (2) physical placement of the pages is irrelevant: move every page, same bits
+    perm2 = torch.randperm(n_blocks, generator=g)
+    inv = torch.empty_like(perm2)
+    inv[perm2] = torch.arange(n_blocks)
+    kc2, vc2 = kc[perm2.to(DEV)], vc[perm2.to(DEV)]                   # new block i holds old block perm2[i]
+    out2 = ops.paged_attention(q, kc2, vc2, None, len_d, inv[table.long()].to(torch.int32).to(DEV), 1, CTX, scale)
+    assert torch.equal(out2, out)
+    # (3) sequences are independent: a batch of the sampled sequences alone gives the same rows (other launch plan)
+    out3 = ops.paged_attention(q[sample], kc, vc, None, len_d[sample], tbl_d[sample].contiguous(), 1, CTX, scale)
+    assert rel_l2(out3, out[sample]) <= 2e-4
+    # (4) softmax weights form a convex combination: constant V rows come back (to rounding)
+    vconst = torch.randn(NKV, D, generator=g).bfloat16().to(DEV)
+    vc.copy_(vconst.expand_as(vc))
+    out4 = ops.paged_attention(q, kc, vc, None, len_d, tbl_d, 1, CTX, scale).view(B, NQ, D)
+    want = vconst.repeat_interleave(NQ // NKV, 0).expand(B, NQ, D).float()
+    assert ((out4.float() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6).all()
+
+
+def test_kv_write_full_size_round_trip():
+    g = torch.Generator().manual_seed(101)
+    T = 8192
+    n_blocks, table = _paged_cache(g, 2, CTX)
+    pos = torch.arange(CTX)
+    slots = torch.cat([table[s].long()[pos // BS] * BS + pos % BS for s in range(2)]).to(torch.int32)
+    k = torch.randn(T, NKV, D, generator=g).bfloat16().to(DEV)
+    v = torch.randn(T, NKV, D, generator=g).bfloat16().to(DEV)
+    kc = torch.zeros(n_blocks, BS, NKV, D, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.reshape_paged_cache(slots.to(DEV), k, v, kc, vc)
+    rows = slots.long().to(DEV)
+    assert torch.equal(kc.view(-1, NKV, D)[rows], k) and torch.equal(vc.view(-1, NKV, D)[rows], v)
+    untouched = torch.ones(n_blocks * BS, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    assert int(kc.view(-1, NKV * D)[untouched].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 2 * I, H), (256, H, I), (8192, 2 * I, H), (8192, H, I), (8192, 4608, H)])
+def test_int8_gemm_full_size_checksums(M, N, K):
+    """exact int32 accumulators at the full Qwen2-7B shapes: column / row checksums over the WHOLE output (int64,
+    exact), exact rows on a sample, and the fused dequant epilogue on the sample against the oracle formula"""
+    gd = torch.Generator(device=DEV).manual_seed(M + N)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=DEV, generator=gd)
+    w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=DEV, generator=gd)
+    a_s = torch.rand(M, device=DEV, generator=gd) * 0.02 + 0.001
+    w_s = torch.rand(N, device=DEV, generator=gd) * 0.02 + 0.001
+    acc = torch.empty(M, N, dtype=torch.int32, device=DEV)
+    out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, acc_out=acc)
+    out_planned = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16)      # the kernel the planner really picks
+    assert torch.equal(out_planned, out)
+    a64, w64 = a.double(), w.double()                                      # |sums| < 2^53: exact in fp64
+    assert torch.equal(acc.sum(0, dtype=torch.int64), (a64.sum(0) @ w64.T).to(torch.int64))   # per column
+    assert torch.equal(acc.sum(1, dtype=torch.int64), (a64 @ w64.sum(0)).to(torch.int64))     # per row
+    rows = torch.randint(0, M, (48,), device=DEV, generator=gd)
+    exact = (a64[rows] @ w64.T).to(torch.int32)
+    assert torch.equal(acc[rows], exact)
+    ref = orc.scaled_matmul(a[rows].cpu(), w.cpu(), a_s[rows].cpu(), w_s.cpu(), torch.bfloat16, None) \
+        if N * K <= 2 * I * H and M <= 256 else None
+    want = (exact.float() * a_s[rows, None] * w_s[None, :]).bfloat16()    # same expression, same rounding
+    assert torch.equal(out[rows], want)
+    if ref is not None:
+        assert torch.equal(out[rows].cpu(), ref)
+
+
+def test_silu_mul_quant_full_size():
+    gd = torch.Generator(device=DEV).manual_seed(7)
+    M = 8192
+    x = torch.empty(M, 2 * I, dtype=torch.bfloat16, device=DEV).normal_(generator=gd) * 2
+    q, s = ops.act_and_mul_dynamic_int8_quant(x, "silu")
+    act = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ops.act_and_mul(act, x, "silu")
+    q2, s2 = ops.scaled_quantize(act)
+    assert torch.equal(q, q2) and torch.equal(s, s2)                       # fusion == two operators, every row
+    amax = act.float().abs().amax(-1)                                      # scale = amax / 127 on all rows
+    torch.testing.assert_close(s, amax / 127.0, rtol=3e-7, atol=0)        # torch divides by reciprocal-multiply: 1 ulp
+    assert int(q.abs().max()) == 127 and int((q.abs().amax(-1) != 127).sum()) == 0
+    rows = [0, 1234, 8191]
+    ref = torch.empty(len(rows), I, dtype=torch.bfloat16)
+    orc.act_and_mul(ref, x[rows].cpu(), "silu")
+    got = act[rows].cpu()
+    assert (got == ref).float().mean() >= 0.995
+    assert ((got.float() - ref.float()).abs() <= 2.0 ** -7 * ref.float().abs() + 1e-30).all()
+
+
+def test_prefill_full_size_causality_and_sample():
+    """two sequences of 4096 tokens (the bench's prefill chunk): (a) the last 48 queries of a sequence against the
+    oracle (run as a chunked-prefill problem: 48 queries over 4096 keys, bottom-right causal), (b) causality: changing
+    K/V of the last 1000 tokens cannot change the outputs of the earlier queries (bitwise)"""
+    gd = torch.Generator(device=DEV).manual_seed(9)
+    S, nseq = 4096, 2
+    T = S * nseq
+    qkv = torch.empty(T, (NQ + 2 * NKV) * D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    q = qkv[:, :NQ * D].unflatten(-1, (NQ, D))
+    k = qkv[:, NQ * D:(NQ + NKV) * D].unflatten(-1, (NKV, D))
+    v = qkv[:, (NQ + NKV) * D:].unflatten(-1, (NKV, D))
+    cu = torch.tensor([0, S, 2 * S], dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(D)
+    out = ops.prefill_attention(q, k, v, cu, cu, S, scale, True).clone()
+    tail = 48
+    ref = orc.attention_varlen(q[S - tail:S].cpu().contiguous(), k[:S].cpu().contiguous(), v[:S].cpu().contiguous(),
+                               torch.tensor([0, tail], dtype=torch.int32), torch.tensor([0, S], dtype=torch.int32),
+                               scale, causal=True)
+    assert rel_l2(out[S - tail:S], ref) <= 1e-3
+    cut = S - 1000
+    qkv[cut:S, NQ * D:] = torch.empty(S - cut, 2 * NKV * D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    out2 = ops.prefill_attention(q, k, v, cu, cu, S, scale, True)
+    assert torch.equal(out2[:cut], out[:cut])          # the past is untouched
+    assert torch.equal(out2[S:], out[S:])              # and so is the other sequence
+    assert not torch.equal(out2[cut:S], out[cut:S])
