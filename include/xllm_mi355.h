@@ -284,6 +284,30 @@ XM_API int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out,
                                   float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* ---- N3: sampler kernels of the decode step ---------------------------------------------------
+ * dcu::random_sample (kernels/dcu/random_sample.hip:88-270; ops_api.h random_sample): probs [batch, vocab] fp32
+ * -> one token id per row by CDF inversion: the first index with p > 0 whose inclusive prefix sum exceeds u; rows whose
+ * total never exceeds u return their last index with p > 0 (0 if none).  u: `uniform` [batch] when non-null, else
+ * the first hiprand_uniform() of hiprand_init(philox_seed, subsequence = row, philox_offset) (Philox4x32-10, the
+ * reference's generator; xllm_mi355_philox_uniform exposes that stream).  Prefix sums are fp32 in a fixed order, so
+ * the result is deterministic; it can differ from another summation order only when u is within fp32 rounding of a
+ * CDF step. */
+XM_API int xllm_mi355_random_sample(const float* probs, int32_t* out, int64_t batch, int64_t vocab,
+                                    const float* uniform, uint64_t philox_seed, uint64_t philox_offset,
+                                    void* stream);
+XM_API int xllm_mi355_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* dcu::rejection_sample (kernels/dcu/rejection_sample.hip:33-215): speculative-decoding verification.  For sequence
+ * s with n = num_draft_tokens[s] drafts ending at cu_num_draft_tokens[s] (inclusive prefix sums): output slots
+ * [start + s, start + s + n] are set to -1, draft i is accepted while uniform_rand[row] < target[row, tok] /
+ * draft[row, tok]; the first rejected position gets argmax_t max(target - draft, 0)[t] / max(uniform_probs[row, t],
+ * FLT_MIN) (lowest index on ties) and the sequence stops; if all drafts pass, slot n gets bonus_token_ids[s].
+ * output has batch + total_drafts entries.  Integer output, bit-exact. */
+XM_API int xllm_mi355_rejection_sample(const int32_t* draft_token_ids, const int32_t* num_draft_tokens,
+                                       const int32_t* cu_num_draft_tokens, const float* draft_probs,
+                                       const float* target_probs, const int32_t* bonus_token_ids,
+                                       const float* uniform_rand, const float* uniform_probs, int64_t batch,
+                                       int64_t vocab, int32_t* output, void* stream);
+
 /* ---- MoE -----------------------------------------------------------------------------------
  * kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (kernels/cuda/moe/moe_compute_index.cu:111-160)
  * expert_id [T,topk] int32 -> src_dst[T*topk], dst_src[T*topk], expert_sizes[E]; DETERMINISTIC

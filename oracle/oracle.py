@@ -322,3 +322,28 @@ def group_gemm(a, w, token_count):
     lib().orc_group_gemm(_p(a.contiguous()), _p(w.contiguous()), _p(token_count), _p(out), _i64(E), _i64(N),
                          _i64(K), C.c_int(_dt(a)))
     return out
+
+
+# --------------------------------------------------------------------------- N3 sampler
+def philox_uniform(n, seed, offset):
+    out = torch.empty(n, dtype=torch.float32)
+    lib().orc_philox_uniform(_p(out), _i64(n), C.c_uint64(seed), C.c_uint64(offset))
+    return out
+
+
+def random_sample(probs, u):
+    """probs [B, V] fp32, u [B] fp32 -> int32 [B] (fp64 CDF)"""
+    B, V = probs.shape
+    out = torch.empty(B, dtype=torch.int32)
+    lib().orc_random_sample(_p(probs.contiguous()), _p(u.contiguous()), _i64(B), _i64(V), _p(out))
+    return out
+
+
+def rejection_sample(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, draft_probs, target_probs,
+                     bonus_token_ids, uniform_rand, uniform_probs):
+    B, V = num_draft_tokens.numel(), target_probs.size(1)
+    out = torch.empty(B + draft_token_ids.numel(), dtype=torch.int32)
+    lib().orc_rejection_sample(_p(draft_token_ids), _p(num_draft_tokens), _p(cu_num_draft_tokens),
+                               _p(draft_probs.contiguous()), _p(target_probs.contiguous()), _p(bonus_token_ids),
+                               _p(uniform_rand.contiguous()), _p(uniform_probs.contiguous()), _i64(B), _i64(V), _p(out))
+    return out

@@ -731,3 +731,87 @@ ORC_API void orc_group_gemm(const void* a, const void* w, const int32_t* token_c
     off += Me;
   }
 }
+
+
+/* ------------------------------------------------------------------------- */
+/* N3 sampler: kernels/dcu/random_sample.hip:88-270, rejection_sample.hip:33-139 */
+/* ------------------------------------------------------------------------- */
+/* Philox4x32-10 (Salmon et al. 2011) as hiprand / rocRAND drive it for hiprand_init(seed, subsequence, offset):
+ * counter = (offset/4 lo, offset/4 hi, subsequence lo, subsequence hi), key = seed, output word offset%4;
+ * hiprand_uniform = 2^-32 + x*2^-32 in fp32 (rocrand_uniform.h). The GPU test pins this against hiprand itself. */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t m0 = (uint64_t)0xD2511F53u * c[0], m1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(m1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)m1, n2 = (uint32_t)(m0 >> 32) ^ c[3] ^ k1,
+             n3 = (uint32_t)m0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+ORC_API void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { /* known-answer tests */
+  uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  philox4x32_10(c, key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+ORC_API void orc_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset) {
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t blk = offset >> 2;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)i, (uint32_t)((uint64_t)i >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    volatile float x = (float)c[offset & 3];
+    volatile float y = x * 2.3283064e-10f;
+    out[i] = 2.3283064e-10f + y;
+  }
+}
+/* CDF inversion in exact-enough arithmetic (fp64 prefix sums): first index with p > 0 and cdf > u, else the last index
+ * with p > 0, else 0. Also returns cdf just below / at the chosen index so that callers can bound fp32 kernels. */
+ORC_API void orc_random_sample(const float* probs, const float* u, int64_t B, int64_t V, int32_t* out) {
+  for (int64_t b = 0; b < B; ++b) {
+    const float* p = probs + b * V;
+    double cdf = 0.0;
+    int32_t pick = -1, last = -1;
+    for (int64_t i = 0; i < V; ++i) {
+      if (!(p[i] > 0.0f)) continue;
+      last = (int32_t)i;
+      cdf += (double)p[i];
+      if (pick < 0 && cdf > (double)u[b]) pick = (int32_t)i;
+    }
+    out[b] = pick >= 0 ? pick : (last >= 0 ? last : 0);
+  }
+}
+ORC_API void orc_rejection_sample(const int32_t* draft_token_ids, const int32_t* num_draft_tokens,
+                                  const int32_t* cu_num_draft_tokens, const float* draft_probs,
+                                  const float* target_probs, const int32_t* bonus_token_ids,
+                                  const float* uniform_rand, const float* uniform_probs, int64_t B, int64_t V,
+                                  int32_t* output) {
+  for (int64_t s = 0; s < B; ++s) {
+    const int32_t n = num_draft_tokens[s], end = cu_num_draft_tokens[s], start = end - n;
+    const int64_t o = start + s;
+    for (int32_t i = 0; i < n + 1; ++i) output[o + i] = -1;
+    int32_t di = 0;
+    int stopped = 0;
+    for (; di < n; ++di) {
+      const int64_t row = start + di;
+      const int32_t tok = draft_token_ids[row];
+      if (tok < 0 || tok >= V) { stopped = 1; break; }
+      const float* dp = draft_probs + row * V;
+      const float* tp = target_probs + row * V;
+      const float d = dp[tok] > 0.0f ? dp[tok] : 0.0f, t = tp[tok] > 0.0f ? tp[tok] : 0.0f;
+      const float accept = d > 0.0f ? t / d : (t > 0.0f ? 1.0f : 0.0f);
+      if (uniform_rand[row] < accept) { output[o + di] = tok; continue; }
+      float best = -1.0f;
+      int32_t best_tok = 0;
+      for (int64_t v = 0; v < V; ++v) {
+        const float rec = fmaxf(tp[v] - dp[v], 0.0f);
+        const float uu = fmaxf(uniform_probs[row * V + v], 1.17549435e-38f);
+        const float sc = rec / uu;
+        if (sc > best) { best = sc; best_tok = (int32_t)v; }   /* ascending v: ties keep the lowest index */
+      }
+      output[o + di] = best_tok;
+      stopped = 1;
+      break;
+    }
+    if (!stopped) output[o + n] = bonus_token_ids[s];
+  }
+}

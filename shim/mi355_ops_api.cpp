@@ -5,6 +5,7 @@
 // ROCm builds of torch present HIP devices as "cuda": use the masquerading guard / stream accessors
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/HIPGeneratorImpl.h>
 
 #include "../include/xllm_mi355.h"
 
@@ -246,6 +247,55 @@ torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const
                                                    (int32_t)total, table.data_ptr<int32_t>(), cur_stream()),
         "build_block_table_from_paged_kv");
   return table;
+}
+
+torch::Tensor random_sample(const torch::Tensor& probs) {
+  TORCH_CHECK(probs.dim() == 2 || probs.dim() == 3, "probs must be a 2D or 3D tensor");      // random_sample.hip:241
+  TORCH_CHECK(probs.scalar_type() == torch::kFloat32, "probs must be float32");               // :253
+  DeviceGuard guard(probs.device());
+  torch::Tensor flat = probs.reshape({-1, probs.size(-1)}).contiguous();
+  const int64_t batch = flat.size(0);
+  auto out = torch::empty({batch}, flat.options().dtype(torch::kInt32));
+  // Philox (seed, offset) of the device's default generator, advanced like get_seed_and_offset (random_sample.hip:58-74:
+  // the offset is bumped by the rounded-up increment and the NEW offset seeds the kernel)
+  uint64_t seed = 0, offset = 0;
+  {
+    at::Generator gen = at::cuda::detail::getDefaultCUDAGenerator(probs.device().index());
+    std::lock_guard<std::mutex> lock(gen.mutex());
+    auto* impl = at::check_generator<at::CUDAGeneratorImpl>(gen);
+    seed = impl->current_seed();
+    offset = impl->get_offset() + (uint64_t)((batch + 3) / 4 * 4);
+    impl->set_offset(offset);
+  }
+  check(xllm_mi355_random_sample(flat.data_ptr<float>(), out.data_ptr<int32_t>(), batch, flat.size(1), nullptr, seed, offset,
+                                 cur_stream()),
+        "random_sample");
+  if (probs.dim() == 3) return out.view({probs.size(0), probs.size(1)});
+  return out;
+}
+
+torch::Tensor rejection_sample(const torch::Tensor& draft_token_ids, const torch::Tensor& num_draft_tokens,
+                               const torch::Tensor& cu_num_draft_tokens, const std::optional<torch::Tensor>& draft_probs,
+                               const torch::Tensor& target_probs, const torch::Tensor& bonus_token_ids,
+                               const torch::Tensor& uniform_rand, const torch::Tensor& uniform_probs,
+                               int64_t max_spec_len) {
+  (void)max_spec_len;
+  TORCH_CHECK(draft_probs.has_value(), "rejection_sample requires dense draft_probs");        // rejection_sample.hip:151
+  DeviceGuard guard(target_probs.device());
+  auto f32 = [](const torch::Tensor& t) { return t.to(torch::kFloat32).contiguous(); };
+  torch::Tensor dp = f32(*draft_probs), tp = f32(target_probs), ur = f32(uniform_rand), up = f32(uniform_probs);
+  TORCH_CHECK(dp.dim() == 2 && dp.sizes() == tp.sizes() && up.sizes() == tp.sizes(), "probs must be [drafts, vocab]");
+  const int64_t batch = num_draft_tokens.size(0);
+  TORCH_CHECK(cu_num_draft_tokens.numel() == batch && bonus_token_ids.numel() == batch);
+  TORCH_CHECK(ur.numel() == draft_token_ids.numel() && dp.size(0) == draft_token_ids.numel());
+  auto out = torch::empty({batch + draft_token_ids.size(0)}, draft_token_ids.options().dtype(torch::kInt32));
+  if (batch == 0) return out;
+  check(xllm_mi355_rejection_sample(draft_token_ids.contiguous().data_ptr<int32_t>(), num_draft_tokens.data_ptr<int32_t>(),
+                                    cu_num_draft_tokens.data_ptr<int32_t>(), dp.data_ptr<float>(), tp.data_ptr<float>(),
+                                    bonus_token_ids.data_ptr<int32_t>(), ur.data_ptr<float>(), up.data_ptr<float>(), batch,
+                                    tp.size(1), out.data_ptr<int32_t>(), cur_stream()),
+        "rejection_sample");
+  return out;
 }
 
 void update_llm_decode_metadata(const LlmDecodeMetadataUpdateParams& params, void* stream) {

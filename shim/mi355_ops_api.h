@@ -66,6 +66,14 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& paged_kv_indptr,
                                               const torch::Tensor& paged_kv_indices);
 
+// sampler (N3): dcu_ops_api.h:71-81
+torch::Tensor random_sample(const torch::Tensor& probs);
+torch::Tensor rejection_sample(const torch::Tensor& draft_token_ids, const torch::Tensor& num_draft_tokens,
+                               const torch::Tensor& cu_num_draft_tokens, const std::optional<torch::Tensor>& draft_probs,
+                               const torch::Tensor& target_probs, const torch::Tensor& bonus_token_ids,
+                               const torch::Tensor& uniform_rand, const torch::Tensor& uniform_probs,
+                               int64_t max_spec_len);
+
 // graph-mode decode: kernels/cuda/llm_decode_metadata_update.h:34-57 (same field names; the struct IS the C-ABI one,
 // whose first 19 members are the reference's LlmDecodeMetadataUpdateParams in order, followed by the optional
 // dense-block-table extension)

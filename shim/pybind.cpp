@@ -13,6 +13,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("reshape_paged_cache", &k::reshape_paged_cache);
   m.def("rotary_embedding", [](torch::Tensor pos, torch::Tensor q, std::optional<torch::Tensor> kk, torch::Tensor cache, bool neox) { k::rotary_embedding(pos, q, kk, cache, neox); });
   m.def("matmul", &k::matmul);
+  m.def("random_sample", &k::random_sample);
+  m.def("rejection_sample", &k::rejection_sample);
   m.def("scaled_quantize", [](const torch::Tensor& x) {
     return k::scaled_quantize(x, torch::Tensor(), std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, "none", 1.0, false, torch::kInt8);
   });

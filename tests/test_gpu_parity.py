@@ -738,3 +738,71 @@ def test_model_step_fused_equals_reference_operator_order():
         positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
         outs.append(model.logits(model.forward(tokens, positions, md, caches)).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------- N3 sampler
+def test_philox_uniform_matches_oracle_and_hiprand(tmp_path):
+    for seed, off in [(0, 0), (1234567, 5), (2 ** 63 + 11, 4 * 10 ** 9 + 3)]:
+        assert torch.equal(ops.philox_uniform(3000, seed, off).cpu(), orc.philox_uniform(3000, seed, off))
+    # pin against hiprand itself (header-only device API of the ROCm install) when a compiler is on the box
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "hiprand_probe.hip")
+    exe = tmp_path / "probe"
+    try:
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-o", str(exe), src], check=True, capture_output=True,
+                       timeout=300)
+    except (OSError, subprocess.SubprocessError):
+        pytest.skip("no hipcc / hiprand headers on this box")
+    vals = [float.fromhex(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True,
+                                                     timeout=120).stdout.split()]
+    got = torch.cat([ops.philox_uniform(512, 1234567, 5), ops.philox_uniform(512, 99, 4000000003)]).cpu()
+    assert torch.equal(got, torch.tensor(vals, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("B,V", [(64, 152064), (33, 1003), (5, 8192)])
+def test_random_sample(B, V):
+    g = torch.Generator().manual_seed(B + V)
+    probs = torch.softmax(torch.randn(B, V, generator=g) * 3, -1)
+    probs[probs < 1e-6] = 0.0                      # top-p style zeros
+    probs[1] = 0.0                                  # nothing valid -> 0
+    u = torch.rand(B, generator=g)
+    u[2] = 1.0                                      # beyond the total -> last valid index
+    ref = orc.random_sample(probs, u)
+    got = ops.random_sample(probs.to(DEV), uniform=u.to(DEV)).cpu()
+    assert got[1] == 0 and got[2] == ref[2]
+    same = (got == ref)
+    assert same.float().mean() >= 0.95
+    cdf = torch.cumsum(probs.double(), -1)          # any difference must sit on an fp32-rounding tie of the CDF
+    for b in (~same).nonzero().flatten().tolist():
+        i = int(got[b])
+        assert probs[b, i] > 0 and cdf[b, i] > u[b] - 1e-4 and (i == 0 or cdf[b, i - 1] <= u[b] + 1e-4)
+    # RNG path: u from the Philox stream == the explicit-uniform path on the same numbers
+    seed, off = 424242, 9
+    got_rng = ops.random_sample(probs.to(DEV), seed=seed, offset=off)
+    got_u = ops.random_sample(probs.to(DEV), uniform=ops.philox_uniform(B, seed, off))
+    assert torch.equal(got_rng, got_u)
+
+
+def test_rejection_sample_bit_exact():
+    g = torch.Generator().manual_seed(77)
+    B, V = 48, 4099
+    n = torch.randint(0, 5, (B,), generator=g, dtype=torch.int32)
+    cu = torch.cumsum(n, 0).to(torch.int32)
+    T = int(cu[-1])
+    draft = torch.randint(0, V, (T,), generator=g, dtype=torch.int32)
+    draft[3] = V + 5                                  # an out-of-range draft id stops its sequence
+    dp = torch.softmax(torch.randn(T, V, generator=g) * 2, -1)
+    tp = torch.softmax(torch.randn(T, V, generator=g) * 2, -1)
+    dp[:, ::7] = 0.0
+    rows = torch.arange(T)
+    tp[rows[::3], draft[::3].clamp(max=V - 1).long()] *= 50.0     # force some certain accepts
+    ur, up = torch.rand(T, generator=g), torch.rand(T, V, generator=g)
+    up[5, :10] = 0.0                                  # FLT_MIN clamp path
+    bonus = torch.randint(0, V, (B,), generator=g, dtype=torch.int32)
+    ref = orc.rejection_sample(draft, n, cu, dp, tp, bonus, ur, up)
+    got = ops.rejection_sample(*[t.to(DEV) for t in (draft, n, cu, dp, tp, bonus, ur, up)]).cpu()
+    assert torch.equal(got, ref)
+    assert (ref == -1).any() and (ref[cu.long() + torch.arange(B)] >= 0).any()   # both stop and bonus paths exercised

@@ -372,3 +372,47 @@ def test_moe_helpers():
     out = orc.moe_combine(g, w, T, topk)
     ref = (g.float().view(T, topk, Hd) * w[..., None]).sum(1)
     torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------- N3 sampler
+def test_philox4x32_10_known_answers():
+    """Random123 known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution)"""
+    import ctypes as C
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        orc.lib().orc_philox4x32_10(c, k, o)
+        assert tuple(o) == want
+    # hiprand_init(seed, subsequence, offset) + hiprand_uniform: counter (offset/4, subsequence), word offset%4
+    u = orc.philox_uniform(1, 0, 2)       # seed 0, row 0, offset 2 -> third word of the all-zero vector
+    assert u.item() == np.float32(2.3283064e-10) + np.float32(0xbc57ac4c) * np.float32(2.3283064e-10)
+    assert 0.0 < float(orc.philox_uniform(4096, 1234, 7).min()) and float(orc.philox_uniform(4096, 1234, 7).max()) <= 1.0
+
+
+def test_random_sample_oracle_rules():
+    probs = torch.tensor([[0.1, 0.0, 0.2, 0.7], [0.0, 0.0, 0.0, 0.0], [0.5, 0.5, 0.0, 0.0], [0.25, 0.25, 0.25, 0.25]])
+    u = torch.tensor([0.25, 0.5, 1.0, 0.75])
+    # row0: cdf .1,.1,.3,1 -> first > .25 is index 2; row1: nothing valid -> 0; row2: total 1.0 !> 1.0 -> last valid 1;
+    # row3: cdf .25,.5,.75,1 -> first > .75 is index 3
+    assert orc.random_sample(probs, u).tolist() == [2, 0, 1, 3]
+
+
+def test_rejection_sample_oracle_rules():
+    V = 5
+    draft = torch.tensor([1, 2, 3, 0, 7], dtype=torch.int32)            # seq0: 2 drafts, seq1: 2 drafts, seq2: 1 (bad id)
+    n = torch.tensor([2, 2, 1], dtype=torch.int32)
+    cu = torch.tensor([2, 4, 5], dtype=torch.int32)
+    dp = torch.full((5, V), 0.2)
+    tp = torch.full((5, V), 0.2)
+    tp[1] = torch.tensor([0.0, 0.1, 0.0, 0.6, 0.3])                      # seq0 draft 1 (token 2): target 0 -> reject
+    ur = torch.tensor([0.5, 0.5, 0.5, 0.5, 0.5])
+    up = torch.full((5, V), 0.5)
+    bonus = torch.tensor([11, 12, 13], dtype=torch.int32)
+    out = orc.rejection_sample(draft, n, cu, dp, tp, bonus, ur, up)
+    # seq0: accept token 1 (ratio 1), reject token 2 -> recovered argmax(max(tp-dp,0)/u) = index 3; no bonus
+    # seq1: both accepted -> bonus 12; seq2: draft id 7 out of range -> all -1
+    assert out.tolist() == [1, 3, -1, 3, 0, 12, -1, -1]

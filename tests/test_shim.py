@@ -25,13 +25,15 @@ def _shim():
 def test_shim_builds_and_exposes_reference_operator_names():
     m = _shim()
     for name in ("rms_norm", "fused_add_rms_norm", "act_and_mul", "reshape_paged_cache", "rotary_embedding", "matmul",
-                 "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward"):
+                 "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
+                 "random_sample", "rejection_sample"):
         assert hasattr(m, name)
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
                 "static_scaled_fp8_quant", "fp8_scaled_quantize", "rms_norm_static_fp8_quant",
                 "fused_add_rms_norm_static_fp8_quant", "fp8_scaled_matmul", "fused_qk_norm_rope", "scaled_quantize",
-                "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv"):
+                "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
+                "update_llm_decode_metadata"):
         assert sym + "(" in hdr, sym
 
 
@@ -84,3 +86,19 @@ def test_shim_matches_oracle_and_ctypes_path():
     assert torch.equal(kc_d.cpu(), kc_r) and torch.equal(vc_d.cpu(), vc_r)
     err = (got.float().cpu() - ref.float()).norm() / ref.float().norm()
     assert err < 1e-3
+
+
+@pytest.mark.gpu
+def test_shim_random_sample_uses_the_default_generator_stream():
+    """random_sample(probs) draws u from the device's default Philox generator exactly like the reference wrapper
+    (random_sample.hip:58-74): re-seeding reproduces the tokens, and they equal the explicit (seed, offset) call"""
+    from xllm_amd import ops
+    m = _shim()
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(torch.randn(37, 5000, generator=g) * 2, -1).cuda()
+    torch.cuda.manual_seed(2024)
+    a = m.random_sample(probs)
+    b = m.random_sample(probs)                      # the generator offset advanced: a different draw
+    torch.cuda.manual_seed(2024)
+    assert torch.equal(m.random_sample(probs), a) and not torch.equal(a, b)
+    assert torch.equal(a, ops.random_sample(probs, seed=2024, offset=(37 + 3) // 4 * 4))

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("XLLM_MI355_LIB") or os.path.join(_HERE, "lib", "libxl
 
 vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 ci = C.c_int
+u64 = C.c_uint64
 
 
 
@@ -61,6 +62,9 @@ _OPTIONAL = {
     "xllm_mi355_mla_decode": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, vp, sz, vp], ci),
     "xllm_mi355_mla_prefill": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, ci, vp, sz,
                                 vp], ci),
+    "xllm_mi355_random_sample": ([vp, vp, i64, i64, vp, u64, u64, vp], ci),
+    "xllm_mi355_philox_uniform": ([vp, i64, u64, u64, vp], ci),
+    "xllm_mi355_rejection_sample": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp], ci),
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),
     "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),

@@ -513,3 +513,40 @@ def decode_metadata_update(src: dict, dst: dict, actual_num_tokens: int, padded_
     md.max_blocks_per_seq = bt.size(1) if bt is not None else 0
     md.padded_batch_size = padded_batch_size or (bt.size(0) if bt is not None else actual_batch_size)
     check(_lib.lib().xllm_mi355_decode_metadata_update(C.byref(md), _stream()), "decode_metadata_update")
+
+
+# ------------------------------------------------------------------------------------------------ N3: sampler
+def philox_uniform(n: int, seed: int, offset: int, device="cuda"):
+    """u[i] = the first hiprand_uniform() of hiprand_init(seed, subsequence=i, offset) (Philox4x32-10)"""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().xllm_mi355_philox_uniform(_p(out), n, seed, offset, _stream()), "philox_uniform")
+    return out
+
+
+def random_sample(probs, uniform=None, seed: int = 0, offset: int = 0):
+    """dcu::random_sample (kernels/dcu/random_sample.hip:240-270): probs [B, V] or [B, S, V] fp32 -> int32 ids"""
+    _need_cuda(probs)
+    if probs.dim() not in (2, 3) or probs.dtype != torch.float32:
+        raise Mi355Error("probs must be a 2D or 3D float32 tensor")   # reference CHECKs :241-254
+    flat = probs.reshape(-1, probs.size(-1)).contiguous()
+    out = torch.empty(flat.size(0), dtype=torch.int32, device=probs.device)
+    check(_lib.lib().xllm_mi355_random_sample(_p(flat), _p(out), flat.size(0), flat.size(1), _p(uniform), seed, offset,
+                                              _stream()), "random_sample")
+    return out.view(probs.shape[:-1])
+
+
+def rejection_sample(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, draft_probs, target_probs,
+                     bonus_token_ids, uniform_rand, uniform_probs):
+    """dcu::rejection_sample (kernels/dcu/rejection_sample.hip:141-215) -> int32 [batch + total_drafts]"""
+    _need_cuda(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, draft_probs, target_probs, bonus_token_ids,
+               uniform_rand, uniform_probs)
+    f = lambda t: t.to(torch.float32).contiguous()
+    dp, tp, ur, up = f(draft_probs), f(target_probs), f(uniform_rand), f(uniform_probs)
+    if dp.shape != tp.shape or up.shape != tp.shape or dp.dim() != 2:
+        raise Mi355Error("draft_probs / target_probs / uniform_probs must be [total_drafts, vocab]")
+    B = num_draft_tokens.numel()
+    out = torch.empty(B + draft_token_ids.numel(), dtype=torch.int32, device=tp.device)
+    check(_lib.lib().xllm_mi355_rejection_sample(
+        _p(draft_token_ids.contiguous()), _p(num_draft_tokens), _p(cu_num_draft_tokens), _p(dp), _p(tp),
+        _p(bonus_token_ids), _p(ur), _p(up), B, tp.size(1), _p(out), _stream()), "rejection_sample")
+    return out
