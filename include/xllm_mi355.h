@@ -284,6 +284,16 @@ XM_API int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out,
                                   float scale, int causal, int dtype, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* N4: cuda::moe_fused_topk (kernels/cuda/moe/moe_fused_topk.cu:31-61; DCU falls back to it from moe_active_topk,
+ * kernels/dcu/topk_gate.cpp:127-146): gating [T, E] (f32 / bf16 / f16) -> topk_weights [T, topk] f32, topk_ids
+ * [T, topk] int32.  scoring 0 = softmax, 1 = sigmoid (+ optional fp32 correction_bias [E]: added for the selection,
+ * removed from the returned weight); ties go to the lower expert index; renormalize divides by the selected sum.
+ * E <= 512.  The grouped variant (moe_grouped_topk -> aiter::grouped_topk, an external library absent from the
+ * reference tree) is not built. */
+XM_API int xllm_mi355_moe_fused_topk(const void* gating, int dtype, int64_t n_tokens, int64_t n_experts,
+                                     int64_t topk, int renormalize, const float* correction_bias, int scoring,
+                                     float* topk_weights, int32_t* topk_ids, void* stream);
+
 /* ---- N3: sampler kernels of the decode step ---------------------------------------------------
  * dcu::random_sample (kernels/dcu/random_sample.hip:88-270; ops_api.h random_sample): probs [batch, vocab] fp32
  * -> one token id per row by CDF inversion: the first index with p > 0 whose inclusive prefix sum exceeds u; rows whose

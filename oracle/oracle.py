@@ -207,7 +207,8 @@ def scaled_quantize(x):
     M, K = x.shape
     q = torch.empty(M, K, dtype=torch.int8)
     s = torch.empty(M, dtype=torch.float32)
-    lib().orc_scaled_quantize_i8(_p(x.contiguous()), _p(q), _p(s), _i64(M), _i64(K), C.c_int(_dt(x)))
+    x_c = x.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_scaled_quantize_i8(_p(x_c), _p(q), _p(s), _i64(M), _i64(K), C.c_int(_dt(x)))
     return q, s
 
 
@@ -216,7 +217,9 @@ def scaled_matmul(a, w, a_scale, w_scale, out_dtype=torch.bfloat16, bias=None, w
     N = w.shape[0]
     out = torch.empty(M, N, dtype=out_dtype)
     acc = torch.empty(M, N, dtype=torch.int32) if want_acc else None
-    lib().orc_scaled_matmul_i8(_p(a), _p(w), _p(a_scale.contiguous()), _p(w_scale.reshape(-1).contiguous()),
+    a_scale_c = a_scale.contiguous()  # keep the (possibly new) tensor alive across the call
+    w_scale_c = w_scale.reshape(-1).contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_scaled_matmul_i8(_p(a), _p(w), _p(a_scale_c), _p(w_scale_c),
                                _p(bias), _p(out), _p(acc), _i64(M), _i64(N), _i64(K), C.c_int(_DT[out_dtype]))
     return (out, acc) if want_acc else out
 
@@ -225,21 +228,25 @@ def matmul(a, w, bias=None):
     M, K = a.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=a.dtype)
-    lib().orc_matmul(_p(a.contiguous()), _p(w.contiguous()), _p(bias), _p(out), _i64(M), _i64(N), _i64(K),
+    a_c = a.contiguous()  # keep the (possibly new) tensor alive across the call
+    w_c = w.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_matmul(_p(a_c), _p(w_c), _p(bias), _p(out), _i64(M), _i64(N), _i64(K),
                      C.c_int(_dt(a)))
     return out
 
 
 def static_scaled_fp8_quant(x, scale):
     out = torch.empty(x.shape, dtype=torch.uint8)
-    lib().orc_static_scaled_fp8_quant(_p(out), _p(x.contiguous()), _p(scale), _i64(x.numel()), C.c_int(_dt(x)))
+    x_c = x.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_static_scaled_fp8_quant(_p(out), _p(x_c), _p(scale), _i64(x.numel()), C.c_int(_dt(x)))
     return out
 
 
 def fp8_scaled_quantize(x, scale=None):
     if scale is None:
         scale = torch.empty(1, dtype=torch.float32)
-        lib().orc_fp8_dynamic_scale(_p(x.contiguous()), _i64(x.numel()), C.c_int(_dt(x)), _p(scale))
+        x_c = x.contiguous()  # keep the (possibly new) tensor alive across the call
+        lib().orc_fp8_dynamic_scale(_p(x_c), _i64(x.numel()), C.c_int(_dt(x)), _p(scale))
     return static_scaled_fp8_quant(x, scale), scale
 
 
@@ -255,7 +262,8 @@ def fp8_scaled_matmul(a_u8, w_u8, a_scale, w_scale, out_dtype=torch.bfloat16, bi
 
 def e4m3_to_f32(u8):
     out = torch.empty(u8.shape, dtype=torch.float32)
-    lib().orc_e4m3_to_f32(_p(u8.contiguous()), _p(out), _i64(u8.numel()))
+    u8_c = u8.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_e4m3_to_f32(_p(u8_c), _p(out), _i64(u8.numel()))
     return out
 
 
@@ -293,9 +301,10 @@ def paged_attention(q, k_cache, v_cache, cu_q, kv_lens, block_table, scale, caus
 
 
 def fused_qk_norm_rope(qkv, nq, nk, nv, d, eps, qw, kw, cos_sin, interleaved, positions):
+    positions_c = positions.to(torch.int64).contiguous()  # keep the (possibly new) tensor alive across the call
     lib().orc_fused_qk_norm_rope(_p(qkv), _i64(qkv.shape[0]), _i64(nq), _i64(nk), _i64(nv), _i64(d), _f32(eps),
                                  _p(qw), _p(kw), _p(cos_sin), C.c_int(_dt(cos_sin)), C.c_int(int(interleaved)),
-                                 _p(positions.to(torch.int64).contiguous()), C.c_int(_dt(qkv)))
+                                 _p(positions_c), C.c_int(_dt(qkv)))
 
 
 def moe_compute_index(expert_id, E):
@@ -303,7 +312,8 @@ def moe_compute_index(expert_id, E):
     src_dst = torch.empty(T * topk, dtype=torch.int32)
     dst_src = torch.empty(T * topk, dtype=torch.int32)
     sizes = torch.empty(E, dtype=torch.int32)
-    lib().orc_moe_compute_index(_p(expert_id.contiguous()), _i64(T), _i64(topk), _i64(E), _p(src_dst),
+    expert_id_c = expert_id.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_moe_compute_index(_p(expert_id_c), _i64(T), _i64(topk), _i64(E), _p(src_dst),
                                 _p(dst_src), _p(sizes))
     return src_dst, dst_src, sizes
 
@@ -311,7 +321,9 @@ def moe_compute_index(expert_id, E):
 def moe_combine(gemm2, w, T, topk):
     H = gemm2.shape[-1]
     out = torch.empty(T, H, dtype=gemm2.dtype)
-    lib().orc_moe_combine(_p(out), _p(gemm2.contiguous()), _p(w.contiguous()), _i64(T), _i64(topk), _i64(H),
+    gemm2_c = gemm2.contiguous()  # keep the (possibly new) tensor alive across the call
+    w_c = w.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_moe_combine(_p(out), _p(gemm2_c), _p(w_c), _i64(T), _i64(topk), _i64(H),
                           C.c_int(_dt(gemm2)))
     return out
 
@@ -319,7 +331,9 @@ def moe_combine(gemm2, w, T, topk):
 def group_gemm(a, w, token_count):
     E, N, K = w.shape
     out = torch.zeros(a.shape[0], N, dtype=a.dtype)
-    lib().orc_group_gemm(_p(a.contiguous()), _p(w.contiguous()), _p(token_count), _p(out), _i64(E), _i64(N),
+    a_c = a.contiguous()  # keep the (possibly new) tensor alive across the call
+    w_c = w.contiguous()  # keep the (possibly new) tensor alive across the call
+    lib().orc_group_gemm(_p(a_c), _p(w_c), _p(token_count), _p(out), _i64(E), _i64(N),
                          _i64(K), C.c_int(_dt(a)))
     return out
 
@@ -335,7 +349,8 @@ def random_sample(probs, u):
     """probs [B, V] fp32, u [B] fp32 -> int32 [B] (fp64 CDF)"""
     B, V = probs.shape
     out = torch.empty(B, dtype=torch.int32)
-    lib().orc_random_sample(_p(probs.contiguous()), _p(u.contiguous()), _i64(B), _i64(V), _p(out))
+    pc, uc = probs.contiguous(), u.contiguous()
+    lib().orc_random_sample(_p(pc), _p(uc), _i64(B), _i64(V), _p(out))
     return out
 
 
@@ -343,7 +358,18 @@ def rejection_sample(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, dra
                      bonus_token_ids, uniform_rand, uniform_probs):
     B, V = num_draft_tokens.numel(), target_probs.size(1)
     out = torch.empty(B + draft_token_ids.numel(), dtype=torch.int32)
+    dp, tp, ur, up = (t.contiguous() for t in (draft_probs, target_probs, uniform_rand, uniform_probs))
     lib().orc_rejection_sample(_p(draft_token_ids), _p(num_draft_tokens), _p(cu_num_draft_tokens),
-                               _p(draft_probs.contiguous()), _p(target_probs.contiguous()), _p(bonus_token_ids),
-                               _p(uniform_rand.contiguous()), _p(uniform_probs.contiguous()), _i64(B), _i64(V), _p(out))
+                               _p(dp), _p(tp), _p(bonus_token_ids), _p(ur), _p(up), _i64(B), _i64(V), _p(out))
     return out
+
+
+def moe_fused_topk(gating, topk, renormalize, correction_bias=None, scoring_func="softmax"):
+    T, E = gating.shape
+    w = torch.empty(T, topk, dtype=torch.float32)
+    ids = torch.empty(T, topk, dtype=torch.int32)
+    b = correction_bias.float().contiguous() if (correction_bias is not None and scoring_func == "sigmoid") else None
+    g32 = gating.float().contiguous()   # keep the converted copy alive across the call (ctypes only sees its address)
+    lib().orc_moe_fused_topk(_p(g32), _i64(T), _i64(E), _i64(topk), C.c_int(int(renormalize)),
+                             _p(b), C.c_int(int(scoring_func == "sigmoid")), _p(w), _p(ids))
+    return w, ids

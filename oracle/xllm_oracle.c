@@ -815,3 +815,43 @@ ORC_API void orc_rejection_sample(const int32_t* draft_token_ids, const int32_t*
     if (!stopped) output[o + n] = bonus_token_ids[s];
   }
 }
+
+
+/* N4 gating top-k: kernels/cuda/moe/moe_fused_topk.cu:31-61, moe_topk_softmax_kernels.cuh:324-625,
+ * moe_topk_sigmoid_kernels.cuh:156-392. gating is fp32 here (callers convert). */
+ORC_API void orc_moe_fused_topk(const float* gating, int64_t T, int64_t E, int64_t topk, int renormalize,
+                                const float* bias, int sigmoid, float* out_w, int32_t* out_id) {
+  float* v = (float*)malloc(sizeof(float) * (size_t)E);
+  for (int64_t t = 0; t < T; ++t) {
+    const float* x = gating + t * E;
+    if (sigmoid) {
+      for (int64_t e = 0; e < E; ++e) {
+        float s = 1.0f / (1.0f + expf(-x[e]));
+        v[e] = bias ? s + bias[e] : s;
+      }
+    } else {
+      float mx = -INFINITY, sum = 0.0f;
+      for (int64_t e = 0; e < E; ++e) mx = fmaxf(mx, x[e]);
+      for (int64_t e = 0; e < E; ++e) { v[e] = expf(x[e] - mx); sum += v[e]; }
+      const float inv = 1.0f / sum;
+      for (int64_t e = 0; e < E; ++e) v[e] = v[e] * inv;
+    }
+    float wsum = 0.0f;
+    for (int64_t k = 0; k < topk; ++k) {
+      int64_t best = 0;
+      for (int64_t e = 1; e < E; ++e)
+        if (v[e] > v[best]) best = e;            /* ascending scan: ties keep the lower index */
+      float w = v[best];
+      if (sigmoid && bias) w = w - bias[best];
+      out_w[t * topk + k] = w;
+      out_id[t * topk + k] = (int32_t)best;
+      wsum += w;
+      v[best] = -INFINITY;
+    }
+    if (renormalize) {
+      const float inv = 1.0f / wsum;
+      for (int64_t k = 0; k < topk; ++k) out_w[t * topk + k] = out_w[t * topk + k] * inv;
+    }
+  }
+  free(v);
+}

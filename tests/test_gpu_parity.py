@@ -806,3 +806,23 @@ def test_rejection_sample_bit_exact():
     got = ops.rejection_sample(*[t.to(DEV) for t in (draft, n, cu, dp, tp, bonus, ur, up)]).cpu()
     assert torch.equal(got, ref)
     assert (ref == -1).any() and (ref[cu.long() + torch.arange(B)] >= 0).any()   # both stop and bonus paths exercised
+
+
+@pytest.mark.parametrize("E,topk,scoring,bias,renorm,dtype", [
+    (128, 8, "softmax", False, True, torch.bfloat16), (256, 8, "sigmoid", True, True, torch.float32),
+    (64, 6, "softmax", False, False, torch.float32), (60, 4, "sigmoid", False, True, torch.float16),
+    (512, 8, "sigmoid", True, False, torch.bfloat16)])
+def test_moe_fused_topk(E, topk, scoring, bias, renorm, dtype):
+    """N4: cuda::moe_fused_topk; ids bit-exact (incl. lower-index tie-break), weights to fp32 rounding"""
+    g = torch.Generator().manual_seed(E + topk)
+    T = 300
+    x = (torch.randn(T, E, generator=g) * 2).to(dtype)
+    x[0] = 0.5                                            # a row of exact ties: experts 0..topk-1 must win in order
+    x[1, 7] = x[1, 3]                                     # a pairwise tie
+    b = (torch.randn(E, generator=g) * 0.1) if bias else None
+    w_ref, id_ref = orc.moe_fused_topk(x, topk, renorm, b, scoring)
+    w, ids = ops.moe_fused_topk(x.to(DEV), topk, renorm, b.to(DEV) if bias else None, scoring)
+    if not bias:
+        assert ids[0].tolist() == list(range(topk))      # all-equal scores: lowest indices in order
+    assert torch.equal(ids.cpu(), id_ref)
+    torch.testing.assert_close(w.cpu(), w_ref, rtol=3e-6, atol=1e-7)

@@ -99,6 +99,95 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N4: fused gating top-k. Reference: cuda::moe_fused_topk (kernels/cuda/moe/moe_fused_topk.cu:31-61) ->
+// topk_softmax / topk_sigmoid (moe_topk_softmax_kernels.cuh:324-625, moe_topk_sigmoid_kernels.cuh:156-392):
+//   softmax: p = exp(x - max) * (1 / sum), k rounds of argmax (lower index wins ties), weight = p
+//   sigmoid: s = 1 / (1 + exp(-x)); selection score v = s + bias[e] when a correction bias is given, weight = v - bias[e]
+//   renormalize: weights *= 1 / (sum of the selected weights)
+// One wave per token; lane l holds experts l, l + 64, ... (E <= 512), the k argmax rounds are 6-step butterflies.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTopkMaxPerLane = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict__ gating, int n_tokens, int E, int topk,
+                                                             int renormalize, const float* __restrict__ bias,
+                                                             int sigmoid, float* __restrict__ out_w,
+                                                             int32_t* __restrict__ out_id) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  const T* row = gating + (int64_t)tok * E;
+  float v[kTopkMaxPerLane];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    const int e = lane + 64 * j;
+    v[j] = e < E ? to_f32(row[e]) : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  if (sigmoid) {
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      const int e = lane + 64 * j;
+      if (e < E) {
+        float sg = 1.0f / (1.0f + expf(-v[j]));
+        if (bias) sg = sg + bias[e];
+        v[j] = sg;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      const int e = lane + 64 * j;
+      v[j] = e < E ? expf(v[j] - mx) : 0.0f;
+      sum += v[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      const int e = lane + 64 * j;
+      v[j] = e < E ? v[j] * inv : -INFINITY;
+    }
+  }
+  float wsum = 0.0f;
+  float my_w = 0.0f;   // lane i keeps the i-th selected weight for the renormalisation pass
+  for (int kk = 0; kk < topk; ++kk) {
+    float best = -INFINITY;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      const int e = lane + 64 * j;
+      if (e < E && (v[j] > best || (v[j] == best && e < best_e))) { best = v[j]; best_e = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oe = __shfl_xor(best_e, o);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+    }
+    if ((best_e & 63) == lane) {  // the owner retires the expert
+#pragma unroll
+      for (int j = 0; j < kTopkMaxPerLane; ++j)
+        if (lane + 64 * j == best_e) v[j] = -INFINITY;
+    }
+    float w = best;
+    if (sigmoid && bias) w = best - bias[best_e];
+    wsum += w;
+    if (lane == kk) my_w = w;
+    if (lane == 0) out_id[(int64_t)tok * topk + kk] = best_e;
+  }
+  if (lane < topk) {
+    if (renormalize) my_w = my_w * (1.0f / wsum);
+    out_w[(int64_t)tok * topk + lane] = my_w;
+  }
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -144,3 +233,20 @@ int xllm_mi355_moe_combine(void* out, const void* gemm2, const float* weights, i
 }
 
 }  // extern "C"
+
+extern "C" int xllm_mi355_moe_fused_topk(const void* gating, int dtype, int64_t n_tokens, int64_t n_experts, int64_t topk,
+                                         int renormalize, const float* correction_bias, int scoring,
+                                         float* topk_weights, int32_t* topk_ids, void* stream) {
+  if (!gating || !topk_weights || !topk_ids || n_tokens < 0 || n_experts <= 0 || topk <= 0) return XM_ERR_INVALID;
+  if (scoring != 0 && scoring != 1) return XM_ERR_INVALID;
+  if (scoring == 0 && correction_bias) return XM_ERR_INVALID;  // the reference's softmax path drops the bias (:47-53)
+  if (n_experts > 64 * kTopkMaxPerLane || topk > 64 || topk > n_experts) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  const dim3 grid((unsigned)((n_tokens + 3) / 4));
+  XM_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((moe_fused_topk_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,
+                       (int)n_tokens, (int)n_experts, (int)topk, renormalize, correction_bias, scoring, topk_weights,
+                       topk_ids);
+  });
+  return hip_check_launch();
+}

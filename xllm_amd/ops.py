@@ -280,7 +280,8 @@ def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, ep
 def static_scaled_fp8_quant(output, input, scale) -> None:
     """cuda::static_scaled_fp8_quant(out, in, scale) (cuda_ops_api.h:184-186, fp8_quant.cu:115-155)."""
     _need_cuda(output, input, scale)
-    check(_lib.lib().xllm_mi355_static_scaled_fp8_quant(_p(output), _p(input.contiguous()), _p(scale), input.numel(),
+    input_c = input.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_static_scaled_fp8_quant(_p(output), _p(input_c), _p(scale), input.numel(),
                                                        _dt(input), _stream()), "static_scaled_fp8_quant")
 
 
@@ -325,7 +326,8 @@ def matmul(a, b, bias=None):
         a2 = a2.contiguous()
     N = b.size(0)
     out = torch.empty(a2.size(0), N, dtype=a.dtype, device=a.device)
-    check(_lib.lib().xllm_mi355_matmul(_p(a2), _p(b.contiguous()), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
+    b_c = b.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_matmul(_p(a2), _p(b_c), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
                                       _stream()), "matmul")
     return out.view(*a.shape[:-1], N)
 
@@ -384,7 +386,8 @@ def mla_decode(q, k_cache, seqlens_k, block_table, head_size_v: int, scale: floa
     o = out if out is not None else torch.empty(B, H, head_size_v, dtype=q.dtype, device=q.device)
     ws = _attn_workspace(q.device, B * H * 32 * (head_size_v + 2) * 4)
     bt = block_table if block_table.is_contiguous() else block_table.contiguous()
-    check(_lib.lib().xllm_mi355_mla_decode(_p(q.contiguous()), _p(k_cache), _p(o), _p(seqlens_k), _p(bt), bt.size(1), B, H,
+    q_c = q.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_mla_decode(_p(q_c), _p(k_cache), _p(o), _p(seqlens_k), _p(bt), bt.size(1), B, H,
                                           D, head_size_v, bs, n_blocks, max_kv_len, scale, _dt(q), _p(ws), ws.numel(),
                                           _stream()), "mla_decode")
     return o
@@ -427,7 +430,8 @@ def moe_compute_index(expert_id, num_experts: int):
     src_dst = torch.empty(T * topk, dtype=torch.int32, device=dev)
     dst_src = torch.empty(T * topk, dtype=torch.int32, device=dev)
     sizes = torch.empty(num_experts, dtype=torch.int32, device=dev)
-    check(_lib.lib().xllm_mi355_moe_compute_index(_p(expert_id.contiguous()), T, topk, num_experts, _p(src_dst),
+    expert_id_c = expert_id.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_moe_compute_index(_p(expert_id_c), T, topk, num_experts, _p(src_dst),
                                                  _p(dst_src), _p(sizes), _stream()), "moe_compute_index")
     return src_dst, dst_src, sizes
 
@@ -437,7 +441,9 @@ def moe_combine_result(gemm2, weights, n_tokens: int, topk: int):
     _need_cuda(gemm2, weights)
     H = gemm2.size(-1)
     out = torch.empty(n_tokens, H, dtype=gemm2.dtype, device=gemm2.device)
-    check(_lib.lib().xllm_mi355_moe_combine(_p(out), _p(gemm2.contiguous()), _p(weights.contiguous()), n_tokens, topk, H,
+    gemm2_c = gemm2.contiguous()  # keep the (possibly new) tensor alive across the call
+    weights_c = weights.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_moe_combine(_p(out), _p(gemm2_c), _p(weights_c), n_tokens, topk, H,
                                            _dt(gemm2), _stream()), "moe_combine_result")
     return out
 
@@ -447,7 +453,9 @@ def group_gemm(input, weight, token_count, output=None):
     _need_cuda(input, weight, token_count)
     E, N, K = weight.shape
     out = output if output is not None else torch.empty(input.size(0), N, dtype=input.dtype, device=input.device)
-    check(_lib.lib().xllm_mi355_group_gemm(_p(input.contiguous()), _p(weight.contiguous()), _p(token_count), _p(out),
+    input_c = input.contiguous()  # keep the (possibly new) tensor alive across the call
+    weight_c = weight.contiguous()  # keep the (possibly new) tensor alive across the call
+    check(_lib.lib().xllm_mi355_group_gemm(_p(input_c), _p(weight_c), _p(token_count), _p(out),
                                           input.size(0), E, N, K, _dt(input), _stream()), "group_gemm")
     return out
 
@@ -546,7 +554,24 @@ def rejection_sample(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, dra
         raise Mi355Error("draft_probs / target_probs / uniform_probs must be [total_drafts, vocab]")
     B = num_draft_tokens.numel()
     out = torch.empty(B + draft_token_ids.numel(), dtype=torch.int32, device=tp.device)
+    draft_token_ids_c = draft_token_ids.contiguous()  # keep the (possibly new) tensor alive across the call
     check(_lib.lib().xllm_mi355_rejection_sample(
-        _p(draft_token_ids.contiguous()), _p(num_draft_tokens), _p(cu_num_draft_tokens), _p(dp), _p(tp),
+        _p(draft_token_ids_c), _p(num_draft_tokens), _p(cu_num_draft_tokens), _p(dp), _p(tp),
         _p(bonus_token_ids), _p(ur), _p(up), B, tp.size(1), _p(out), _stream()), "rejection_sample")
     return out
+
+
+def moe_fused_topk(gating_output, topk: int, renormalize: bool, correction_bias=None, scoring_func: str = "softmax"):
+    """cuda::moe_fused_topk (kernels/cuda/moe/moe_fused_topk.cu:31-61) -> (topk_weights f32, topk_ids int32)"""
+    _need_cuda(gating_output)
+    if scoring_func not in ("softmax", "sigmoid"):
+        raise Mi355Error(f"Unsupported scoring function for moe topk: {scoring_func}")   # reference LOG(FATAL) :55
+    T, E = gating_output.shape
+    g = gating_output.contiguous()
+    w = torch.empty(T, topk, dtype=torch.float32, device=g.device)
+    ids = torch.empty(T, topk, dtype=torch.int32, device=g.device)
+    bias = correction_bias.to(torch.float32).contiguous() if (correction_bias is not None and scoring_func == "sigmoid") else None
+    check(_lib.lib().xllm_mi355_moe_fused_topk(_p(g), _dt(g), T, E, topk, int(renormalize), _p(bias),
+                                               0 if scoring_func == "softmax" else 1, _p(w), _p(ids), _stream()),
+          "moe_fused_topk")
+    return w, ids
