@@ -35,10 +35,10 @@ constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
 
 // Shared epilogue of the 256x256 kernels. On entry every wave has drained its DMAs (vmcnt(0)); the function
 // synchronises the workgroup before it reuses the LDS.
-template <int KIND, bool SPLITK>
-__device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&acc)[4][2], uint8_t* lds, int M, int N,
-                                            int m0, int n0, int wr, int wc, int wave, int lane, int tid,
-                                            const GemmEpi& epi) {
+template <int KIND, bool SPLITK, bool OUT_BF16>
+__device__ __forceinline__ void p8_epilogue_impl(typename MmaTraits<KIND>::acc_t (&acc)[4][2], uint8_t* lds, int M,
+                                                 int N, int m0, int n0, int wr, int wc, int wave, int lane, int tid,
+                                                 const GemmEpi& epi) {
   // ---- epilogue (N % 8 == 0 is checked on the host). Tile acc[mb][nb]: lane & 31 = m within the block, register
   // r = 4*g + e <-> n within the block = 8*g + 4*(lane >> 5) + e: four consecutive n per g -> one 8-byte store.
 #ifdef P8_ABL_NOEPI  /* ablation build: one store per lane so the accumulators stay live */
@@ -161,8 +161,8 @@ __device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&ac
             else v[e] = acc[mb][nb][4 * g + e] + bsv[nb][g][e];
           }
           uint2 pk;
-          pk.x = pack16(v[0], out_bf16) | (pack16(v[1], out_bf16) << 16);
-          pk.y = pack16(v[2], out_bf16) | (pack16(v[3], out_bf16) << 16);
+          pk.x = pack2x16<OUT_BF16>(v[0], v[1]);
+          pk.y = pack2x16<OUT_BF16>(v[2], v[3]);
           *reinterpret_cast<uint2*>(blk + ml * 128 + (((nb * 4 + g) ^ (ml & 7)) << 4) + 8 * half) = pk;
         }
 #pragma unroll
@@ -174,6 +174,15 @@ __device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&ac
       }
     }
   }
+}
+
+template <int KIND, bool SPLITK>
+__device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&acc)[4][2], uint8_t* lds, int M, int N,
+                                            int m0, int n0, int wr, int wc, int wave, int lane, int tid,
+                                            const GemmEpi& epi) {
+  // the output dtype is a launch constant: one uniform branch instead of a select per converted element
+  if (epi.out_bf16) p8_epilogue_impl<KIND, SPLITK, true>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
+  else p8_epilogue_impl<KIND, SPLITK, false>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
 }
 
 template <int KIND, bool SPLITK>

@@ -124,6 +124,20 @@ __device__ __forceinline__ unsigned pack16(float v, bool out_bf16) {
   return out_bf16 ? (bf & 0xffffu) : (unsigned)hb;
 }
 
+// two fp32 -> one packed pair of 16-bit outputs (RNE): v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950
+template <bool OUT_BF16>
+__device__ __forceinline__ unsigned pack2x16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  if constexpr (OUT_BF16) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  } else {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+  }
+}
+
 #define P8_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define P8_WAIT4(F)                                                                                             \
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
