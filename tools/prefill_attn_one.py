@@ -1,0 +1,19 @@
+import math, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from xllm_amd import ops
+NQ, NKV, D, S, nseq = 28, 4, 128, 4096, 2
+T = S * nseq
+qkv = torch.randn(T, (NQ + 2 * NKV) * D, device="cuda").bfloat16()
+q = qkv[:, :NQ * D].unflatten(-1, (NQ, D)); k = qkv[:, NQ * D:(NQ + NKV) * D].unflatten(-1, (NKV, D)); v = qkv[:, (NQ + NKV) * D:].unflatten(-1, (NKV, D))
+cu = torch.tensor([0, S, 2 * S], dtype=torch.int32, device="cuda")
+for _ in range(4):
+    ops.prefill_attention(q, k, v, cu, cu, S, 1.0 / math.sqrt(D), True)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.prefill_attention(q, k, v, cu, cu, S, 1.0 / math.sqrt(D), True)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+fl = 4 * NQ * D * nseq * S * S / 2
+print(f"[prefill attn] {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s")
