@@ -208,31 +208,33 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
           mx = fmaxf(mx, __shfl_xor(mx, 16));
           mx = fmaxf(mx, __shfl_xor(mx, 32));
           const float m_new = fmaxf(m_run[nb], mx);
-          const float alpha = exp2f(m_run[nb] - m_new);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);  // v_exp_f32: results below 2^-126 flush to 0
           m_run[nb] = m_new;
           float psum = 0.0f;
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p = exp2f(s[nb][blk][r] - m_new);
+              const float p = __builtin_amdgcn_exp2f(s[nb][blk][r] - m_new);
               psum += p;
               const elem hi = (elem)p;
               pf[nb][blk * 4 + r] = hi;
               pl[nb][blk * 4 + r] = (elem)(p - (float)hi);
             }
           l_run[nb] = l_run[nb] * alpha + psum;
+          // the running maximum settles after a few tiles; once no lane of the wave raised it, alpha == 1 everywhere
+          // and the DB*4 multiplies are skipped (wave-uniform branch; multiplying by 1.0f is exact, so same bits)
+          if (__any(alpha != 1.0f)) {
 #pragma unroll
-          for (int i = 0; i < DB; ++i) acc_o[nb][i] *= alpha;
+            for (int i = 0; i < DB; ++i) acc_o[nb][i] *= alpha;
+          }
         }
         const char* trb = lv + (4 * g + (p16 >> 2)) * RSV + (p16 & 3) * 8;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
           const x4 lo = TR::tr_read(trb + db * 32);
           const x4 hi = TR::tr_read(trb + 16 * RSV + db * 32);
-          x8 vt;
-          vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
-          vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
+          const x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             acc_o[nb][db] = TR::mfma(vt, pf[nb], acc_o[nb][db]);
