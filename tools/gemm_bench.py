@@ -13,13 +13,20 @@ dev = "cuda"
 shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
 Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
 kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k == "GEMM_DIST")
 for M in Ms:
     for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
         copies = max(2, min(8, int(600e6 // (N * K)) + 1))
         if kind == "int8":
-            ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(copies)]
-            a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+            if os.environ.get("GEMM_DIST", "uniform") == "gauss":
+                # what W8A8 quantisation of Gaussian tensors yields (per-row amax -> 127): sigma ~ 127 / 4, most bits quiet
+                def q(t):
+                    return torch.round(t / (t.abs().amax(-1, keepdim=True) / 127.0)).to(torch.int8)
+                ws = [q(torch.randn(N, K, device=dev)) for _ in range(copies)]
+                a = q(torch.randn(M, K, device=dev))
+            else:
+                ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(copies)]
+                a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
             a_s = torch.rand(M, device=dev)
             w_s = torch.rand(N, device=dev)
             fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)

@@ -35,6 +35,10 @@ constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
 
 // Shared epilogue of the 256x256 kernels. On entry every wave has drained its DMAs (vmcnt(0)); the function
 // synchronises the workgroup before it reuses the LDS.
+#ifdef P8_ABL_TIMING
+__device__ long long p8_dbg[4];
+#endif
+
 template <int KIND, bool SPLITK, bool OUT_BF16>
 __device__ __forceinline__ void p8_epilogue_impl(typename MmaTraits<KIND>::acc_t (&acc)[4][2], uint8_t* lds, int M,
                                                  int N, int m0, int n0, int wr, int wc, int wave, int lane, int tid,
@@ -260,6 +264,12 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
 #ifdef P8_ABL_NOSTAGE  /* ablation build: no DMA inside the K loop (stale LDS is computed on) */
     if (in_loop) return;
 #endif
+#ifdef P8_ABL_NOSTAGE_W  /* ablation builds: drop only the weight / only the activation stream inside the K loop */
+    if (in_loop && !(slot & 1)) return;
+#endif
+#ifdef P8_ABL_NOSTAGE_A
+    if (in_loop && (slot & 1)) return;
+#endif
     const int soff = kwalk(kt) * P8_BK;
     const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
     const int h = slot >> 1;
@@ -366,11 +376,21 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     __builtin_amdgcn_s_barrier();
   };
 
+#ifdef P8_ABL_TIMING  /* ablation build: shader-clock / wall-clock span of the K loop of workgroup 0 */
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
   for (int t = 0; t < nk; t += 2) {
     ktile(std::integral_constant<int, 0>{}, kt_begin + t);
     if (t + 1 >= nk) break;
     ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
   }
+#ifdef P8_ABL_TIMING
+  if (blockIdx.x == 0 && tid == 0) {
+    p8_dbg[0] = clock64() - dbg_c0;
+    p8_dbg[1] = wall_clock64() - dbg_w0;
+    p8_dbg[2] = nk;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
   if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
 #undef P8_MMA
@@ -645,3 +665,9 @@ template int launch_gemm_p8<kF16>(const void*, const void*, int64_t, int64_t, in
                                   hipStream_t);
 
 }  // namespace xm
+
+#ifdef P8_ABL_TIMING
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_p8(long long* out4) {
+  return hipMemcpyFromSymbol(out4, HIP_SYMBOL(xm::p8_dbg), 4 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
