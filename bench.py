@@ -47,6 +47,9 @@ def parse():
                    help="multi-GPU: capture the RCCL collectives INTO one HIP graph (default for N>1 is the piecewise "
                         "replay of xllm_amd.parallel.PiecewiseGraph: kernels between collectives are graphs, the "
                         "collectives stay eager -- a failed capture of a collective cannot be recovered in-process)")
+    p.add_argument("--dual", action="store_true",
+                   help="decode the batch as two micro-batches on two streams (attention of one half under the linear "
+                        "layers of the other; xllm_amd.layers.DualBatchDecoder), TP=1 only")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -230,8 +233,10 @@ def main():
 
     ops.paged_decode_attention_int8 = timed_fused
 
+    dual = layers.DualBatchDecoder(model, md, B) if (a.dual and world == 1 and not a.no_fuse and mode == "int8") else None
+
     def step():
-        hidden = model.forward(tokens, positions, md, kv_caches)
+        hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
         logits = model.logits(hidden)
         return torch.argmax(logits, dim=-1)
 
@@ -330,7 +335,7 @@ def main():
                                    f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
                        "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
-                       "quant_fusion": not a.no_fuse,
+                       "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,
                        "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ split-KV merge when the launch splits)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -186,6 +186,11 @@ XM_API int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const floa
 /* optional scratch for the int8 split-K path of scaled_matmul (>= M*N*4 bytes; the reference operator
  * has no workspace argument, so it is registered once per stream owner; NULL disables split-K). */
 XM_API int xllm_mi355_set_gemm_workspace(void* workspace, size_t bytes);
+/* Per-stream split-K workspace (same invariant: all-zero between calls). GEMMs launched on `stream` use it instead of
+ * the global one, so that two micro-batches running concurrently on two streams (the reference's
+ * enable_multi_stream_parallel / micro_batch_num, framework/config/parallel_config.h:83-85) never share partial sums.
+ * ws == NULL unregisters the stream. At most 8 streams. */
+XM_API int xllm_mi355_set_gemm_workspace_for_stream(void* stream, void* ws, size_t bytes);
 
 /* ---- fp8 (OCP e4m3fn) ------------------------------------------------------------------------
  * kernel::static_scaled_fp8_quant (ops_api.h:160) -> kernels/cuda/fp8_quant.cu:115-155 */

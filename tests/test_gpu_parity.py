@@ -826,3 +826,27 @@ def test_moe_fused_topk(E, topk, scoring, bias, renorm, dtype):
         assert ids[0].tolist() == list(range(topk))      # all-equal scores: lowest indices in order
     assert torch.equal(ids.cpu(), id_ref)
     torch.testing.assert_close(w.cpu(), w_ref, rtol=3e-6, atol=1e-7)
+
+
+def test_dual_micro_batch_decoder_equals_single_batch_step():
+    """two micro-batches on two streams (attention of one half under the linear layers of the other) produce the bits
+    of the single-batch step: per-sequence arithmetic is unchanged"""
+    import bench
+    from xllm_amd import layers
+    from xllm_amd.attention import KVCache
+    args = layers.ModelArgs(1024, 3, 16, 4, 128, 2048, 4096, 1e-6, 1e6, 4096)
+    B, ctx, bs = 256, 300, 128
+    model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=11, n_layers=3)
+    md, n_blocks = bench.build_metadata(B, ctx, bs, torch.device(DEV), seed=2)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    mk = lambda: [KVCache(torch.randn(n_blocks, bs, 4, 128, device=DEV, generator=g).bfloat16(),
+                          torch.randn(n_blocks, bs, 4, 128, device=DEV, generator=g).bfloat16()) for _ in model.layers]
+    caches = mk()
+    tokens = torch.randint(0, args.vocab_size, (B,), device=DEV, generator=g)
+    positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
+    ref = model.forward(tokens, positions, md, caches).clone()
+    dual = layers.DualBatchDecoder(model, md, B)
+    for _ in range(3):   # repeated runs: stream ordering must hold every time
+        out = dual.forward(tokens, positions, caches)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

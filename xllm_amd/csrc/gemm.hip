@@ -904,10 +904,35 @@ extern "C" {
 // ops_api-shaped entry point below has no workspace argument because the reference operator has none.
 static void* g_gemm_ws = nullptr;
 static size_t g_gemm_ws_bytes = 0;
+// per-stream workspaces (xllm_mi355_set_gemm_workspace_for_stream): GEMMs of two micro-batches that run concurrently
+// on two streams must not accumulate split-K partial sums into the same buffer. A handful of slots is enough.
+struct StreamWs { void* stream; void* ws; size_t bytes; };
+static StreamWs g_stream_ws[8] = {};
+static int g_stream_ws_n = 0;
+static void gemm_ws_for(void* stream, void** ws, size_t* bytes) {
+  for (int i = 0; i < g_stream_ws_n; ++i)
+    if (g_stream_ws[i].stream == stream) { *ws = g_stream_ws[i].ws; *bytes = g_stream_ws[i].bytes; return; }
+  *ws = g_gemm_ws;
+  *bytes = g_gemm_ws_bytes;
+}
 XM_API int xllm_mi355_set_gemm_workspace(void* ws, size_t bytes) {
   g_gemm_ws = ws;
   g_gemm_ws_bytes = bytes;
   if (ws && bytes && hipMemset(ws, 0, bytes) != hipSuccess) return XM_ERR_HIP;
+  return XM_OK;
+}
+XM_API int xllm_mi355_set_gemm_workspace_for_stream(void* stream, void* ws, size_t bytes) {
+  if (ws && bytes && hipMemset(ws, 0, bytes) != hipSuccess) return XM_ERR_HIP;
+  for (int i = 0; i < g_stream_ws_n; ++i)
+    if (g_stream_ws[i].stream == stream) {
+      if (!ws) { g_stream_ws[i] = g_stream_ws[--g_stream_ws_n]; return XM_OK; }  // ws == NULL unregisters
+      g_stream_ws[i].ws = ws;
+      g_stream_ws[i].bytes = bytes;
+      return XM_OK;
+    }
+  if (!ws) return XM_OK;
+  if (g_stream_ws_n == 8) return XM_ERR_UNSUPPORTED;
+  g_stream_ws[g_stream_ws_n++] = StreamWs{stream, ws, bytes};
   return XM_OK;
 }
 
@@ -920,7 +945,10 @@ int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_sc
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
-  return launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
+  void* ws;
+  size_t ws_bytes;
+  gemm_ws_for(stream, &ws, &ws_bytes);
+  return launch_gemm<kI8>(a, w, M, N, K, epi, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int xllm_mi355_scaled_matmul_add_rms_norm(const int8_t* a, const int8_t* w, const float* a_scale,
@@ -933,11 +961,14 @@ int xllm_mi355_scaled_matmul_add_rms_norm(const int8_t* a, const int8_t* w, cons
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
   if (M == 0) return XM_OK;
-  if (!g_gemm_ws || g_gemm_ws_bytes < (size_t)M * N * 4) return XM_ERR_WORKSPACE;
+  void* ws;
+  size_t ws_bytes;
+  gemm_ws_for(stream, &ws, &ws_bytes);
+  if (!ws || ws_bytes < (size_t)M * N * 4) return XM_ERR_WORKSPACE;
   GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0, 1};
-  const int rc = launch_gemm<kI8>(a, w, M, N, K, epi, g_gemm_ws, g_gemm_ws_bytes, (hipStream_t)stream);
+  const int rc = launch_gemm<kI8>(a, w, M, N, K, epi, ws, ws_bytes, (hipStream_t)stream);
   if (rc != XM_OK) return rc;
-  return launch_acc_add_rms_norm(out_q ? (void*)out_q : out_norm, out_q_scale, reinterpret_cast<int32_t*>(g_gemm_ws),
+  return launch_acc_add_rms_norm(out_q ? (void*)out_q : out_norm, out_q_scale, reinterpret_cast<int32_t*>(ws),
                                  a_scale, w_scale, bias, residual, norm_weight, eps, M, N, dtype, out_q != nullptr,
                                  (hipStream_t)stream);
 }

@@ -133,6 +133,46 @@ class Qwen2DecoderLayer:
         return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
                                               self.args.rms_norm_eps, lin.bias, quantize=quantize)
 
+    # ---- the decode step cut at the attention kernel (dual micro-batch executor, DualBatchDecoder below) ----------
+    def pre_attention(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin, h_in=None):
+        """input norm (unless the previous layer fused it) + qkv_proj + RoPE + KV write; returns (q, residual)"""
+        if h_in is not None:
+            h = h_in
+        else:
+            h, residual = self._norm(x, residual, self.input_norm_w)
+        qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
+        q = qkv[:, :self.q_size]
+        k = qkv[:, self.q_size:self.q_size + self.kv_size]
+        v = qkv[:, self.q_size + self.kv_size:]
+        ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache, kv_cache.v_cache,
+                                       self.d, True)
+        return q, residual
+
+    def attention_kernel(self, q, md: AttentionMetadata, kv_cache: KVCache):
+        """the HBM-bound kernel alone; returns the int8 operand of o_proj (q8, scale)"""
+        fused = ops.paged_decode_attention_int8(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache, kv_cache.v_cache,
+                                                md.kv_seq_lens, md.block_table, md.max_seq_len, self.attn.scale,
+                                                self.attn.window_left)
+        if fused is not None:
+            return fused
+        attn = ops.paged_attention(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache, kv_cache.v_cache, None,
+                                   md.kv_seq_lens, md.block_table, 1, md.max_seq_len, self.attn.scale, False,
+                                   self.attn.window_left)
+        return ops.scaled_quantize(attn)
+
+    def post_attention(self, o_in, residual, next_norm_w, next_quant):
+        """o_proj (+ post norm) + MLP (+ the next layer's input norm); returns (x, residual, h_next) like forward()"""
+        h = self._fused_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)
+        if h is None:
+            x = self.o_proj.forward(None, pre_quant=o_in)
+            h, residual = self._norm(x, residual, self.post_norm_w)
+        gate_up = self.gate_up_proj.forward(None, pre_quant=h)
+        act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+        h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
+        if h_next is not None:
+            return None, residual, h_next
+        return self.down_proj.forward(None, pre_quant=act_q), residual, None
+
     def forward(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin, h_in=None,
                 next_norm_w=None, next_quant=True):
         """returns (x, residual, h_next): h_next is the NEXT layer's (or the model's final) norm output when this
@@ -227,3 +267,72 @@ class Qwen2Model:
     def logits(self, hidden):
         y = self.lm_head.forward(hidden)
         return parallel.gather(y, self.tp)
+
+
+class DualBatchDecoder:
+    """Decode step of two micro-batches on two HIP streams (the reference's enable_multi_stream_parallel with
+    micro_batch_num = 2, framework/config/parallel_config.h:83-85). The paged-attention kernel of a layer is bound by
+    HBM and leaves the matrix pipes, the LDS and most of the power budget idle; the linear layers are bound by exactly
+    those. So the attention kernels of the two halves are chained back to back (A0, B0, A1, B1, ...) and everything
+    else of a half (o_proj, MLP, next qkv_proj, RoPE + KV write) runs on that half's own stream underneath the other
+    half's attention. Arithmetic per sequence is unchanged (row-wise kernels and GEMM rows are independent, the
+    attention kernel handles sequences independently), so the logits equal the single-batch step bit for bit.
+    W8A8 fused decode path, TP = 1 only."""
+
+    def __init__(self, model: "Qwen2Model", md: AttentionMetadata, batch: int):
+        assert model.tp is None and all(l.fuse for l in model.layers)
+        self.model, self.B = model, batch
+        h = batch // 2
+        self.cut = [(0, h), (h, batch)]
+        self.md = [AttentionMetadata(
+            q_cu_seq_lens=torch.arange(e - b + 1, dtype=torch.int32, device=md.kv_seq_lens.device),
+            kv_cu_seq_lens=None, kv_seq_lens=md.kv_seq_lens[b:e].contiguous(), slot_mapping=md.slot_mapping[b:e].contiguous(),
+            block_table=md.block_table[b:e].contiguous(), max_query_len=1, max_seq_len=md.max_seq_len) for b, e in self.cut]
+        self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        import os
+        self.chain = os.environ.get("XLLM_DUAL_NOCHAIN", "0") != "1"
+        for st, (b, e) in zip(self.streams, self.cut):   # split-K partial sums of the two halves must not mix
+            ops.set_gemm_workspace_for_stream(st, 32 << 20)
+
+    def forward(self, tokens, positions, kv_caches):
+        m = self.model
+        main = torch.cuda.current_stream()
+        x_full = torch.nn.functional.embedding(tokens, m.embed)
+        out = torch.empty_like(x_full)
+        n = len(m.layers)
+        state = []
+        for i, ((b, e), st) in enumerate(zip(self.cut, self.streams)):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                q, res = m.layers[0].pre_attention(x_full[b:e], None, positions[b:e], self.md[i], kv_caches[0], m.cos_sin)
+            state.append([q, res])
+        prev_attn_done = None
+        for li, layer in enumerate(m.layers):
+            last = li + 1 == n
+            nxt = m.norm_w if last else m.layers[li + 1].input_norm_w
+            for i, ((b, e), st) in enumerate(zip(self.cut, self.streams)):
+                with torch.cuda.stream(st):
+                    if prev_attn_done is not None and self.chain:
+                        # attention kernels of the two halves never overlap. The dependency is routed through the
+                        # origin stream: ROCm 7.2 segfaults in hipStreamEndCapture when a forked stream waits on an
+                        # event recorded by another forked stream.
+                        main.wait_event(prev_attn_done)
+                        hub = torch.cuda.Event()
+                        hub.record(main)
+                        st.wait_event(hub)
+                    o_in = layer.attention_kernel(state[i][0], self.md[i], kv_caches[li])
+                    prev_attn_done = torch.cuda.Event()
+                    prev_attn_done.record(st)
+                    x, res, h_next = layer.post_attention(o_in, state[i][1], nxt, not last)
+                    if last:
+                        if h_next is None:   # down_proj was not fused with the final norm
+                            ops.fused_add_rms_norm(x, res, m.norm_w, m.args.rms_norm_eps)
+                            h_next = x
+                        out[b:e].copy_(h_next)
+                    else:
+                        q, res = m.layers[li + 1].pre_attention(x, res, positions[b:e], self.md[i], kv_caches[li + 1],
+                                                               m.cos_sin, h_in=h_next)
+                        state[i] = [q, res]
+        for st in self.streams:
+            main.wait_stream(st)
+        return out

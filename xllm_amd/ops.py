@@ -225,6 +225,17 @@ def _ensure_gemm_workspace(device, nbytes):
         check(_lib.lib().xllm_mi355_set_gemm_workspace(ws.data_ptr(), ws.numel()), "set_gemm_workspace")
 
 
+_stream_ws = {}
+
+
+def set_gemm_workspace_for_stream(stream: "torch.cuda.Stream", nbytes: int) -> None:
+    """register a private split-K workspace for GEMMs launched on `stream` (micro-batches on concurrent streams)"""
+    ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=stream.device)
+    _stream_ws[stream.cuda_stream] = ws
+    check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, ws.data_ptr(), ws.numel()),
+          "set_gemm_workspace_for_stream")
+
+
 def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, acc_out=None,
                   quant_bit_size: int = 8, a_quant_bit_size: int = 8):
     """dcu::scaled_matmul (dcu_ops_api.h, scaled_matmul.cpp:103-300): a [M,K] int8, b [N,K] int8,
