@@ -1,0 +1,27 @@
+"""The opt-in GEMM kernels (env-selected experiments kept in the library) stay parity-green: the int8 / 16-bit GEMM
+parity tests are re-run in subprocesses with each selector (the selectors are read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELECT = "scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmul_16bit or gemm_add_norm"
+
+
+@pytest.mark.parametrize("env", [
+    {"XLLM_MI355_P8": "1"},                                  # 8-phase kernel forced on every legal shape (+ split-K)
+    {"XLLM_MI355_P8": "1", "XLLM_MI355_P8_RING": "1"},       # role-split DMA + 3-deep weight ring variant
+    {"XLLM_MI355_P8N": "1"},                                 # narrow-tile decode kernel, 64 columns
+    {"XLLM_MI355_P8N": "1", "XLLM_MI355_P8N_NB": "4"},       # narrow-tile decode kernel, 128 columns
+    {"XLLM_MI355_P8": "0", "XLLM_MI355_SKINNY_DISABLE": "1"},  # 128x128 kernel only
+], ids=["p8_forced", "p8_ring", "p8n_64", "p8n_128", "general_only"])
+def test_gemm_parity_under_kernel_selector(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-k", SELECT, "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
