@@ -19,9 +19,13 @@ d, bs = 128, 128
 for name, B, nq, nkv, S in cases:
     pages = S // bs
     nb = B * pages + 7
-    caches = [(torch.randn(nb, bs, nkv, d, device=dev).bfloat16(), torch.randn(nb, bs, nkv, d, device=dev).bfloat16())
-              for _ in range(3)]
-    table = torch.randperm(nb, device=dev)[: B * pages].to(torch.int32).view(B, pages)
+    mk = (lambda: torch.zeros(nb, bs, nkv, d, device=dev, dtype=torch.bfloat16)) if os.environ.get("ATTN_KV") == "zero" \
+        else (lambda: torch.randn(nb, bs, nkv, d, device=dev).bfloat16())
+    caches = [(mk(), mk()) for _ in range(3)]
+    if os.environ.get("ATTN_PAGES") == "linear":   # pages in address order: is the random page placement a cost?
+        table = torch.arange(B * pages, device=dev, dtype=torch.int32).view(B, pages)
+    else:
+        table = torch.randperm(nb, device=dev)[: B * pages].to(torch.int32).view(B, pages)
     kv_lens = torch.full((B,), S, dtype=torch.int32, device=dev)
     q = torch.randn(B, nq, d, device=dev).bfloat16()
     fn = lambda i: ops.paged_attention(q, caches[i % 3][0], caches[i % 3][1], None, kv_lens, table, 1, S, d ** -0.5)

@@ -522,220 +522,6 @@ int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// "W-direct" kernel: 256 x 256 block tile, 8 waves as 2 (m) x 4 (n), each wave 128 rows x 64 columns.
-// Round-1 ablations of the skinny kernel (profiles/r01_gemm_ablation.txt) showed that with BOTH the global
-// loads and the MFMAs removed it still took 60-85 % of its time: the LDS staging itself (52 KiB written +
-// 192 KiB read + two barriers per K step) was the bound. Here
-//   * only the A operand (activations, L2 resident) goes through LDS: 32 KiB written per K step, three
-//     buffers, ONE barrier per K step;
-//   * the weight rows of a wave stream HBM -> VGPR directly in MFMA B-fragment layout (lane = row, 16
-//     contiguous K bytes), two register stages, issued right after the MFMAs that consumed the old stage:
-//     no LDS traffic, no barrier dependency for the HBM stream;
-//   * a wave computes 4 x 2 MFMA tiles per 32-byte K slice from 4 LDS fragment reads (0.5 LDS reads per
-//     MFMA instead of 1.2), accumulators in AGPRs.
-// grid.x = n tiles (256 columns), grid.y = m tiles (256 rows), grid.z = int8 split-K slices.
-// ------------------------------------------------------------------------------------------------
-constexpr int WD_BM = 256, WD_BN = 256, WD_THREADS = 512, WD_NBUF = 3;
-
-template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(WD_THREADS, 2) void gemm_wdirect_kernel(const uint8_t* __restrict__ A,
-                                                                    const uint8_t* __restrict__ W, int M, int N,
-                                                                    int64_t Kb, int ksteps_per_split, GemmEpi epi) {
-  using MT = MmaTraits<KIND>;
-  using acc_t = typename MT::acc_t;
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int A_BYTES = WD_BM * BKB;                 // 32 KiB per K step
-  constexpr int NLA = A_BYTES / 16 / WD_THREADS;        // 4 chunks per thread
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WD_NBUF][A_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = wave >> 1;
-  const int n0 = blockIdx.x * WD_BN, m0 = blockIdx.y * WD_BM;
-  const int total_ksteps = (int)(Kb / BKB);
-  const int ks_begin = blockIdx.z * ksteps_per_split;
-  int ks_end = ks_begin + ksteps_per_split;
-  ks_end = ks_end > total_ksteps ? total_ksteps : ks_end;
-  const int nsteps = ks_end - ks_begin;
-  if (nsteps <= 0) return;
-
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
-  int a_off[NLA], lds_off_a[NLA];
-#pragma unroll
-  for (int i = 0; i < NLA; ++i) {
-    const int c = tid + i * WD_THREADS, row = c >> 3, col = c & 7;
-    int ar = m0 + row; ar = ar < M ? ar : M - 1;
-    a_off[i] = (int)((int64_t)ar * Kb + col * 16);
-    lds_off_a[i] = row * BKB + ((col ^ ((row >> 1) & 7)) << 4);
-  }
-  int w_off[2];  // this lane's two weight rows (one per 32-column tile), + its 16-byte half of a 32-byte K slice
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int wr = n0 + wn * 64 + j * 32 + (lane & 31);
-    wr = wr < N ? wr : N - 1;
-    w_off[j] = (int)((int64_t)wr * Kb + (lane >> 5) * 16);
-  }
-  // LDS fragment offsets of the 4 m-tiles of this wave for the 4 K slices of a step (swizzled, precomputed)
-  int fa_off[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) fa_off[t] = (wm * 128 + t * 32 + (lane & 31)) * BKB;
-  const int fa_sw = ((lane & 31) >> 1) & 7;  // (row >> 1) & 7 with row = ...*32 + (lane & 31)
-
-  u32x4 a0[NLA], a1[NLA];     // A register stages (ping-pong by step parity)
-  u32x4 w0[8], w1[8];          // W register stages: [j * 4 + kk]
-  acc_t acc[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[t][j] = MT::zero();
-
-#define XM_WD_LOAD_A(STEP, AR)                                                                                  \
-  {                                                                                                             \
-    int ks_ = ks_begin + (STEP);                                                                                \
-    ks_ = ks_ < ks_end ? ks_ : ks_end - 1;                                                                      \
-    const int kb0_ = ks_ * BKB;                                                                                 \
-    static_for<NLA>([&](auto I_) { AR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_off[I_], kb0_, 0); }); \
-  }
-#define XM_WD_LOAD_W(STEP, WR)                                                                                  \
-  {                                                                                                             \
-    int ks_ = ks_begin + (STEP);                                                                                \
-    ks_ = ks_ < ks_end ? ks_ : ks_end - 1;                                                                      \
-    const int kb0_ = ks_ * BKB;                                                                                 \
-    static_for<8>([&](auto I_) {                                                                                \
-      WR[I_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_off[I_ / 4], kb0_ + (I_ % 4) * 32, 0);          \
-    });                                                                                                         \
-  }
-#define XM_WD_WRITE_A(BUF, AR) \
-  static_for<NLA>([&](auto I_) { *reinterpret_cast<u32x4*>(&lds[BUF][lds_off_a[I_]]) = AR[I_]; });
-#define XM_WD_COMPUTE(BUF, WR)                                                                                  \
-  {                                                                                                             \
-    const uint8_t* la_ = lds[BUF];                                                                              \
-    static_for<4>([&](auto KK_) {                                                                               \
-      const int chunk_ = ((KK_ * 2 + (lane >> 5)) ^ fa_sw) << 4;                                                \
-      uint4 fa_[4];                                                                                             \
-      static_for<4>([&](auto T_) { fa_[T_] = *reinterpret_cast<const uint4*>(la_ + fa_off[T_] + chunk_); });    \
-      static_for<2>([&](auto J_) {                                                                              \
-        uint4 fw_;                                                                                              \
-        __builtin_memcpy(&fw_, &WR[J_ * 4 + KK_], 16);                                                          \
-        static_for<4>([&](auto T_) { acc[T_][J_] = MT::mma(fa_[T_], fw_, acc[T_][J_]); });                      \
-      });                                                                                                       \
-    });                                                                                                         \
-  }
-
-  // prologue: A(0) -> LDS buf 0, A(1) in a1, W(0) in w0, W(1) in w1
-  XM_WD_LOAD_A(0, a0)
-  XM_WD_LOAD_W(0, w0)
-  XM_WD_LOAD_A(1, a1)
-  XM_WD_LOAD_W(1, w1)
-  XM_WD_WRITE_A(0, a0)
-  __syncthreads();
-  // step i (parity p): refill A regs p with A(i+2); compute stage i (LDS buf i%3, W regs p); refill W regs p
-  // with W(i+2); publish A(i+1) (regs 1-p) into LDS buf (i+1)%3; one barrier.
-  int i = 0, buf = 0;
-  while (true) {
-    {
-      XM_WD_LOAD_A(i + 2, a0)
-      XM_WD_COMPUTE(buf, w0)
-      XM_WD_LOAD_W(i + 2, w0)
-      const int nb = buf == WD_NBUF - 1 ? 0 : buf + 1;
-      if (i + 1 < nsteps) XM_WD_WRITE_A(nb, a1)
-      __syncthreads();
-      buf = nb;
-      if (++i >= nsteps) break;
-    }
-    {
-      XM_WD_LOAD_A(i + 2, a1)
-      XM_WD_COMPUTE(buf, w1)
-      XM_WD_LOAD_W(i + 2, w1)
-      const int nb = buf == WD_NBUF - 1 ? 0 : buf + 1;
-      if (i + 1 < nsteps) XM_WD_WRITE_A(nb, a0)
-      __syncthreads();
-      buf = nb;
-      if (++i >= nsteps) break;
-    }
-  }
-#undef XM_WD_LOAD_A
-#undef XM_WD_LOAD_W
-#undef XM_WD_WRITE_A
-#undef XM_WD_COMPUTE
-
-  // epilogue: C tile layout col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (n >= N) continue;
-    float ws = 1.0f, bs = 0.0f;
-    if constexpr (!SPLITK) {
-      if constexpr (KIND == kI8) ws = epi.w_scale[n];
-      if constexpr (KIND == kFP8) ws = epi.w_scale[epi.w_scale_n > 1 ? n : 0];
-      if (epi.bias) bs = load16(epi.bias, n, epi.out_bf16);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 128 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= M) continue;
-        const int64_t idx = (int64_t)m * N + n;
-        if constexpr (KIND == kI8) {
-          const int a = acc[t][j][r];
-          if constexpr (SPLITK) {
-            atomicAdd(epi.acc_out + idx, a);
-          } else {
-            if (epi.acc_out) epi.acc_out[idx] = a;
-            if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
-          }
-        } else if constexpr (KIND == kFP8) {
-          const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
-          store16(epi.out, idx, as * (ws * acc[t][j][r]) + bs, epi.out_bf16);
-        } else {
-          store16(epi.out, idx, acc[t][j][r] + bs, epi.out_bf16);
-        }
-      }
-  }
-}
-
-static int g_wd_enable = -2, g_wd_splits = -2;
-
-template <int KIND>
-int launch_wdirect(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
-                   size_t ws_bytes, hipStream_t s) {
-  const int ksteps = (int)(Kb / BKB);
-  const int64_t n_tiles = (N + WD_BN - 1) / WD_BN, m_tiles = (M + WD_BM - 1) / WD_BM;
-  int splits = 1;
-  const bool can_split = KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
-  if (can_split) {
-    splits = (int)(256 / (n_tiles * m_tiles));
-    const int by_k = ksteps / 8 > 0 ? ksteps / 8 : 1;
-    splits = splits > by_k ? by_k : splits;
-    splits = splits < 1 ? 1 : (splits > 32 ? 32 : splits);
-    if (g_wd_splits > 0) splits = g_wd_splits;
-  }
-  int per = (ksteps + splits - 1) / splits;
-  splits = (ksteps + per - 1) / per;
-  const dim3 grid((unsigned)n_tiles, (unsigned)m_tiles, (unsigned)splits);
-  if (splits > 1) {
-    if constexpr (KIND == kI8) {
-      GemmEpi e2 = epi;
-      e2.acc_out = reinterpret_cast<int32_t*>(workspace);
-      hipLaunchKernelGGL((gemm_wdirect_kernel<KIND, true>), grid, dim3(WD_THREADS), 0, s, (const uint8_t*)A,
-                         (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
-      int64_t blocks = (M * N + 255) / 256;
-      blocks = blocks > 1024 ? 1024 : blocks;
-      hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                         reinterpret_cast<int32_t*>(workspace), M, N, epi);
-    }
-  } else {
-    hipLaunchKernelGGL((gemm_wdirect_kernel<KIND, false>), grid, dim3(WD_THREADS), 0, s, (const uint8_t*)A,
-                       (const uint8_t*)W, (int)M, (int)N, Kb, per, epi);
-  }
-  return hip_check_launch();
-}
-
 template <int KIND>
 int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                 size_t ws_bytes, hipStream_t s) {
@@ -753,12 +539,6 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   // decode-shaped problems take the skinny kernel (32-bit buffer offsets: operands < 2 GiB); for the 16-bit / fp8
   // kinds only while the general kernel's 128x128 grid would under-fill the chip (measured at M=256: lm_head
   // 436 vs 553 us, bf16 gate_up 119 vs 146 us in favour of the general kernel)
-  if (g_wd_enable == -2) {
-    const char* e = getenv("XLLM_MI355_WDIRECT");
-    g_wd_enable = e ? atoi(e) : 0;
-    e = getenv("XLLM_MI355_WDIRECT_SPLITS");
-    g_wd_splits = e ? atoi(e) : -1;
-  }
   // 256x256 8-phase kernel (gemm_p8.hip): XLLM_MI355_P8 = 0 off, 1 forced wherever it is legal, unset = the
   // planner below (round-1 sweep, profiles/r01_gemm_p8.txt): it wins whenever its grid has enough tiles to fill the
   // chip without split-K; small grids stay on the skinny / 128x128 split-K kernels.
@@ -840,9 +620,6 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
       return launch_gemm_p8n<KIND>(A, W, M, N, Kb, epi, nb, 1, s);
     }
   }
-  if (g_wd_enable && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts &&
-      (g_wd_enable == 2 || N >= 8192 || Kb >= 8192))
-    return launch_wdirect<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
   const bool skinny_pays = KIND == kI8 || ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 256;
   if (M <= 512 && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && skinny_pays && !g_sk_disable)
     return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
