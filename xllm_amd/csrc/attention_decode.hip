@@ -180,6 +180,23 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
   };
 
   auto compute_tile = [&](int tile, const x8 (&kr)[2][KK], const u32x4 (&vr)[NV]) {
+#ifdef XM_ABL_ATTN_NOCOMPUTE  /* ablation build: consume the loaded registers, no LDS / MFMA / softmax work */
+    {
+      unsigned fold = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) fold ^= vr[i].x ^ vr[i].y ^ vr[i].z ^ vr[i].w;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          u32x4 t;
+          __builtin_memcpy(&t, &kr[blk][kk], 16);
+          fold ^= t.x ^ t.y ^ t.z ^ t.w;
+        }
+      l_run += (fold == 0x12345678u) ? 1.0f : 0.0f;
+      return;
+    }
+#endif
     const int t0 = tile * kTile;
     const bool partial = (t0 + kTile > kv_len) || (t0 < t_lo);
 
