@@ -59,9 +59,13 @@ class QuantLinear:
     def __init__(self, n: int, k: int, bias: bool, mode: str, dtype, device, gen, row_parallel_pg=None):
         self.mode, self.dtype, self.pg = mode, dtype, row_parallel_pg
         if mode == "int8":
-            self.weight = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device, generator=gen)
-            # w_scale = u*0.02+0.01 scaled so outputs stay O(1) (linear_w8a8_dynamic_tests.cpp:73-78 pattern)
-            self.w_scale = (torch.rand(n, device=device, generator=gen) * 0.02 + 0.01) / (73.0 * math.sqrt(k)) * 8
+            # random-init weights of the architecture (N(0, initializer_range = 0.02), models/llm/qwen2.h) put through
+            # the symmetric per-output-channel int8 quantisation a W8A8 checkpoint carries: w_q = round(w / s),
+            # s = amax_row / 127. (A uniform draw over [-127, 127] is not what any quantised checkpoint looks like.)
+            w = torch.empty(n, k, device=device, dtype=torch.float32).normal_(0.0, 0.02, generator=gen)
+            self.w_scale = (w.abs().amax(dim=1) / 127.0).clamp_min(1e-12)
+            self.weight = torch.round(w / self.w_scale[:, None]).clamp_(-127, 127).to(torch.int8)
+            del w
         elif mode == "fp8":
             self.weight = (torch.randn(n, k, device=device, generator=gen)).to(torch.float8_e4m3fn)
             self.w_scale = torch.full((1,), 1.0 / math.sqrt(k), device=device)
