@@ -12,12 +12,13 @@ SELECT = "scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmu
 
 
 @pytest.mark.parametrize("env", [
-    {"XLLM_MI355_P8": "1"},                                  # 8-phase kernel forced on every legal shape (+ split-K)
+    {"XLLM_MI355_P8": "1"},                                  # 8-phase kernels forced on every legal shape (+ split-K)
+    {"XLLM_MI355_P8": "1", "XLLM_MI355_P8_MFMA32": "1"},     # int8 on the 32x32x32 8-phase kernel instead of 16x16x64
     {"XLLM_MI355_P8": "1", "XLLM_MI355_P8_RING": "1"},       # role-split DMA + 3-deep weight ring variant
     {"XLLM_MI355_P8N": "1"},                                 # narrow-tile decode kernel, 64 columns
     {"XLLM_MI355_P8N": "1", "XLLM_MI355_P8N_NB": "4"},       # narrow-tile decode kernel, 128 columns
     {"XLLM_MI355_P8": "0", "XLLM_MI355_SKINNY_DISABLE": "1"},  # 128x128 kernel only
-], ids=["p8_forced", "p8_ring", "p8n_64", "p8n_128", "general_only"])
+], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

@@ -614,6 +614,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8r_kernel(const uint8_t* 
   p8_epilogue<KIND, SPLITK>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
 }
 
+int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
+                    int per, int splits, dim3 grid, hipStream_t s);  // gemm_p8i.hip
+
 template <int KIND>
 int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                    size_t ws_bytes, int splits, hipStream_t s) {
@@ -628,6 +631,19 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
   const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  if constexpr (KIND == kI8) {
+    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless XLLM_MI355_P8_MFMA32=1 asks for the 32x32x32 kernel
+    static int mfma32 = -2;
+    if (mfma32 == -2) {
+      const char* e = getenv("XLLM_MI355_P8_MFMA32");
+      mfma32 = e ? atoi(e) : 0;
+    }
+    const char* r = getenv("XLLM_MI355_P8_RING");
+    if (!mfma32 && !(r && atoi(r))) {
+      if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
+      return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
+    }
+  }
   static int ring = -2;  // XLLM_MI355_P8_RING: 1 = role-split kernel with the 3-deep weight ring, 0 = first version
   if (ring == -2) {
     const char* e = getenv("XLLM_MI355_P8_RING");

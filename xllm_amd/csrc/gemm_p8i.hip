@@ -1,0 +1,323 @@
+// gemm_p8i.hip -- the int8 specialisation of the 256x256 8-phase kernel (gemm_p8.hip) on v_mfma_i32_16x16x64_i8.
+//
+// Why a second MFMA shape: the 8-phase int8 kernel issues an MFMA in 94.7 % of the ideal slots, but the shader clock
+// it is granted under that load is only 1.05-1.16 GHz (profiles/r01_gemm_p8_timing.txt): it is power-bound. Per MAC
+// the 16x16x64 shape moves 20 % fewer accumulator registers through the register file than 32x32x32 (C/D = 4 + 4
+// registers per 16384 MACs instead of 16 + 16 per 32768) at the same operand traffic; with the same MAC count the
+// clock rises to 1.25 GHz at M = 8192 / 1.65 GHz at M = 256 and the wall time per K step drops by 10-12 % even though
+// the shape needs 17 instead of 16 cycles per instruction (measured with a mock before this file was written).
+//
+// Everything but the fragment geometry is gemm_p8_kernel's: half-tile LDS-DMA staging, counted vmcnt(6), inline-asm
+// ds_read_b128, two wave groups one barrier apart, four phases per K tile (hazard rules: header of gemm_p8.hip).
+//   fragment: lane l <-> row (l & 15), 16 K-bytes at chunk 4*kb + (l >> 4) of the 128-B row (kb = 64-byte K half);
+//   a 64 (m) x 32 (n) quadrant = 4 x 2 tiles of 16 x 16, 2 K halves: 16 MFMAs per phase, 8 + 4 fragment reads;
+//   D layout with the W fragment as the row operand: lane & 15 = m, register r <-> n = 4*(lane >> 4) + r.
+#include <stdlib.h>
+
+#include "gemm_types.h"
+
+namespace xm {
+
+constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
+constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
+
+// epilogue of the 16x16 accumulator layout: acc[mb][nb] (mb = 16-row block 0..7, nb = 16-column block 0..3)
+template <bool SPLITK, bool OUT_BF16>
+__device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds, int M, int N, int m0, int n0, int wr,
+                                             int wc, int wave, int lane, const GemmEpi& epi) {
+  const int g4 = lane >> 4, ml = lane & 15;
+  __builtin_amdgcn_s_barrier();  // every wave has drained its DMAs and finished its fragment reads
+  if constexpr (SPLITK) {
+    // [32 rows][64 cols] int32 per pair of m blocks, 16-B units swizzled by row & 15; one atomic instruction adds a
+    // whole 256-B row segment (lane = column)
+    uint8_t* const tbuf = lds + wave * 8192;
+    const int n_at = n0 + wc * 64 + lane;
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int row = h * 16 + ml;
+          *reinterpret_cast<i32x4_t*>(tbuf + row * 256 + (((nb * 4 + g4) ^ (row & 15)) << 4)) = acc[mp * 2 + h][nb];
+        }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const int v = *reinterpret_cast<const int*>(tbuf + r * 256 + ((((lane >> 2) ^ (r & 15)) << 4) | ((lane & 3) << 2)));
+        const int mr = m0 + wr * 128 + mp * 32 + r;
+        if (mr < M && n_at < N) atomicAdd(epi.acc_out + (int64_t)mr * N + n_at, v);
+      }
+    }
+  } else {
+    const bool has_bias = epi.bias != nullptr;
+    const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+    float wsv[4][4], bsv[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      int n = n0 + wc * 64 + nb * 16 + 4 * g4;
+      n = n + 3 < N ? n : N - 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wsv[nb][e] = 1.0f; bsv[nb][e] = 0.0f; }
+      if (epi.out) {
+        const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+        wsv[nb][0] = w4.x; wsv[nb][1] = w4.y; wsv[nb][2] = w4.z; wsv[nb][3] = w4.w;
+      }
+      if (has_bias) {
+        const uint2 bw = *reinterpret_cast<const uint2*>(bias16 + n);
+        const uint16_t b16[4] = {(uint16_t)(bw.x & 0xffff), (uint16_t)(bw.x >> 16), (uint16_t)(bw.y & 0xffff),
+                                 (uint16_t)(bw.y >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f16_t hv;
+          __builtin_memcpy(&hv, &b16[e], 2);
+          bsv[nb][e] = OUT_BF16 ? bf16_bits_to_f32(b16[e]) : (float)hv;
+        }
+      }
+    }
+    uint8_t* const tbuf = lds + wave * 16384;
+    const int rrow = lane >> 3;
+    const int rcol = ((lane & 7) ^ (rrow & 7)) << 4;
+    const int n_st = n0 + wc * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp) {  // pairs of 16-row blocks = 32 rows = one 4-KiB transposition block
+      uint8_t* const blk = tbuf + mp * 4096;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int mb = mp * 2 + h, row = h * 16 + ml;
+        const int m = m0 + wr * 128 + mb * 16 + ml;
+        const int mc = m < M ? m : M - 1;
+        const float as = epi.a_scale ? epi.a_scale[mc] : 1.0f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          if (epi.acc_out) {  // raw accumulators requested (tests)
+            const int n = n0 + wc * 64 + nb * 16 + 4 * g4;
+            if (m < M && n < N) *reinterpret_cast<i32x4_t*>(epi.acc_out + (int64_t)m * N + n) = acc[mb][nb];
+          }
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][nb][e] * as * wsv[nb][e] + bsv[nb][e];
+          uint2 pk;
+          pk.x = pack2x16<OUT_BF16>(v[0], v[1]);
+          pk.y = pack2x16<OUT_BF16>(v[2], v[3]);
+          // n within the wave's 64 columns = nb*16 + 4*g4 (+e): 16-B unit nb*2 + (g4 >> 1), 8-B half g4 & 1
+          *reinterpret_cast<uint2*>(blk + row * 128 + (((nb * 2 + (g4 >> 1)) ^ (row & 7)) << 4) + 8 * (g4 & 1)) = pk;
+        }
+      }
+      if (!epi.out) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
+        const int mr = m0 + wr * 128 + mp * 32 + i * 8 + rrow;
+        if (mr < M && n_st < N)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st) = row16;
+      }
+    }
+  }
+}
+
+template <bool SPLITK>
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A,
+                                                                const uint8_t* __restrict__ W, int M, int N,
+                                                                int64_t Kb, int m_tiles, int n_tiles,
+                                                                int ktiles_per_split, GemmEpi epi) {
+  // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: wr is the phase group
+
+  // XCD-aware rasterisation: block b runs on XCD b%8; every XCD walks its own super-blocks of 32 tiles
+  // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
+  // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
+  int mt, nt;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int sb = j >> 5, within = j & 31;
+    const int S = sb * 8 + xcd;
+    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
+    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
+    const int SM = S % n_sb_m, SN = S / n_sb_m;
+    mt = (SM << lm) + (within & ((1 << lm) - 1));
+    nt = (SN << (5 - lm)) + (within >> lm);
+    if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
+  }
+  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
+  const int total_kt = (int)(Kb / P8_BK);
+  const int kt_begin = blockIdx.z * ktiles_per_split;
+  int kt_end = kt_begin + ktiles_per_split;
+  kt_end = kt_end > total_kt ? total_kt : kt_end;
+  const int nk = kt_end - kt_begin;
+  if (nk <= 0) return;
+
+  // K walk: every workgroup walks K in the same order (steps past the end re-load the last tile: every DMA is
+  // unconditional, so the vmcnt arithmetic is static). Starting each workgroup at a different K tile (to spread the
+  // readers of a shared operand panel over more L2 channels) was measured and is WORSE: 1033 -> 1272 us on
+  // gate_up at M = 8192 -- the workgroups of a super-block re-use each other's L2 lines only while they move in step.
+  auto kwalk = [&](int kt) { return kt < kt_end ? kt : kt_end - 1; };
+  // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
+  // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
+  // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
+  int voff_a[2][2], voff_w[2][2];  // [i][half]
+  {
+    const int srow = wave * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
+        int ar = m0 + i * 128 + h * 64 + srow;
+        ar = ar < M ? ar : M - 1;
+        voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
+        // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
+        int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);
+        wrow = wrow < N ? wrow : N - 1;
+        voff_w[i][h] = (int)((int64_t)wrow * Kb) + scol;
+      }
+  }
+  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  // stage one half-tile: (buffer, slot) <- K tile kt (clamped: tail prefetches re-load the last tile, every load
+  // is unconditional so the vmcnt arithmetic is static)
+  auto stage = [&](int buf, int slot, int kt, bool in_loop = true) {
+#ifdef P8_ABL_NOSTAGE  /* ablation build: no DMA inside the K loop (stale LDS is computed on) */
+    if (in_loop) return;
+#endif
+    const int soff = kwalk(kt) * P8_BK;
+    const lds_ptr_t dst = lds3 + (buf * 4 + slot) * P8_SLOT + wave * 1024;
+    const int h = slot >> 1;
+    if (slot & 1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, voff_a[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst + 8192, 16, voff_a[1][h], soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, voff_w[0][h], soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + 8192, 16, voff_w[1][h], soff, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses: lane l reads row (l & 15) of a 16-row block, logical chunk 4*kb + (l >> 4),
+  // physical chunk = logical ^ ((row >> 1) & 7) (16-row block offsets do not change the swizzle term)
+  unsigned rd_w[2][2], rd_a[2][2];  // [buffer][kb]
+  {
+    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
+    const int f = (lane & 15) >> 1;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const unsigned o = base + (lane & 15) * P8_BK + (((4 * kb + (lane >> 4)) ^ f) << 4);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        rd_w[b][kb] = o + b * 4 * P8_SLOT + wc * 32 * P8_BK;
+        rd_a[b][kb] = o + b * 4 * P8_SLOT + wr * 64 * P8_BK;
+      }
+    }
+  }
+
+  i32x4_t acc[8][4];  // [16-row m block][16-column n block]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+
+  // ---- prologue: K tile 0 complete + three half-tiles of K tile 1 in flight
+  stage(0, 0, kt_begin, false);
+  stage(0, 1, kt_begin, false);
+  stage(0, 2, kt_begin, false);
+  stage(0, 3, kt_begin, false);
+  stage(1, 0, kt_begin + 1, false);
+  stage(1, 1, kt_begin + 1, false);
+  stage(1, 2, kt_begin + 1, false);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  u32x4 fw0[4], fw1[4], fa[8];  // W fragments [nb*2 + kb] of nh = 0 / 1; A fragments [mb*2 + kb] of the current m half
+
+  // quadrant (MH, NH): m blocks MH*4 .. +3, n blocks NH*2 .. +1; 16 MFMAs, every accumulator touched twice 8 apart
+#define P8I_MMA(MH, NH, FW)                                                                          \
+  __builtin_amdgcn_s_setprio(1);                                                                     \
+  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                   \
+  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                   \
+  _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) {                                                 \
+    const i32x4_t av = __builtin_bit_cast(i32x4_t, FW[nb * 2 + kb]);                                 \
+    const i32x4_t bv = __builtin_bit_cast(i32x4_t, fa[mb * 2 + kb]);                                 \
+    acc[(MH) * 4 + mb][(NH) * 2 + nb] =                                                              \
+        __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, acc[(MH) * 4 + mb][(NH) * 2 + nb], 0, 0, 0);   \
+  }                                                                                                  \
+  __builtin_amdgcn_s_setprio(0);                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+#define P8I_RD_W(FW, BUF, SLOT)                                                                      \
+  P8_DSR(FW[0], rd_w[BUF][0], (SLOT)); P8_DSR(FW[1], rd_w[BUF][1], (SLOT));                          \
+  P8_DSR(FW[2], rd_w[BUF][0], (SLOT) + 16 * P8_BK); P8_DSR(FW[3], rd_w[BUF][1], (SLOT) + 16 * P8_BK);
+#define P8I_RD_A(BUF, SLOT)                                                                          \
+  P8_DSR(fa[0], rd_a[BUF][0], (SLOT)); P8_DSR(fa[1], rd_a[BUF][1], (SLOT));                          \
+  P8_DSR(fa[2], rd_a[BUF][0], (SLOT) + 16 * P8_BK); P8_DSR(fa[3], rd_a[BUF][1], (SLOT) + 16 * P8_BK); \
+  P8_DSR(fa[4], rd_a[BUF][0], (SLOT) + 32 * P8_BK); P8_DSR(fa[5], rd_a[BUF][1], (SLOT) + 32 * P8_BK); \
+  P8_DSR(fa[6], rd_a[BUF][0], (SLOT) + 48 * P8_BK); P8_DSR(fa[7], rd_a[BUF][1], (SLOT) + 48 * P8_BK);
+
+  auto ktile = [&](auto BUF_, int kt) {
+    constexpr int BUF = decltype(BUF_)::value;
+    // ---- P1: W(nh=0) first (retired by lgkmcnt(8): P2 may restage that slot), then A(mh=0)
+    P8I_RD_W(fw0, BUF, 0)
+    P8I_RD_A(BUF, 1 * P8_SLOT)
+    stage(BUF ^ 1, 3, kt + 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw0);
+    P8_WAIT8(fa);
+    P8I_MMA(0, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+    // ---- P2: W(nh=1)
+    P8I_RD_W(fw1, BUF, 2 * P8_SLOT)
+    stage(BUF, 0, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT4(fw1);
+    P8I_MMA(0, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P3: A(mh=1)
+    P8I_RD_A(BUF, 3 * P8_SLOT)
+    stage(BUF, 1, kt + 2);
+    __builtin_amdgcn_s_barrier();
+    P8_WAIT8(fa);
+    P8I_MMA(1, 1, fw1)
+    __builtin_amdgcn_s_barrier();
+    // ---- P4
+    stage(BUF, 2, kt + 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // K tile kt+1 has landed; 3 half-tiles of kt+2 stay in flight
+    __builtin_amdgcn_s_barrier();
+    P8I_MMA(1, 0, fw0)
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, kt_begin + t);
+    if (t + 1 >= nk) break;
+    ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
+  if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
+#undef P8I_MMA
+#undef P8I_RD_W
+#undef P8I_RD_A
+  if (epi.out_bf16) p8i_epilogue<SPLITK, true>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
+  else p8i_epilogue<SPLITK, false>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
+}
+
+// same grid / envelope as launch_gemm_p8 (gemm_p8.hip decides which of the two int8 kernels runs)
+int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
+                    int per, int splits, dim3 grid, hipStream_t s) {
+  if (splits > 1)
+    hipLaunchKernelGGL((gemm_p8i_kernel<true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
+                       (int)N, Kb, m_tiles, n_tiles, per, epi);
+  else
+    hipLaunchKernelGGL((gemm_p8i_kernel<false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+  return hip_check_launch();
+}
+
+}  // namespace xm

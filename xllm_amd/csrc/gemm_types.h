@@ -100,7 +100,16 @@ __device__ __forceinline__ typename MmaTraits<KIND>::acc_t mma4(const u32x4 a, c
                                                                 typename MmaTraits<KIND>::acc_t c) {
   if constexpr (KIND == kI8) {
     i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+#ifdef P8_ABL_MFMA16  /* ablation build (timing / power only, WRONG results): the same MACs as 2 x 16x16x64 */
+    i32x4_t c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, c, 0, 0, 0);
+#endif
   } else if constexpr (KIND == kFP8) {
     long a0 = (long)(((unsigned long)a.y << 32) | a.x), a1 = (long)(((unsigned long)a.w << 32) | a.z);
     long b0 = (long)(((unsigned long)b.y << 32) | b.x), b1 = (long)(((unsigned long)b.w << 32) | b.z);
