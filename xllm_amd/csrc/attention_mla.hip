@@ -12,6 +12,8 @@
 // are staged global -> registers -> LDS once (two buffers, next tile in flight during the MFMAs); each of the
 // 4 waves computes the full 16-head score block (S^T = K Q^T, 36 MFMAs) and softmax redundantly, then owns a
 // 128-wide slice of the 512 output dims (O^T = V^T P^T through ds_read_b64_tr_b16 on the SAME LDS tile).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace xm {
@@ -56,7 +58,9 @@ struct MlaTraits<f16_t> {
 constexpr int kMlaD = 576, kMlaDV = 512, kMlaTile = 32;
 constexpr float kMlaNegBig = -1e30f;
 
-template <typename T>
+// UNIFORM: block_size % 32 == 0, a 32-token tile lives in one page -> one scalar page id per tile, fetched a tile ahead
+// (otherwise every lane loads its page id: a dependent vector load in front of every row load)
+template <typename T, bool UNIFORM>
 __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_ml, const int32_t* __restrict__ seqlens, const int32_t* __restrict__ block_table,
@@ -106,14 +110,21 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   float m_run = kMlaNegBig, l_run = 0.0f;
 
   uint4 rk[NLD];
-  auto load_global = [&](int tile) {
+  auto page_of = [&](int tile) -> int {  // UNIFORM: scalar page id of a tile (clamped into the live range)
+    int t = tile < tile_hi ? tile : tile_hi - 1;
+    t = t < 0 ? 0 : t;
+    return bt_row[(t * kMlaTile) / block_size];
+  };
+  auto load_global = [&](int tile, int page) {
     const int t0 = tile * kMlaTile;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int c = tid + i * 256, row = c / CH, col = c % CH;
       int tok = t0 + row;
       tok = tok < kv_len ? tok : kv_len - 1;
-      const int64_t rowi = (int64_t)bt_row[tok / block_size] * block_size + tok % block_size;
+      int64_t rowi;
+      if constexpr (UNIFORM) rowi = (int64_t)page * block_size + tok % block_size;
+      else rowi = (int64_t)bt_row[tok / block_size] * block_size + tok % block_size;
       rk[i] = *reinterpret_cast<const uint4*>(kc + rowi * kMlaD + col * 8);
     }
   };
@@ -129,13 +140,15 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   };
 
   if (tile_lo < tile_hi) {
-    load_global(tile_lo);
+    load_global(tile_lo, UNIFORM ? page_of(tile_lo) : 0);
+    int page_next = UNIFORM ? page_of(tile_lo + 1) : 0;
     write_lds(0, tile_lo);
     __syncthreads();
     int cur = 0;
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const bool more = tile + 1 < tile_hi;
-      if (more) load_global(tile + 1);
+      if (more) load_global(tile + 1, page_next);
+      if constexpr (UNIFORM) page_next = page_of(tile + 2);
       const int t0 = tile * kMlaTile;
       const char* lk = lds[cur];
       mf32x4_t s[2] = {mf32x4_t{0.f, 0.f, 0.f, 0.f}, mf32x4_t{0.f, 0.f, 0.f, 0.f}};
@@ -260,6 +273,12 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
   const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
   int64_t nsplit = (512 + entries * hblocks - 1) / (entries * hblocks);
   if (nsplit > tiles / 8) nsplit = tiles / 8;
+  static int split_override = -2;  // XLLM_MI355_MLA_SPLITS: tuning override, read once
+  if (split_override == -2) {
+    const char* e = getenv("XLLM_MI355_MLA_SPLITS");
+    split_override = e ? atoi(e) : -1;
+  }
+  if (split_override > 0) nsplit = split_override;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 32) nsplit = 32;
   const size_t per_split = (size_t)entries * n_heads * (kMlaDV + 2) * sizeof(float);
@@ -271,9 +290,14 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(entries * hblocks * nsplit));
   XM_DISPATCH_HALF(dtype, T, {
-    hipLaunchKernelGGL((mla_decode_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out, part_o,
-                       part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale_log2,
-                       (int)nsplit, q_seq, q_kvlen);
+    if (block_size % kMlaTile == 0)
+      hipLaunchKernelGGL((mla_decode_kernel<T, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+                         part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                         scale_log2, (int)nsplit, q_seq, q_kvlen);
+    else
+      hipLaunchKernelGGL((mla_decode_kernel<T, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+                         part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                         scale_log2, (int)nsplit, q_seq, q_kvlen);
     if (nsplit > 1)
       hipLaunchKernelGGL((mla_merge_kernel<T>), dim3((unsigned)(entries * n_heads)), dim3(kMlaDV), 0, s, part_o, part_ml,
                          (T*)out, (int)nsplit);
