@@ -55,11 +55,21 @@ struct MlaTraits<f16_t> {
   }
 };
 
-constexpr int kMlaD = 576, kMlaDV = 512, kMlaTile = 32;
+constexpr int kMlaD = 576, kMlaDV = 512, kMlaTile = 64;
 constexpr float kMlaNegBig = -1e30f;
 
-// UNIFORM: block_size % 32 == 0, a 32-token tile lives in one page -> one scalar page id per tile, fetched a tile ahead
-// (otherwise every lane loads its page id: a dependent vector load in front of every row load)
+// One workgroup (4 waves) per (entry, block of 16 heads, split-KV slice); K/V = the latent rows themselves (V = the
+// first 512 dims). Tile = 64 tokens staged global -> registers -> ONE LDS buffer (rows padded by 16 B); the next tile
+// is in flight in registers (73 KiB per workgroup, two workgroups per CU) while this one is computed.
+//   * wave w computes S^T = K Q^T only for tokens 16w..16w+15 of the tile (18 MFMAs); the first version had every wave
+//     recompute all of S (72 % of its MFMAs and fragment reads were redundant: profiles/r01_mla_decode.txt);
+//   * the per-head maxima of the four token quarters meet in LDS (256 B), every wave turns its 16 tokens into P = hi + lo
+//     16-bit parts and publishes them in LDS (4.5 KiB), then accumulates its own 128-wide slice of the 512 value dims
+//     over all 64 tokens: O^T += V^T P^T with V^T from transposed LDS reads (ds_read_b64_tr_b16);
+//   * l is kept per lane over the lane's own tokens and reduced across lanes / waves once at the end (all waves apply
+//     the same running maximum, so the partial sums stay consistent).
+// UNIFORM: block_size % 64 == 0, a tile lives in one page -> one scalar page id per tile, fetched a tile ahead
+// (otherwise every lane loads its page id: a dependent vector load in front of every row load).
 template <typename T, bool UNIFORM>
 __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
@@ -70,12 +80,17 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   using x8 = typename TR::x8;
   using x4 = typename TR::x4;
   using elem = typename TR::elem;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   constexpr int KK = kMlaD / 32;                    // 18
   constexpr int CH = kMlaD * 2 / 16;                // 72 chunks of 16 B per row
   constexpr int RS = kMlaD * 2 + 16;                // padded LDS row stride
-  constexpr int NLD = kMlaTile * CH / 256;          // 9 chunks per thread per tile
+  constexpr int NLD = kMlaTile * CH / 256;          // 18 chunks per thread per tile
+  static_assert(NLD == 18 && CH == 72, "the staging map below is written for 64 x 72 chunks");
   constexpr int DBW = (kMlaDV / 4) / 16;            // 8 output blocks of 16 dims per wave
-  __shared__ __attribute__((aligned(16))) char lds[2][kMlaTile * RS];
+  constexpr int PS = kMlaTile * 2 + 16;             // P row stride: 64 tokens of 16 bits + pad
+  __shared__ __attribute__((aligned(16))) char lds[kMlaTile * RS];
+  __shared__ __attribute__((aligned(16))) char p_lds[2][16 * PS];  // [hi / lo][head][token]
+  __shared__ float xmax[4][16], xl[4][16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,109 +122,125 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   mf32x4_t acc_o[DBW];
 #pragma unroll
   for (int i = 0; i < DBW; ++i) acc_o[i] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = kMlaNegBig, l_run = 0.0f;
+  float m_run = kMlaNegBig, l_run = 0.0f;  // l_run: this lane's tokens only
 
-  uint4 rk[NLD];
+  u32x4 rk[NLD];  // native vectors: plain 16-byte loads / stores, never spilled through memcpy
   auto page_of = [&](int tile) -> int {  // UNIFORM: scalar page id of a tile (clamped into the live range)
     int t = tile < tile_hi ? tile : tile_hi - 1;
     t = t < 0 ? 0 : t;
     return bt_row[(t * kMlaTile) / block_size];
   };
+  // thread (r = tid >> 3, c8 = tid & 7) moves chunks c8 + 8 j (j < 9) of rows r and r + 32: 128 contiguous bytes per
+  // 8 lanes, two row addresses per thread and immediates for the rest. Every load is unconditional (rows past kv_len
+  // re-load the last row): no branch around a load
+  const int ld_row = tid >> 3, ld_col = (tid & 7) * 16;
   auto load_global = [&](int tile, int page) {
     const int t0 = tile * kMlaTile;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int c = tid + i * 256, row = c / CH, col = c % CH;
-      int tok = t0 + row;
+    for (int h = 0; h < 2; ++h) {
+      int tok = t0 + ld_row + h * 32;
       tok = tok < kv_len ? tok : kv_len - 1;
       int64_t rowi;
       if constexpr (UNIFORM) rowi = (int64_t)page * block_size + tok % block_size;
       else rowi = (int64_t)bt_row[tok / block_size] * block_size + tok % block_size;
-      rk[i] = *reinterpret_cast<const uint4*>(kc + rowi * kMlaD + col * 8);
+      const char* src = reinterpret_cast<const char*>(kc + rowi * kMlaD) + ld_col;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) rk[h * 9 + j] = *reinterpret_cast<const u32x4*>(src + j * 128);
     }
   };
-  auto write_lds = [&](int buf, int tile) {
+  auto write_lds = [&](int tile) {
     const int t0 = tile * kMlaTile;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int c = tid + i * 256, row = c / CH, col = c % CH;
-      uint4 v = rk[i];
-      if (t0 + row >= kv_len) v = make_uint4(0, 0, 0, 0);  // rows past kv_len: zero (they double as V)
-      *reinterpret_cast<uint4*>(&lds[buf][row * RS + col * 16]) = v;
+    for (int h = 0; h < 2; ++h) {
+      const bool dead = t0 + ld_row + h * 32 >= kv_len;  // rows past kv_len: zero (they double as V)
+      char* dst = lds + (ld_row + h * 32) * RS + ld_col;
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+        *reinterpret_cast<u32x4*>(dst + j * 128) = dead ? u32x4{0u, 0u, 0u, 0u} : rk[h * 9 + j];
     }
   };
 
   if (tile_lo < tile_hi) {
     load_global(tile_lo, UNIFORM ? page_of(tile_lo) : 0);
     int page_next = UNIFORM ? page_of(tile_lo + 1) : 0;
-    write_lds(0, tile_lo);
-    __syncthreads();
-    int cur = 0;
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
-      const bool more = tile + 1 < tile_hi;
-      if (more) load_global(tile + 1, page_next);
+      __syncthreads();                      // A: every wave has finished reading the previous tile
+      write_lds(tile);
+      __syncthreads();                      // B: the tile is visible
+      if (tile + 1 < tile_hi) load_global(tile + 1, page_next);   // in flight underneath this tile's work
       if constexpr (UNIFORM) page_next = page_of(tile + 2);
       const int t0 = tile * kMlaTile;
-      const char* lk = lds[cur];
-      mf32x4_t s[2] = {mf32x4_t{0.f, 0.f, 0.f, 0.f}, mf32x4_t{0.f, 0.f, 0.f, 0.f}};
+      // ---- S^T for this wave's token quarter: lane holds S[head p16][token 16*wave + 4g + r]
+      mf32x4_t s4 = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+      const char* krow = lds + (wave * 16 + p16) * RS + g * 16;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const x8 ka = *reinterpret_cast<const x8*>(lk + (blk * 16 + p16) * RS + (kk * 4 + g) * 16);
-          s[blk] = TR::mfma(ka, qf[kk], s[blk]);
-        }
+      for (int kk = 0; kk < KK; ++kk) s4 = TR::mfma(*reinterpret_cast<const x8*>(krow + kk * 64), qf[kk], s4);
       const bool partial = t0 + kMlaTile > kv_len;
       float mx = kMlaNegBig;
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[blk][r] * scale_log2;
-          if (partial && t0 + blk * 16 + g * 4 + r >= kv_len) v = -INFINITY;
-          s[blk][r] = v;
-          mx = fmaxf(mx, v);
-        }
+      for (int r = 0; r < 4; ++r) {
+        float v = s4[r] * scale_log2;
+        if (partial && t0 + wave * 16 + g * 4 + r >= kv_len) v = -INFINITY;
+        s4[r] = v;
+        mx = fmaxf(mx, v);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
+      if (g == 0) xmax[wave][p16] = mx;
+      __syncthreads();                      // C: the four quarter maxima of every head are published
+      const float m_new = fmaxf(fmaxf(m_run, fmaxf(xmax[0][p16], xmax[1][p16])), fmaxf(xmax[2][p16], xmax[3][p16]));
       const float alpha = exp2f(m_run - m_new);
       m_run = m_new;
       float psum = 0.0f;
-      x8 pf, pl;
+      elem ph[4], pl4[4];
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[blk][r] - m_new);
-          psum += p;
-          const elem hi = (elem)p;
-          pf[blk * 4 + r] = hi;
-          pl[blk * 4 + r] = (elem)(p - (float)hi);
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(s4[r] - m_new);
+        psum += p;
+        ph[r] = (elem)p;                     // P = hi + lo 16-bit parts (see attention_decode.hip)
+        pl4[r] = (elem)(p - (float)ph[r]);
+      }
       l_run = l_run * alpha + psum;
+      {
+        x4 hv = {ph[0], ph[1], ph[2], ph[3]}, lv = {pl4[0], pl4[1], pl4[2], pl4[3]};
+        *reinterpret_cast<x4*>(&p_lds[0][p16 * PS + (wave * 16 + g * 4) * 2]) = hv;
+        *reinterpret_cast<x4*>(&p_lds[1][p16 * PS + (wave * 16 + g * 4) * 2]) = lv;
+      }
 #pragma unroll
       for (int i = 0; i < DBW; ++i) acc_o[i] *= alpha;
-      // this wave's 128-wide slice of the 512 value dims
-      const char* trb = lk + (4 * g + (p16 >> 2)) * RS + (p16 & 3) * 8 + wave * 256;
+      __syncthreads();                      // D: P of all 64 tokens is published
+      // ---- O^T += V^T P^T over both 32-token halves; k slot (g, j): j < 4 -> token 4g + j, j >= 4 -> token 16 + 4g + j - 4
 #pragma unroll
-      for (int db = 0; db < DBW; ++db) {
-        const x4 lo = TR::tr_read(trb + db * 32);
-        const x4 hi = TR::tr_read(trb + 16 * RS + db * 32);
-        x8 vt;
-        vt[0] = lo[0]; vt[1] = lo[1]; vt[2] = lo[2]; vt[3] = lo[3];
-        vt[4] = hi[0]; vt[5] = hi[1]; vt[6] = hi[2]; vt[7] = hi[3];
-        acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
-        acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
+      for (int ks = 0; ks < 2; ++ks) {
+        x8 pf, pl;
+        {
+          const x4 h0 = *reinterpret_cast<const x4*>(&p_lds[0][p16 * PS + (ks * 32 + g * 4) * 2]);
+          const x4 h1 = *reinterpret_cast<const x4*>(&p_lds[0][p16 * PS + (ks * 32 + 16 + g * 4) * 2]);
+          const x4 l0 = *reinterpret_cast<const x4*>(&p_lds[1][p16 * PS + (ks * 32 + g * 4) * 2]);
+          const x4 l1 = *reinterpret_cast<const x4*>(&p_lds[1][p16 * PS + (ks * 32 + 16 + g * 4) * 2]);
+          pf = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const char* trb = lds + (ks * 32 + 4 * g + (p16 >> 2)) * RS + (p16 & 3) * 8 + wave * 256;
+#pragma unroll
+        for (int db = 0; db < DBW; ++db) {
+          const x4 lo = TR::tr_read(trb + db * 32);
+          const x4 hi = TR::tr_read(trb + 16 * RS + db * 32);
+          const x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc_o[db] = TR::mfma(vt, pf, acc_o[db]);
+          acc_o[db] = TR::mfma(vt, pl, acc_o[db]);
+        }
       }
-      if (more) write_lds(cur ^ 1, tile + 1);
-      __syncthreads();
-      cur ^= 1;
     }
   }
 
+  // l over all tokens of the slice: lanes of a head (g), then the four waves
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
+  __syncthreads();
+  if (g == 0) xl[wave][p16] = l_run;
+  __syncthreads();
+  l_run = (xl[0][p16] + xl[1][p16]) + (xl[2][p16] + xl[3][p16]);
   if (head >= n_heads) return;
   if (nsplit == 1) {
     const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
