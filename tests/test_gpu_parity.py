@@ -489,7 +489,9 @@ def test_mlu_golden_vectors_through_hip():
 
 
 # ------------------------------------------------------------------------------------------- MLA / MoE
-@pytest.mark.parametrize("H,bs,kv_lens", [(16, 64, [8192 // 8, 70, 1]), (128, 64, [300, 65]), (5, 16, [100])])
+@pytest.mark.parametrize("H,bs,kv_lens", [(16, 64, [8192 // 8, 70, 1]), (128, 64, [300, 65]), (5, 16, [100]),
+                                          (16, 128, [2048, 129, 128, 64, 63]), (16, 32, [1000, 33]),
+                                          (24, 64, [4096])])
 def test_mla_decode(H, bs, kv_lens):
     """flash_mla dense decode == softmax(scale q.K) K[:, :512] over the paged latent cache (oracle: the generic
     paged attention with nkv=1, d=576, dv=512, v_cache aliasing k_cache -- prefill_sdpa's formulation,

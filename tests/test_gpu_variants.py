@@ -1,5 +1,5 @@
-"""The opt-in GEMM kernels (env-selected experiments kept in the library) stay parity-green: the int8 / 16-bit GEMM
-parity tests are re-run in subprocesses with each selector (the selectors are read once per process)."""
+"""The opt-in kernels (env-selected experiments / fallbacks kept in the library) stay parity-green: the parity tests of
+the operator are re-run in subprocesses with each selector (the selectors are read once per process)."""
 import os
 import subprocess
 import sys
@@ -24,5 +24,20 @@ def test_gemm_parity_under_kernel_selector(env):
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
                         "-k", SELECT, "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [
+    {"XLLM_MI355_MLA_DMA": "0"},                             # register-staged MLA kernel on 64-multiple pages too
+    {"XLLM_MI355_MLA_DMA": "0", "XLLM_MI355_MLA_SPLITS": "3"},
+    {"XLLM_MI355_MLA_SPLITS": "3"},                          # LDS-DMA kernel with a forced split-KV (uneven slices)
+    {"XLLM_MI355_MLA_SPLITS": "1"},
+], ids=["mla_regstaged", "mla_regstaged_split3", "mla_dma_split3", "mla_dma_nosplit"])
+def test_mla_parity_under_kernel_selector(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-k", "mla", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -265,6 +265,245 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
   }
 }
 
+// LDS reads of the DMA-filled buffers are inline asm: the compiler fences every LDS load it emits itself against ALL
+// outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would serialise the prefetch of the next tiles with this tile's reads.
+// Waits are counted (LDS returns in order; ops the compiler adds in between only make a counted wait more conservative).
+typedef unsigned mu32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned mu32x2_t __attribute__((ext_vector_type(2)));
+#define MLA_DSR128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define MLA_DSR64(DST, ADDR, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define MLA_DSR64TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define MLA_LGKM1(N, A) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(A) : "n"(N))
+#define MLA_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
+#define MLA_LGKM4(N, A, B, C, D) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "n"(N))
+
+// The same algorithm for block_size % 64 == 0 with the tile staged by LDS-DMA (buffer_load ... lds) into TWO LDS buffers:
+// no staging registers, no register -> LDS copy, and two tiles (147 KB per CU) in flight while a tile is computed; one
+// workgroup per CU. profiles/r01_mla_decode.txt has the measurements that led here.
+//   * a tile's rows are consecutive rows of ONE page, so the DMA source is (scalar page base) + (per-lane constant
+//     offset): 18 offsets per lane computed once; the buffer's num_records = live rows * 1152 zero-fills the rows past
+//     kv_len in hardware (they double as V) and turns the prefetch of a tile past the slice into a no-op;
+//   * every DMA instruction fills 1 KB of contiguous LDS, so rows are unpadded (1152 B) and bank conflicts are avoided by
+//     an XOR swizzle of the 16-byte chunks inside aligned groups of 8: physical = logical ^ f(row),
+//     f = row bit1 -> bit1, bit2 -> bit2, bit3 -> bit0 -- distinct over the 16 consecutive rows a K fragment read touches
+//     AND over the 8 rows x 2 chunks a transposed V read touches;
+//   * wave w DMAs rows 16w..16w+15 -- exactly the rows it scores, so QK^T needs only the wave's own vmcnt, no barrier.
+template <typename T>
+__global__ __launch_bounds__(256, 1) void mla_decode_dma_kernel(
+    const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
+    float* __restrict__ part_ml, const int32_t* __restrict__ seqlens, const int32_t* __restrict__ block_table,
+    int max_blocks, int n_heads, int block_size, float scale_log2, int nsplit,
+    const int32_t* __restrict__ q_seq, const int32_t* __restrict__ q_kvlen) {
+  using TR = MlaTraits<T>;
+  using x8 = typename TR::x8;
+  using x4 = typename TR::x4;
+  using elem = typename TR::elem;
+  constexpr int KK = kMlaD / 32;                    // 18
+  constexpr int ROWB = kMlaD * 2;                   // 1152 bytes per row, unpadded
+  constexpr int BUFB = kMlaTile * ROWB;             // 73,728 bytes per tile buffer
+  constexpr int NDMA = BUFB / 1024 / 4;             // 18 DMA instructions (1 KB each) per wave per tile
+  constexpr int DBW = (kMlaDV / 4) / 16;            // 8 output blocks of 16 dims per wave
+  constexpr int PS = kMlaTile * 2 + 16;             // P row stride: 64 tokens of 16 bits + pad
+  static_assert(NDMA == 18 && ROWB % 128 == 0, "tile = 64 rows of 9 x 128 bytes");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUFB];
+  __shared__ __attribute__((aligned(16))) char p_lds[2][16 * PS];  // [hi / lo][head][token]
+  __shared__ float xmax[4][16], xl[4][16];
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, g = lane >> 4;
+  const int split = blockIdx.x % nsplit;
+  const int hb = (blockIdx.x / nsplit) % ((n_heads + 15) / 16);
+  const int b = blockIdx.x / nsplit / ((n_heads + 15) / 16);
+  const int seq = q_seq ? q_seq[b] : b;
+  const int kv_len = q_kvlen ? q_kvlen[b] : seqlens[seq];
+  const int ntiles = (kv_len + kMlaTile - 1) / kMlaTile;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int tile_lo = split * per;
+  const int tile_hi = tile_lo + per < ntiles ? tile_lo + per : ntiles;
+  const int32_t* bt_row = block_table + (int64_t)seq * max_blocks;
+  const int head = hb * 16 + p16;
+
+  x8 qf[KK];
+  {
+    const T* qp = q + ((int64_t)b * n_heads + (head < n_heads ? head : 0)) * kMlaD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (head < n_heads) qf[kk] = *reinterpret_cast<const x8*>(qp + (kk * 4 + g) * 8);
+      else qf[kk] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  mf32x4_t acc_o[DBW];
+#pragma unroll
+  for (int i = 0; i < DBW; ++i) acc_o[i] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kMlaNegBig, l_run = 0.0f;
+
+  // DMA source offsets: instruction i of wave w fills LDS bytes [(18 w + i) KB, +1 KB) of the tile buffer; lane's 16
+  // bytes are chunk C = (18 w + i) * 64 + lane = (row, physical chunk) and come from logical chunk (physical ^ f(row))
+  int voff[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int c = (wave * NDMA + i) * 64 + lane, row = c / 72, pc = c % 72;
+    const int f = (row & 6) | ((row >> 3) & 1);
+    voff[i] = row * ROWB + ((pc ^ f) << 4);
+  }
+  auto stage = [&](int tile, int buf) {  // unconditional: a tile past the slice gets num_records = 0 (no traffic)
+    int rows = 0;
+    int64_t row0 = 0;
+    if (tile < tile_hi) {
+      const int t0 = tile * kMlaTile;
+      rows = kv_len - t0 < kMlaTile ? kv_len - t0 : kMlaTile;
+      row0 = (int64_t)bt_row[t0 / block_size] * block_size + t0 % block_size;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(kc + row0 * kMlaD), 0, rows * ROWB, 0x00020000);
+    const lds_ptr_t dst = lds3 + buf * BUFB + wave * (NDMA * 1024);
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + i * 1024, 16, voff[i], 0, 0, 0);
+  };
+
+  // fragment read offsets inside a tile buffer (per lane, constant over tiles)
+  const int fq = (p16 & 6) | ((p16 >> 3) & 1);                   // f(row) of K row 16 w + p16
+  const int k_off = (wave * 16 + p16) * ROWB + ((g ^ fq) << 4);  // + (kk >> 1) * 128, ^ 64 for odd kk
+  // V^T (transposed) reads: row 32 ks + 16 hi + 4 g + (p16 >> 2); f of that row depends on the lane only
+  const int ft = (((p16 >> 3) & 1) << 1) | ((g & 1) << 2) | ((g >> 1) & 1);
+  const int v_x = ((((p16 >> 1) & 1) ^ ft) << 4) | ((p16 & 1) << 3);  // chunk (b ^ ft) and the 8-byte half
+  const int v_row = (4 * g + (p16 >> 2)) * ROWB + wave * 256;
+  const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)lds3;
+  const unsigned p_rd = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_t)p_lds + p16 * PS + g * 8;  // + ks * 64 (+ 32): tokens 32 ks (+ 16) + 4 g
+
+  if (tile_lo < tile_hi) {
+    stage(tile_lo, 0);
+    stage(tile_lo + 1, 1);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      const int buf = (tile - tile_lo) & 1;
+      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // this wave's rows of `tile` have landed (tile + 1 still flies)
+      const int t0 = tile * kMlaTile;
+      mf32x4_t sa = mf32x4_t{0.f, 0.f, 0.f, 0.f}, sb = sa;
+      {
+        const unsigned ke = lds_base + buf * BUFB + k_off, ko = lds_base + buf * BUFB + (k_off ^ 64);
+        mu32x4_t kf[KK];
+#define MLA_QK_RD(K_) MLA_DSR128(kf[K_], ((K_) & 1) ? ko : ke, ((K_) >> 1) * 128);
+#define MLA_QK_MM(K_)                                                             \
+  MLA_LGKM1((17 - (K_)) > 15 ? 15 : 17 - (K_), kf[K_]);                           \
+  if ((K_) & 1) sb = TR::mfma(__builtin_bit_cast(x8, kf[K_]), qf[K_], sb);        \
+  else sa = TR::mfma(__builtin_bit_cast(x8, kf[K_]), qf[K_], sa);
+        MLA_QK_RD(0) MLA_QK_RD(1) MLA_QK_RD(2) MLA_QK_RD(3) MLA_QK_RD(4) MLA_QK_RD(5) MLA_QK_RD(6) MLA_QK_RD(7) MLA_QK_RD(8)
+        MLA_QK_RD(9) MLA_QK_RD(10) MLA_QK_RD(11) MLA_QK_RD(12) MLA_QK_RD(13) MLA_QK_RD(14) MLA_QK_RD(15) MLA_QK_RD(16)
+        MLA_QK_RD(17)
+        MLA_QK_MM(0) MLA_QK_MM(1) MLA_QK_MM(2) MLA_QK_MM(3) MLA_QK_MM(4) MLA_QK_MM(5) MLA_QK_MM(6) MLA_QK_MM(7) MLA_QK_MM(8)
+        MLA_QK_MM(9) MLA_QK_MM(10) MLA_QK_MM(11) MLA_QK_MM(12) MLA_QK_MM(13) MLA_QK_MM(14) MLA_QK_MM(15) MLA_QK_MM(16)
+        MLA_QK_MM(17)
+#undef MLA_QK_RD
+#undef MLA_QK_MM
+      }
+      const bool partial = t0 + kMlaTile > kv_len;
+      float sv[4], mx = kMlaNegBig;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (sa[r] + sb[r]) * scale_log2;
+        if (partial && t0 + wave * 16 + g * 4 + r >= kv_len) v = -INFINITY;
+        sv[r] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (g == 0) xmax[wave][p16] = mx;
+      __syncthreads();                      // C: quarter maxima published; every wave's rows of the tile have landed
+      const float m_new = fmaxf(fmaxf(m_run, fmaxf(xmax[0][p16], xmax[1][p16])), fmaxf(xmax[2][p16], xmax[3][p16]));
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.0f;
+      elem ph[4], pl4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(sv[r] - m_new);
+        psum += p;
+        ph[r] = (elem)p;
+        pl4[r] = (elem)(p - (float)ph[r]);
+      }
+      l_run = l_run * alpha + psum;
+      {
+        x4 hv = {ph[0], ph[1], ph[2], ph[3]}, lv = {pl4[0], pl4[1], pl4[2], pl4[3]};
+        *reinterpret_cast<x4*>(&p_lds[0][p16 * PS + (wave * 16 + g * 4) * 2]) = hv;
+        *reinterpret_cast<x4*>(&p_lds[1][p16 * PS + (wave * 16 + g * 4) * 2]) = lv;
+      }
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int i = 0; i < DBW; ++i) acc_o[i] *= alpha;
+      }
+      __syncthreads();                      // D: P of all 64 tokens is published
+      const unsigned vb = lds_base + buf * BUFB + v_row;
+      unsigned va[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) va[j] = vb + (v_x ^ (j << 5));
+#define MLA_PV_RD(KS_, DB_)                                                                       \
+  MLA_DSR64TR(vt[DB_][0], va[(DB_) & 3], (KS_) * 32 * ROWB + ((DB_) >> 2) * 128);                  \
+  MLA_DSR64TR(vt[DB_][1], va[(DB_) & 3], (KS_) * 32 * ROWB + ((DB_) >> 2) * 128 + 16 * ROWB);
+#define MLA_PV_MM(DB_)                                                                             \
+  {                                                                                                \
+    MLA_LGKM2(2 * (DBW - 1 - (DB_)), vt[DB_][0], vt[DB_][1]);                                      \
+    const x8 v8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[DB_][0]), __builtin_bit_cast(x4, vt[DB_][1]), \
+                                          0, 1, 2, 3, 4, 5, 6, 7);                                 \
+    acc_o[DB_] = TR::mfma(v8, pf, acc_o[DB_]);                                                     \
+    acc_o[DB_] = TR::mfma(v8, pl, acc_o[DB_]);                                                     \
+  }
+#define MLA_PV_KS(KS_)                                                                             \
+  {                                                                                                \
+    mu32x2_t ph2[2], pl2[2], vt[DBW][2];                                                           \
+    MLA_DSR64(ph2[0], p_rd, (KS_) * 64);                                                           \
+    MLA_DSR64(ph2[1], p_rd, (KS_) * 64 + 32);                                                      \
+    MLA_DSR64(pl2[0], p_rd, 16 * PS + (KS_) * 64);                                                 \
+    MLA_DSR64(pl2[1], p_rd, 16 * PS + (KS_) * 64 + 32);                                            \
+    MLA_PV_RD(KS_, 0) MLA_PV_RD(KS_, 1) MLA_PV_RD(KS_, 2) MLA_PV_RD(KS_, 3)                        \
+    MLA_PV_RD(KS_, 4) MLA_PV_RD(KS_, 5) MLA_PV_RD(KS_, 6) MLA_PV_RD(KS_, 7)                        \
+    MLA_LGKM4(15, ph2[0], ph2[1], pl2[0], pl2[1]);                                                 \
+    const x8 pf = __builtin_shufflevector(__builtin_bit_cast(x4, ph2[0]), __builtin_bit_cast(x4, ph2[1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+    const x8 pl = __builtin_shufflevector(__builtin_bit_cast(x4, pl2[0]), __builtin_bit_cast(x4, pl2[1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+    MLA_PV_MM(0) MLA_PV_MM(1) MLA_PV_MM(2) MLA_PV_MM(3) MLA_PV_MM(4) MLA_PV_MM(5) MLA_PV_MM(6) MLA_PV_MM(7)                        \
+  }
+      MLA_PV_KS(0)
+      MLA_PV_KS(1)
+#undef MLA_PV_RD
+#undef MLA_PV_MM
+#undef MLA_PV_KS
+      __syncthreads();                      // E: every wave is done with this buffer (and with P)
+      stage(tile + 2, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two trailing (empty) prefetches
+  }
+
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (g == 0) xl[wave][p16] = l_run;
+  __syncthreads();
+  l_run = (xl[0][p16] + xl[1][p16]) + (xl[2][p16] + xl[3][p16]);
+  if (head >= n_heads) return;
+  if (nsplit == 1) {
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    T* op = out + ((int64_t)b * n_heads + head) * kMlaDV + wave * 128;
+#pragma unroll
+    for (int db = 0; db < DBW; ++db) {
+      uint16_t hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T t = from_f32<T>(acc_o[db][r] * inv);
+        __builtin_memcpy(&hv[r], &t, 2);
+      }
+      *reinterpret_cast<uint2*>(op + db * 16 + g * 4) =
+          make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+    }
+  } else {
+    const int64_t pi = ((int64_t)b * n_heads + head) * nsplit + split;
+    float* po = part_o + pi * kMlaDV + wave * 128;
+#pragma unroll
+    for (int db = 0; db < DBW; ++db) *reinterpret_cast<mf32x4_t*>(po + db * 16 + g * 4) = acc_o[db];
+    if (wave == 0 && g == 0) { part_ml[pi * 2] = m_run; part_ml[pi * 2 + 1] = l_run; }
+  }
+}
+
 template <typename T>
 __global__ void mla_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                  T* __restrict__ out, int nsplit) {
@@ -302,13 +541,18 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
                       size_t workspace_bytes, hipStream_t s) {
   const int64_t hblocks = (n_heads + 15) / 16;
   const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
-  int64_t nsplit = (512 + entries * hblocks - 1) / (entries * hblocks);
-  if (nsplit > tiles / 8) nsplit = tiles / 8;
-  static int split_override = -2;  // XLLM_MI355_MLA_SPLITS: tuning override, read once
+  static int split_override = -2, dma_mode = -2;  // XLLM_MI355_MLA_SPLITS / XLLM_MI355_MLA_DMA: tuning overrides, read once
   if (split_override == -2) {
     const char* e = getenv("XLLM_MI355_MLA_SPLITS");
     split_override = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_MLA_DMA");
+    dma_mode = e ? atoi(e) : 1;
   }
+  // LDS-DMA kernel: one workgroup per CU (256 resident); register-staged kernel: two per CU (512 resident)
+  const bool dma = dma_mode != 0 && block_size % kMlaTile == 0;
+  const int64_t resident = dma ? 256 : 512;
+  int64_t nsplit = (resident + entries * hblocks - 1) / (entries * hblocks);
+  if (nsplit > tiles / 8) nsplit = tiles / 8;
   if (split_override > 0) nsplit = split_override;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > 32) nsplit = 32;
@@ -321,7 +565,11 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(entries * hblocks * nsplit));
   XM_DISPATCH_HALF(dtype, T, {
-    if (block_size % kMlaTile == 0)
+    if (dma)
+      hipLaunchKernelGGL((mla_decode_dma_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+                         part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                         scale_log2, (int)nsplit, q_seq, q_kvlen);
+    else if (block_size % kMlaTile == 0)
       hipLaunchKernelGGL((mla_decode_kernel<T, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
                          part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
                          scale_log2, (int)nsplit, q_seq, q_kvlen);
