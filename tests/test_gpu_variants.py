@@ -41,3 +41,17 @@ def test_mla_parity_under_kernel_selector(env):
                         "-k", "mla", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [
+    {"XLLM_MI355_PREFILL_DMA": "0"},                         # register-staged flash prefill kernel for head dim 128 too
+    {"XLLM_MI355_PREFILL_DMA": "2"},                         # ping-pong wave groups (256 queries per workgroup)
+], ids=["prefill_regstaged", "prefill_pingpong"])
+def test_prefill_parity_under_kernel_selector(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_fullsize.py"), "-q", "-x", "-k",
+                        "prefill or chunked or model", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

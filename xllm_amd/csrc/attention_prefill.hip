@@ -13,6 +13,8 @@
 // S^T = K Q^T and O^T = V^T P^T so softmax state is lane-local: each lane owns one query of each block.
 // K fragments: ds_read_b128 from rows padded by 16 B; V^T fragments: ds_read_b64_tr_b16 from rows
 // padded by 32 B.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace xm {
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
     int cur = 0;
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const bool more = tile + 1 < tile_hi;
+#ifndef XM_ABL_PF_NOSTAGE  /* ablation builds (tools/build_ablations.sh): timing only, results are wrong */
       if (more) load_global(tile + 1);
+#endif
       const int t0 = tile * kPfTile;
       const bool compute = wave_active && (!causal || t0 <= wq_hi) && (window_left < 0 || t0 + kPfTile > wq_lo - window_left);
       if (compute) {
@@ -188,6 +192,18 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
         const bool need_mask = (t0 + kPfTile > kv_len) || (causal && t0 + kPfTile - 1 > wq_lo) ||
                                (window_left >= 0 && t0 < wq_hi - window_left);
         x8 pf[2], pl[2];  // P = hi + lo 16-bit parts (see attention_decode.hip)
+#ifdef XM_ABL_PF_NOSOFTMAX
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pf[nb][blk * 4 + r] = (elem)s[nb][blk][r];
+              pl[nb][blk * 4 + r] = (elem)s[nb][blk][r];
+            }
+        (void)need_mask;
+#else
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int qpos = kvoff + qidx[nb];
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
             for (int i = 0; i < DB; ++i) acc_o[nb][i] *= alpha;
           }
         }
+#endif
         const char* trb = lv + (4 * g + (p16 >> 2)) * RSV + (p16 & 3) * 8;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
@@ -237,12 +254,18 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
           const x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
+#ifndef XM_ABL_PF_NOPV
             acc_o[nb][db] = TR::mfma(vt, pf[nb], acc_o[nb][db]);
+#ifndef XM_ABL_PF_NOLO
             acc_o[nb][db] = TR::mfma(vt, pl[nb], acc_o[nb][db]);
+#endif
+#endif
           }
         }
       }
+#ifndef XM_ABL_PF_NOSTAGE
       if (more) write_lds(cur ^ 1, tile + 1);
+#endif
       __syncthreads();
       cur ^= 1;
     }
@@ -252,6 +275,421 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     float l = l_run[nb];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qidx[nb] >= q_len) continue;
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    T* op = out + (int64_t)(q_start + qidx[nb]) * nq * D + (int64_t)h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      uint16_t hv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T t = from_f32<T>(acc_o[nb][db][r] * inv);
+        __builtin_memcpy(&hv[r], &t, 2);
+      }
+      *reinterpret_cast<uint2*>(op + db * 16 + g * 4) =
+          make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// D = 128 fast path: the same math on 64-key tiles staged by LDS-DMA, with the matrix pipe and the VALU of a SIMD kept
+// busy at the same time by two wave groups in opposite phases.
+//   * K and V tiles (64 rows x 256 B each) are DMA'd (buffer_load ... lds, 1 KB per instruction) straight into LDS rings
+//     (2 K + 2 V buffers): no staging registers, no LDS write instructions; a tile is requested two phases before its
+//     first use;
+//   * the buffer descriptor is rebuilt per tile (scalar base = first row of the tile; num_records = live rows), so rows
+//     past kv_len arrive as zeros (V must be 0 there: 0 * NaN guard) and a tile inside ONE page needs one scalar page id;
+//   * rows are unpadded (every DMA instruction fills 1 KB of contiguous LDS = 4 rows); bank conflicts are removed by
+//     XOR-swizzling the 16-byte chunks of a row: K chunk ^= (row & 15) (a K fragment read touches 16 consecutive rows
+//     at one logical chunk), V chunk ^= (row & 7) << 1 (a transposed V read touches 8 consecutive rows x 2 chunks);
+//   * LDS reads of the DMA'd buffers are inline asm with counted waits (see attention_mla.hip: the compiler fences its
+//     own LDS loads against all outstanding LDS-DMA with vmcnt(0));
+//   * PING-PONG (tools/coissue_bench.hip, profiles/r01_prefill_attention.txt): on this chip an MFMA stream of one wave
+//     runs at full rate underneath the VALU work of the OTHER wave of the SIMD, but two symmetric workgroups per CU fall
+//     into lockstep (both in QK^T, both in softmax, both in PV) and get no overlap at all. So one workgroup = 8 waves =
+//     256 queries: waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the same SIMDs and alternate, barrier to
+//     barrier, between an MFMA block [O += P V of tile i-1 ; S = K Q^T of tile i] and a VALU block [softmax of tile i]:
+//     step 2i + g is group g's MFMA block for tile i, step 2i + g + 1 its softmax.
+typedef unsigned pu32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned pu32x2_t __attribute__((ext_vector_type(2)));
+#define PF_DSR128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define PF_DSR64TR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define PF_LGKM1(N, A) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(A) : "n"(N))
+#define PF_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
+
+constexpr int kPf2Tile = 64;
+constexpr int kPf2RowB = 256;                       // D = 128 16-bit elements per row, unpadded
+constexpr int kPf2TileB = kPf2Tile * kPf2RowB;      // 16 KB per operand and tile
+#ifdef XM_ABL_PF_TIMING  /* ablation build: shader-clock / wall-clock span of the tile loop of one workgroup */
+__device__ long long pf_dbg[16];
+#endif
+#ifdef XM_ABL_PF_PHASES  /* with XM_ABL_PF_TIMING: per-phase shader cycles of waves 0 and 4 (forces completion at the marks) */
+#define PF_MARK(I_, DEP_)                                                   \
+  {                                                                         \
+    float dep_;                                                             \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(dep_) : "v"(DEP_));              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
+    const long long now_ = clock64();                                       \
+    ph[I_] += now_ - ph_t;                                                  \
+    ph_t = now_;                                                            \
+  }
+#else
+#define PF_MARK(I_, DEP_)
+#endif
+
+// S^T = K Q^T of one tile for the wave's 2 x 16 queries. Fragment I = 4 blk + kk = rows 16 blk + p16, logical chunk
+// 4 kk + g. The 16 fragment reads roll through 8 registers: read I + 8 is issued into the register of fragment I right
+// after its MFMAs, so (LDS returns in order) fragment I < 8 is complete when 7 younger reads are outstanding.
+template <typename T>
+__device__ __forceinline__ void pf2_qk(pf32x4_t (&s)[2][4], const unsigned (&ka)[4], const typename PfTraits<T>::x8 (&qf)[2][4]) {
+  using TR = PfTraits<T>;
+  using x8 = typename TR::x8;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) s[nb][blk] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+  pu32x4_t kf[8];
+#define PF_K_RD(I_) PF_DSR128(kf[(I_) & 7], ka[(I_) & 3], ((I_) >> 2) * 16 * kPf2RowB);
+#define PF_K_MM(I_, WAIT_)                                                                                      \
+  PF_LGKM1(WAIT_, kf[(I_) & 7]);                                                                                \
+  s[0][(I_) >> 2] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[0][(I_) & 3], s[0][(I_) >> 2]);          \
+  s[1][(I_) >> 2] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[1][(I_) & 3], s[1][(I_) >> 2]);
+  PF_K_RD(0) PF_K_RD(1) PF_K_RD(2) PF_K_RD(3) PF_K_RD(4) PF_K_RD(5) PF_K_RD(6) PF_K_RD(7)
+  PF_K_MM(0, 7) PF_K_RD(8) PF_K_MM(1, 7) PF_K_RD(9) PF_K_MM(2, 7) PF_K_RD(10) PF_K_MM(3, 7) PF_K_RD(11)
+  PF_K_MM(4, 7) PF_K_RD(12) PF_K_MM(5, 7) PF_K_RD(13) PF_K_MM(6, 7) PF_K_RD(14) PF_K_MM(7, 7) PF_K_RD(15)
+  PF_K_MM(8, 7) PF_K_MM(9, 6) PF_K_MM(10, 5) PF_K_MM(11, 4) PF_K_MM(12, 3) PF_K_MM(13, 2) PF_K_MM(14, 1) PF_K_MM(15, 0)
+#undef PF_K_RD
+#undef PF_K_MM
+}
+
+// O^T += V^T P^T of one tile (two 32-key halves, P = hi + lo). The reads of the second half roll into the registers of
+// the first: the pair of block db is complete when 14 younger reads are outstanding (first half) / 2 (7 - db) (second).
+template <typename T>
+__device__ __forceinline__ void pf2_pv(pf32x4_t (&acc_o)[2][8], const typename PfTraits<T>::x8 (&pf)[2][2],
+                                       const typename PfTraits<T>::x8 (&pl)[2][2], const unsigned (&va)[8]) {
+  using TR = PfTraits<T>;
+  using x8 = typename TR::x8;
+  using x4 = typename TR::x4;
+  pu32x2_t vt[8][2];
+#define PF_V_RD(KS_, DB_)                                                 \
+  PF_DSR64TR(vt[DB_][0], va[DB_], (KS_) * 32 * kPf2RowB);                 \
+  PF_DSR64TR(vt[DB_][1], va[DB_], (KS_) * 32 * kPf2RowB + 16 * kPf2RowB);
+#ifdef XM_ABL_PF_NOLO  /* ablation build: timing only */
+#define PF_V_LO(KS_, DB_)
+#else
+#define PF_V_LO(KS_, DB_)                                          \
+  acc_o[0][DB_] = TR::mfma(v8, pl[0][KS_], acc_o[0][DB_]);         \
+  acc_o[1][DB_] = TR::mfma(v8, pl[1][KS_], acc_o[1][DB_]);
+#endif
+#define PF_V_MM(KS_, DB_, WAIT_)                                                                                   \
+  {                                                                                                                \
+    PF_LGKM2(WAIT_, vt[DB_][0], vt[DB_][1]);                                                                       \
+    const x8 v8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[DB_][0]), __builtin_bit_cast(x4, vt[DB_][1]),  \
+                                          0, 1, 2, 3, 4, 5, 6, 7);                                                 \
+    acc_o[0][DB_] = TR::mfma(v8, pf[0][KS_], acc_o[0][DB_]);                                                       \
+    acc_o[1][DB_] = TR::mfma(v8, pf[1][KS_], acc_o[1][DB_]);                                                       \
+    PF_V_LO(KS_, DB_)                                                                                              \
+  }
+  PF_V_RD(0, 0) PF_V_RD(0, 1) PF_V_RD(0, 2) PF_V_RD(0, 3) PF_V_RD(0, 4) PF_V_RD(0, 5) PF_V_RD(0, 6) PF_V_RD(0, 7)
+  PF_V_MM(0, 0, 14) PF_V_RD(1, 0) PF_V_MM(0, 1, 14) PF_V_RD(1, 1) PF_V_MM(0, 2, 14) PF_V_RD(1, 2) PF_V_MM(0, 3, 14) PF_V_RD(1, 3)
+  PF_V_MM(0, 4, 14) PF_V_RD(1, 4) PF_V_MM(0, 5, 14) PF_V_RD(1, 5) PF_V_MM(0, 6, 14) PF_V_RD(1, 6) PF_V_MM(0, 7, 14) PF_V_RD(1, 7)
+  PF_V_MM(1, 0, 14) PF_V_MM(1, 1, 12) PF_V_MM(1, 2, 10) PF_V_MM(1, 3, 8)
+  PF_V_MM(1, 4, 6) PF_V_MM(1, 5, 4) PF_V_MM(1, 6, 2) PF_V_MM(1, 7, 0)
+#undef PF_V_RD
+#undef PF_V_MM
+#undef PF_V_LO
+}
+
+// online softmax of one tile: masks, running max / sum, P = hi + lo 16-bit parts, rescale of O when the max moved
+template <typename T>
+__device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTraits<T>::x8 (&pf)[2][2],
+                                            typename PfTraits<T>::x8 (&pl)[2][2], float (&m_run)[2], pf32x4_t (&l_run)[2],
+                                            pf32x4_t (&acc_o)[2][8], bool need_mask, int t0, int kv_len, int causal,
+                                            int window_left, int kvoff, const int (&qidx)[2], int g, float scale_log2) {
+  using elem = typename PfTraits<T>::elem;
+  using x4 = typename PfTraits<T>::x4;
+#ifdef XM_ABL_PF_NOSOFTMAX  /* ablation build: timing only */
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[nb][blk >> 1][(blk & 1) * 4 + r] = (elem)s[nb][blk][r];
+        pl[nb][blk >> 1][(blk & 1) * 4 + r] = (elem)s[nb][blk][r];
+      }
+#else
+  if (need_mask) {  // wave-uniform: only the diagonal / tail / window-edge tiles of a wave
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int qpos = kvoff + qidx[nb];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tok = t0 + blk * 16 + g * 4 + r;
+          const bool vis = tok < kv_len && (!causal || tok <= qpos) && (window_left < 0 || tok >= qpos - window_left);
+          if (!vis) s[nb][blk][r] = -INFINITY;
+        }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    // maximum on the raw scores (scale > 0), exponent argument by one FMA per value: p = 2^(s * scale - m)
+    pf32x4_t m4 = __builtin_elementwise_max(__builtin_elementwise_max(s[nb][0], s[nb][1]),
+                                            __builtin_elementwise_max(s[nb][2], s[nb][3]));
+    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run[nb], mx * scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);  // v_exp_f32: results below 2^-126 flush to 0
+    m_run[nb] = m_new;
+    const pf32x4_t sc4 = {scale_log2, scale_log2, scale_log2, scale_log2}, nm4 = {-m_new, -m_new, -m_new, -m_new};
+    pf32x4_t l4 = l_run[nb] * alpha;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const pf32x4_t e4 = __builtin_elementwise_fma(s[nb][blk], sc4, nm4);
+      pf32x4_t p4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
+      l4 += p4;
+      if constexpr (__is_same(elem, __bf16)) {
+        // hi = p truncated to bf16 (two values packed by one v_perm), lo = bf16(p - hi): p - hi is exact in fp32
+        const pu32x4_t pb = __builtin_bit_cast(pu32x4_t, p4);
+        const pu32x4_t hb = pb & 0xffff0000u;
+        const pf32x4_t m1 = {-1.f, -1.f, -1.f, -1.f};
+        const pf32x4_t lo4 = __builtin_elementwise_fma(__builtin_bit_cast(pf32x4_t, hb), m1, p4);  // p - hi (exact), packed
+        pu32x2_t hp = {__builtin_amdgcn_perm(pb[1], pb[0], 0x07060302u), __builtin_amdgcn_perm(pb[3], pb[2], 0x07060302u)};
+        const x4 h4 = __builtin_bit_cast(x4, hp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[nb][blk >> 1][(blk & 1) * 4 + r] = h4[r];
+          pl[nb][blk >> 1][(blk & 1) * 4 + r] = (elem)lo4[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const elem hi = (elem)p4[r];
+          pf[nb][blk >> 1][(blk & 1) * 4 + r] = hi;
+          pl[nb][blk >> 1][(blk & 1) * 4 + r] = (elem)(p4[r] - (float)hi);
+        }
+      }
+    }
+    l_run[nb] = l4;
+    // the running maximum settles after a few tiles; once no lane of the wave raised it, alpha == 1 everywhere
+    // and the 32 multiplies are skipped (wave-uniform branch; multiplying by 1.0f is exact, so same bits)
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc_o[nb][i] *= alpha;
+    }
+  }
+#endif
+}
+
+// NW = 8: ping-pong groups, 256 queries per workgroup, one workgroup per CU. NW = 4: one group, 128 queries per
+// workgroup, two workgroups per CU (short query blocks: no second group to alternate with).
+template <typename T, bool PAGED, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, const int32_t* __restrict__ kv_lens,
+    const int32_t* __restrict__ block_table, int max_blocks, int nq, int nkv, int block_size, int64_t q_stride,
+    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left) {
+  using TR = PfTraits<T>;
+  using x8 = typename TR::x8;
+  constexpr int D = 128, KK = D / 32, DB = D / 16;
+  constexpr int ROWB = kPf2RowB, TILEB = kPf2TileB;
+  constexpr int QB = NW * 32;                   // queries per workgroup
+  constexpr int NDMA = 16 / NW;                 // 1 KB DMA instructions per wave, operand and tile
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILEB];  // K ring [2] | V ring [2]
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)&lds[0];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = NW == 8 ? wave >> 2 : 0;
+  const int p16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.z;
+  const int qb = gridDim.y - 1 - blockIdx.y;  // heaviest (latest) causal blocks first
+  const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
+  const int q0 = qb * QB;
+  if (q0 >= q_len) return;
+  const int kv_len = PAGED ? kv_lens[b] : (cu_k[b + 1] - cu_k[b]);
+  const int k_start = PAGED ? 0 : cu_k[b];
+  const int G = nq / nkv, kvh = h / G;
+  const int kvoff = kv_len - q_len;
+
+  int q_hi = q0 + QB < q_len ? q0 + QB : q_len;
+  int hi_tok = kv_len;
+  if (causal) { int c = kvoff + q_hi; hi_tok = c < kv_len ? c : kv_len; }
+  if (hi_tok < 0) hi_tok = 0;
+  int lo_tok = 0;
+  if (window_left >= 0) { lo_tok = kvoff + q0 - window_left; lo_tok = lo_tok > 0 ? lo_tok : 0; }
+  const int tile_lo = lo_tok / kPf2Tile, tile_hi = (hi_tok + kPf2Tile - 1) / kPf2Tile;
+  const int nt = tile_hi - tile_lo;
+
+  const int32_t* bt_row = PAGED ? block_table + (int64_t)b * max_blocks : nullptr;
+  const int64_t krow = PAGED ? (int64_t)nkv * D : k_stride;  // row pitch in elements
+  const int64_t vrow = PAGED ? (int64_t)nkv * D : v_stride;
+
+  x8 qf[2][KK];
+  int qidx[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    qidx[nb] = q0 + wave * 32 + nb * 16 + p16;
+    const bool ok = qidx[nb] < q_len;
+    const T* qp = q + (int64_t)(q_start + (ok ? qidx[nb] : 0)) * q_stride + (int64_t)h * D;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (ok) qf[nb][kk] = *reinterpret_cast<const x8*>(qp + (kk * 4 + g) * 8);
+      else qf[nb][kk] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  const int wq_lo = kvoff + q0 + wave * 32;
+  int wq_hi = kvoff + (q0 + wave * 32 + 31 < q_len - 1 ? q0 + wave * 32 + 31 : q_len - 1);
+  const bool wave_active = (q0 + wave * 32) < q_len;
+  auto computes = [&](int i) -> bool {  // does this wave have visible keys in tile tile_lo + i ?
+    const int t0 = (tile_lo + i) * kPf2Tile;
+    return i >= 0 && i < nt && wave_active && (!causal || t0 <= wq_hi) && (window_left < 0 || t0 + kPf2Tile > wq_lo - window_left);
+  };
+
+  pf32x4_t acc_o[2][DB];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int i = 0; i < DB; ++i) acc_o[nb][i] = pf32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {kPfNegBig, kPfNegBig};
+  pf32x4_t l_run[2] = {pf32x4_t{0.f, 0.f, 0.f, 0.f}, pf32x4_t{0.f, 0.f, 0.f, 0.f}};  // lane-partial sums, 4 slots
+
+  // DMA source offsets: instruction j of wave w fills LDS rows 4 (NDMA w + j) .. + 3 of the tile; lane = (row, physical chunk)
+  int voff_k[4], voff_v[4];  // [NDMA] used; a template-dependent array size captured by a lambda makes hipcc drop the host stub
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int row = 4 * (NDMA * wave + j) + (lane >> 4), pc = lane & 15;
+    voff_k[j] = row * (int)(krow * 2) + ((pc ^ (row & 15)) << 4);
+    voff_v[j] = row * (int)(vrow * 2) + ((pc ^ ((row & 7) << 1)) << 4);
+  }
+  auto stage = [&](int i, bool is_v) {  // tile tile_lo + i of K or V -> ring slot i & 1
+    const int t0 = (tile_lo + i) * kPf2Tile;
+    int rows = kv_len - t0 < kPf2Tile ? kv_len - t0 : kPf2Tile;
+    rows = rows > 0 ? rows : 0;
+    int64_t row0;
+    if constexpr (PAGED) row0 = (int64_t)bt_row[(t0 < kv_len ? t0 : 0) / block_size] * block_size + t0 % block_size;
+    else row0 = k_start + t0;
+    const int64_t pitch = is_v ? vrow : krow;
+    const T* src = (is_v ? v : k) + row0 * pitch + (int64_t)kvh * D;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(src), 0, rows ? (int)((rows - 1) * pitch * 2) + ROWB : 0, 0x00020000);
+    const lds_ptr_t dst = lds3 + ((is_v ? 2 : 0) + (i & 1)) * TILEB + wave * (NDMA * 1024);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + j * 1024, 16, is_v ? voff_v[j] : voff_k[j], 0, 0, 0);
+  };
+
+  // fragment read offsets inside a ring slot (per lane, constant over tiles)
+  const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)lds3;
+  unsigned kofs[KK], vofs[DB];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) kofs[kk] = p16 * ROWB + (((kk * 4 + g) ^ p16) << 4);   // + blk * 16 rows
+  {
+    const int vr = 4 * g + (p16 >> 2), ft = vr & 7;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) vofs[db] = 2 * TILEB + vr * ROWB + ((db ^ ft) << 5) + (p16 & 3) * 8;  // + 32 ks (+ 16) rows
+  }
+
+#ifdef XM_ABL_PF_TIMING
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
+  if (nt > 0) {
+    pf32x4_t s[2][4];
+    x8 pf[2][2], pl[2][2];
+    // MFMA block of tile i: O += P V of tile i - 1 (P from the previous softmax), then S = K Q^T of tile i
+#ifdef XM_ABL_PF_PHASES
+    long long ph[4] = {0, 0, 0, 0}, ph_t = clock64();
+#endif
+    auto mfma_block = [&](int i) {
+#if defined(XM_ABL_PF_PRIO_MFMA)
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      PF_MARK(0, m_run[0])  // barrier wait + DMA issue
+      if (computes(i - 1)) {
+        unsigned va[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) va[db] = lds_base + ((i - 1) & 1) * TILEB + vofs[db];
+        pf2_pv<T>(acc_o, pf, pl, va);
+      }
+      PF_MARK(1, acc_o[1][7][3])  // V reads + PV
+      if (computes(i)) {
+        unsigned ka[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) ka[kk] = lds_base + (i & 1) * TILEB + kofs[kk];
+        pf2_qk<T>(s, ka, qf);
+      }
+      PF_MARK(2, s[1][3][3])  // K reads + QK^T
+#if defined(XM_ABL_PF_PRIO_MFMA)
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    auto softmax_block = [&](int i) {
+      PF_MARK(0, m_run[0])
+      if (!computes(i)) return;
+      const int t0 = (tile_lo + i) * kPf2Tile;
+      const bool need_mask = (t0 + kPf2Tile > kv_len) || (causal && t0 + kPf2Tile - 1 > wq_lo) ||
+                             (window_left >= 0 && t0 < wq_hi - window_left);
+#if defined(XM_ABL_PF_PRIO_VALU)
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      pf2_softmax<T>(s, pf, pl, m_run, l_run, acc_o, need_mask, t0, kv_len, causal, window_left, kvoff, qidx, g,
+                     scale_log2);
+#if defined(XM_ABL_PF_PRIO_VALU)
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      PF_MARK(3, l_run[1][3])
+    };
+    // even step 2 i: the tiles requested two steps ago are published, K of tile i + 1 and V of tile i are requested
+    // (first read at step 2 i + 2). A macro, not a lambda: hipcc drops the host stub of a kernel whose lambdas nest.
+#define PF_EVEN_STEP(I_)                                                                                 \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's slices of the requested tiles */      \
+  __syncthreads();                                                                                       \
+  if ((I_) + 1 < nt) stage((I_) + 1, false);                                                             \
+  if ((I_) < nt) stage((I_), true);
+    stage(0, false);
+    // group g runs the MFMA block of tile i in step 2 i + g and the softmax of tile i in step 2 i + g + 1; each group
+    // has its own straight-line loop (the same number of barriers in both)
+    if (grp == 0) {
+      for (int i = 0; i <= nt; ++i) {
+        PF_EVEN_STEP(i)
+        mfma_block(i);
+        if constexpr (NW == 8) __syncthreads();
+        softmax_block(i);
+      }
+    } else {
+      for (int i = 0; i <= nt; ++i) {
+        PF_EVEN_STEP(i)
+        softmax_block(i - 1);
+        __syncthreads();
+        mfma_block(i);
+      }
+    }
+#undef PF_EVEN_STEP
+#ifdef XM_ABL_PF_PHASES
+    if (blockIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == gridDim.y / 2 && lane == 0 && (wave & 3) == 0)
+      for (int i = 0; i < 4; ++i) pf_dbg[4 + grp * 4 + i] = ph[i];
+#endif
+  }
+#ifdef XM_ABL_PF_TIMING
+  if (blockIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == gridDim.y / 2 && tid == 0) {
+    pf_dbg[0] = clock64() - dbg_c0;
+    pf_dbg[1] = wall_clock64() - dbg_w0;
+    pf_dbg[2] = nt;
+  }
+#endif
+
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float l = (l_run[nb][0] + l_run[nb][1]) + (l_run[nb][2] + l_run[nb][3]);
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     if (qidx[nb] >= q_len) continue;
@@ -281,6 +719,26 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
   if (qblocks <= 0) return XM_OK;
   const dim3 grid((unsigned)nq, (unsigned)qblocks, (unsigned)batch);
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
+  if constexpr (D == 128) {
+    // LDS-DMA kernels: a 64-key tile must sit inside one page, and 64 row pitches must fit a 32-bit buffer offset
+    static int dma_mode = -1;  // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = one wave group, 2 = ping-pong
+    if (dma_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_DMA"); dma_mode = e ? atoi(e) : 1; }  // (A/B, read once)
+    const int64_t pitch = PAGED ? nkv * D : (k_stride > v_stride ? k_stride : v_stride);
+    if (dma_mode && (!PAGED || block_size % kPf2Tile == 0) && pitch * 2 * kPf2Tile < (1ll << 31)) {
+      const float sl2 = scale * 1.4426950408889634f;
+      if (dma_mode >= 2 && max_q_len > kPfQBlock) {  // two wave groups need more than 128 queries to alternate
+        const dim3 grid2((unsigned)nq, (unsigned)((max_q_len + 2 * kPfQBlock - 1) / (2 * kPfQBlock)), (unsigned)batch);
+        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
+                           (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl);
+      } else {
+        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4>), grid, dim3(256), 0, s, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
+                           (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl);
+      }
+      return hip_check_launch();
+    }
+  }
   hipLaunchKernelGGL((flash_prefill_kernel<T, D, PAGED>), grid, dim3(256), 0, s, (const T*)q, (const T*)k,
                      (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
                      (int)block_size, q_stride, k_stride, v_stride, scale * 1.4426950408889634f, causal, wl);
@@ -302,3 +760,9 @@ XM_INST_PREFILL(f16_t, 64, true)
 XM_INST_PREFILL(f16_t, 64, false)
 
 }  // namespace xm
+
+#ifdef XM_ABL_PF_TIMING
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_pf(long long* out4) {
+  return hipMemcpyFromSymbol(out4, HIP_SYMBOL(xm::pf_dbg), 12 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
