@@ -327,7 +327,9 @@ XM_API int xllm_mi355_rejection_sample(const int32_t* draft_token_ids, const int
  * kernel::moe_gen_idx (ops_api.h:73) -> cuda::moe_compute_index (kernels/cuda/moe/moe_compute_index.cu:111-160)
  * expert_id [T,topk] int32 -> src_dst[T*topk], dst_src[T*topk], expert_sizes[E]; DETERMINISTIC
  * (stable by expanded row index) unlike the reference's atomics order. workspace >= 4*(E+1)*... see .hip */
-/* scratch for moe_compute_index: >= 4 * ceil(T*topk/1024) * n_experts bytes, registered once */
+/* scratch for moe_compute_index: >= 4 * ceil(T*topk/1024) * n_experts bytes, registered once; group_gemm keeps the
+ * tile table of its 256x256 kernel (16 * (rows / 256 + n_experts) bytes) in the tail of the same scratch and falls back
+ * to the 128x128 kernel when the scratch is absent or too small */
 XM_API int xllm_mi355_set_moe_workspace(void* workspace, size_t bytes);
 XM_API int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int64_t topk,
                                         int64_t n_experts, int32_t* src_dst, int32_t* dst_src,
@@ -335,6 +337,13 @@ XM_API int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_toke
 /* kernel::moe_combine_result (ops_api.h:77) -> cuda::moe_combine_result (moe/moe_combine.cu:64-...) */
 XM_API int xllm_mi355_moe_combine(void* out, const void* gemm2, const float* weights, int64_t n_tokens,
                                   int64_t topk, int64_t hidden, int dtype, void* stream);
+/* fusion of the reference's `index_copy_` + moe_combine_result (layers/dcu/fused_moe.cpp:296-303): the rows of the second
+ * grouped GEMM stay in expert order and are gathered through src_dst (from moe_compute_index) while they are combined:
+ * out[t] = sum_k weights[t,k] * gemm2_sorted[src_dst[t*topk+k]] -- the same fp32 sum in the same order as the two
+ * operators (bit-identical). 16-bit dtypes, topk <= 16, hidden % 8 == 0. */
+XM_API int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, const int32_t* src_dst,
+                                         const float* weights, int64_t n_tokens, int64_t topk, int64_t hidden,
+                                         int dtype, void* stream);
 /* kernel::group_gemm (ops_api.h:57) -> dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74):
  * rows of `a` sorted by expert; out[off_e:off_e+M_e] = a[...] @ w[e]^T, w [E,N,K]; token_count is a
  * DEVICE int32 [E] (no host read). max_rows = a's row count. */

@@ -573,6 +573,31 @@ def test_moe_index_combine_group_gemm():
     outc = ops.moe_combine_result(g2.to(DEV), w.to(DEV), T, topk)
     refc = orc.moe_combine(g2, w.contiguous(), T, topk)
     assert_ulp_close(outc, refc, torch.bfloat16, ulps=1.0, min_exact=0.99)
+    # fused un-sort + combine == index_copy_ + combine, bit for bit
+    g2_sorted = torch.empty_like(g2).to(DEV)
+    g2_sorted[src_dst.long()] = g2.to(DEV)
+    assert torch.equal(ops.moe_combine_sorted(g2_sorted, src_dst, w.to(DEV), T, topk), outc)
+
+
+@pytest.mark.parametrize("T,topk,E,K,N", [(1024, 8, 128, 2048, 1536), (777, 8, 128, 768, 2048), (300, 2, 8, 512, 264),
+                                          (1024, 4, 5, 256, 512)])
+def test_moe_group_gemm_tile_table_path(T, topk, E, K, N):
+    """grouped GEMM on the 256x256 kernel behind the device-built tile table (cfg5 shapes, ragged / empty experts, N
+    that is not a tile multiple) == per-expert oracle matmul; index build == oracle on the same ids (stable order)"""
+    g = torch.Generator().manual_seed(T + E)
+    logits = torch.randn(T, E, generator=g)
+    if E == 5:
+        logits[:, 3] = -1e9                              # an expert that receives no token at all
+    ids = logits.topk(topk, -1).indices.to(torch.int32)
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.to(DEV), E)
+    r_src_dst, r_dst_src, r_sizes = orc.moe_compute_index(ids, E)
+    assert torch.equal(sizes.cpu(), r_sizes) and torch.equal(src_dst.cpu(), r_src_dst) and torch.equal(dst_src.cpu(), r_dst_src)
+    x = torch.randn(T, K, generator=g).bfloat16()
+    xs = x[(r_dst_src.long() // topk)]
+    we = (torch.randn(E, N, K, generator=g) / math.sqrt(K)).bfloat16()
+    got = ops.group_gemm(xs.to(DEV), we.to(DEV), sizes)
+    ref = orc.group_gemm(xs, we, r_sizes)
+    assert_ulp_close(got, ref, torch.bfloat16, ulps=2.0, min_exact=0.9)
 
 
 # ------------------------------------------------------------------------------------------- N1 fusions

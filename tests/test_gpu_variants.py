@@ -55,3 +55,12 @@ def test_prefill_parity_under_kernel_selector(env):
                         "prefill or chunked or model", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_group_gemm_parity_on_the_fallback_kernel():
+    e = dict(os.environ)
+    e["XLLM_MI355_GROUP_P8"] = "0"                          # 128x128 kernel with the per-workgroup expert walk
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-k", "moe", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

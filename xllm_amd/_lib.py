@@ -70,6 +70,7 @@ _OPTIONAL = {
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),
     "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_moe_combine_sorted": ([vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_group_gemm": ([vp, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),
 }
 

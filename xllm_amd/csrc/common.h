@@ -103,6 +103,9 @@ inline int hip_check_launch() {
 }
 
 // rowwise.hip: consumes (and re-zeroes) int32 GEMM sums: dequant + residual add + RMSNorm (+ int8 quant)
+// library scratch registered by xllm_mi355_set_moe_workspace (moe.hip): chunk counts of the index build; the grouped GEMM
+// keeps its tile table in the tail of it
+void xm_moe_scratch(void** ws, size_t* bytes);
 int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
                             const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
                             int dtype, int quant, hipStream_t s);

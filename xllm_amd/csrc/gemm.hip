@@ -671,6 +671,31 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   return hip_check_launch();
 }
 
+// grouped GEMM tile table (one workgroup): slot t of the m-tile axis -> (expert, first row, rows, tile inside the expert),
+// experts in order, ceil(rows / bm) slots each; the remaining slots get expert = -1
+__global__ __launch_bounds__(1024) void group_plan_kernel(const int32_t* __restrict__ counts, int E, int bm,
+                                                          int32_t* __restrict__ table, int slots) {
+  __shared__ int32_t rows_incl[1024], tiles_incl[1024];
+  const int e = threadIdx.x;
+  const int c = e < E ? counts[e] : 0;
+  rows_incl[e] = c;
+  tiles_incl[e] = (c + bm - 1) / bm;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scans
+    const int r = e >= d ? rows_incl[e - d] : 0, t = e >= d ? tiles_incl[e - d] : 0;
+    __syncthreads();
+    rows_incl[e] += r;
+    tiles_incl[e] += t;
+    __syncthreads();
+  }
+  const int used = tiles_incl[1023];
+  for (int t = used + e; t < slots; t += 1024) reinterpret_cast<int4*>(table)[t] = make_int4(-1, 0, 0, 0);
+  if (e < E) {
+    const int nt = (c + bm - 1) / bm, t0 = tiles_incl[e] - nt, off = rows_incl[e] - c;
+    for (int j = 0; j < nt && t0 + j < slots; ++j) reinterpret_cast<int4*>(table)[t0 + j] = make_int4(e, off, c, j);
+  }
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -778,12 +803,33 @@ int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_cou
   if (K % 64 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
   if (max_rows == 0) return XM_OK;
   GemmEpi epi{nullptr, 0, nullptr, 0, nullptr, out, nullptr, dtype == XM_BF16, token_count, (int)n_experts};
+  hipStream_t s = (hipStream_t)stream;
+  // 256x256 8-phase kernel behind a device-built tile table (kept in the tail of the MoE scratch); the 128x128 kernel
+  // with its per-workgroup expert walk is the fallback (no scratch registered, shape outside the 8-phase envelope)
+  static int p8_mode = -2;  // XLLM_MI355_GROUP_P8=0: 128x128 kernel only (A/B), read once
+  if (p8_mode == -2) {
+    const char* e = getenv("XLLM_MI355_GROUP_P8");
+    p8_mode = e ? atoi(e) : 1;
+  }
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  xm_moe_scratch(&scratch, &scratch_bytes);
+  const int64_t slots = (max_rows + 255) / 256 + n_experts;
+  const size_t table_bytes = (size_t)slots * 16;
+  if (p8_mode && scratch && scratch_bytes >= table_bytes + 64 && n_experts <= 1024 && max_rows >= 256 * 4) {
+    int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));
+    hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
+    GemmEpi e2 = epi;
+    e2.group_tiles = table;
+    const int rc = dtype == XM_BF16 ? launch_gemm_p8<kBF16>(a, w, max_rows, N, K * 2, e2, nullptr, 0, 1, s)
+                                    : launch_gemm_p8<kF16>(a, w, max_rows, N, K * 2, e2, nullptr, 0, 1, s);
+    if (rc != XM_ERR_UNSUPPORTED) return rc;
+  }
   // worst case number of 128-row tiles over all experts: every expert may waste < 1 tile
   const int m_tiles = (int)((max_rows + BM - 1) / BM + n_experts);
   const int n_tiles = (int)((N + BN - 1) / BN);
   const int ksteps = (int)((K * 2 + BKB - 1) / BKB);
   const dim3 grid((unsigned)(m_tiles * n_tiles), 1, 1);
-  hipStream_t s = (hipStream_t)stream;
   if (dtype == XM_BF16)
     hipLaunchKernelGGL((gemm_kernel<kBF16, false, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
                        (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);

@@ -190,11 +190,15 @@ __device__ __forceinline__ void p8_epilogue(typename MmaTraits<KIND>::acc_t (&ac
 }
 
 template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A,
-                                                               const uint8_t* __restrict__ W, int M, int N,
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* __restrict__ A_in,
+                                                               const uint8_t* __restrict__ W_in, int M_in, int N,
                                                                int64_t Kb, int m_tiles, int n_tiles,
-                                                               int ktiles_per_split, GemmEpi epi) {
+                                                               int ktiles_per_split, GemmEpi epi_in) {
   using acc_t = typename MmaTraits<KIND>::acc_t;
+  const uint8_t* A = A_in;
+  const uint8_t* W = W_in;
+  int M = M_in;
+  GemmEpi epi = epi_in;
   // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
 
@@ -217,6 +221,20 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     mt = (SM << lm) + (within & ((1 << lm) - 1));
     nt = (SN << (5 - lm)) + (within >> lm);
     if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
+  }
+  if (epi.group_tiles) {
+    // grouped (MoE) mode, reference dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74): rows of A are sorted by expert,
+    // expert e owns rows [off, off + cnt) and weight W[e]. m-tile slot mt -> (e, off, cnt, tile inside e) from the
+    // table group_plan_kernel built on the DEVICE from the expert sizes (no host sync: graph-capturable)
+    const int4 gt = reinterpret_cast<const int4*>(epi.group_tiles)[mt];
+    const int ge = __builtin_amdgcn_readfirstlane(gt.x);
+    if (ge < 0) return;  // surplus slot (the grid is sized for the worst case)
+    const int goff = __builtin_amdgcn_readfirstlane(gt.y);
+    M = __builtin_amdgcn_readfirstlane(gt.z);
+    mt = __builtin_amdgcn_readfirstlane(gt.w);
+    A += (int64_t)goff * Kb;
+    W += (int64_t)ge * N * Kb;
+    epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)goff * N * 2;
   }
   const int m0 = mt * P8_BM, n0 = nt * P8_BN;
   const int total_kt = (int)(Kb / P8_BK);
@@ -622,8 +640,13 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
                    size_t ws_bytes, int splits, hipStream_t s) {
   (void)workspace;
   (void)ws_bytes;
-  if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || epi.group_counts) return XM_ERR_UNSUPPORTED;
-  const int m_tiles = (int)((M + P8_BM - 1) / P8_BM), n_tiles = (int)((N + P8_BN - 1) / P8_BN);
+  if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) ||
+      (epi.group_counts && !epi.group_tiles))
+    return XM_ERR_UNSUPPORTED;
+  if (epi.group_tiles && (KIND == kI8 || splits > 1)) return XM_ERR_UNSUPPORTED;
+  // grouped: M = total rows; every expert may add one partial tile (the table has that many slots)
+  const int m_tiles = (int)((M + P8_BM - 1) / P8_BM) + (epi.group_tiles ? epi.n_groups : 0);
+  const int n_tiles = (int)((N + P8_BN - 1) / P8_BN);
   const int ktiles = (int)(Kb / P8_BK);
   splits = splits < 1 ? 1 : splits;
   const int per = (ktiles + splits - 1) / splits;
@@ -649,10 +672,11 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
     const char* e = getenv("XLLM_MI355_P8_RING");
     ring = e ? atoi(e) : 0;  // measured: the deeper weight ring is 2-4 % slower at M = 8192 and no faster at M = 256
   }
+  const bool use_ring = ring && !epi.group_tiles;  // the grouped mode lives in the first-version kernel only
   if (splits > 1) {
     if constexpr (KIND == kI8) {
       if (!epi.acc_out) return XM_ERR_INVALID;  // the caller points acc_out at the zeroed split-K workspace
-      if (ring)
+      if (use_ring)
         hipLaunchKernelGGL((gemm_p8r_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                            (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
       else
@@ -661,7 +685,7 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
     } else {
       return XM_ERR_UNSUPPORTED;
     }
-  } else if (ring) {
+  } else if (use_ring) {
     hipLaunchKernelGGL((gemm_p8r_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   } else {

@@ -73,6 +73,9 @@ struct GemmEpi {
   const int32_t* group_counts;  // grouped GEMM (MoE): rows per expert, DEVICE array [n_groups]; null otherwise
   int n_groups;
   int defer;  // int8: leave the exact int32 sums in the (zeroed) split-K workspace, no dequant epilogue launch
+  // grouped GEMM on the 256x256 kernels: DEVICE table built by group_plan_kernel, one int4 per m-tile slot =
+  // (expert or -1, first row of the expert, rows of the expert, tile index inside the expert); null otherwise
+  const int32_t* group_tiles;
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {

@@ -25,26 +25,26 @@ __global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict
   for (int e = threadIdx.x; e < E; e += blockDim.x) chunk_cnt[(int64_t)blockIdx.x * E + e] = h[e];
 }
 
-// pass 2 (one workgroup): expert sizes, expert offsets (exclusive scan over experts), and per-chunk bases
-// chunk_cnt[c][e] <- offset[e] + sum_{c' < c} cnt[c'][e]
+// pass 2 (one workgroup, one thread per expert): expert sizes, expert offsets (exclusive scan over experts), and
+// per-chunk bases chunk_cnt[c][e] <- offset[e] + sum_{c' < c} cnt[c'][e]
 __global__ __launch_bounds__(1024) void moe_scan_kernel(int32_t* __restrict__ chunk_cnt, int nchunks, int E,
                                                         int32_t* __restrict__ expert_sizes) {
-  __shared__ int32_t sizes[kMaxExperts];
-  __shared__ int32_t offs[kMaxExperts];
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    int32_t s = 0;
+  __shared__ int32_t incl[kMaxExperts];
+  const int e = threadIdx.x;
+  int32_t s = 0;
+  if (e < E)
     for (int c = 0; c < nchunks; ++c) s += chunk_cnt[(int64_t)c * E + e];
-    sizes[e] = s;
-    expert_sizes[e] = s;
-  }
+  if (e < E) expert_sizes[e] = s;
+  incl[e] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int32_t run = 0;
-    for (int e = 0; e < E; ++e) { offs[e] = run; run += sizes[e]; }
+  for (int d = 1; d < kMaxExperts; d <<= 1) {  // Hillis-Steele inclusive scan over the experts
+    const int32_t v = e >= d ? incl[e - d] : 0;
+    __syncthreads();
+    incl[e] += v;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    int32_t run = offs[e];
+  if (e < E) {
+    int32_t run = incl[e] - s;
     for (int c = 0; c < nchunks; ++c) {
       const int32_t v = chunk_cnt[(int64_t)c * E + e];
       chunk_cnt[(int64_t)c * E + e] = run;
@@ -53,39 +53,42 @@ __global__ __launch_bounds__(1024) void moe_scan_kernel(int32_t* __restrict__ ch
   }
 }
 
-// pass 3: one wave per chunk walks its rows in order, 64 at a time; rank inside the wave by ballot
-__global__ __launch_bounds__(64) void moe_place_kernel(const int32_t* __restrict__ expert_id, int64_t n, int E,
-                                                       const int32_t* __restrict__ chunk_base,
-                                                       int32_t* __restrict__ src_dst, int32_t* __restrict__ dst_src) {
-  extern __shared__ int32_t run[];  // running position per expert inside this chunk
-  const int lane = threadIdx.x;
-  for (int e = lane; e < E; e += 64) run[e] = chunk_base[(int64_t)blockIdx.x * E + e];
-  __syncthreads();
+// pass 3: one workgroup (16 waves) per chunk of 1024 rows. Every wave holds the whole chunk's expert ids (16 per lane)
+// and owns a slice of the experts; for each of its experts it walks the 16 row groups in order: the rows of that expert
+// get consecutive positions (ballot rank inside a group, running count across groups) -> stable inside an expert.
+// Every row is placed by exactly one wave (the owner of its expert).
+__global__ __launch_bounds__(1024) void moe_place_kernel(const int32_t* __restrict__ expert_id, int64_t n, int E,
+                                                         const int32_t* __restrict__ chunk_base,
+                                                         int32_t* __restrict__ src_dst, int32_t* __restrict__ dst_src) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * kMoeChunk;
-  for (int it = 0; it < kMoeChunk / 64; ++it) {
-    const int64_t i = base + it * 64 + lane;
-    const bool valid = i < n;
-    const int e = valid ? expert_id[i] : -1;
-    unsigned long long todo = __ballot(valid);
-    int pos = -1;
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int e0 = __shfl(e, leader);
-      const unsigned long long m = __ballot(valid && e == e0);
-      if (valid && e == e0) {
-        const unsigned long long lt = (lane == 0) ? 0ull : (m & ((1ull << lane) - 1ull));
-        pos = run[e0] + __popcll(lt);
-      }
-      __syncthreads();  // single wave: orders the LDS read above before the update below
-      if (lane == leader) run[e0] += __popcll(m);
-      __syncthreads();
-      todo &= ~m;
-    }
-    if (valid) {
-      src_dst[i] = pos;
-      dst_src[pos] = (int32_t)i;
+  int eid[kMoeChunk / 64], pos[kMoeChunk / 64];
+#pragma unroll
+  for (int r = 0; r < kMoeChunk / 64; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    eid[r] = i < n ? expert_id[i] : -1;
+    pos[r] = -1;
+  }
+  const int per_wave = (E + 15) / 16;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int k = 0; k < per_wave; ++k) {
+    const int e = wave * per_wave + k;
+    if (e >= E) break;
+    int run = chunk_base[(int64_t)blockIdx.x * E + e];
+#pragma unroll
+    for (int r = 0; r < kMoeChunk / 64; ++r) {
+      const unsigned long long m = __ballot(eid[r] == e);
+      if (eid[r] == e) pos[r] = run + __popcll(m & lt);
+      run += __popcll(m);
     }
   }
+#pragma unroll
+  for (int r = 0; r < kMoeChunk / 64; ++r)
+    if (pos[r] >= 0) {
+      const int64_t i = base + r * 64 + lane;
+      src_dst[i] = pos[r];
+      dst_src[pos[r]] = (int32_t)i;
+    }
 }
 
 template <typename T>
@@ -96,6 +99,38 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, c
     float acc = 0.0f;
     for (int k = 0; k < topk; ++k) acc += w[t * topk + k] * to_f32(gemm2[(t * topk + k) * (int64_t)H + i]);
     out[t * (int64_t)H + i] = from_f32<T>(acc);
+  }
+}
+
+// N1-style fusion of the reference's index_copy_ + moe_combine_result (layers/dcu/fused_moe.cpp:296-303): the second
+// grouped GEMM's rows stay in expert order and are gathered through src_dst while they are combined:
+// out[t] = sum_k w[t, k] * gemm2_sorted[src_dst[t * topk + k]] (same fp32 sum, same order as the two operators).
+template <typename T>
+__global__ __launch_bounds__(256) void moe_combine_sorted_kernel(T* __restrict__ out, const T* __restrict__ gemm2,
+                                                                 const int32_t* __restrict__ src_dst,
+                                                                 const float* __restrict__ w, int topk, int H) {
+  const int64_t t = blockIdx.x;
+  constexpr int kMaxTopk = 16;
+  __shared__ int rows[kMaxTopk];
+  __shared__ float ws[kMaxTopk];
+  if (threadIdx.x < topk) {
+    rows[threadIdx.x] = src_dst[t * topk + threadIdx.x];
+    ws[threadIdx.x] = w[t * topk + threadIdx.x];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {  // H % 8 == 0: one 16-byte load per row and thread
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < topk; ++k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(gemm2 + (int64_t)rows[k] * H + i);
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ws[k] * to_f32(e[j]);
+    }
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oe[j] = from_f32<T>(acc[j]);
+    *reinterpret_cast<uint4*>(out + t * (int64_t)H + i) = o;
   }
 }
 
@@ -195,6 +230,12 @@ using namespace xm;
 // scratch for the chunk histograms (nchunks * E int32); sized for 1M expanded rows x 1024 experts at most
 static int32_t* g_moe_scratch = nullptr;
 static size_t g_moe_scratch_elems = 0;
+namespace xm {
+void xm_moe_scratch(void** ws, size_t* bytes) {
+  *ws = g_moe_scratch;
+  *bytes = g_moe_scratch_elems * 4;
+}
+}  // namespace xm
 
 extern "C" {
 
@@ -217,7 +258,7 @@ int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int
   if (!g_moe_scratch || g_moe_scratch_elems < (size_t)nchunks * E) return XM_ERR_WORKSPACE;
   hipLaunchKernelGGL(moe_hist_kernel, dim3(nchunks), dim3(256), E * sizeof(int32_t), s, expert_id, n, E, g_moe_scratch);
   hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, g_moe_scratch, nchunks, E, expert_sizes);
-  hipLaunchKernelGGL(moe_place_kernel, dim3(nchunks), dim3(64), E * sizeof(int32_t), s, expert_id, n, E,
+  hipLaunchKernelGGL(moe_place_kernel, dim3(nchunks), dim3(1024), 0, s, expert_id, n, E,
                      g_moe_scratch, src_dst, dst_src);
   return hip_check_launch();
 }
@@ -229,6 +270,18 @@ int xllm_mi355_moe_combine(void* out, const void* gemm2, const float* weights, i
   XM_DISPATCH_FLOAT(dtype, T,
                     hipLaunchKernelGGL((moe_combine_kernel<T>), dim3(n_tokens), dim3(256), 0, (hipStream_t)stream,
                                        (T*)out, (const T*)gemm2, weights, (int)topk, (int)hidden));
+  return hip_check_launch();
+}
+
+int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, const int32_t* src_dst, const float* weights,
+                                  int64_t n_tokens, int64_t topk, int64_t hidden, int dtype, void* stream) {
+  if (!out || !gemm2_sorted || !src_dst || !weights || n_tokens < 0 || topk <= 0 || hidden <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (topk > 16 || hidden % 8 != 0 || ((uintptr_t)gemm2_sorted % 16) || ((uintptr_t)out % 16)) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  XM_DISPATCH_HALF(dtype, T,
+                   hipLaunchKernelGGL((moe_combine_sorted_kernel<T>), dim3(n_tokens), dim3(256), 0, (hipStream_t)stream,
+                                      (T*)out, (const T*)gemm2_sorted, src_dst, weights, (int)topk, (int)hidden));
   return hip_check_launch();
 }
 

@@ -459,6 +459,20 @@ def moe_combine_result(gemm2, weights, n_tokens: int, topk: int):
     return out
 
 
+def moe_combine_sorted(gemm2_sorted, src_dst, weights, n_tokens: int, topk: int):
+    """index_copy_ + kernel::moe_combine_result in one pass (layers/dcu/fused_moe.cpp:296-303): gemm2_sorted holds the rows
+    of the second grouped GEMM in expert order; out[t] = sum_k w[t,k] * gemm2_sorted[src_dst[t*topk+k]]."""
+    _need_cuda(gemm2_sorted, src_dst, weights)
+    H = gemm2_sorted.size(-1)
+    out = torch.empty(n_tokens, H, dtype=gemm2_sorted.dtype, device=gemm2_sorted.device)
+    gemm2_c = gemm2_sorted.contiguous()  # keep the (possibly new) tensors alive across the call
+    src_dst_c = src_dst.contiguous()
+    weights_c = weights.contiguous()
+    check(_lib.lib().xllm_mi355_moe_combine_sorted(_p(out), _p(gemm2_c), _p(src_dst_c), _p(weights_c), n_tokens, topk, H,
+                                                  _dt(gemm2_sorted), _stream()), "moe_combine_sorted")
+    return out
+
+
 def group_gemm(input, weight, token_count, output=None):
     """dcu::group_gemm(input [total, K], weight [E, N, K], token_count [E] int32 (device), out?) (dcu_ops_api.h:48-51)"""
     _need_cuda(input, weight, token_count)
