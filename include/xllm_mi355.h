@@ -350,6 +350,14 @@ XM_API int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, co
 XM_API int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out,
                                  int64_t max_rows, int64_t n_experts, int64_t N, int64_t K, int dtype,
                                  void* stream);
+/* group_gemm with the reference's expand step fused in (layers/dcu/fused_moe.cpp:195-197: `index_select(hidden,
+ * dst_src / topk)` then group_gemm): sorted row r of the grouped problem is row row_index[r] / index_div of `a`
+ * ([a_rows, K], the un-expanded activations); the expanded copy is never materialised. Runs on the 256x256 kernel only:
+ * XM_ERR_UNSUPPORTED (caller expands and calls group_gemm) when that kernel cannot take the shape or no MoE scratch is
+ * registered. Results are bit-identical to index_select + group_gemm. */
+XM_API int xllm_mi355_group_gemm_gather(const void* a, int64_t a_rows, const int32_t* row_index, int64_t index_div,
+                                        const void* w, const int32_t* token_count, void* out, int64_t max_rows,
+                                        int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@ elements; bf16 attention <= 1e-3 relative (L2 over the tensor) and <= 2 bf16 ulp
 element-wise; fp8 <= 2e-2.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -598,6 +599,34 @@ def test_moe_group_gemm_tile_table_path(T, topk, E, K, N):
     got = ops.group_gemm(xs.to(DEV), we.to(DEV), sizes)
     ref = orc.group_gemm(xs, we, r_sizes)
     assert_ulp_close(got, ref, torch.bfloat16, ulps=2.0, min_exact=0.9)
+    fused = ops.group_gemm_gather(x.to(DEV), dst_src, topk, we.to(DEV), sizes)   # expand fused into the A staging
+    assert fused is None or torch.equal(fused, got)
+    assert fused is not None or T * topk < max(1024, 64 * E) or os.environ.get("XLLM_MI355_GROUP_P8") == "0"
+
+
+def test_fused_moe_layer_matches_dense_reference_and_unfused_operators():
+    """FusedMoE.forward_experts (fused_moe.cpp:217-337): (a) fused expand / un-sort == the reference operator sequence,
+    bit for bit; (b) == a dense per-token evaluation of the selected experts with the same rounding points
+    (16-bit GEMM outputs, 16-bit SiLU * mul, fp32 weighted sum)"""
+    from xllm_amd import layers
+    T, H, I, E, topk = 1200, 512, 384, 16, 4
+    gd = torch.Generator(device=DEV).manual_seed(3)
+    moe = layers.FusedMoE(H, I, E, topk, torch.bfloat16, DEV, gd)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    logits = torch.randn(T, E, device=DEV, generator=gd).bfloat16()
+    out = moe.forward_experts(x, logits)
+    moe.fuse = False
+    assert torch.equal(moe.forward_experts(x, logits), out)
+    w, ids = ops.moe_fused_topk(logits, topk, True)
+    xf = x.float()
+    ref = torch.zeros(T, H, device=DEV)
+    for k in range(topk):
+        e = ids[:, k].long()
+        h13 = torch.einsum("th,tnh->tn", xf, moe.w13[e].float()).bfloat16().float()
+        act = (torch.nn.functional.silu(h13[:, :I]).bfloat16().float() * h13[:, I:]).bfloat16().float()
+        ref += w[:, k, None] * torch.einsum("ti,thi->th", act, moe.w2[e].float()).bfloat16().float()
+    got, ref = out.float(), ref.bfloat16().float()
+    assert ((got - ref).norm() / ref.norm()).item() <= 4e-3
 
 
 # ------------------------------------------------------------------------------------------- N1 fusions

@@ -34,6 +34,8 @@ us_topk, (w, ids) = timed(lambda: ops.moe_fused_topk(logits, topk, True))
 us_idx, (src_dst, dst_src, sizes) = timed(lambda: ops.moe_compute_index(ids, E))
 us_exp, xs = timed(lambda: x.index_select(0, (dst_src // topk).long()))
 us_g1, h13 = timed(lambda: ops.group_gemm(xs, w13, sizes))
+us_g1g, h13g = timed(lambda: ops.group_gemm_gather(x, dst_src, topk, w13, sizes))
+assert h13g is None or torch.equal(h13g, h13)
 act = torch.empty(T * topk, I, dtype=torch.bfloat16, device=dev)
 us_act, _ = timed(lambda: ops.act_and_mul(act, h13, "silu"))
 us_g2, h2 = timed(lambda: ops.group_gemm(act, w2, sizes))
@@ -43,7 +45,8 @@ us_comb, out = timed(lambda: ops.moe_combine_result(h2u, w, T, topk))
 us_fused, out2 = timed(lambda: ops.moe_combine_sorted(h2, src_dst, w, T, topk))
 assert torch.equal(out, out2)
 f1, f2 = 2 * T * topk * 2 * I * H, 2 * T * topk * H * I
-tot = us_topk + us_idx + us_exp + us_g1 + us_act + us_g2 + us_fused
-print(f"[moe cfg5] T={T}: topk {us_topk:.0f} | index {us_idx:.0f} | expand {us_exp:.0f} | w13 {us_g1:.0f} us ({f1 / us_g1 / 1e6:.0f} TF/s) | "
+g1g_txt = f"{us_g1g:.0f} us ({f1 / us_g1g / 1e6:.0f} TF/s)" if h13g is not None else "n/a (falls back)"
+tot = us_topk + us_idx + (us_g1g if h13g is not None else us_exp + us_g1) + us_act + us_g2 + us_fused
+print(f"[moe cfg5] T={T}: topk {us_topk:.0f} | index {us_idx:.0f} | (expand {us_exp:.0f} + w13 {us_g1:.0f} ->) w13 with gather {g1g_txt} | "
       f"act {us_act:.0f} | w2 {us_g2:.0f} us ({f2 / us_g2 / 1e6:.0f} TF/s) | (unsort {us_unsort:.0f} + combine {us_comb:.0f} ->) fused combine {us_fused:.0f} | "
       f"total {tot:.0f} us = {(f1 + f2) / tot / 1e6:.0f} TF/s   expert sizes min/max {int(sizes.min())}/{int(sizes.max())}")

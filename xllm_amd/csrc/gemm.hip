@@ -796,11 +796,13 @@ int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out,
   return launch_gemm<kF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
 }
 
-int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,
-                          int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream) {
+static int group_gemm_impl(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,
+                           int64_t n_experts, int64_t N, int64_t K, int dtype, const int32_t* gather_rows,
+                           int64_t gather_div, int64_t src_rows, void* stream) {
   if (!a || !w || !token_count || !out || max_rows < 0 || n_experts <= 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 64 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  if (gather_rows && (gather_div <= 0 || src_rows <= 0 || src_rows * K * 2 >= (1ll << 31))) return XM_ERR_INVALID;
   if (max_rows == 0) return XM_OK;
   GemmEpi epi{nullptr, 0, nullptr, 0, nullptr, out, nullptr, dtype == XM_BF16, token_count, (int)n_experts};
   hipStream_t s = (hipStream_t)stream;
@@ -816,15 +818,21 @@ int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_cou
   xm_moe_scratch(&scratch, &scratch_bytes);
   const int64_t slots = (max_rows + 255) / 256 + n_experts;
   const size_t table_bytes = (size_t)slots * 16;
-  if (p8_mode && scratch && scratch_bytes >= table_bytes + 64 && n_experts <= 1024 && max_rows >= 256 * 4) {
+  // 256-row tiles pay once the experts hold rows of their own: below ~64 rows per expert the launch streams weights only
+  if (p8_mode && scratch && scratch_bytes >= table_bytes + 64 && n_experts <= 1024 && max_rows >= 256 * 4 &&
+      max_rows >= 64 * n_experts) {
     int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));
     hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
     GemmEpi e2 = epi;
     e2.group_tiles = table;
+    e2.gather_rows = gather_rows;
+    e2.gather_div = (int)gather_div;
+    e2.gather_src_rows = (int)src_rows;
     const int rc = dtype == XM_BF16 ? launch_gemm_p8<kBF16>(a, w, max_rows, N, K * 2, e2, nullptr, 0, 1, s)
                                     : launch_gemm_p8<kF16>(a, w, max_rows, N, K * 2, e2, nullptr, 0, 1, s);
     if (rc != XM_ERR_UNSUPPORTED) return rc;
   }
+  if (gather_rows) return XM_ERR_UNSUPPORTED;  // the caller expands with index_select and calls group_gemm
   // worst case number of 128-row tiles over all experts: every expert may waste < 1 tile
   const int m_tiles = (int)((max_rows + BM - 1) / BM + n_experts);
   const int n_tiles = (int)((N + BN - 1) / BN);
@@ -837,6 +845,18 @@ int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_cou
     hipLaunchKernelGGL((gemm_kernel<kF16, false, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)a, (const uint8_t*)w,
                        (int)max_rows, (int)N, K * 2, m_tiles, n_tiles, ksteps, epi);
   return hip_check_launch();
+}
+
+int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,
+                          int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream) {
+  return group_gemm_impl(a, w, token_count, out, max_rows, n_experts, N, K, dtype, nullptr, 0, 0, stream);
+}
+
+int xllm_mi355_group_gemm_gather(const void* a, int64_t a_rows, const int32_t* row_index, int64_t index_div, const void* w,
+                                 const int32_t* token_count, void* out, int64_t max_rows, int64_t n_experts, int64_t N,
+                                 int64_t K, int dtype, void* stream) {
+  if (!row_index) return XM_ERR_INVALID;
+  return group_gemm_impl(a, w, token_count, out, max_rows, n_experts, N, K, dtype, row_index, index_div, a_rows, stream);
 }
 
 }  // extern "C"

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     nt = (SN << (5 - lm)) + (within >> lm);
     if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
   }
+  int grow0 = 0;  // first sorted row of the expert (gather mode)
   if (epi.group_tiles) {
     // grouped (MoE) mode, reference dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74): rows of A are sorted by expert,
     // expert e owns rows [off, off + cnt) and weight W[e]. m-tile slot mt -> (e, off, cnt, tile inside e) from the
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     const int goff = __builtin_amdgcn_readfirstlane(gt.y);
     M = __builtin_amdgcn_readfirstlane(gt.z);
     mt = __builtin_amdgcn_readfirstlane(gt.w);
-    A += (int64_t)goff * Kb;
+    if (!epi.gather_rows) A += (int64_t)goff * Kb;
     W += (int64_t)ge * N * Kb;
     epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)goff * N * 2;
+    grow0 = goff;
   }
   const int m0 = mt * P8_BM, n0 = nt * P8_BN;
   const int total_kt = (int)(Kb / P8_BK);
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
   // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
   // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(A), 0, (int)((int64_t)(epi.gather_rows ? epi.gather_src_rows : M) * Kb), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
   int voff_a[2][2], voff_w[2][2];  // [i][half]
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
         // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
         int ar = m0 + i * 128 + h * 64 + srow;
         ar = ar < M ? ar : M - 1;
+        if (epi.gather_rows) ar = epi.gather_rows[grow0 + ar] / epi.gather_div;  // expand fused into the staging
         voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
         // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
         int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);

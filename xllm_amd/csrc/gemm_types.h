@@ -76,6 +76,11 @@ struct GemmEpi {
   // grouped GEMM on the 256x256 kernels: DEVICE table built by group_plan_kernel, one int4 per m-tile slot =
   // (expert or -1, first row of the expert, rows of the expert, tile index inside the expert); null otherwise
   const int32_t* group_tiles;
+  // grouped GEMM with the expand fused in (layers/dcu/fused_moe.cpp:195-197: index_select(hidden, dst_src / topk)):
+  // sorted row r of the grouped problem is row gather_rows[r] / gather_div of A (A = the un-expanded activations)
+  const int32_t* gather_rows;
+  int gather_div;
+  int gather_src_rows;  // rows of the un-expanded A
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {

@@ -4,7 +4,8 @@ Reference: Qwen2DecoderLayerImpl::forward (xllm/core/layers/qwen2_decoder_layer.
 Qwen2AttentionImpl::forward (layers/common/qwen2_attention.cpp:132-193), DenseMLPImpl::forward
 (layers/common/dense_mlp.cpp:97-116), the w8a8-dynamic linear (layers/common/linear.cpp:481-507: scaled_quantize
 then scaled_matmul), Row/Column-parallel sharding (linear.cpp:616-716, 1405-1522) and
-LlmModelImplBase::forward (models/llm/llm_model_base.h:60-125) for the layer loop + final norm + lm_head.
+LlmModelImplBase::forward (models/llm/llm_model_base.h:60-125) for the layer loop + final norm + lm_head;
+FusedMoEImpl::forward_experts (layers/dcu/fused_moe.cpp:143-337) for the routed-expert FFN.
 
 Weights are synthetic (random-init of the architecture): this module is the fixed-shape harness of SURVEY 8d,
 not a checkpoint loader.
@@ -271,6 +272,45 @@ class Qwen2Model:
     def logits(self, hidden):
         y = self.lm_head.forward(hidden)
         return parallel.gather(y, self.tp)
+
+
+class FusedMoE:
+    """FusedMoEImpl (layers/dcu/fused_moe.cpp:143-337), one expert-parallel rank (all experts local), bf16 like the
+    reference's DCU path: select_experts = fused gating top-k + index build, expand, grouped GEMM w13
+    [E, 2 * I / tp, H], SiLU * mul, grouped GEMM w2 [E, H, I / tp], weighted combine, all-reduce over TP.
+    Differences from the reference, none of them visible in the result: the expanded activations and the un-sorted
+    second GEMM output are never materialised (group_gemm_gather / moe_combine_sorted fuse the index_select and the
+    index_copy_), and nothing reads a device tensor on the host, so the whole layer is graph-capturable."""
+
+    def __init__(self, hidden: int, inter: int, n_experts: int, topk: int, dtype, device, gen, renormalize: bool = True,
+                 scoring_func: str = "softmax", correction_bias=None, tp: Optional[parallel.ProcessGroup] = None,
+                 fuse: bool = True):
+        self.E, self.topk, self.renorm, self.scoring, self.bias, self.tp, self.fuse = (
+            n_experts, topk, renormalize, scoring_func, correction_bias, tp, fuse)
+        tp_size = tp.world_size() if tp is not None else 1
+        assert inter % tp_size == 0
+        i_local = inter // tp_size
+        self.w13 = (torch.randn(n_experts, 2 * i_local, hidden, device=device, generator=gen) / math.sqrt(hidden)).to(dtype)
+        self.w2 = (torch.randn(n_experts, hidden, i_local, device=device, generator=gen) / math.sqrt(inter)).to(dtype)
+
+    def forward_experts(self, hidden_states, router_logits):
+        x = hidden_states.reshape(-1, hidden_states.size(-1))
+        T = x.size(0)
+        weights, ids = ops.moe_fused_topk(router_logits.reshape(T, -1), self.topk, self.renorm, self.bias, self.scoring)
+        src_dst, dst_src, sizes = ops.moe_compute_index(ids, self.E)
+        h13 = ops.group_gemm_gather(x, dst_src, self.topk, self.w13, sizes) if self.fuse else None
+        if h13 is None:  # reference order: expand with index_select, then the grouped GEMM
+            h13 = ops.group_gemm(x.index_select(0, (dst_src // self.topk).long()), self.w13, sizes)
+        act = torch.empty(h13.size(0), h13.size(1) // 2, dtype=h13.dtype, device=h13.device)
+        ops.act_and_mul(act, h13, "silu")
+        h2 = ops.group_gemm(act, self.w2, sizes)
+        if self.fuse:
+            out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk)
+        else:
+            full = torch.empty_like(h2)
+            full.index_copy_(0, dst_src.long(), h2)
+            out = ops.moe_combine_result(full, weights, T, self.topk)
+        return parallel.reduce(out, self.tp).reshape(hidden_states.shape)
 
 
 class DualBatchDecoder:

@@ -485,6 +485,24 @@ def group_gemm(input, weight, token_count, output=None):
     return out
 
 
+def group_gemm_gather(input, row_index, index_div: int, weight, token_count):
+    """index_select(input, row_index / index_div) + dcu::group_gemm without the expanded copy (layers/dcu/fused_moe.cpp:195-197,
+    250-262); returns None when the 256x256 kernel cannot take the shape (the caller then expands and calls group_gemm)"""
+    _need_cuda(input, row_index, weight, token_count)
+    E, N, K = weight.shape
+    rows = row_index.numel()
+    out = torch.empty(rows, N, dtype=input.dtype, device=input.device)
+    input_c = input.contiguous()  # keep the (possibly new) tensors alive across the call
+    weight_c = weight.contiguous()
+    index_c = row_index.contiguous()
+    rc = _lib.lib().xllm_mi355_group_gemm_gather(_p(input_c), input.size(0), _p(index_c), index_div, _p(weight_c),
+                                                 _p(token_count), _p(out), rows, E, N, K, _dt(input), _stream())
+    if rc == -2:  # XM_ERR_UNSUPPORTED
+        return None
+    check(rc, "group_gemm_gather")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ N1 fusions
 def rotary_embedding_and_cache(positions, query, key, value, cos_sin_cache, slot_ids, key_cache, value_cache,
                                head_size: int, is_neox: bool = True) -> None:
