@@ -52,6 +52,7 @@ def parse():
                         "layers of the other; xllm_amd.layers.DualBatchDecoder), TP=1 only")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
+    p.add_argument("--no-engine", action="store_true", help="skip the step-level harness leg (xllm_amd.engine.DecodeEngine)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
@@ -61,20 +62,14 @@ def parse():
 
 def build_metadata(B, ctx, block_size, device, seed):
     """BatchInputBuilder-shaped decode metadata (framework/batch/batch_input_builder.cpp:739-830, 904-938)."""
-    from xllm_amd.attention import AttentionMetadata
     pages = (ctx + block_size - 1) // block_size
     n_blocks = int(B * pages * 1.1) + 1
     g = torch.Generator().manual_seed(seed)
     perm = torch.randperm(n_blocks, generator=g)[: B * pages].to(torch.int32).view(B, pages)
-    pos = ctx - 1  # the new token
-    slots = perm[:, pos // block_size] * block_size + pos % block_size
-    md = AttentionMetadata(
-        q_cu_seq_lens=torch.arange(B + 1, dtype=torch.int32, device=device),
-        kv_cu_seq_lens=torch.arange(0, (B + 1) * ctx, ctx, dtype=torch.int32, device=device),
-        kv_seq_lens=torch.full((B,), ctx, dtype=torch.int32, device=device),
-        slot_mapping=slots.to(torch.int32).to(device),
-        block_table=perm.contiguous().to(device),
-        max_query_len=1, max_seq_len=ctx, is_prefill=False, is_chunked_prefill=False)
+    # the product's own host-side builder (C++ behind the C ABI): one new token per sequence, ctx - 1 already cached
+    from xllm_amd import attention
+    bi = attention.build_batch_input([ctx - 1] * B, [ctx] * B, perm.tolist(), block_size)
+    md = attention.build_attention_metadata(bi, is_prefill=False, is_chunked_prefill=False, device=device)
     return md, n_blocks
 
 
@@ -322,6 +317,10 @@ def main():
     if not a.no_prefill and a.config == "cfg3":
         prefill = prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all)
 
+    engine_info = None
+    if world == 1 and not a.no_engine and dual is None and tp_size == 1:
+        engine_info = engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, a.steps, margs)
+
     if a.micro and rank == 0:
         micro(model, md, kv_caches, tokens, positions, B, sys.stderr)
 
@@ -345,6 +344,8 @@ def main():
         }
         if prefill is not None:
             out["prefill"] = prefill
+        if engine_info is not None:
+            out["engine"] = engine_info
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
         print(json.dumps(out), flush=True)
@@ -352,22 +353,46 @@ def main():
         dist.destroy_process_group()
 
 
+def engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, steps, margs):
+    """the same decode workload driven through the step-level harness (SURVEY 8f N2 + N3): per step the HOST builds the
+    batch's indexing data, one H2D copy, device-side metadata refresh, ONE graph replay (model + lm_head + argmax) and
+    the sampled tokens come back to the host -- the sequences really advance by one token per step. Reported beside the
+    headline number (which times the graph alone): the difference is the per-step host work + the D2H sync."""
+    from xllm_amd import engine
+    warm = 2
+    pages = (ctx + warm + steps + block_size - 1) // block_size
+    if B * pages > n_blocks:
+        return None
+    g = torch.Generator().manual_seed(4321)
+    blocks = torch.randperm(n_blocks, generator=g)[: B * pages].view(B, pages).tolist()
+    first = torch.randint(0, margs.vocab_size, (B,), generator=g).to(torch.int32).to(dev)
+    eng = engine.DecodeEngine(model, kv_caches, block_size, [ctx - 1] * B, blocks, first, ctx + warm + steps, 0.0)
+    for _ in range(warm):
+        eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"ms_per_step": round(el / steps * 1e3, 4), "tokens_per_s": round(B * steps / el, 2), "steps": steps,
+            "what": "xllm_amd.engine.DecodeEngine: host batch builder + H2D + device metadata refresh + graph replay + "
+                    "argmax + D2H per step, sequences grow from ctx-1"}
+
+
 def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all):
     """prefill TFLOPS (second half of the BASELINE metric): one chunk of 2 x ctx tokens through the
     full model -- causal varlen flash attention, W8A8 GEMMs at M = 8192, KV written to fresh pages; logits only
     for the last token of each sequence (llm_model_base.h:193-204). flops = 2*T*sum(N*K) + 2*nq*d*S^2*L per seq."""
-    from xllm_amd.attention import AttentionMetadata
+    from xllm_amd import attention
     nseq = 2
     T = nseq * ctx
     pages = ctx // block_size
     table = torch.arange(nseq * pages, dtype=torch.int32).view(nseq, pages)
-    slots = (table.repeat_interleave(block_size, 1) * block_size + torch.arange(block_size).repeat(pages)).flatten()
-    cu = torch.arange(0, (nseq + 1) * ctx, ctx, dtype=torch.int32, device=dev)
-    md = AttentionMetadata(q_cu_seq_lens=cu, kv_cu_seq_lens=cu, kv_seq_lens=torch.full((nseq,), ctx, dtype=torch.int32, device=dev),
-                           slot_mapping=slots.to(torch.int32).to(dev), block_table=table.to(dev), max_query_len=ctx,
-                           max_seq_len=ctx, is_prefill=True)
+    bi = attention.build_batch_input([0] * nseq, [ctx] * nseq, table.tolist(), block_size)   # nothing cached: pure prefill
+    md = attention.build_attention_metadata(bi, is_prefill=True, is_chunked_prefill=False, device=dev)
     tokens = torch.randint(0, margs.vocab_size, (T,), device=dev)
-    positions = torch.arange(ctx, device=dev).repeat(nseq)
+    positions = bi.positions.to(dev).long()
     last = torch.arange(ctx - 1, T, ctx, device=dev)
 
     def chunk():

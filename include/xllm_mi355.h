@@ -359,6 +359,45 @@ XM_API int xllm_mi355_group_gemm_gather(const void* a, int64_t a_rows, const int
                                         const void* w, const int32_t* token_count, void* out, int64_t max_rows,
                                         int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * HOST side of the path: per-step indexing data, built on the CPU as the reference's BatchInputBuilder does.
+ * No GPU is touched by these two entry points.
+ *
+ * xllm_mi355_host_cache_slots = KVCacheState::cache_slots (framework/request/sequence_kv_state.cpp:86-104):
+ *   slots[i - pos_start] = block_ids[i / block_size] * block_size + i % block_size for i in [pos_start, pos_end).
+ * xllm_mi355_host_build_batch = BatchInputBuilder::setup_kv_cache_info + finalisation on the CUDA / DCU branch
+ *   (framework/batch/batch_input_builder.cpp:525-537, 739-830, 900-938) and the length bookkeeping of
+ *   build_attention_metadata (layers/common/attention_metadata_builder.cpp:45-244): for sequence b with
+ *   n_kv_cache_tokens[b] tokens already cached and seq_lens[b] tokens after this step (q = the difference) and the
+ *   blocks block_ids[block_indptr[b] .. block_indptr[b+1]):
+ *     new_cache_slots / positions [sum q], paged_kv_indptr [B+1], paged_kv_indices [sum blocks],
+ *     paged_kv_last_page_len [B] (= len % block_size, or block_size), block_tables [B, max_blocks] padded with 0,
+ *     q_cu_seq_lens / kv_cu_seq_lens [B+1] (cumulative, leading 0), q_seq_lens / kv_seq_lens [B] (their differences),
+ *     q_max_seq_len, kv_max_seq_len, total_kv_len.
+ *   Output arrays are caller-owned host buffers with capacities cap_*; a null array is skipped. The counts
+ *   (n_tokens, n_indices, max_blocks) are always written; XM_ERR_WORKSPACE = a capacity is too small (size the buffers from
+ *   the counts and call again). XM_ERR_INVALID where the reference CHECK-fails (no blocks, sequence longer than its pages). */
+typedef struct {
+  int64_t cap_tokens, cap_indices, cap_sequences, cap_block_table; /* in: capacities (elements) of the arrays below */
+  int32_t* new_cache_slots;
+  int32_t* positions;
+  int32_t* paged_kv_indptr;
+  int32_t* paged_kv_indices;
+  int32_t* paged_kv_last_page_len;
+  int32_t* block_tables;
+  int32_t* q_cu_seq_lens;
+  int32_t* kv_cu_seq_lens;
+  int32_t* q_seq_lens;
+  int32_t* kv_seq_lens;
+  int32_t num_sequences, q_max_seq_len, kv_max_seq_len; /* out */
+  int64_t n_tokens, n_indices, max_blocks, total_kv_len; /* out */
+} xllm_mi355_host_batch_t;
+XM_API int xllm_mi355_host_cache_slots(const int32_t* block_ids, int64_t n_blocks, int64_t block_size, int64_t pos_start,
+                                       int64_t pos_end, int32_t* slots);
+XM_API int xllm_mi355_host_build_batch(const int32_t* n_kv_cache_tokens, const int32_t* seq_lens,
+                                       const int32_t* block_indptr, const int32_t* block_ids, int64_t num_sequences,
+                                       int64_t block_size, xllm_mi355_host_batch_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -906,3 +906,60 @@ def test_dual_micro_batch_decoder_equals_single_batch_step():
         out = dual.forward(tokens, positions, caches)
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------------- N3: step-level harness
+@pytest.mark.parametrize("temperature", [0.0, 0.8])
+def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):
+    """xllm_amd.engine.DecodeEngine (host batch builder -> H2D -> device metadata refresh -> one graph replay -> sampler)
+    produces, step after step, the tokens and the KV cache of a loop that rebuilds fresh metadata tensors from the oracle
+    every step and calls the model eagerly; graph replay == eager engine."""
+    from xllm_amd import engine, layers
+    from xllm_amd.attention import AttentionMetadata, KVCache
+    args = layers.ModelArgs(512, 2, 8, 2, 64, 1024, 1000, 1e-6, 1e4, 4096)
+    bs, B, steps = 16, 5, 6
+    lens0 = [33, 16, 1, 47, 20]
+    g = torch.Generator().manual_seed(5)
+    need = [(L + steps + bs - 1) // bs for L in lens0]
+    perm = torch.randperm(sum(need) + 3, generator=g).tolist()
+    blocks, used = [], 0
+    for n in need:
+        blocks.append(perm[used:used + n]); used += n
+    nb = sum(need) + 3
+    model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=7)
+    first = torch.randint(0, args.vocab_size, (B,), generator=g).to(torch.int32)
+
+    def fresh_caches():
+        gd = torch.Generator(device=DEV).manual_seed(11)
+        return [KVCache(torch.empty(nb, bs, 2, 64, dtype=torch.bfloat16, device=DEV).normal_(generator=gd),
+                        torch.empty(nb, bs, 2, 64, dtype=torch.bfloat16, device=DEV).normal_(generator=gd))
+                for _ in model.layers]
+
+    runs = []
+    for use_graph in (True, False):
+        caches = fresh_caches()
+        eng = engine.DecodeEngine(model, caches, bs, lens0, blocks, first.to(DEV), max(lens0) + steps, temperature, seed=3,
+                                  use_graph=use_graph)
+        toks = [eng.step() for _ in range(steps)]
+        runs.append((torch.stack(toks), caches))
+        assert eng.seq_lens == [L + steps for L in lens0]
+    assert torch.equal(runs[0][0], runs[1][0])
+    # hand-driven loop: oracle metadata, fresh tensors, eager model
+    caches, lens, cur, ref = fresh_caches(), list(lens0), first.clone(), []
+    for s in range(steps):
+        md_o = orc.build_batch_metadata([n + 1 for n in lens], [1] * B, blocks, bs)
+        md = AttentionMetadata(q_cu_seq_lens=md_o["q_cu_seq_lens"].to(DEV), kv_cu_seq_lens=md_o["kv_cu_seq_lens"].to(DEV),
+                               kv_seq_lens=md_o["kv_seq_lens"].to(DEV), slot_mapping=md_o["new_cache_slots"].to(DEV),
+                               block_table=md_o["block_tables"].to(DEV), max_query_len=1, max_seq_len=max(lens) + 1)
+        hidden = model.forward(cur.long().to(DEV), torch.tensor(lens, device=DEV), md, caches)
+        logits = model.logits(hidden)
+        if temperature <= 0:
+            cur = torch.argmax(logits, -1).to(torch.int32).cpu()
+        else:
+            cur = ops.random_sample(torch.softmax(logits.float() / temperature, -1),
+                                    uniform=ops.philox_uniform(B, 3, s, device=DEV)).cpu()
+        ref.append(cur)
+        lens = [n + 1 for n in lens]
+    assert torch.equal(torch.stack(ref), runs[0][0])
+    for a, b in zip(caches, runs[0][1]):
+        assert torch.equal(a.k_cache, b.k_cache) and torch.equal(a.v_cache, b.v_cache)

@@ -26,7 +26,20 @@ class DecodeMetadata(C.Structure):
         [("dst_block_table", vp), ("dst_kv_lens", vp), ("max_blocks_per_seq", i64), ("padded_batch_size", i64)])
 
 
+
+class HostBatch(C.Structure):
+    """xllm_mi355_host_batch_t (include/xllm_mi355.h)"""
+    _fields_ = ([(n, i64) for n in ("cap_tokens", "cap_indices", "cap_sequences", "cap_block_table")] +
+                [(n, vp) for n in ("new_cache_slots", "positions", "paged_kv_indptr", "paged_kv_indices",
+                                   "paged_kv_last_page_len", "block_tables", "q_cu_seq_lens", "kv_cu_seq_lens",
+                                   "q_seq_lens", "kv_seq_lens")] +
+                [(n, i32) for n in ("num_sequences", "q_max_seq_len", "kv_max_seq_len")] +
+                [(n, i64) for n in ("n_tokens", "n_indices", "max_blocks", "total_kv_len")])
+
+
 _SIGS = {
+    "xllm_mi355_host_cache_slots": ([vp, i64, i64, i64, i64, vp], ci),
+    "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
     "xllm_mi355_decode_metadata_update": ([C.POINTER(DecodeMetadata), vp], ci),
     "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),

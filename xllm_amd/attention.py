@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 @dataclass
@@ -34,6 +34,82 @@ class AttentionMetadata:
     @property
     def is_causal(self) -> bool:  # attention_metadata_builder.cpp:240-241
         return self.is_prefill or self.is_chunked_prefill
+
+
+@dataclass
+class BatchInput:
+    """The per-step indexing data of a batch: what BatchInputBuilder leaves in ModelInputParams.attention
+    (framework/batch/batch_input_builder.cpp:900-938, CUDA / DCU branch). Host int32 tensors."""
+    new_cache_slots: torch.Tensor        # [sum q]
+    positions: torch.Tensor              # [sum q]
+    paged_kv_indptr: torch.Tensor        # [B+1]
+    paged_kv_indices: torch.Tensor       # [sum blocks]
+    paged_kv_last_page_len: torch.Tensor  # [B]
+    block_tables: torch.Tensor           # [B, max_blocks], padded with 0
+    q_cu_seq_lens: torch.Tensor          # [B+1] cumulative, leading 0 (ModelInputParams calls it q_seq_lens)
+    kv_cu_seq_lens: torch.Tensor         # [B+1] cumulative, leading 0 (ModelInputParams calls it kv_seq_lens)
+    q_seq_lens: torch.Tensor             # [B]
+    kv_seq_lens: torch.Tensor            # [B]
+    q_max_seq_len: int
+    kv_max_seq_len: int
+    total_kv_len: int
+
+
+def cache_slots(block_ids, block_size: int, pos_start: int, pos_end: int) -> torch.Tensor:
+    """KVCacheState::cache_slots (framework/request/sequence_kv_state.cpp:86-104)"""
+    blocks = torch.as_tensor(block_ids, dtype=torch.int32).contiguous()
+    out = torch.empty(max(pos_end - pos_start, 0), dtype=torch.int32)
+    _lib.check(_lib.lib().xllm_mi355_host_cache_slots(blocks.data_ptr(), blocks.numel(), block_size, pos_start, pos_end,
+                                                      out.data_ptr()), "host_cache_slots")
+    return out
+
+
+def build_batch_input(n_kv_cache_tokens, seq_lens, block_ids_per_seq, block_size: int) -> BatchInput:
+    """BatchInputBuilder::setup_kv_cache_info + finalisation (batch_input_builder.cpp:525-537, 739-830, 900-938): sequence
+    b has n_kv_cache_tokens[b] tokens in the cache, seq_lens[b] after this step and owns block_ids_per_seq[b]."""
+    B = len(seq_lens)
+    cached = torch.as_tensor(n_kv_cache_tokens, dtype=torch.int32).contiguous()
+    lens = torch.as_tensor(seq_lens, dtype=torch.int32).contiguous()
+    indptr = torch.zeros(B + 1, dtype=torch.int32)
+    if B:
+        indptr[1:] = torch.cumsum(torch.tensor([len(b) for b in block_ids_per_seq], dtype=torch.int64), 0).to(torch.int32)
+    flat = torch.tensor([int(x) for b in block_ids_per_seq for x in b], dtype=torch.int32)
+    hb = _lib.HostBatch()  # first call with zero capacities: counts only
+    rc = _lib.lib().xllm_mi355_host_build_batch(cached.data_ptr(), lens.data_ptr(), indptr.data_ptr(), flat.data_ptr(), B,
+                                                block_size, hb)
+    if rc not in (0, -4):  # -4 = XM_ERR_WORKSPACE: the counts are valid, the buffers are not sized yet
+        _lib.check(rc, "host_build_batch")
+    i32 = lambda n: torch.empty(int(n), dtype=torch.int32)
+    bufs = dict(new_cache_slots=i32(hb.n_tokens), positions=i32(hb.n_tokens), paged_kv_indptr=i32(B + 1),
+                paged_kv_indices=i32(hb.n_indices), paged_kv_last_page_len=i32(B),
+                block_tables=torch.empty(B, int(hb.max_blocks), dtype=torch.int32), q_cu_seq_lens=i32(B + 1),
+                kv_cu_seq_lens=i32(B + 1), q_seq_lens=i32(B), kv_seq_lens=i32(B))
+    hb.cap_tokens, hb.cap_indices, hb.cap_sequences, hb.cap_block_table = hb.n_tokens, hb.n_indices, B, B * hb.max_blocks
+    for k, t in bufs.items():
+        setattr(hb, k, t.data_ptr())
+    _lib.check(_lib.lib().xllm_mi355_host_build_batch(cached.data_ptr(), lens.data_ptr(), indptr.data_ptr(),
+                                                      flat.data_ptr(), B, block_size, hb), "host_build_batch")
+    return BatchInput(q_max_seq_len=int(hb.q_max_seq_len), kv_max_seq_len=int(hb.kv_max_seq_len),
+                      total_kv_len=int(hb.total_kv_len), **bufs)
+
+
+def build_attention_metadata(batch: BatchInput, is_prefill: bool, is_chunked_prefill: bool, device) -> "AttentionMetadata":
+    """build_attention_metadata, DCU branch (layers/common/attention_metadata_builder.cpp:45-244): cumulative lengths
+    straight from the batch, per-sequence lengths = their differences, block table for every phase but pure prefill,
+    the dummy batch of :214-232 when no sequence has a query token."""
+    to = lambda t: t.to(device, non_blocking=True)
+    md = AttentionMetadata(
+        q_cu_seq_lens=to(batch.q_cu_seq_lens), kv_cu_seq_lens=to(batch.kv_cu_seq_lens), kv_seq_lens=to(batch.kv_seq_lens),
+        slot_mapping=to(batch.new_cache_slots), block_table=to(batch.block_tables),
+        max_query_len=batch.q_max_seq_len, max_seq_len=batch.kv_max_seq_len, is_prefill=is_prefill,
+        is_chunked_prefill=is_chunked_prefill, paged_kv_indptr=to(batch.paged_kv_indptr),
+        paged_kv_indices=to(batch.paged_kv_indices), paged_kv_last_page_len=to(batch.paged_kv_last_page_len))
+    if batch.q_max_seq_len == 0:  # is_dummy
+        one = torch.ones(1, dtype=torch.int32, device=device)
+        md.slot_mapping, md.kv_seq_lens = one, one.clone()
+        md.q_cu_seq_lens = torch.tensor([0, 1], dtype=torch.int32, device=device)
+        md.max_query_len, md.max_seq_len = 1, max(md.max_seq_len, 1)
+    return md
 
 
 class KVCache:
