@@ -70,3 +70,18 @@ def test_batch_input_rejects_what_the_reference_check_fails_on():
         attention.cache_slots([1, 2], 16, 0, 33)
     empty = attention.build_batch_input([], [], [], 16)
     assert empty.q_cu_seq_lens.tolist() == [0] and empty.block_tables.shape == (0, 0)
+
+
+def test_batch_builder_reuses_buffers_and_matches_the_one_shot_builder():
+    cached, seq_lens, blocks = _case(21, 9, 16, 200, decode=True)
+    bb = attention.BatchBuilder(blocks, 16, max_tokens=9)
+    for step in range(3):
+        c = [x + step for x in cached]
+        L = [x + step for x in seq_lens]
+        if any(n > len(b) * 16 for n, b in zip(L, blocks)):
+            break
+        got, ref = bb.build(c, L), attention.build_batch_input(c, L, blocks, 16)
+        for k in ("new_cache_slots", "positions", "paged_kv_indptr", "paged_kv_indices", "paged_kv_last_page_len",
+                  "block_tables", "q_cu_seq_lens", "kv_cu_seq_lens", "q_seq_lens", "kv_seq_lens"):
+            assert torch.equal(getattr(got, k), getattr(ref, k)), k
+        assert (got.q_max_seq_len, got.kv_max_seq_len, got.total_kv_len) == (ref.q_max_seq_len, ref.kv_max_seq_len, ref.total_kv_len)

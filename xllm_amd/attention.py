@@ -93,6 +93,44 @@ def build_batch_input(n_kv_cache_tokens, seq_lens, block_ids_per_seq, block_size
                       total_kv_len=int(hb.total_kv_len), **bufs)
 
 
+class BatchBuilder:
+    """build_batch_input for a FIXED set of sequences and pages, called every step (the engine's decode loop): the block
+    lists are flattened once and the output buffers are reused, so a step costs one C call and no allocation. The
+    returned BatchInput aliases the builder's buffers (valid until the next build)."""
+
+    def __init__(self, block_ids_per_seq, block_size: int, max_tokens: int):
+        self.B, self.block_size = len(block_ids_per_seq), block_size
+        B = self.B
+        self._indptr = torch.zeros(B + 1, dtype=torch.int32)
+        if B:
+            self._indptr[1:] = torch.cumsum(torch.tensor([len(b) for b in block_ids_per_seq], dtype=torch.int64), 0).to(torch.int32)
+        self._flat = torch.tensor([int(x) for b in block_ids_per_seq for x in b], dtype=torch.int32)
+        n_idx, max_blocks = self._flat.numel(), max((len(b) for b in block_ids_per_seq), default=0)
+        i32 = lambda n: torch.empty(int(n), dtype=torch.int32)
+        self._bufs = dict(new_cache_slots=i32(max_tokens), positions=i32(max_tokens), paged_kv_indptr=i32(B + 1),
+                          paged_kv_indices=i32(n_idx), paged_kv_last_page_len=i32(B),
+                          block_tables=torch.empty(B, max_blocks, dtype=torch.int32), q_cu_seq_lens=i32(B + 1),
+                          kv_cu_seq_lens=i32(B + 1), q_seq_lens=i32(B), kv_seq_lens=i32(B))
+        self._hb = _lib.HostBatch()
+        self._hb.cap_tokens, self._hb.cap_indices, self._hb.cap_sequences = max_tokens, n_idx, B
+        self._hb.cap_block_table = B * max_blocks
+        for k, t in self._bufs.items():
+            setattr(self._hb, k, t.data_ptr())
+        self._cached, self._lens = i32(B), i32(B)
+
+    def build(self, n_kv_cache_tokens, seq_lens) -> BatchInput:
+        self._cached.copy_(torch.as_tensor(n_kv_cache_tokens, dtype=torch.int32))
+        self._lens.copy_(torch.as_tensor(seq_lens, dtype=torch.int32))
+        hb = self._hb
+        _lib.check(_lib.lib().xllm_mi355_host_build_batch(self._cached.data_ptr(), self._lens.data_ptr(),
+                                                          self._indptr.data_ptr(), self._flat.data_ptr(), self.B,
+                                                          self.block_size, hb), "host_build_batch")
+        b = dict(self._bufs)
+        b["new_cache_slots"], b["positions"] = b["new_cache_slots"][:hb.n_tokens], b["positions"][:hb.n_tokens]
+        return BatchInput(q_max_seq_len=int(hb.q_max_seq_len), kv_max_seq_len=int(hb.kv_max_seq_len),
+                          total_kv_len=int(hb.total_kv_len), **b)
+
+
 def build_attention_metadata(batch: BatchInput, is_prefill: bool, is_chunked_prefill: bool, device) -> "AttentionMetadata":
     """build_attention_metadata, DCU branch (layers/common/attention_metadata_builder.cpp:45-244): cumulative lengths
     straight from the batch, per-sequence lengths = their differences, block table for every phase but pure prefill,

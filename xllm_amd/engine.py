@@ -36,7 +36,7 @@ class DecodeEngine:
         self.model, self.kv_caches, self.block_size = model, kv_caches, block_size
         self.dev = last_tokens.device
         self.B = len(seq_lens)
-        self.seq_lens: List[int] = [int(x) for x in seq_lens]
+        self.seq_lens_init: List[int] = [int(x) for x in seq_lens]
         self.blocks = [list(map(int, b)) for b in block_ids_per_seq]
         self.max_seq_len, self.temperature, self.seed, self.step_no = int(max_seq_len), float(temperature), int(seed), 0
         B = self.B
@@ -64,6 +64,8 @@ class DecodeEngine:
             q_cu_seq_lens=torch.arange(B + 1, dtype=torch.int32, device=self.dev), kv_cu_seq_lens=self.dst["kv_seq_lens"],
             kv_seq_lens=self.dst["kv_lens"], slot_mapping=self.dst["new_cache_slots"], block_table=self.dst["block_table"],
             max_query_len=1, max_seq_len=self.max_seq_len, is_prefill=False, is_chunked_prefill=False)
+        self._builder = attention.BatchBuilder(self.blocks, block_size, max_tokens=B)
+        self._lens_t = torch.tensor(self.seq_lens_init, dtype=torch.int32)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._use_graph = use_graph
         self._out = None
@@ -79,11 +81,13 @@ class DecodeEngine:
         probs = torch.softmax(logits.float() / self.temperature, dim=-1)
         return ops.random_sample(probs, uniform=self._uniform)
 
+    @property
+    def seq_lens(self) -> List[int]:
+        return self._lens_t.tolist()
+
     def _host_batch(self) -> None:
         """BatchInputBuilder for a decode step: one new token per sequence, the rest of it cached"""
-        cached = self.seq_lens
-        lens = [n + 1 for n in cached]
-        bi = attention.build_batch_input(cached, lens, self.blocks, self.block_size)
+        bi = self._builder.build(self._lens_t, self._lens_t + 1)
         parts = {"tokens": self._next_host, "positions": bi.positions, "new_cache_slots": bi.new_cache_slots,
                  "kv_seq_lens": bi.kv_cu_seq_lens, "paged_kv_indptr": bi.paged_kv_indptr,
                  "paged_kv_indices": bi.paged_kv_indices, "paged_kv_last_page_len": bi.paged_kv_last_page_len}
@@ -94,8 +98,8 @@ class DecodeEngine:
 
     def step(self) -> torch.Tensor:
         """one engine step; returns the sampled tokens (host int32 [B]) and extends every sequence by one token"""
-        if any(n + 1 > self.max_seq_len or n + 1 > len(b) * self.block_size for n, b in zip(self.seq_lens, self.blocks)):
-            raise ValueError("a sequence would outgrow its pre-assigned pages / the planned max_seq_len")
+        if int(self._lens_t.max()) + 1 > self.max_seq_len:  # (the builder itself rejects a sequence that outgrows its pages)
+            raise ValueError("a sequence would outgrow the planned max_seq_len")
         self._host_batch()
         self._stage.copy_(self._host, non_blocking=True)
         ops.decode_metadata_update(self.src, self.dst, self.B, self.B, self.B, self.n_idx, self.B)
@@ -115,6 +119,6 @@ class DecodeEngine:
             self._graph.replay()
         out = self._out.cpu()                          # the step's host sync: the scheduler needs the tokens
         self._next_host = out
-        self.seq_lens = [n + 1 for n in self.seq_lens]
+        self._lens_t += 1
         self.step_no += 1
         return out
