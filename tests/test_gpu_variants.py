@@ -46,7 +46,8 @@ def test_mla_parity_under_kernel_selector(env):
 @pytest.mark.parametrize("env", [
     {"XLLM_MI355_PREFILL_DMA": "0"},                         # register-staged flash prefill kernel for head dim 128 too
     {"XLLM_MI355_PREFILL_DMA": "2"},                         # ping-pong wave groups (256 queries per workgroup)
-], ids=["prefill_regstaged", "prefill_pingpong"])
+    {"XLLM_MI355_PREFILL_DMA": "3"},                         # the same two groups, offset by half a tile, one barrier per tile
+], ids=["prefill_regstaged", "prefill_pingpong", "prefill_pingpong_free"])
 def test_prefill_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

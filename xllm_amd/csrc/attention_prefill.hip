@@ -491,12 +491,12 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
 
 // NW = 8: ping-pong groups, 256 queries per workgroup, one workgroup per CU. NW = 4: one group, 128 queries per
 // workgroup, two workgroups per CU (short query blocks: no second group to alternate with).
-template <typename T, bool PAGED, int NW>
+template <typename T, bool PAGED, int NW, bool MIDBAR>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, const int32_t* __restrict__ kv_lens,
     const int32_t* __restrict__ block_table, int max_blocks, int nq, int nkv, int block_size, int64_t q_stride,
-    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left) {
+    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left, int n_seqs, int n_qblocks) {
   using TR = PfTraits<T>;
   using x8 = typename TR::x8;
   constexpr int D = 128, KK = D / 32, DB = D / 16;
@@ -511,8 +511,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = NW == 8 ? wave >> 2 : 0;
   const int p16 = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x, b = blockIdx.z;
-  const int qb = gridDim.y - 1 - blockIdx.y;  // heaviest (latest) causal blocks first
+  // 1-D grid, dispatched in order: the q block is the SLOWEST index and runs from the last (heaviest under a causal
+  // mask) to the first, so the long workgroups of EVERY sequence start first and the short ones fill the tail
+  // (with a (head, q block, sequence) grid the heaviest blocks of the last sequence started last: +12 % makespan)
+  const int h = blockIdx.x % nq, b = (blockIdx.x / nq) % n_seqs;
+  const int qb = n_qblocks - 1 - blockIdx.x / (nq * n_seqs);
   const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
   const int q0 = qb * QB;
   if (q0 >= q_len) return;
@@ -662,25 +665,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
       for (int i = 0; i <= nt; ++i) {
         PF_EVEN_STEP(i)
         mfma_block(i);
-        if constexpr (NW == 8) __syncthreads();
+        if constexpr (NW == 8 && MIDBAR) __syncthreads();
         softmax_block(i);
       }
     } else {
       for (int i = 0; i <= nt; ++i) {
         PF_EVEN_STEP(i)
         softmax_block(i - 1);
-        __syncthreads();
+        if constexpr (MIDBAR) __syncthreads();
         mfma_block(i);
       }
     }
 #undef PF_EVEN_STEP
 #ifdef XM_ABL_PF_PHASES
-    if (blockIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == gridDim.y / 2 && lane == 0 && (wave & 3) == 0)
+    if (blockIdx.x == gridDim.x / 2 && lane == 0 && (wave & 3) == 0)
       for (int i = 0; i < 4; ++i) pf_dbg[4 + grp * 4 + i] = ph[i];
 #endif
   }
 #ifdef XM_ABL_PF_TIMING
-  if (blockIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == gridDim.y / 2 && tid == 0) {
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
     pf_dbg[0] = clock64() - dbg_c0;
     pf_dbg[1] = wall_clock64() - dbg_w0;
     pf_dbg[2] = nt;
@@ -721,20 +724,29 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
   if constexpr (D == 128) {
     // LDS-DMA kernels: a 64-key tile must sit inside one page, and 64 row pitches must fit a 32-bit buffer offset
-    static int dma_mode = -1;  // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = one wave group, 2 = ping-pong
+    // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = one wave group per workgroup (default), 2 = ping-pong groups
+    // with a barrier at every phase switch, 3 = the two groups offset by half a tile with one barrier per tile
+    static int dma_mode = -1;
     if (dma_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_DMA"); dma_mode = e ? atoi(e) : 1; }  // (A/B, read once)
     const int64_t pitch = PAGED ? nkv * D : (k_stride > v_stride ? k_stride : v_stride);
     if (dma_mode && (!PAGED || block_size % kPf2Tile == 0) && pitch * 2 * kPf2Tile < (1ll << 31)) {
       const float sl2 = scale * 1.4426950408889634f;
       if (dma_mode >= 2 && max_q_len > kPfQBlock) {  // two wave groups need more than 128 queries to alternate
-        const dim3 grid2((unsigned)nq, (unsigned)((max_q_len + 2 * kPfQBlock - 1) / (2 * kPfQBlock)), (unsigned)batch);
-        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
-                           (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
-                           (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl);
+        const int qb2 = (int)((max_q_len + 2 * kPfQBlock - 1) / (2 * kPfQBlock));
+        const dim3 grid2((unsigned)(nq * batch * qb2));
+        if (dma_mode == 2)
+          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8, true>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
+                             (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
+                             (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
+        else
+          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8, false>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
+                             (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
+                             (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
       } else {
-        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4>), grid, dim3(256), 0, s, (const T*)q, (const T*)k,
-                           (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
-                           (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl);
+        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+                           (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
+                           (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch,
+                           qblocks);
       }
       return hip_check_launch();
     }
