@@ -239,6 +239,114 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
   return out;
 }
 
+namespace {
+// one MoE scratch per process, grown on demand (chunk counts of the index build + the grouped-GEMM tile table): the C ABI
+// never allocates, so the shim owns it the way the reference's backends own their workspaces
+void ensure_moe_scratch(const torch::Tensor& like, int64_t bytes) {
+  static torch::Tensor ws;
+  if (!ws.defined() || ws.numel() < bytes || ws.device() != like.device()) {
+    ws = torch::empty({std::max<int64_t>(bytes, 1 << 20)}, like.options().dtype(torch::kUInt8));
+    check(xllm_mi355_set_moe_workspace(ws.data_ptr(), (size_t)ws.numel()), "set_moe_workspace");
+  }
+}
+}  // namespace
+
+std::tuple<torch::Tensor, torch::Tensor> moe_fused_topk(const torch::Tensor& gating_output, int64_t topk, bool renormalize,
+                                                        const std::optional<torch::Tensor>& correction_bias,
+                                                        const std::string& scoring_func) {
+  TORCH_CHECK(scoring_func == "softmax" || scoring_func == "sigmoid", "Unsupported scoring function for moe topk: ",
+              scoring_func);
+  TORCH_CHECK(gating_output.dim() == 2, "gating_output must be [num_tokens, num_experts]");
+  DeviceGuard guard(gating_output.device());
+  const torch::Tensor g = gating_output.contiguous();
+  const int64_t T = g.size(0), E = g.size(1);
+  auto w = torch::empty({T, topk}, g.options().dtype(torch::kFloat32));
+  auto ids = torch::empty({T, topk}, g.options().dtype(torch::kInt32));
+  torch::Tensor bias;
+  if (correction_bias.has_value() && correction_bias->defined() && scoring_func == "sigmoid")
+    bias = correction_bias->to(torch::kFloat32).contiguous();
+  check(xllm_mi355_moe_fused_topk(p(g), dt(g), T, E, topk, renormalize ? 1 : 0, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                                  scoring_func == "softmax" ? 0 : 1, w.data_ptr<float>(), ids.data_ptr<int32_t>(), cur_stream()),
+        "moe_fused_topk");
+  return {w, ids};
+}
+
+std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t expert_num) {
+  TORCH_CHECK(expert_id.dim() == 2 && expert_id.scalar_type() == torch::kInt32, "expert_id must be int32 [num_tokens, topk]");
+  DeviceGuard guard(expert_id.device());
+  const torch::Tensor ids = expert_id.contiguous();
+  const int64_t T = ids.size(0), topk = ids.size(1), n = T * topk;
+  ensure_moe_scratch(ids, 4 * ((n + 1023) / 1024 + 1) * expert_num + 16 * (n / 256 + expert_num) + 64);
+  auto src_dst = torch::empty({n}, ids.options()), dst_src = torch::empty({n}, ids.options());
+  auto sizes = torch::empty({expert_num}, ids.options());
+  check(xllm_mi355_moe_compute_index(ids.data_ptr<int32_t>(), T, topk, expert_num, src_dst.data_ptr<int32_t>(),
+                                     dst_src.data_ptr<int32_t>(), sizes.data_ptr<int32_t>(), cur_stream()),
+        "moe_gen_idx");
+  return {src_dst, dst_src, sizes};
+}
+
+torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight) {
+  TORCH_CHECK(input.dim() == 2 && reduce_weight.dim() == 2 && reduce_weight.numel() == input.size(0) &&
+                  reduce_weight.scalar_type() == torch::kFloat32,
+              "moe_combine_result: input [T*topk, H], reduce_weight float32 [T, topk]");
+  DeviceGuard guard(input.device());
+  const torch::Tensor x = input.contiguous(), w = reduce_weight.contiguous();
+  const int64_t T = w.size(0), topk = w.size(1), H = x.size(1);
+  auto out = torch::empty({T, H}, x.options());
+  check(xllm_mi355_moe_combine(p(out), p(x), w.data_ptr<float>(), T, topk, H, dt(x), cur_stream()), "moe_combine_result");
+  return out;
+}
+
+torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const torch::Tensor& reduce_weight,
+                                        const torch::Tensor& gather_ids) {
+  TORCH_CHECK(input_sorted.dim() == 2 && reduce_weight.dim() == 2 && reduce_weight.numel() == input_sorted.size(0) &&
+                  gather_ids.numel() == input_sorted.size(0) && gather_ids.scalar_type() == torch::kInt32 &&
+                  reduce_weight.scalar_type() == torch::kFloat32,
+              "moe_combine_result_sorted: input [T*topk, H], reduce_weight float32 [T, topk], gather_ids int32 [T*topk]");
+  DeviceGuard guard(input_sorted.device());
+  const torch::Tensor x = input_sorted.contiguous(), w = reduce_weight.contiguous(), g = gather_ids.contiguous();
+  const int64_t T = w.size(0), topk = w.size(1), H = x.size(1);
+  auto out = torch::empty({T, H}, x.options());
+  check(xllm_mi355_moe_combine_sorted(p(out), p(x), g.data_ptr<int32_t>(), w.data_ptr<float>(), T, topk, H, dt(x), cur_stream()),
+        "moe_combine_result_sorted");
+  return out;
+}
+
+torch::Tensor group_gemm_gather(const torch::Tensor& input, const torch::Tensor& row_index, int64_t index_div,
+                                const torch::Tensor& weight, const torch::Tensor& token_count) {
+  DeviceGuard guard(input.device());
+  TORCH_CHECK(input.dim() == 2 && weight.dim() == 3 && input.size(1) == weight.size(2) &&
+                  row_index.scalar_type() == torch::kInt32 && token_count.scalar_type() == torch::kInt32,
+              "group_gemm_gather shapes");
+  const torch::Tensor x = input.contiguous(), w = weight.contiguous(), idx = row_index.contiguous();
+  const int64_t E = w.size(0), N = w.size(1), K = w.size(2), rows = idx.numel();
+  ensure_moe_scratch(x, 16 * (rows / 256 + E) + 64);
+  auto out = torch::empty({rows, N}, x.options());
+  const int rc = xllm_mi355_group_gemm_gather(p(x), x.size(0), idx.data_ptr<int32_t>(), index_div, p(w),
+                                              token_count.data_ptr<int32_t>(), p(out), rows, E, N, K, dt(x), cur_stream());
+  if (rc == XM_ERR_UNSUPPORTED) return torch::Tensor();
+  check(rc, "group_gemm_gather");
+  return out;
+}
+
+torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& seqlens_k,
+                         const torch::Tensor& block_table, int64_t head_size_v, double softmax_scale, int64_t max_kv_len) {
+  TORCH_CHECK(q.dim() == 3 && k_cache.dim() == 4 && k_cache.size(2) == 1 && k_cache.size(3) == q.size(2),
+              "mla_decode: q [B, H, D], k_cache [n_blocks, block, 1, D]");
+  TORCH_CHECK(seqlens_k.scalar_type() == torch::kInt32 && block_table.scalar_type() == torch::kInt32, "int32 metadata");
+  DeviceGuard guard(q.device());
+  const torch::Tensor qc = q.contiguous(), bt = block_table.contiguous();
+  const int64_t B = qc.size(0), H = qc.size(1), D = qc.size(2);
+  auto out = torch::empty({B, H, head_size_v}, qc.options());
+  // split-KV partials: (head_size_v + 2) floats per (entry, head, split), at most 32 splits
+  auto ws = torch::empty({B * H * 32 * (head_size_v + 2)}, qc.options().dtype(torch::kFloat32));
+  check(xllm_mi355_mla_decode(p(qc), p(k_cache), p(out), seqlens_k.data_ptr<int32_t>(), bt.data_ptr<int32_t>(), bt.size(1),
+                              B, H, D, head_size_v, k_cache.size(1), k_cache.size(0), max_kv_len, (float)softmax_scale,
+                              dt(qc), ws.data_ptr(), (size_t)ws.numel() * 4, cur_stream()),
+        "mla_decode");
+  return out;
+}
+
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const torch::Tensor& indices) {
   DeviceGuard guard(indptr.device());
   const int64_t B = indptr.size(0) - 1, total = indices.size(0);

@@ -8,6 +8,8 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <vector>
+
 #include "../include/xllm_mi355.h"
 
 #include <optional>
@@ -63,6 +65,30 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
 // dcu_ops_api.h:48-51, 71-73
 torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
                          std::optional<torch::Tensor> output = std::nullopt);
+// kernel::moe_active_topk / cuda::moe_fused_topk (ops_api.h:70; kernels/cuda/moe/moe_fused_topk.cu:31-61):
+// (topk_weights float32 [T, topk], topk_ids int32 [T, topk]); scoring_func "softmax" | "sigmoid" (anything else throws,
+// like the reference's LOG(FATAL)); the correction bias only takes part in the sigmoid selection.
+std::tuple<torch::Tensor, torch::Tensor> moe_fused_topk(const torch::Tensor& gating_output, int64_t topk, bool renormalize,
+                                                        const std::optional<torch::Tensor>& correction_bias,
+                                                        const std::string& scoring_func);
+// kernel::moe_gen_idx (ops_api.h:73) -> {src_dst, dst_src, expert_sizes} (int32); stable inside an expert
+std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t expert_num);
+// kernel::moe_combine_result (ops_api.h:77; MoeCombineResultParams param.h:575-...): input [T*topk, H] in TOKEN order
+// (after the caller's index_copy_), reduce_weight [T, topk] float32
+torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight);
+// the same with MoeCombineResultParams::gather_ids honoured: input stays in EXPERT order (the second grouped GEMM's
+// output) and row gather_ids[t*topk+k] is read for (t, k) -- index_copy_ + moe_combine_result in one pass
+torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const torch::Tensor& reduce_weight,
+                                        const torch::Tensor& gather_ids);
+// index_select(hidden, dst_src / topk) + group_gemm without the expanded copy (fused_moe.cpp:195-197, 250-262);
+// returns an undefined tensor when the 256x256 kernel cannot take the shape (the caller keeps the two reference calls)
+torch::Tensor group_gemm_gather(const torch::Tensor& input, const torch::Tensor& row_index, int64_t index_div,
+                                const torch::Tensor& weight, const torch::Tensor& token_count);
+// flash_mla::dense_decode (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] (nope || pe), k_cache
+// [n_blocks, block, 1, 576], values = the first head_size_v dims of the latent
+torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& seqlens_k,
+                         const torch::Tensor& block_table, int64_t head_size_v, double softmax_scale, int64_t max_kv_len);
+
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& paged_kv_indptr,
                                               const torch::Tensor& paged_kv_indices);
 

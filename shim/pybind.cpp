@@ -14,6 +14,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rotary_embedding", [](torch::Tensor pos, torch::Tensor q, std::optional<torch::Tensor> kk, torch::Tensor cache, bool neox) { k::rotary_embedding(pos, q, kk, cache, neox); });
   m.def("matmul", &k::matmul);
   m.def("random_sample", &k::random_sample);
+  m.def("moe_fused_topk", &k::moe_fused_topk);
+  m.def("moe_gen_idx", &k::moe_gen_idx);
+  m.def("moe_combine_result", &k::moe_combine_result);
+  m.def("moe_combine_result_sorted", &k::moe_combine_result_sorted);
+  m.def("group_gemm", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& c) { return k::group_gemm(x, w, c, std::nullopt); });
+  m.def("group_gemm_gather", &k::group_gemm_gather);
+  m.def("mla_decode", &k::mla_decode);
   m.def("rejection_sample", &k::rejection_sample);
   m.def("scaled_quantize", [](const torch::Tensor& x) {
     return k::scaled_quantize(x, torch::Tensor(), std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, "none", 1.0, false, torch::kInt8);

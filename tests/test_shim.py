@@ -26,14 +26,16 @@ def test_shim_builds_and_exposes_reference_operator_names():
     m = _shim()
     for name in ("rms_norm", "fused_add_rms_norm", "act_and_mul", "reshape_paged_cache", "rotary_embedding", "matmul",
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
-                 "random_sample", "rejection_sample"):
+                 "random_sample", "rejection_sample", "moe_fused_topk", "moe_gen_idx", "moe_combine_result",
+                 "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "mla_decode"):
         assert hasattr(m, name)
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
                 "static_scaled_fp8_quant", "fp8_scaled_quantize", "rms_norm_static_fp8_quant",
                 "fused_add_rms_norm_static_fp8_quant", "fp8_scaled_matmul", "fused_qk_norm_rope", "scaled_quantize",
                 "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
-                "update_llm_decode_metadata"):
+                "update_llm_decode_metadata", "moe_fused_topk", "moe_gen_idx", "moe_combine_result", "group_gemm_gather",
+                "mla_decode"):
         assert sym + "(" in hdr, sym
 
 
@@ -102,3 +104,43 @@ def test_shim_random_sample_uses_the_default_generator_stream():
     torch.cuda.manual_seed(2024)
     assert torch.equal(m.random_sample(probs), a) and not torch.equal(a, b)
     assert torch.equal(a, ops.random_sample(probs, seed=2024, offset=(37 + 3) // 4 * 4))
+
+
+@pytest.mark.gpu
+def test_shim_moe_and_mla_equal_the_ctypes_path():
+    """the C++ shim's MoE / MLA operators (what ops_api.cpp's USE_MI355 branch would call) == xllm_amd.ops, bit for bit"""
+    from xllm_amd import ops
+    m = _shim()
+    dev = "cuda"
+    gd = torch.Generator(device=dev).manual_seed(4)
+    T, E, topk, H, I = 700, 32, 4, 512, 256
+    logits = torch.randn(T, E, device=dev, generator=gd).bfloat16()
+    w, ids = m.moe_fused_topk(logits, topk, True, None, "softmax")
+    w2, ids2 = ops.moe_fused_topk(logits, topk, True)
+    assert torch.equal(w, w2) and torch.equal(ids, ids2)
+    with pytest.raises(RuntimeError):
+        m.moe_fused_topk(logits, topk, True, None, "tanh")
+    src_dst, dst_src, sizes = m.moe_gen_idx(ids, E)
+    r = ops.moe_compute_index(ids, E)
+    assert torch.equal(src_dst, r[0]) and torch.equal(dst_src, r[1]) and torch.equal(sizes, r[2])
+    x = torch.randn(T, H, device=dev, generator=gd).bfloat16()
+    w13 = (torch.randn(E, 2 * I, H, device=dev, generator=gd) / 22).bfloat16()
+    xs = x.index_select(0, (dst_src // topk).long())
+    h = m.group_gemm(xs, w13, sizes)
+    assert torch.equal(h, ops.group_gemm(xs, w13, sizes))
+    hg = m.group_gemm_gather(x, dst_src, topk, w13, sizes)
+    assert hg is not None and torch.equal(hg, h)
+    g2 = torch.randn(T * topk, H, device=dev, generator=gd).bfloat16()
+    full = torch.empty_like(g2)
+    full.index_copy_(0, dst_src.long(), g2)
+    out = m.moe_combine_result(full, w)
+    assert torch.equal(out, ops.moe_combine_result(full, w, T, topk))
+    assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst), out)
+    # MLA decode
+    B, Hh, bs = 3, 16, 64
+    kv_lens = torch.tensor([200, 64, 1], dtype=torch.int32, device=dev)
+    table = torch.randperm(12, device=dev, generator=gd)[:12].to(torch.int32).view(3, 4)
+    kc = torch.randn(13, bs, 1, 576, device=dev, generator=gd).bfloat16()
+    q = torch.randn(B, Hh, 576, device=dev, generator=gd).bfloat16()
+    o = m.mla_decode(q, kc, kv_lens, table, 512, 192 ** -0.5, 200)
+    assert torch.equal(o, ops.mla_decode(q, kc, kv_lens, table, 512, 192 ** -0.5, 200))
