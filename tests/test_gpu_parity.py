@@ -908,6 +908,74 @@ def test_dual_micro_batch_decoder_equals_single_batch_step():
         assert torch.equal(out, ref)
 
 
+def test_deepseek_v2_attention_layer_matches_a_plain_restatement():
+    """layers.DeepseekV2Attention (deepseek_v2_attention.cpp:264-317): prefill of ragged sequences, then one decode step on
+    top of the cache it wrote, against the reference forward restated with plain fp32 torch ops on the same weights
+    (non-paged latent per sequence, softmax(scale q.K^T) K[:, :kv_lora], bottom-right causal)"""
+    from xllm_amd import layers
+    from xllm_amd.attention import AttentionMetadata, KVCache, build_attention_metadata, build_batch_input
+    H, heads, q_lora, kv_lora, nope, rope, v = 1024, 16, 384, 512, 128, 64, 128
+    bs, lens = 64, [70, 1, 131]
+    gd = torch.Generator(device=DEV).manual_seed(12)
+    attn = layers.DeepseekV2Attention(H, heads, q_lora, kv_lora, nope, rope, v, 1e-6, torch.bfloat16, DEV, gd)
+    blocks = [[5, 2, 9], [7], [1, 8, 3]]
+    cache = KVCache(torch.zeros(11, bs, 1, kv_lora + rope, dtype=torch.bfloat16, device=DEV), None)
+
+    def reference(x, pos, seq_ranges, past):
+        """fp32 restatement; `past[b]` = latent rows of sequence b already cached; returns (out, new latents)"""
+        f = lambda t: t.float()
+        rms = lambda t, w: (t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6)).bfloat16().float() * f(w)
+        lat = (f(x) @ f(attn.kv_a_w).T).bfloat16().float()
+        ckv = rms(lat[:, :kv_lora], attn.kv_a_norm_w).bfloat16().float()
+
+        def rope_ds(t):  # t [T, n, rope] in deepseek layout (evens || odds), rotate-half with the same 16-bit roundings
+            cs = f(attn.cos_sin[pos])
+            c, s_ = cs[:, None, :rope // 2], cs[:, None, rope // 2:]
+            a, b = t[..., :rope // 2], t[..., rope // 2:]
+            r = lambda u: u.bfloat16().float()
+            return torch.cat([r(r(a * c) - r(b * s_)), r(r(b * c) + r(a * s_))], -1)
+        kpe = rope_ds(layers.to_deepseek_rope_layout(lat[:, kv_lora:].unsqueeze(1))).squeeze(1)
+        latn = torch.cat([ckv, kpe], -1)
+        q = (rms((f(x) @ f(attn.q_a_w).T).bfloat16().float(), attn.q_a_norm_w).bfloat16().float() @ f(attn.q_b_w).T).bfloat16().float()
+        q = q.view(-1, heads, nope + rope)
+        qpe = rope_ds(layers.to_deepseek_rope_layout(q[..., nope:]))
+        qabs = torch.einsum("thn,hnk->thk", q[..., :nope], f(attn.w_kc)).bfloat16().float()
+        qin = torch.cat([qabs, qpe], -1)
+        outs = []
+        for b, (a0, a1) in enumerate(seq_ranges):
+            K = torch.cat([past[b], latn[a0:a1]], 0) if past[b] is not None else latn[a0:a1]
+            sq, sk = a1 - a0, K.size(0)
+            sc = torch.einsum("qhd,kd->hqk", qin[a0:a1], K) * attn.scale
+            mask = torch.arange(sk, device=DEV)[None, :] <= (torch.arange(sq, device=DEV)[:, None] + sk - sq)
+            p = torch.softmax(sc.masked_fill(~mask, float("-inf")), -1)
+            outs.append(torch.einsum("hqk,kd->qhd", p, K[:, :kv_lora]))
+        o = torch.cat(outs, 0).bfloat16().float()
+        o = torch.einsum("thk,hkv->thv", o, f(attn.w_vc)).bfloat16().float().flatten(1, 2)
+        return (o @ f(attn.o_w).T), latn
+
+    # prefill
+    T = sum(lens)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    bi = build_batch_input([0] * 3, lens, blocks, bs)
+    md = build_attention_metadata(bi, True, False, DEV)
+    pos = bi.positions.to(DEV).long()
+    out = attn.forward(pos, x, md, cache)
+    cu = [0, 70, 71, 202]
+    ref, latn = reference(x, pos, list(zip(cu[:-1], cu[1:])), [None] * 3)
+    assert ((out.float() - ref).norm() / ref.norm()).item() <= 8e-3
+    rows = cache.k_cache.view(-1, kv_lora + rope)[bi.new_cache_slots.to(DEV).long()].float()
+    assert ((rows - latn).abs() <= 2.0 ** -7 * latn.abs() + 1e-3).all()          # the latent rows the layer cached
+    # one decode step per sequence on top of that cache
+    x2 = torch.randn(3, H, device=DEV, generator=gd).bfloat16()
+    bi2 = build_batch_input(lens, [n + 1 for n in lens], blocks, bs)
+    md2 = build_attention_metadata(bi2, False, False, DEV)
+    pos2 = bi2.positions.to(DEV).long()
+    out2 = attn.forward(pos2, x2, md2, cache)
+    past = [cache.k_cache.view(-1, kv_lora + rope)[bi.new_cache_slots.to(DEV).long()[a:b]].float() for a, b in zip(cu[:-1], cu[1:])]
+    ref2, _ = reference(x2, pos2, [(0, 1), (1, 2), (2, 3)], past)
+    assert ((out2.float() - ref2).norm() / ref2.norm()).item() <= 8e-3
+
+
 # ------------------------------------------------------------------------------------------- N3: step-level harness
 @pytest.mark.parametrize("temperature", [0.0, 0.8])
 def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):

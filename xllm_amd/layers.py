@@ -5,7 +5,8 @@ Qwen2AttentionImpl::forward (layers/common/qwen2_attention.cpp:132-193), DenseML
 (layers/common/dense_mlp.cpp:97-116), the w8a8-dynamic linear (layers/common/linear.cpp:481-507: scaled_quantize
 then scaled_matmul), Row/Column-parallel sharding (linear.cpp:616-716, 1405-1522) and
 LlmModelImplBase::forward (models/llm/llm_model_base.h:60-125) for the layer loop + final norm + lm_head;
-FusedMoEImpl::forward_experts (layers/dcu/fused_moe.cpp:143-337) for the routed-expert FFN.
+FusedMoEImpl::forward_experts (layers/dcu/fused_moe.cpp:143-337) for the routed-expert FFN;
+DeepseekV2AttentionImpl::forward (layers/dcu/deepseek_v2_attention.cpp:264-317) for MLA.
 
 Weights are synthetic (random-init of the architecture): this module is the fixed-shape harness of SURVEY 8d,
 not a checkpoint loader.
@@ -272,6 +273,79 @@ class Qwen2Model:
     def logits(self, hidden):
         y = self.lm_head.forward(hidden)
         return parallel.gather(y, self.tp)
+
+
+def to_deepseek_rope_layout(t: torch.Tensor) -> torch.Tensor:
+    """deepseek_v2_attention.cpp:35-46: [.., d] viewed as [.., d/2, 2], transposed to [.., 2, d/2]: even dims first"""
+    shape = t.shape
+    return t.reshape(*shape[:-1], shape[-1] // 2, 2).transpose(-1, -2).reshape(shape).contiguous()
+
+
+class DeepseekV2Attention:
+    """DeepseekV2AttentionImpl (layers/dcu/deepseek_v2_attention.cpp:50-317), MLA in the absorbed form: the cache holds
+    one latent row [rms_norm(c_kv) (kv_lora) || rope(k_pe) (rope)] per token; q_nope is absorbed by w_kc, scores run over
+    the (kv_lora + rope)-dim latent, values are its first kv_lora dims, then bmm(w_vc) and o_proj (whose TP reduction
+    is left to the decoder layer, enable_result_reduction = false). The projections are 16-bit here (the reference
+    quantises q_b_proj / o_proj through QuantArgs; kv_a / kv_b / q_a are never quantised, :75-118).
+    Differences from the reference, none visible in the result: prefill reads the latent rows back from the paged cache
+    it has just written (mla_prefill) instead of looping over sequences on the host with torch SDPA (:212-262), so the
+    layer has no host sync; chunked prefill works the same way (the reference CHECK-fails on it, :270-271)."""
+
+    def __init__(self, hidden: int, n_heads: int, q_lora: int, kv_lora: int, nope: int, rope: int, v_dim: int, eps: float,
+                 dtype, device, gen, tp: Optional[parallel.ProcessGroup] = None, rope_theta: float = 1e4,
+                 max_pos: int = 8192, mscale: float = 1.0):
+        tp_size = tp.world_size() if tp is not None else 1
+        assert n_heads % tp_size == 0, "num_heads must be divisible by tensor parallel size"   # :64-65
+        self.h, self.q_lora, self.kv_lora, self.nope, self.rope, self.v_dim = n_heads // tp_size, q_lora, kv_lora, nope, rope, v_dim
+        self.eps, self.dtype, self.tp = eps, dtype, tp
+        rnd = lambda n, k: (torch.randn(n, k, device=device, generator=gen) / math.sqrt(k)).to(dtype)
+        ones = lambda n: (torch.rand(n, device=device, generator=gen) + 0.5).to(dtype)
+        if q_lora > 0:
+            self.q_a_w, self.q_a_norm_w, self.q_b_w = rnd(q_lora, hidden), ones(q_lora), rnd(self.h * (nope + rope), q_lora)
+        else:
+            self.q_w = rnd(self.h * (nope + rope), hidden)
+        self.kv_a_w, self.kv_a_norm_w = rnd(kv_lora + rope, hidden), ones(kv_lora)
+        kv_b = rnd(self.h * (nope + v_dim), kv_lora).unflatten(0, (self.h, nope + v_dim))
+        self.w_kc = kv_b[:, :nope].contiguous()                       # [h, nope, kv_lora]
+        self.w_vc = kv_b[:, nope:].transpose(1, 2).contiguous()       # [h, kv_lora, v]  (load_state_dict :335-339)
+        self.o_w = rnd(hidden, self.h * v_dim)
+        self.scale = float((nope + rope) ** -0.5) * mscale * mscale   # :148-154
+        inv_freq = 1.0 / torch.pow(torch.tensor(rope_theta), torch.arange(0, rope, 2, dtype=torch.float32) / rope)
+        fr = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv_freq)
+        self.cos_sin = torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(device)
+
+    def _norm(self, x, w):
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        ops.rms_norm(out, x, w, self.eps)
+        return out
+
+    def forward(self, positions, hidden_states, md: AttentionMetadata, kv_cache: KVCache):
+        T = hidden_states.size(0)
+        assert positions.numel() == T, "position/token mismatch"                                  # :272-279
+        latent = ops.matmul(hidden_states, self.kv_a_w)                                           # [T, kv_lora + rope]
+        c_kv_normed = self._norm(latent[:, :self.kv_lora], self.kv_a_norm_w)
+        k_pe = to_deepseek_rope_layout(latent[:, self.kv_lora:].contiguous().unsqueeze(1))      # [T, 1, rope]
+        ops.rotary_embedding(positions, k_pe, None, self.cos_sin, True, head_size=self.rope)
+        latent_normed = torch.cat([c_kv_normed, k_pe.squeeze(1)], -1)
+        ops.store_latent_cache(latent_normed, md.slot_mapping, kv_cache.get_k_cache())
+        if self.q_lora > 0:                                                                       # prepare_query :156-168
+            q = ops.matmul(self._norm(ops.matmul(hidden_states, self.q_a_w), self.q_a_norm_w), self.q_b_w)
+        else:
+            q = ops.matmul(hidden_states, self.q_w)
+        q = q.view(T, self.h, self.nope + self.rope)
+        q_nope = q[..., :self.nope].contiguous()
+        q_pe = to_deepseek_rope_layout(q[..., self.nope:].contiguous())
+        ops.rotary_embedding(positions, q_pe, None, self.cos_sin, True, head_size=self.rope)
+        q_abs = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)                      # [T, h, kv_lora]
+        q_in = torch.cat([q_abs, q_pe], -1).contiguous()
+        if md.is_prefill or md.is_chunked_prefill:
+            attn = ops.mla_prefill(q_in, kv_cache.get_k_cache(), md.q_cu_seq_lens, md.kv_seq_lens, md.block_table,
+                                   self.kv_lora, self.scale, md.max_seq_len, True)
+        else:
+            attn = ops.mla_decode(q_in, kv_cache.get_k_cache(), md.kv_seq_lens, md.block_table, self.kv_lora, self.scale,
+                                  md.max_seq_len)
+        out = torch.bmm(attn.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)            # project_output :180-187
+        return ops.matmul(out, self.o_w)   # partial sums under TP: the decoder layer reduces
 
 
 class FusedMoE:
