@@ -657,23 +657,21 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
   const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  // tuning selectors, read once: XLLM_MI355_P8_RING = 1 -> role-split kernel with the 3-deep weight ring (measured 2-4 %
+  // slower at M = 8192 and no faster at M = 256: off), XLLM_MI355_P8_MFMA32 = 1 -> int8 on the 32x32x32 kernel
+  static int ring = -2, mfma32 = -2;
+  if (ring == -2) {
+    const char* e = getenv("XLLM_MI355_P8_RING");
+    ring = e ? atoi(e) : 0;
+    e = getenv("XLLM_MI355_P8_MFMA32");
+    mfma32 = e ? atoi(e) : 0;
+  }
   if constexpr (KIND == kI8) {
-    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless XLLM_MI355_P8_MFMA32=1 asks for the 32x32x32 kernel
-    static int mfma32 = -2;
-    if (mfma32 == -2) {
-      const char* e = getenv("XLLM_MI355_P8_MFMA32");
-      mfma32 = e ? atoi(e) : 0;
-    }
-    const char* r = getenv("XLLM_MI355_P8_RING");
-    if (!mfma32 && !(r && atoi(r))) {
+    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless one of the selectors asks for a 32x32x32 kernel
+    if (!mfma32 && !ring) {
       if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
       return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
     }
-  }
-  static int ring = -2;  // XLLM_MI355_P8_RING: 1 = role-split kernel with the 3-deep weight ring, 0 = first version
-  if (ring == -2) {
-    const char* e = getenv("XLLM_MI355_P8_RING");
-    ring = e ? atoi(e) : 0;  // measured: the deeper weight ring is 2-4 % slower at M = 8192 and no faster at M = 256
   }
   const bool use_ring = ring && !epi.group_tiles;  // the grouped mode lives in the first-version kernel only
   if (splits > 1) {
