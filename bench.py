@@ -454,19 +454,22 @@ def micro(model, md, kv_caches, tokens, positions, B, fh):
     q8, s8 = ops.scaled_quantize(x)
     t("rms_norm+int8 quant (fused add)", lambda: ops.rms_norm_dynamic_int8_quant(x, L.input_norm_w, 1e-6, residual=res),
       bytes_=B * H * (2 + 2 + 2 + 1))
-    for nm, lin, inp in (("qkv", L.qkv_proj, q8), ("gate_up", L.gate_up_proj, q8)):
-        N, K = lin.weight.shape
-        t(f"scaled_matmul {nm} [{B}x{N}x{K}]", lambda lin=lin: ops.scaled_matmul(q8, lin.weight, s8, lin.w_scale, torch.bfloat16, lin.bias),
-          bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
     at = torch.randn(B, L.q_size, device=dev).bfloat16()
-    qa, sa = ops.scaled_quantize(at)
-    N, K = L.o_proj.weight.shape
-    t(f"scaled_matmul o [{B}x{N}x{K}]", lambda: ops.scaled_matmul(qa, L.o_proj.weight, sa, L.o_proj.w_scale, torch.bfloat16),
-      bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
-    qd, sd = ops.act_and_mul_dynamic_int8_quant(gu)
-    N, K = L.down_proj.weight.shape
-    t(f"scaled_matmul down [{B}x{N}x{K}]", lambda: ops.scaled_matmul(qd, L.down_proj.weight, sd, L.down_proj.w_scale, torch.bfloat16),
-      bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
+    act = torch.randn(B, I, device=dev).bfloat16()
+    if L.qkv_proj.mode == "int8":
+        qa, sa = ops.scaled_quantize(at)
+        qd, sd = ops.act_and_mul_dynamic_int8_quant(gu)
+        for nm, lin, (qi, si) in (("qkv", L.qkv_proj, (q8, s8)), ("gate_up", L.gate_up_proj, (q8, s8)), ("o", L.o_proj, (qa, sa)),
+                                  ("down", L.down_proj, (qd, sd))):
+            N, K = lin.weight.shape
+            t(f"scaled_matmul {nm} [{B}x{N}x{K}]",
+              lambda lin=lin, qi=qi, si=si: ops.scaled_matmul(qi, lin.weight, si, lin.w_scale, torch.bfloat16, lin.bias),
+              bytes_=N * K + B * K + B * N * 2, flops=2 * B * N * K)
+    else:  # 16-bit linears (cfg2): dcu::matmul
+        for nm, lin, inp in (("qkv", L.qkv_proj, x), ("gate_up", L.gate_up_proj, x), ("o", L.o_proj, at), ("down", L.down_proj, act)):
+            N, K = lin.weight.shape
+            t(f"matmul {nm} [{B}x{N}x{K}]", lambda lin=lin, inp=inp: ops.matmul(inp, lin.weight, lin.bias),
+              bytes_=(N * K + B * K + B * N) * 2, flops=2 * B * N * K)
     t("silu_mul+int8 quant", lambda: ops.act_and_mul_dynamic_int8_quant(gu), bytes_=B * I * 5)
     t("rope", lambda: ops.rotary_embedding(positions, qkv[:, :L.q_size], qkv[:, L.q_size:L.q_size + L.kv_size], model.cos_sin, True, head_size=L.d))
     q3 = qkv[:, :L.q_size].unflatten(-1, (L.nq, L.d))

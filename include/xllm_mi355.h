@@ -210,7 +210,10 @@ XM_API int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, cons
                                         int64_t N, int64_t K, int out_dtype, void* stream);
 
 /* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
- * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0. */
+ * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0.
+ * Decode-shaped problems with a long K and few columns (M <= 512, N % 4 == 0) split K when a GEMM workspace is
+ * registered (xllm_mi355_set_gemm_workspace): fp32 partial slabs [slices][M][N] in the workspace, reduced in slice order
+ * (bit-reproducible) and re-zeroed, so the workspace stays zero at rest for the int8 split-K path. */
 XM_API int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M,
                              int64_t N, int64_t K, int dtype, void* stream);
 

@@ -489,6 +489,30 @@ def test_mlu_golden_vectors_through_hip():
     assert (got - exp).norm() / exp.norm() < 3e-2 and (got - exp).abs().max() <= 4e-5
 
 
+@pytest.mark.parametrize("M,N,K,dtype", [(64, 3584, 18944, torch.bfloat16), (64, 4608, 3584, torch.bfloat16),
+                                         (256, 3584, 3584, torch.float16), (7, 1000, 8192, torch.bfloat16)])
+def test_matmul_16bit_split_k_is_deterministic_and_keeps_the_workspace_zero(M, N, K, dtype):
+    """decode-shaped 16-bit GEMMs split K through fp32 slabs in the workspace: == oracle (<= 1 ulp), identical bits run to
+    run, and the workspace is zero again afterwards (an int8 split-K GEMM right after stays exact)"""
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, generator=g).to(dtype)
+    ref = orc.matmul(a, w, bias)
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    out1 = ops.matmul(ad, wd, bd)
+    out2 = ops.matmul(ad, wd, bd)
+    assert torch.equal(out1, out2)
+    assert_ulp_close(out1, ref, dtype, ulps=1.0, min_exact=0.97)
+    ai = torch.randint(-127, 128, (M, 3584), dtype=torch.int8, device=DEV)
+    wi = torch.randint(-127, 128, (256, 3584), dtype=torch.int8, device=DEV)
+    ones_m, ones_n = torch.ones(M, device=DEV), torch.ones(256, device=DEV)
+    acc = torch.empty(M, 256, dtype=torch.int32, device=DEV)
+    ops.scaled_matmul(ai, wi, ones_m, ones_n, torch.bfloat16, acc_out=acc)          # exact accumulators (no split)
+    y = ops.scaled_matmul(ai, wi, ones_m, ones_n, torch.bfloat16)                   # planner's path (may split K)
+    assert torch.equal(y, acc.float().bfloat16())
+
+
 # ------------------------------------------------------------------------------------------- MLA / MoE
 @pytest.mark.parametrize("H,bs,kv_lens", [(16, 64, [8192 // 8, 70, 1]), (128, 64, [300, 65]), (5, 16, [100]),
                                           (16, 128, [2048, 129, 128, 64, 63]), (16, 32, [1000, 33]),

@@ -394,6 +394,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
         } else if constexpr (KIND == kFP8) {
           const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
           store16(epi.out, idx, as * (ws * acc[t][j][r]) + bs, epi.out_bf16);
+        } else if constexpr (SPLITK) {
+          // 16-bit split-K: this K slice's fp32 partial sums go to slab blockIdx.z of the workspace (plain stores); the
+          // reduce kernel adds the slabs in slice order (deterministic) and re-zeroes them
+          reinterpret_cast<float*>(epi.acc_out)[(int64_t)blockIdx.z * M * N + idx] = acc[t][j][r];
         } else {
           store16(epi.out, idx, acc[t][j][r] + bs, epi.out_bf16);
         }
@@ -416,8 +420,52 @@ __global__ __launch_bounds__(256) void i8_splitk_epilogue_zero_kernel(int32_t* _
   }
 }
 
+// reduce after 16-bit split-K: out = sum over the K slices IN ORDER of the fp32 partial slabs (+ bias), and the slabs
+// are re-zeroed (the workspace is zero at rest: the int8 split-K path relies on it)
+__global__ __launch_bounds__(256) void f32_splitk_reduce_zero_kernel(float* __restrict__ part, int64_t M, int64_t N,
+                                                                     int splits, GemmEpi epi) {
+  const int64_t total = M * N;
+  for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x * 4) {  // N % 4 == 0 (checked on the host): four columns of one row
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sl = 0; sl < splits; ++sl) {
+      float4* p = reinterpret_cast<float4*>(part + (int64_t)sl * total + idx);
+      const float4 v = *p;
+      *p = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int64_t n = idx % N;
+    const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      store16(epi.out, idx + j, a4[j] + (epi.bias ? load16(epi.bias, n + j, epi.out_bf16) : 0.0f), epi.out_bf16);
+  }
+}
+
 struct SkinnyPlan { int nt; int splits; };
 static int g_sk_nt = -2, g_sk_splits = -2, g_sk_disable = -2;
+
+// 16-bit kinds: pick (NT, K slices) by a small cost model instead of the int8 rule below (which is tuned on the W8A8
+// decode shapes and left alone): rounds of 256 workgroups x K steps per slice x relative step cost (the 32 KiB activation
+// stage dominates, each 32-column block adds 4 KiB of weights), plus the reduce pass when K is split
+inline SkinnyPlan plan_skinny_half(int64_t M, int64_t N, int ksteps, bool can_split, int max_slices) {
+  const int64_t m_tiles = (M + SK_BM - 1) / SK_BM;
+  const int64_t nt32 = (N + 31) / 32;
+  SkinnyPlan best{1, 1};
+  double best_cost = 1e30;
+  for (int nt = 1; nt <= 5; ++nt) {
+    const int64_t wgs = ((nt32 + nt - 1) / nt) * m_tiles;
+    const int smax = can_split ? (max_slices < 16 ? max_slices : 16) : 1;
+    for (int sp = 1; sp <= smax; ++sp) {
+      const int per = (ksteps + sp - 1) / sp;
+      if (sp > 1 && per < 6) break;
+      const int64_t rounds = (wgs * sp + 255) / 256;
+      const double cost = (double)rounds * (per + 4) * (8.0 + nt) + (sp > 1 ? 40.0 + 4.0 * sp : 0.0);
+      if (cost < best_cost) { best_cost = cost; best = SkinnyPlan{nt, sp}; }
+    }
+  }
+  return best;
+}
 
 inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) {
   if (g_sk_nt == -2) {
@@ -465,6 +513,17 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
         hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<int32_t*>(workspace), M, N, epi);
       }
+    } else if constexpr (KIND == kBF16 || KIND == kF16) {
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);  // fp32 partial slabs [splits][M][N]
+      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
+      int64_t blocks = (M * N / 4 + 255) / 256;
+      blocks = blocks > 1024 ? 1024 : blocks;
+      hipLaunchKernelGGL(f32_splitk_reduce_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         reinterpret_cast<float*>(workspace), M, N, splits, epi);
+    } else {
+      return XM_ERR_UNSUPPORTED;
     }
   } else if (epi.defer) {
     GemmEpi e2 = epi;  // single pass: plain int32 stores into the workspace, nothing else
@@ -509,9 +568,16 @@ template <int KIND>
 int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                   size_t ws_bytes, hipStream_t s) {
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
-  const bool can_split =
-      KIND == kI8 && workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
-  const SkinnyPlan p = plan_skinny(M, N, ksteps, can_split);
+  const bool half_kind = KIND == kBF16 || KIND == kF16;
+  const bool can_split = (KIND == kI8 || (half_kind && N % 4 == 0 && ((uintptr_t)epi.out % 8) == 0)) && workspace &&
+                         ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
+  SkinnyPlan p;
+  if (half_kind) {  // one fp32 slab per K slice must fit the workspace
+    const int64_t fit = can_split ? (int64_t)(ws_bytes / ((size_t)M * N * 4)) : 1;
+    p = plan_skinny_half(M, N, ksteps, can_split, (int)(fit > 16 ? 16 : fit));
+  } else {
+    p = plan_skinny(M, N, ksteps, can_split);
+  }
   switch (p.nt) {
     case 1: return launch_skinny_nt<KIND, 1>(A, W, M, N, Kb, epi, p.splits, workspace, s);
     case 2: return launch_skinny_nt<KIND, 2>(A, W, M, N, Kb, epi, p.splits, workspace, s);
@@ -792,8 +858,13 @@ int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out,
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 64 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16, nullptr, 0};
-  if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
-  return launch_gemm<kF16>(a, w, M, N, K * 2, epi, nullptr, 0, (hipStream_t)stream);
+  // decode-shaped problems with a long K and few columns split K through the registered workspace (fp32 partial slabs,
+  // reduced in slice order: deterministic); without a workspace the launch is unsplit as before
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  gemm_ws_for(stream, &ws, &ws_bytes);
+  if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, ws, ws_bytes, (hipStream_t)stream);
+  return launch_gemm<kF16>(a, w, M, N, K * 2, epi, ws, ws_bytes, (hipStream_t)stream);
 }
 
 static int group_gemm_impl(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,

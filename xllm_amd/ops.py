@@ -337,6 +337,8 @@ def matmul(a, b, bias=None):
         a2 = a2.contiguous()
     N = b.size(0)
     out = torch.empty(a2.size(0), N, dtype=a.dtype, device=a.device)
+    if a2.size(0) <= 512:
+        _ensure_gemm_workspace(a.device, 1)  # decode shapes may split K through it (fp32 slabs, deterministic reduce)
     b_c = b.contiguous()  # keep the (possibly new) tensor alive across the call
     check(_lib.lib().xllm_mi355_matmul(_p(a2), _p(b_c), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
                                       _stream()), "matmul")
