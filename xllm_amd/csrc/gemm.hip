@@ -219,21 +219,22 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------
 constexpr int SK_BM = 256;
 
-template <int KIND, int NT, bool SPLITK, int WAVES, int DEPTH>
+template <int KIND, int NT, bool SPLITK, int WAVES, int DEPTH, int BM = SK_BM>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(const uint8_t* __restrict__ A,
                                                                    const uint8_t* __restrict__ W, int M, int N,
                                                                    int64_t Kb, int ksteps_per_split, GemmEpi epi) {
   using MT = MmaTraits<KIND>;
   using acc_t = typename MT::acc_t;
   constexpr int BNW = NT * 32;                            // columns per workgroup
-  constexpr int A_BYTES = SK_BM * BKB, W_BYTES = BNW * BKB;
-  constexpr int SK_THREADS = WAVES * 64, MT_PER_WAVE = 8 / WAVES;  // m-tiles (32 rows) per wave
+  constexpr int A_BYTES = BM * BKB, W_BYTES = BNW * BKB;           // BM = 256 rows, or 128 for M <= 128 (4 waves)
+  constexpr int SK_THREADS = WAVES * 64, MT_PER_WAVE = (BM / 32) / WAVES;  // m-tiles (32 rows) per wave
+  static_assert(MT_PER_WAVE >= 1 && MT_PER_WAVE * WAVES * 32 == BM, "rows per workgroup = waves x m-tiles x 32");
   constexpr int NLA = A_BYTES / 16 / SK_THREADS;
   constexpr int NLW = (W_BYTES / 16 + SK_THREADS - 1) / SK_THREADS;
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][A_BYTES + W_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * SK_BM;
+  const int n0 = blockIdx.x * BNW, m0 = blockIdx.y * BM;
   const int total_ksteps = (int)((Kb + BKB - 1) / BKB);
   const int ks_begin = blockIdx.z * ksteps_per_split;
   int ks_end = ks_begin + ksteps_per_split;
@@ -449,7 +450,8 @@ static int g_sk_nt = -2, g_sk_splits = -2, g_sk_disable = -2;
 // decode shapes and left alone): rounds of 256 workgroups x K steps per slice x relative step cost (the 32 KiB activation
 // stage dominates, each 32-column block adds 4 KiB of weights), plus the reduce pass when K is split
 inline SkinnyPlan plan_skinny_half(int64_t M, int64_t N, int ksteps, bool can_split, int max_slices) {
-  const int64_t m_tiles = (M + SK_BM - 1) / SK_BM;
+  const int64_t bm = M <= 128 ? 128 : SK_BM;
+  const int64_t m_tiles = (M + bm - 1) / bm;
   const int64_t nt32 = (N + 31) / 32;
   SkinnyPlan best{1, 1};
   double best_cost = 1e30;
@@ -460,14 +462,14 @@ inline SkinnyPlan plan_skinny_half(int64_t M, int64_t N, int ksteps, bool can_sp
       const int per = (ksteps + sp - 1) / sp;
       if (sp > 1 && per < 6) break;
       const int64_t rounds = (wgs * sp + 255) / 256;
-      const double cost = (double)rounds * (per + 4) * (8.0 + nt) + (sp > 1 ? 40.0 + 4.0 * sp : 0.0);
+      const double cost = (double)rounds * (per + 4) * ((bm == 128 ? 4.0 : 8.0) + nt) + (sp > 1 ? 40.0 + 4.0 * sp : 0.0);
       if (cost < best_cost) { best_cost = cost; best = SkinnyPlan{nt, sp}; }
     }
   }
   return best;
 }
 
-inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) {
+inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) {  // (m_tiles = 1 for every M <= 256)
   if (g_sk_nt == -2) {
     const char* e = getenv("XLLM_MI355_SKINNY_NT");
     g_sk_nt = e ? atoi(e) : -1;
@@ -494,18 +496,18 @@ inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) 
 
 static int g_sk_waves = -2, g_sk_depth = -2;
 
-template <int KIND, int NT, int WV, int DP>
+template <int KIND, int NT, int WV, int DP, int BM = SK_BM>
 int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int splits,
                       void* workspace, hipStream_t s) {
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
   int per = (ksteps + splits - 1) / splits;
   splits = (ksteps + per - 1) / per;
-  const dim3 grid((unsigned)((N + NT * 32 - 1) / (NT * 32)), (unsigned)((M + SK_BM - 1) / SK_BM), (unsigned)splits);
+  const dim3 grid((unsigned)((N + NT * 32 - 1) / (NT * 32)), (unsigned)((M + BM - 1) / BM), (unsigned)splits);
   if (splits > 1) {
     if constexpr (KIND == kI8) {
       GemmEpi e2 = epi;
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);
-      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP, BM>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                          (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
       if (!epi.defer) {
         int64_t blocks = (M * N + 255) / 256;
@@ -516,7 +518,7 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
     } else if constexpr (KIND == kBF16 || KIND == kF16) {
       GemmEpi e2 = epi;
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);  // fp32 partial slabs [splits][M][N]
-      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+      hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP, BM>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                          (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
       int64_t blocks = (M * N / 4 + 255) / 256;
       blocks = blocks > 1024 ? 1024 : blocks;
@@ -529,10 +531,10 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
     GemmEpi e2 = epi;  // single pass: plain int32 stores into the workspace, nothing else
     e2.acc_out = reinterpret_cast<int32_t*>(workspace);
     e2.out = nullptr;
-    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP, BM>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, per, e2);
   } else {
-    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
+    hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, false, WV, DP, BM>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, per, epi);
   }
   return hip_check_launch();
@@ -550,6 +552,10 @@ int launch_skinny_nt(const void* A, const void* W, int64_t M, int64_t N, int64_t
   // defaults from the round-1 sweep (tools/gemm_sweep.sh, profiles/r01_gemm_sweep.txt): 8 waves x 32 rows with
   // 2 register stages wins on every decode shape (two waves per SIMD overlap one wave's MFMAs with the other's
   // LDS traffic; a third register stage only costs occupancy)
+  // M <= 128: 128-row tile, 4 waves x 32 rows (half the activation stage, half the padded MFMA rows)
+  static int bm128 = -2;  // XLLM_MI355_SKINNY_BM128=0 keeps the 256-row tile (A/B), read once
+  if (bm128 == -2) { const char* e = getenv("XLLM_MI355_SKINNY_BM128"); bm128 = e ? atoi(e) : 1; }
+  if (M <= 128 && bm128) return launch_skinny_cfg<KIND, NT, 4, 2, 128>(A, W, M, N, Kb, epi, splits, workspace, s);
   int wv = 8, dp = 2;
   if constexpr (KIND == kI8) {  // tuning overrides are only compiled for the int8 kernels
     if (g_sk_waves == 4 || g_sk_waves == 8) wv = g_sk_waves;
