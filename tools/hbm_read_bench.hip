@@ -36,6 +36,42 @@ __global__ __launch_bounds__(256) void kp(const u32x4* __restrict__ p, size_t n_
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the paged-decode access pattern: the buffer is [pages][128 tokens][NH heads][256 B]; a block = (sequence, head) streams
+// its sequence's 32 + 32 pages and reads only ITS head's 256-byte slice of every token row (stride NH * 256 B);
+// HEAD_FAST: the NH blocks of a sequence are adjacent in the grid (as in the kernel). Compare with kp<> (one block
+// reads the whole 1 KiB rows = what a workgroup covering all kv heads of a sequence would do).
+template <int UNROLL, int NH, bool HEAD_FAST>
+__global__ __launch_bounds__(256) void ks(const u32x4* __restrict__ p, size_t n_vec, unsigned* sink) {
+  const int nseq = gridDim.x / NH;
+  const int seq = HEAD_FAST ? blockIdx.x / NH : blockIdx.x % nseq, head = HEAD_FAST ? blockIdx.x % NH : blockIdx.x / nseq;
+  const size_t per_seq = n_vec / nseq;               // 16-byte vectors of one sequence (all heads)
+  const u32x4* q = p + per_seq * seq;
+  const size_t rows = per_seq / (NH * 16);             // token rows of NH * 256 B
+  unsigned acc = 0;
+  // thread t: row (t / 16) of a group of 16 rows, 16-byte chunk (t % 16) of the head's 256-byte slice
+  for (size_t r0 = 0; r0 + 16 * UNROLL <= rows; r0 += 16 * UNROLL) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) v[i] = q[(r0 + i * 16 + threadIdx.x / 16) * (NH * 16) + head * 16 + threadIdx.x % 16];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int UNROLL, int NH, bool HEAD_FAST>
+void run_strided(const u32x4* buf, size_t bytes, int nseq, unsigned* sink) {
+  const int grid = nseq * NH;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  ks<UNROLL, NH, HEAD_FAST><<<grid, 256>>>(buf, bytes / 16, sink);
+  hipEventRecord(e0);
+  for (int r = 0; r < 5; ++r) ks<UNROLL, NH, HEAD_FAST><<<grid, 256>>>(buf, bytes / 16, sink);
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+  printf("head slices (256 B of every %4d-B row): %4d sequences x %d heads, %s, loads_in_flight/lane=%2d  %7.1f us  %5.2f TB/s\n",
+         NH * 256, nseq, NH, HEAD_FAST ? "heads adjacent in the grid" : "heads far apart in the grid", UNROLL, ms * 1e3, bytes / ms / 1e9);
+}
+
 template <int UNROLL>
 void run_private(const u32x4* buf, size_t bytes, int blocks_per_cu, unsigned* sink) {
   const int grid = 256 * blocks_per_cu;
@@ -68,5 +104,11 @@ int main() {
   hipMalloc(&buf, bytes); hipMalloc(&sink, 4); hipMemset(buf, 1, bytes);
   for (int b : {1, 2, 4, 8}) { run<4>(buf, bytes, b, sink); run<8>(buf, bytes, b, sink); run<16>(buf, bytes, b, sink); }
   for (int b : {1, 2, 4}) { run_private<8>(buf, bytes, b, sink); run_private<16>(buf, bytes, b, sink); }
+  run_strided<8, 4, true>(buf, bytes, 256, sink);
+  run_strided<16, 4, true>(buf, bytes, 256, sink);
+  run_strided<8, 4, false>(buf, bytes, 256, sink);
+  run_strided<16, 4, false>(buf, bytes, 256, sink);
+  run_strided<16, 4, true>(buf, bytes, 512, sink);
+  run_strided<16, 1, true>(buf, bytes, 1024, sink);
   return 0;
 }
