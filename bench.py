@@ -57,6 +57,8 @@ def parse():
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
                    help="single GPU: run ONE rank's shard of a TP=k job with the collectives stubbed (tuning aid)")
+    p.add_argument("--emulate-dp", type=int, default=0,
+                   help="single GPU: run ONE replica's share of the batch of a DP=k job (tuning aid, with --emulate-tp)")
     return p.parse_args()
 
 
@@ -173,6 +175,8 @@ def main():
     dp_size = world // tp_size
     tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_size) if world > 1 else (None, 0))
     B = gbatch // dp_size
+    if a.emulate_dp > 1 and world == 1:
+        B = gbatch // a.emulate_dp
     dtype = torch.bfloat16
 
     if a.emulate_tp > 1 and world == 1:
