@@ -392,13 +392,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
             if (epi.acc_out) epi.acc_out[idx] = a;
             if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
           }
+        } else if constexpr (SPLITK) {
+          // fp8 / 16-bit split-K: this K slice's fp32 partial sums go to slab blockIdx.z of the workspace (plain stores);
+          // the reduce kernel adds the slabs in slice order (deterministic), applies scales / bias and re-zeroes them
+          reinterpret_cast<float*>(epi.acc_out)[(int64_t)blockIdx.z * M * N + idx] = acc[t][j][r];
         } else if constexpr (KIND == kFP8) {
           const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
           store16(epi.out, idx, as * (ws * acc[t][j][r]) + bs, epi.out_bf16);
-        } else if constexpr (SPLITK) {
-          // 16-bit split-K: this K slice's fp32 partial sums go to slab blockIdx.z of the workspace (plain stores); the
-          // reduce kernel adds the slabs in slice order (deterministic) and re-zeroes them
-          reinterpret_cast<float*>(epi.acc_out)[(int64_t)blockIdx.z * M * N + idx] = acc[t][j][r];
         } else {
           store16(epi.out, idx, acc[t][j][r] + bs, epi.out_bf16);
         }
@@ -435,11 +435,15 @@ __global__ __launch_bounds__(256) void f32_splitk_reduce_zero_kernel(float* __re
       *p = make_float4(0.f, 0.f, 0.f, 0.f);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    const int64_t n = idx % N;
+    const int64_t m = idx / N, n = idx - m * N;
     const float a4[4] = {acc.x, acc.y, acc.z, acc.w};
+    const float as = epi.a_scale ? epi.a_scale[epi.a_scale_n > 1 ? m : 0] : 1.0f;  // fp8: the unsplit epilogue's formula
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      store16(epi.out, idx + j, a4[j] + (epi.bias ? load16(epi.bias, n + j, epi.out_bf16) : 0.0f), epi.out_bf16);
+    for (int j = 0; j < 4; ++j) {
+      const float bs = epi.bias ? load16(epi.bias, n + j, epi.out_bf16) : 0.0f;
+      const float v = epi.a_scale ? as * (epi.w_scale[epi.w_scale_n > 1 ? n + j : 0] * a4[j]) + bs : a4[j] + bs;
+      store16(epi.out, idx + j, v, epi.out_bf16);
+    }
   }
 }
 
@@ -462,7 +466,9 @@ inline SkinnyPlan plan_skinny_half(int64_t M, int64_t N, int ksteps, bool can_sp
       const int per = (ksteps + sp - 1) / sp;
       if (sp > 1 && per < 6) break;
       const int64_t rounds = (wgs * sp + 255) / 256;
-      const double cost = (double)rounds * (per + 4) * ((bm == 128 ? 4.0 : 8.0) + nt) + (sp > 1 ? 40.0 + 4.0 * sp : 0.0);
+      // units ~ 0.06 us; the reduce pass is one more launch plus sp fp32 slabs of M x N written, read and re-zeroed
+      const double cost = (double)rounds * (per + 10) * ((bm == 128 ? 4.0 : 8.0) + nt) +
+                          (sp > 1 ? 70.0 + 4.0 * sp + (double)M * N * sp / 30000.0 : 0.0);
       if (cost < best_cost) { best_cost = cost; best = SkinnyPlan{nt, sp}; }
     }
   }
@@ -515,7 +521,7 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
         hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<int32_t*>(workspace), M, N, epi);
       }
-    } else if constexpr (KIND == kBF16 || KIND == kF16) {
+    } else if constexpr (KIND == kBF16 || KIND == kF16 || KIND == kFP8) {
       GemmEpi e2 = epi;
       e2.acc_out = reinterpret_cast<int32_t*>(workspace);  // fp32 partial slabs [splits][M][N]
       hipLaunchKernelGGL((gemm_skinny_kernel<KIND, NT, true, WV, DP, BM>), grid, dim3(WV * 64), 0, s, (const uint8_t*)A,
@@ -574,7 +580,7 @@ template <int KIND>
 int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                   size_t ws_bytes, hipStream_t s) {
   const int ksteps = (int)((Kb + BKB - 1) / BKB);
-  const bool half_kind = KIND == kBF16 || KIND == kF16;
+  const bool half_kind = KIND == kBF16 || KIND == kF16 || KIND == kFP8;  // kinds that split K through fp32 slabs
   const bool can_split = (KIND == kI8 || (half_kind && N % 4 == 0 && ((uintptr_t)epi.out % 8) == 0)) && workspace &&
                          ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
   SkinnyPlan p;
@@ -855,7 +861,10 @@ int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float
   if ((a_scale_numel != 1 && a_scale_numel != M) || (w_scale_numel != 1 && w_scale_numel != N)) return XM_ERR_INVALID;
   if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
   GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16, nullptr, 0};
-  return launch_gemm<kFP8>(a, w, M, N, K, epi, nullptr, 0, (hipStream_t)stream);
+  void* ws = nullptr;  // decode shapes split K through the registered workspace (fp32 slabs, deterministic reduce)
+  size_t ws_bytes = 0;
+  gemm_ws_for(stream, &ws, &ws_bytes);
+  return launch_gemm<kFP8>(a, w, M, N, K, epi, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,

@@ -28,6 +28,10 @@
 
 #include "gemm_types.h"
 
+#ifndef P8_FP8_K64  /* -DP8_FP8_K64=0: A/B build on the two 32x32x16 fp8 MFMAs per fragment (half the matrix rate) */
+#define P8_FP8_K64 1
+#endif
+
 namespace xm {
 
 constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
@@ -347,9 +351,16 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
 #else
 #define P8_MMA(MB, NB, FW)                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                              \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
-    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
-    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
+  if constexpr (KIND == kFP8 && P8_FP8_K64) {                                                 \
+    _Pragma("unroll") for (int kp = 0; kp < 2; ++kp) {                                        \
+      acc[MB][NB] = mma_fp8x2(FW[2 * kp], FW[2 * kp + 1], fa[2 * kp], fa[2 * kp + 1], acc[MB][NB]);                 \
+      acc[MB + 1][NB] = mma_fp8x2(FW[2 * kp], FW[2 * kp + 1], fa[4 + 2 * kp], fa[5 + 2 * kp], acc[MB + 1][NB]);     \
+    }                                                                                         \
+  } else {                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                        \
+      acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                  \
+      acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                      \
+    }                                                                                         \
   }                                                                                           \
   __builtin_amdgcn_s_setprio(0);                                                              \
   __builtin_amdgcn_sched_barrier(0);

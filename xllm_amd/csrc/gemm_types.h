@@ -132,6 +132,17 @@ __device__ __forceinline__ typename MmaTraits<KIND>::acc_t mma4(const u32x4 a, c
   }
 }
 
+// fp8 (OCP e4m3) on the gfx950 rate: one v_mfma_f32_32x32x64_f8f6f4 consumes 32 bytes of K per lane and operand (two 16-byte
+// fragments) -- 1024 MAC/clk/SIMD, twice the rate of the two v_mfma_f32_32x32x16_fp8_fp8 it replaces. Zero scale operands
+// select the unscaled encoding (scales of 1). Lane (row, h = lane >> 5) of BOTH operands holds the same 32 K-bytes of its
+// row, so any fragment pair works as long as A and B use the same pair.
+typedef int gi32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16_t mma_fp8x2(const u32x4 a0, const u32x4 a1, const u32x4 b0, const u32x4 b1, f32x16_t c) {
+  const gi32x8_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+  const gi32x8_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0, 0, 0, 0, 0, 0);
+}
+
 // 16-bit output conversion without branches (same bits as f32_to_bf16_bits / the f16 cast of common.h)
 __device__ __forceinline__ unsigned pack16(float v, bool out_bf16) {
   const unsigned bf = f32_to_bf16_bits(v);

@@ -322,6 +322,8 @@ def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=
     if a_scale.numel() not in (1, M) or b_scale.numel() not in (1, N):
         raise Mi355Error("fp8_scaled_matmul: scales must be scalar or per-token / per-channel")
     out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+    if M <= 512:
+        _ensure_gemm_workspace(a.device, 1)  # decode shapes may split K through it (fp32 slabs, deterministic reduce)
     check(_lib.lib().xllm_mi355_fp8_scaled_matmul(_p(a), _p(b), _p(a_scale), a_scale.numel(), _p(b_scale),
                                                  b_scale.numel(), _p(bias), _p(out), M, N, K, _DT[output_dtype],
                                                  _stream()), "fp8_scaled_matmul")
