@@ -403,6 +403,9 @@ __device__ __forceinline__ void pf2_pv(pf32x4_t (&acc_o)[2][8], const typename P
 #undef PF_V_LO
 }
 
+// (__builtin_bit_cast(float, vec[i]) on a vector ELEMENT reads element 0 for every i with hipcc / ROCm 7.2: by-value helper)
+__device__ __forceinline__ float as_f32(unsigned v) { return __builtin_bit_cast(float, v); }
+
 // online softmax of one tile: masks, running max / sum, P = hi + lo 16-bit parts, rescale of O when the max moved
 template <typename T>
 __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTraits<T>::x8 (&pf)[2][2],
@@ -442,8 +445,23 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
     pf32x4_t m4 = __builtin_elementwise_max(__builtin_elementwise_max(s[nb][0], s[nb][1]),
                                             __builtin_elementwise_max(s[nb][2], s[nb][3]));
     float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+#ifdef XM_ABL_PF_BPERMUTE  /* A/B build: the cross-lane maximum through ds_bpermute (LDS pipe, ~100 cycles each) */
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+#else
+    {  // lanes l, l^16, l^32, l^48 hold the same query: v_permlane16_swap / v_permlane32_swap (VALU) exchange the rows.
+       // swap(a, b) -> ([a0 b0 a2 b2], [a1 b1 a3 b3]) (rows of 16 / 32 lanes), so with b = a the maximum of the two results
+       // is the xor-16 / xor-32 reduction (checked by tools/probe_permlane_swap.hip; the second operand is a separate copy).
+      unsigned u = __builtin_bit_cast(unsigned, mx), c;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+      const auto r16 = __builtin_amdgcn_permlane16_swap(u, c, false, false);
+      mx = fmaxf(as_f32(r16[0]), as_f32(r16[1]));
+      u = __builtin_bit_cast(unsigned, mx);
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+      const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
+      mx = fmaxf(as_f32(r32[0]), as_f32(r32[1]));
+    }
+#endif
     const float m_new = fmaxf(m_run[nb], mx * scale_log2);
     const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);  // v_exp_f32: results below 2^-126 flush to 0
     m_run[nb] = m_new;
