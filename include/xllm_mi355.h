@@ -353,6 +353,17 @@ XM_API int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, co
 XM_API int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out,
                                  int64_t max_rows, int64_t n_experts, int64_t N, int64_t K, int dtype,
                                  void* stream);
+/* W8A8 grouped GEMM (GroupGemmParams with a_scale / b_scale, kernels/param.h:374-394; the reference implements it on
+ * MLU / NPU only, its DCU path is 16-bit): out[off_e + m, n] = r16( i32(sum_k a[.., k] w[e, n, k]) * a_scale[..] * w_scale[e, n] ).
+ * a int8 rows sorted by expert ([max_rows, K], a_scale [max_rows]) -- or, with row_index != NULL, the UN-expanded
+ * activations [a_rows, K] / a_scale [a_rows] gathered as row row_index[r] / index_div (the expand of
+ * layers/dcu/fused_moe.cpp:195-197 fused in, so each token is quantised once, not topk times). w [E, N, K] int8, w_scale
+ * [E, N] float32 (16-byte aligned), token_count DEVICE int32 [E]. K % 128 == 0, N % 8 == 0. Needs the MoE scratch
+ * (xllm_mi355_set_moe_workspace) for the device-built tile table: XM_ERR_WORKSPACE otherwise. int32 accumulators exact. */
+XM_API int xllm_mi355_group_gemm_w8a8(const int8_t* a, int64_t a_rows, const float* a_scale, const int32_t* row_index,
+                                      int64_t index_div, const int8_t* w, const float* w_scale,
+                                      const int32_t* token_count, void* out, int64_t max_rows, int64_t n_experts,
+                                      int64_t N, int64_t K, int out_dtype, void* stream);
 /* group_gemm with the reference's expand step fused in (layers/dcu/fused_moe.cpp:195-197: `index_select(hidden,
  * dst_src / topk)` then group_gemm): sorted row r of the grouped problem is row row_index[r] / index_div of `a`
  * ([a_rows, K], the un-expanded activations); the expanded copy is never materialised. Runs on the 256x256 kernel only:

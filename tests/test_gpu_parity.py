@@ -628,6 +628,37 @@ def test_moe_group_gemm_tile_table_path(T, topk, E, K, N):
     assert fused is not None or T * topk < max(1024, 64 * E) or os.environ.get("XLLM_MI355_GROUP_P8") == "0"
 
 
+@pytest.mark.parametrize("T,topk,E,K,N", [(1024, 8, 128, 2048, 1536), (700, 4, 16, 768, 2048), (1200, 2, 5, 256, 520)])
+def test_moe_group_gemm_w8a8(T, topk, E, K, N):
+    """W8A8 grouped GEMM on the int8 8-phase kernel == the oracle's scaled_matmul per expert, bit for bit (exact int32 sums,
+    same fp32 dequant expression); the gather form (each token quantised once, expanded inside the A staging) == the
+    expanded form"""
+    g = torch.Generator().manual_seed(T + E + N)
+    logits = torch.randn(T, E, generator=g)
+    if E == 5:
+        logits[:, 2] = -1e9
+    ids = logits.topk(topk, -1).indices.to(torch.int32)
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.to(DEV), E)
+    r_sizes = sizes.cpu()
+    x = torch.randn(T, K, generator=g).bfloat16()
+    xq, xs = orc.scaled_quantize(x)
+    wq = torch.randint(-127, 128, (E, N, K), generator=g, dtype=torch.int8)
+    ws = torch.rand(E, N, generator=g) * 0.02 + 0.001
+    tok = (dst_src.cpu().long() // topk)
+    xq_s, xs_s = xq[tok], xs[tok]
+    ref = torch.empty(T * topk, N, dtype=torch.bfloat16)
+    off = 0
+    for e in range(E):
+        c = int(r_sizes[e])
+        if c:
+            ref[off:off + c] = orc.scaled_matmul(xq_s[off:off + c].contiguous(), wq[e], xs_s[off:off + c].contiguous(), ws[e], torch.bfloat16, None)
+        off += c
+    got = ops.group_gemm_w8a8(xq_s.to(DEV), xs_s.to(DEV), wq.to(DEV), ws.to(DEV), sizes)
+    assert torch.equal(got.cpu(), ref)
+    fused = ops.group_gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), sizes, row_index=dst_src, index_div=topk)
+    assert torch.equal(fused, got)
+
+
 def test_fused_moe_layer_matches_dense_reference_and_unfused_operators():
     """FusedMoE.forward_experts (fused_moe.cpp:217-337): (a) fused expand / un-sort == the reference operator sequence,
     bit for bit; (b) == a dense per-token evaluation of the selected experts with the same rounding points
@@ -653,10 +684,26 @@ def test_fused_moe_layer_matches_dense_reference_and_unfused_operators():
     assert ((got - ref).norm() / ref.norm()).item() <= 4e-3
 
 
+def test_fused_moe_layer_w8a8_tracks_the_16bit_layer():
+    """FusedMoE(mode="int8"): W8A8 experts (per-token activation scales, per-channel expert weight scales) stay within the
+    quantisation error of the 16-bit layer on the same weights and routing, and are reproducible bit for bit"""
+    from xllm_amd import layers
+    T, H, I, E, topk = 2048, 512, 384, 16, 4
+    mk = lambda mode: layers.FusedMoE(H, I, E, topk, torch.bfloat16, DEV, torch.Generator(device=DEV).manual_seed(3), mode=mode)
+    m16, m8 = mk("16bit"), mk("int8")
+    gd = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    logits = torch.randn(T, E, device=DEV, generator=gd).bfloat16()
+    ref, out = m16.forward_experts(x, logits), m8.forward_experts(x, logits)
+    assert torch.equal(out, m8.forward_experts(x, logits))
+    assert ((out.float() - ref.float()).norm() / ref.float().norm()).item() <= 4e-2
+
+
 # ------------------------------------------------------------------------------------------- N1 fusions
-@pytest.mark.parametrize("d,mode", [(18944, "silu"), (4864, "silu"), (32000, "silu"), (1024, "gelu")])
-def test_act_and_mul_int8_fusion_equals_two_ops(d, mode):
-    T = 7
+@pytest.mark.parametrize("d,mode,T", [(18944, "silu", 7), (4864, "silu", 7), (32000, "silu", 7), (1024, "gelu", 7),
+                                       (768, "silu", 3001), (512, "silu", 600), (1024, "silu", 1000), (96, "silu", 513)])
+def test_act_and_mul_int8_fusion_equals_two_ops(d, mode, T):
+    """(the short-row / many-row cases run the one-wave-per-row kernel used for MoE expert widths)"""
     g = torch.Generator().manual_seed(d)
     x = (torch.randn(T, 2 * d, generator=g) * 2).bfloat16().to(DEV)
     act = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)

@@ -50,3 +50,22 @@ tot = us_topk + us_idx + (us_g1g if h13g is not None else us_exp + us_g1) + us_a
 print(f"[moe cfg5] T={T}: topk {us_topk:.0f} | index {us_idx:.0f} | (expand {us_exp:.0f} + w13 {us_g1:.0f} ->) w13 with gather {g1g_txt} | "
       f"act {us_act:.0f} | w2 {us_g2:.0f} us ({f2 / us_g2 / 1e6:.0f} TF/s) | (unsort {us_unsort:.0f} + combine {us_comb:.0f} ->) fused combine {us_fused:.0f} | "
       f"total {tot:.0f} us = {(f1 + f2) / tot / 1e6:.0f} TF/s   expert sizes min/max {int(sizes.min())}/{int(sizes.max())}")
+
+# ---- W8A8 experts (config 5 names a grouped QUANT GEMM): per-token int8 activations, per-channel int8 expert weights
+def q8(t):
+    sc = t.abs().amax(-1, keepdim=True).clamp_min(1e-8) / 127.0
+    return torch.round(t / sc).clamp_(-127, 127).to(torch.int8), sc.squeeze(-1).float()
+
+
+w13q, w13s = q8(w13.float())
+w2q, w2s = q8(w2.float())
+us_q1, (xq, xs) = timed(lambda: ops.scaled_quantize(x))
+us_i1, h13i = timed(lambda: ops.group_gemm_w8a8(xq, xs, w13q, w13s, sizes, row_index=dst_src, index_div=topk))
+us_aq, (aq, as_) = timed(lambda: ops.act_and_mul_dynamic_int8_quant(h13i, "silu"))
+us_i2, h2i = timed(lambda: ops.group_gemm_w8a8(aq, as_, w2q, w2s, sizes))
+us_ci, outi = timed(lambda: ops.moe_combine_sorted(h2i, src_dst, w, T, topk))
+toti = us_topk + us_idx + us_q1 + us_i1 + us_aq + us_i2 + us_ci
+err = ((outi.float() - out.float()).norm() / out.float().norm()).item()
+print(f"[moe cfg5 W8A8] T={T}: quant {us_q1:.0f} | w13 int8 with gather {us_i1:.0f} us ({f1 / us_i1 / 1e6:.0f} TOP/s) | silu*mul+quant {us_aq:.0f} | "
+      f"w2 int8 {us_i2:.0f} us ({f2 / us_i2 / 1e6:.0f} TOP/s) | combine {us_ci:.0f} | total {toti:.0f} us = {(f1 + f2) / toti / 1e6:.0f} TOP/s   "
+      f"(vs the 16-bit path: relative L2 difference {err:.1e})")

@@ -933,6 +933,35 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   return hip_check_launch();
 }
 
+int xllm_mi355_group_gemm_w8a8(const int8_t* a, int64_t a_rows, const float* a_scale, const int32_t* row_index,
+                               int64_t index_div, const int8_t* w, const float* w_scale, const int32_t* token_count,
+                               void* out, int64_t max_rows, int64_t n_experts, int64_t N, int64_t K, int out_dtype,
+                               void* stream) {
+  if (!a || !a_scale || !w || !w_scale || !token_count || !out || max_rows < 0 || n_experts <= 0 || N <= 0 || K <= 0)
+    return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (row_index && (index_div <= 0 || a_rows <= 0 || a_rows * K >= (1ll << 31))) return XM_ERR_INVALID;
+  if (K % 128 != 0 || N % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 16) ||
+      ((uintptr_t)w_scale % 16) || n_experts > 1024)
+    return XM_ERR_UNSUPPORTED;
+  if (max_rows == 0) return XM_OK;
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  xm_moe_scratch(&scratch, &scratch_bytes);
+  const int64_t slots = (max_rows + 255) / 256 + n_experts;
+  const size_t table_bytes = (size_t)slots * 16;
+  if (!scratch || scratch_bytes < table_bytes + 64) return XM_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));
+  hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
+  GemmEpi epi{a_scale, max_rows, w_scale, N, nullptr, out, nullptr, out_dtype == XM_BF16, token_count, (int)n_experts};
+  epi.group_tiles = table;
+  epi.gather_rows = row_index;
+  epi.gather_div = (int)index_div;
+  epi.gather_src_rows = (int)a_rows;
+  return launch_gemm_p8<kI8>(a, w, max_rows, N, K, epi, nullptr, 0, 1, s);
+}
+
 int xllm_mi355_group_gemm(const void* a, const void* w, const int32_t* token_count, void* out, int64_t max_rows,
                           int64_t n_experts, int64_t N, int64_t K, int dtype, void* stream) {
   return group_gemm_impl(a, w, token_count, out, max_rows, n_experts, N, K, dtype, nullptr, 0, 0, stream);

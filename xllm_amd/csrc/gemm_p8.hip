@@ -657,7 +657,7 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) ||
       (epi.group_counts && !epi.group_tiles))
     return XM_ERR_UNSUPPORTED;
-  if (epi.group_tiles && (KIND == kI8 || splits > 1)) return XM_ERR_UNSUPPORTED;
+  if (epi.group_tiles && (splits > 1 || KIND == kFP8)) return XM_ERR_UNSUPPORTED;
   // grouped: M = total rows; every expert may add one partial tile (the table has that many slots)
   const int m_tiles = (int)((M + P8_BM - 1) / P8_BM) + (epi.group_tiles ? epi.n_groups : 0);
   const int n_tiles = (int)((N + P8_BN - 1) / P8_BN);
@@ -679,7 +679,7 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   }
   if constexpr (KIND == kI8) {
     // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless one of the selectors asks for a 32x32x32 kernel
-    if (!mfma32 && !ring) {
+    if ((!mfma32 && !ring) || epi.group_tiles) {  // (the grouped mode lives in the 16x16x64 kernel)
       if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
       return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
     }

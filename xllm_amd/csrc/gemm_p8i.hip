@@ -86,7 +86,7 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
         const int mb = mp * 2 + h, row = h * 16 + ml;
         const int m = m0 + wr * 128 + mb * 16 + ml;
         const int mc = m < M ? m : M - 1;
-        const float as = epi.a_scale ? epi.a_scale[mc] : 1.0f;
+        const float as = epi.a_scale ? epi.a_scale[epi.gather_rows ? epi.gather_rows[mc] / epi.gather_div : mc] : 1.0f;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           if (epi.acc_out) {  // raw accumulators requested (tests)
@@ -116,10 +116,14 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
 }
 
 template <bool SPLITK>
-__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A,
-                                                                const uint8_t* __restrict__ W, int M, int N,
+__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A_in,
+                                                                const uint8_t* __restrict__ W_in, int M_in, int N,
                                                                 int64_t Kb, int m_tiles, int n_tiles,
-                                                                int ktiles_per_split, GemmEpi epi) {
+                                                                int ktiles_per_split, GemmEpi epi_in) {
+  const uint8_t* A = A_in;
+  const uint8_t* W = W_in;
+  int M = M_in;
+  GemmEpi epi = epi_in;
   // [K-tile buffer 2][slot 4][128 rows x 128 B]; slot 0 = W rows nh=0, 1 = A rows mh=0, 2 = W nh=1, 3 = A mh=1
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * 4 * P8_SLOT];
 
@@ -143,6 +147,22 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
     nt = (SN << (5 - lm)) + (within >> lm);
     if (mt >= m_tiles || nt >= n_tiles) return;  // padding of the rasterised grid (whole workgroup)
   }
+  if (epi.group_tiles) {
+    // grouped (MoE) W8A8: see gemm_p8_kernel. Expert e owns sorted rows [off, off + cnt), weight W[e] and the weight
+    // scales w_scale[e * N ..]; the per-token activation scales follow the rows (a_scale[off + m], or -- with the
+    // expand fused in -- a_scale[gather_rows[off + m] / gather_div] of the un-expanded activations)
+    const int4 gt = reinterpret_cast<const int4*>(epi.group_tiles)[mt];
+    const int ge = __builtin_amdgcn_readfirstlane(gt.x);
+    if (ge < 0) return;  // surplus slot (the grid is sized for the worst case)
+    const int goff = __builtin_amdgcn_readfirstlane(gt.y);
+    M = __builtin_amdgcn_readfirstlane(gt.z);
+    mt = __builtin_amdgcn_readfirstlane(gt.w);
+    if (epi.gather_rows) epi.gather_rows += goff;  // row r of the expert -> source row gather_rows[r] / gather_div
+    else { A += (int64_t)goff * Kb; epi.a_scale += goff; }
+    W += (int64_t)ge * N * Kb;
+    epi.w_scale += (int64_t)ge * N;
+    epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)goff * N * 2;
+  }
   const int m0 = mt * P8_BM, n0 = nt * P8_BN;
   const int total_kt = (int)(Kb / P8_BK);
   const int kt_begin = blockIdx.z * ktiles_per_split;
@@ -159,8 +179,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
   // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
   // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
   // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
-  const __amdgpu_buffer_rsrc_t rsrc_a =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * Kb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(A), 0, (int)((int64_t)(epi.gather_rows ? epi.gather_src_rows : M) * Kb), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
   int voff_a[2][2], voff_w[2][2];  // [i][half]
@@ -174,6 +194,7 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
         // A slot (mh = h): LDS row i*64 + r  <->  activation row m0 + i*128 + h*64 + r   (i = reading group wr)
         int ar = m0 + i * 128 + h * 64 + srow;
         ar = ar < M ? ar : M - 1;
+        if (epi.gather_rows) ar = epi.gather_rows[ar] / epi.gather_div;  // expand fused into the staging
         voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
         // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
         int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);

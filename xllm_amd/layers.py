@@ -358,20 +358,35 @@ class FusedMoE:
 
     def __init__(self, hidden: int, inter: int, n_experts: int, topk: int, dtype, device, gen, renormalize: bool = True,
                  scoring_func: str = "softmax", correction_bias=None, tp: Optional[parallel.ProcessGroup] = None,
-                 fuse: bool = True):
+                 fuse: bool = True, mode: str = "16bit"):
         self.E, self.topk, self.renorm, self.scoring, self.bias, self.tp, self.fuse = (
             n_experts, topk, renormalize, scoring_func, correction_bias, tp, fuse)
+        self.mode = mode  # "16bit" = the reference's DCU path; "int8" = W8A8 experts (GroupGemmParams a_scale / b_scale)
         tp_size = tp.world_size() if tp is not None else 1
         assert inter % tp_size == 0
         i_local = inter // tp_size
         self.w13 = (torch.randn(n_experts, 2 * i_local, hidden, device=device, generator=gen) / math.sqrt(hidden)).to(dtype)
         self.w2 = (torch.randn(n_experts, hidden, i_local, device=device, generator=gen) / math.sqrt(inter)).to(dtype)
+        if mode == "int8":  # symmetric per-output-channel int8 (what a W8A8 checkpoint carries)
+            def q8(w):
+                sc = (w.float().abs().amax(-1) / 127.0).clamp_min(1e-12)
+                return torch.round(w.float() / sc[..., None]).clamp_(-127, 127).to(torch.int8), sc
+            self.w13_q, self.w13_s = q8(self.w13)
+            self.w2_q, self.w2_s = q8(self.w2)
 
     def forward_experts(self, hidden_states, router_logits):
         x = hidden_states.reshape(-1, hidden_states.size(-1))
         T = x.size(0)
         weights, ids = ops.moe_fused_topk(router_logits.reshape(T, -1), self.topk, self.renorm, self.bias, self.scoring)
         src_dst, dst_src, sizes = ops.moe_compute_index(ids, self.E)
+        if self.mode == "int8":
+            # each token is quantised ONCE; the expand happens inside the first grouped GEMM's A staging (scales follow)
+            xq, xs = ops.scaled_quantize(x)
+            h13 = ops.group_gemm_w8a8(xq, xs, self.w13_q, self.w13_s, sizes, x.dtype, row_index=dst_src, index_div=self.topk)
+            aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu")
+            h2 = ops.group_gemm_w8a8(aq, a_s, self.w2_q, self.w2_s, sizes, x.dtype)
+            out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk)
+            return parallel.reduce(out, self.tp).reshape(hidden_states.shape)
         h13 = ops.group_gemm_gather(x, dst_src, self.topk, self.w13, sizes) if self.fuse else None
         if h13 is None:  # reference order: expand with index_select, then the grouped GEMM
             h13 = ops.group_gemm(x.index_select(0, (dst_src // self.topk).long()), self.w13, sizes)

@@ -507,6 +507,29 @@ def group_gemm_gather(input, row_index, index_div: int, weight, token_count):
     return out
 
 
+def group_gemm_w8a8(a, a_scale, weight, w_scale, token_count, output_dtype=torch.bfloat16, row_index=None, index_div: int = 1):
+    """W8A8 grouped GEMM (GroupGemmParams.a_scale / b_scale, param.h:374-394): a int8 [rows, K] sorted by expert with
+    a_scale [rows] -- or, with row_index, the un-expanded activations [T, K] / [T] gathered as row_index[r] / index_div;
+    weight int8 [E, N, K], w_scale float32 [E, N]; token_count int32 [E] (device). Returns 16-bit [rows, N]."""
+    _need_cuda(a, a_scale, weight, w_scale, token_count)
+    E, N, K = weight.shape
+    rows = row_index.numel() if row_index is not None else a.size(0)
+    need = 16 * (rows // 256 + E) + 64
+    ws = _moe_ws.get(a.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=a.device)
+        _moe_ws[a.device] = ws
+        check(_lib.lib().xllm_mi355_set_moe_workspace(ws.data_ptr(), ws.numel()), "set_moe_workspace")
+    out = torch.empty(rows, N, dtype=output_dtype, device=a.device)
+    a_c, as_c, w_c = a.contiguous(), a_scale.contiguous(), weight.contiguous()  # keep the (possibly new) tensors alive
+    ws_c = w_scale.to(torch.float32).contiguous()
+    idx_c = row_index.contiguous() if row_index is not None else None
+    check(_lib.lib().xllm_mi355_group_gemm_w8a8(_p(a_c), a.size(0), _p(as_c), _p(idx_c), index_div, _p(w_c), _p(ws_c),
+                                                _p(token_count), _p(out), rows, E, N, K, _DT[output_dtype], _stream()),
+          "group_gemm_w8a8")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ N1 fusions
 def rotary_embedding_and_cache(positions, query, key, value, cos_sin_cache, slot_ids, key_cache, value_cache,
                                head_size: int, is_neox: bool = True) -> None:
