@@ -329,6 +329,31 @@ torch::Tensor group_gemm_gather(const torch::Tensor& input, const torch::Tensor&
   return out;
 }
 
+torch::Tensor group_gemm_w8a8(const torch::Tensor& input, const torch::Tensor& a_scale, const torch::Tensor& weight,
+                              const torch::Tensor& b_scale, const torch::Tensor& token_count, torch::ScalarType out_dtype,
+                              const std::optional<torch::Tensor>& gather_index, int64_t index_div) {
+  DeviceGuard guard(input.device());
+  TORCH_CHECK(input.dim() == 2 && weight.dim() == 3 && input.size(1) == weight.size(2) &&
+                  input.scalar_type() == torch::kInt8 && weight.scalar_type() == torch::kInt8 &&
+                  a_scale.scalar_type() == torch::kFloat32 && b_scale.scalar_type() == torch::kFloat32 &&
+                  token_count.scalar_type() == torch::kInt32,
+              "group_gemm_w8a8: int8 input [rows, K] / weight [E, N, K], float32 scales, int32 token_count");
+  const bool gather = gather_index.has_value() && gather_index->defined();
+  const torch::Tensor x = input.contiguous(), w = weight.contiguous(), as = a_scale.contiguous(), bs = b_scale.contiguous();
+  torch::Tensor idx;
+  if (gather) idx = gather_index->contiguous();
+  const int64_t E = w.size(0), N = w.size(1), K = w.size(2), rows = gather ? idx.numel() : x.size(0);
+  TORCH_CHECK(as.numel() == x.size(0) && bs.numel() == E * N, "group_gemm_w8a8: scale shapes");
+  ensure_moe_scratch(x, 16 * (rows / 256 + E) + 64);
+  auto out = torch::empty({rows, N}, x.options().dtype(out_dtype));
+  check(xllm_mi355_group_gemm_w8a8(x.data_ptr<int8_t>(), x.size(0), as.data_ptr<float>(),
+                                   gather ? idx.data_ptr<int32_t>() : nullptr, index_div, w.data_ptr<int8_t>(),
+                                   bs.data_ptr<float>(), token_count.data_ptr<int32_t>(), p(out), rows, E, N, K, dt(out_dtype),
+                                   cur_stream()),
+        "group_gemm_w8a8");
+  return out;
+}
+
 torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& seqlens_k,
                          const torch::Tensor& block_table, int64_t head_size_v, double softmax_scale, int64_t max_kv_len) {
   TORCH_CHECK(q.dim() == 3 && k_cache.dim() == 4 && k_cache.size(2) == 1 && k_cache.size(3) == q.size(2),

@@ -84,6 +84,12 @@ torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const
 // returns an undefined tensor when the 256x256 kernel cannot take the shape (the caller keeps the two reference calls)
 torch::Tensor group_gemm_gather(const torch::Tensor& input, const torch::Tensor& row_index, int64_t index_div,
                                 const torch::Tensor& weight, const torch::Tensor& token_count);
+// kernel::group_gemm with GroupGemmParams::a_scale / b_scale (kernels/param.h:374-394): W8A8 experts. input int8
+// [rows, K] sorted by expert with a_scale [rows]; or, with gather_index defined, the un-expanded [T, K] / [T] gathered
+// as gather_index[r] / index_div. weight int8 [E, N, K], b_scale float32 [E, N]. Returns [rows, N] in out_dtype.
+torch::Tensor group_gemm_w8a8(const torch::Tensor& input, const torch::Tensor& a_scale, const torch::Tensor& weight,
+                              const torch::Tensor& b_scale, const torch::Tensor& token_count, torch::ScalarType out_dtype,
+                              const std::optional<torch::Tensor>& gather_index, int64_t index_div);
 // flash_mla::dense_decode (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] (nope || pe), k_cache
 // [n_blocks, block, 1, 576], values = the first head_size_v dims of the latent
 torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& seqlens_k,

@@ -20,6 +20,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("moe_combine_result_sorted", &k::moe_combine_result_sorted);
   m.def("group_gemm", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& c) { return k::group_gemm(x, w, c, std::nullopt); });
   m.def("group_gemm_gather", &k::group_gemm_gather);
+  m.def("group_gemm_w8a8", [](const torch::Tensor& x, const torch::Tensor& as, const torch::Tensor& w, const torch::Tensor& bs, const torch::Tensor& c, std::optional<torch::Tensor> idx, int64_t div) { return k::group_gemm_w8a8(x, as, w, bs, c, torch::kBFloat16, idx, div); });
   m.def("mla_decode", &k::mla_decode);
   m.def("rejection_sample", &k::rejection_sample);
   m.def("scaled_quantize", [](const torch::Tensor& x) {

@@ -27,7 +27,7 @@ def test_shim_builds_and_exposes_reference_operator_names():
     for name in ("rms_norm", "fused_add_rms_norm", "act_and_mul", "reshape_paged_cache", "rotary_embedding", "matmul",
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
                  "random_sample", "rejection_sample", "moe_fused_topk", "moe_gen_idx", "moe_combine_result",
-                 "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "mla_decode"):
+                 "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode"):
         assert hasattr(m, name)
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
@@ -136,6 +136,11 @@ def test_shim_moe_and_mla_equal_the_ctypes_path():
     out = m.moe_combine_result(full, w)
     assert torch.equal(out, ops.moe_combine_result(full, w, T, topk))
     assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst), out)
+    xq, xs = ops.scaled_quantize(x)
+    w13q = torch.randint(-127, 128, (E, 2 * I, H), dtype=torch.int8, device=dev, generator=gd)
+    w13s = torch.rand(E, 2 * I, device=dev, generator=gd) * 0.02 + 0.001
+    h8 = m.group_gemm_w8a8(xq, xs, w13q, w13s, sizes, dst_src, topk)
+    assert torch.equal(h8, ops.group_gemm_w8a8(xq, xs, w13q, w13s, sizes, row_index=dst_src, index_div=topk))
     # MLA decode
     B, Hh, bs = 3, 16, 64
     kv_lens = torch.tensor([200, 64, 1], dtype=torch.int32, device=dev)
