@@ -308,6 +308,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
   auto compute = [&](int buf) {
     const uint8_t* la = lds[buf];
     const uint8_t* lw = lds[buf] + A_BYTES;
+    if constexpr (KIND == kFP8) {
+      // fp8 on the gfx950 rate: v_mfma_f32_32x32x64_f8f6f4 takes 32 bytes of K per lane and operand = the fragment pair
+      // (chunks 4 kp + h, 4 kp + 2 + h) of the 128-byte K step (see mma_fp8x2 in gemm_types.h)
+#pragma unroll
+      for (int kp = 0; kp < BKB / 64; ++kp) {
+        const int c0 = kp * 4 + (lane >> 5), c1 = c0 + 2;
+        u32x4 fa0[MT_PER_WAVE], fa1[MT_PER_WAVE];
+#pragma unroll
+        for (int t = 0; t < MT_PER_WAVE; ++t) {
+          const int rowa = wave * (32 * MT_PER_WAVE) + t * 32 + (lane & 31);
+          fa0[t] = *reinterpret_cast<const u32x4*>(la + rowa * BKB + ((c0 ^ ((rowa >> 1) & 7)) << 4));
+          fa1[t] = *reinterpret_cast<const u32x4*>(la + rowa * BKB + ((c1 ^ ((rowa >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int roww = j * 32 + (lane & 31);
+          const u32x4 fw0 = *reinterpret_cast<const u32x4*>(lw + roww * BKB + ((c0 ^ ((roww >> 1) & 7)) << 4));
+          const u32x4 fw1 = *reinterpret_cast<const u32x4*>(lw + roww * BKB + ((c1 ^ ((roww >> 1) & 7)) << 4));
+#pragma unroll
+          for (int t = 0; t < MT_PER_WAVE; ++t) acc[t][j] = mma_fp8x2(fa0[t], fa1[t], fw0, fw1, acc[t][j]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BKB / 32; ++kk) {
       const int chunk = kk * 2 + (lane >> 5);
