@@ -699,6 +699,29 @@ def test_fused_moe_layer_w8a8_tracks_the_16bit_layer():
     assert ((out.float() - ref.float()).norm() / ref.float().norm()).item() <= 4e-2
 
 
+@pytest.mark.parametrize("mode", ["16bit", "int8"])
+def test_fused_moe_layer_replays_from_a_hip_graph(mode):
+    """the whole expert path (top-k, index build, tile-table plan, gathered grouped GEMMs, combine) has no host sync: one
+    captured graph, replayed on NEW inputs written into the static buffers, equals the eager layer bit for bit (the
+    reference's DCU group_gemm reads token_count on the host, kernels/dcu/group_gemm.cpp:45, and cannot be captured)"""
+    from xllm_amd import layers
+    T, H, I, E, topk = 1536, 512, 384, 16, 4
+    moe = layers.FusedMoE(H, I, E, topk, torch.bfloat16, DEV, torch.Generator(device=DEV).manual_seed(5), mode=mode)
+    gd = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    logits = torch.randn(T, E, device=DEV, generator=gd).bfloat16()
+    moe.forward_experts(x, logits)                      # warm-up: workspaces are registered outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = moe.forward_experts(x, logits)
+    x.copy_(torch.randn(T, H, device=DEV, generator=gd).bfloat16())
+    logits.copy_(torch.randn(T, E, device=DEV, generator=gd).bfloat16())   # new routing, new expert sizes
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, moe.forward_experts(x, logits))
+
+
 # ------------------------------------------------------------------------------------------- N1 fusions
 @pytest.mark.parametrize("d,mode,T", [(18944, "silu", 7), (4864, "silu", 7), (32000, "silu", 7), (1024, "gelu", 7),
                                        (768, "silu", 3001), (512, "silu", 600), (1024, "silu", 1000), (96, "silu", 513)])
