@@ -1070,6 +1070,37 @@ def test_deepseek_v2_attention_layer_matches_a_plain_restatement():
     assert ((out2.float() - ref2).norm() / ref2.norm()).item() <= 8e-3
 
 
+def test_deepseek_v2_attention_decode_replays_from_a_hip_graph():
+    """MLA decode layer (latent projection, cache write, absorbed query, flash-MLA decode, output projections) captured
+    once and replayed on new hidden states / positions / slots == eager, bit for bit"""
+    from xllm_amd import layers
+    from xllm_amd.attention import AttentionMetadata, KVCache
+    H, heads, bs, B = 1024, 16, 64, 6
+    gd = torch.Generator(device=DEV).manual_seed(21)
+    attn = layers.DeepseekV2Attention(H, heads, 384, 512, 128, 64, 128, 1e-6, torch.bfloat16, DEV, gd)
+    cache = KVCache(torch.randn(B * 3 + 1, bs, 1, 576, device=DEV, generator=gd).bfloat16(), None)
+    table = torch.randperm(B * 3, device=DEV, generator=gd).to(torch.int32).view(B, 3)
+    kv_lens = torch.tensor([130, 64, 1, 99, 191, 65], dtype=torch.int32, device=DEV)
+    pos = (kv_lens - 1).long()
+    slots = (table.long()[torch.arange(B, device=DEV), pos // bs] * bs + pos % bs).to(torch.int32)
+    md = AttentionMetadata(q_cu_seq_lens=torch.arange(B + 1, dtype=torch.int32, device=DEV), kv_cu_seq_lens=None,
+                           kv_seq_lens=kv_lens, slot_mapping=slots, block_table=table, max_query_len=1, max_seq_len=192)
+    x = torch.randn(B, H, device=DEV, generator=gd).bfloat16()
+    attn.forward(pos, x, md, cache)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = attn.forward(pos, x, md, cache)
+    x.copy_(torch.randn(B, H, device=DEV, generator=gd).bfloat16())
+    kv_lens.copy_(torch.tensor([131, 65, 2, 100, 192, 66], dtype=torch.int32, device=DEV))
+    pos.copy_((kv_lens - 1).long())
+    slots.copy_((table.long()[torch.arange(B, device=DEV), pos // bs] * bs + pos % bs).to(torch.int32))
+    g.replay()
+    torch.cuda.synchronize()
+    ref_cache = cache.k_cache.clone()
+    assert torch.equal(out, attn.forward(pos, x, md, cache)) and torch.equal(cache.k_cache, ref_cache)
+
+
 # ------------------------------------------------------------------------------------------- N3: step-level harness
 @pytest.mark.parametrize("temperature", [0.0, 0.8])
 def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):
