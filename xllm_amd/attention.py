@@ -173,14 +173,17 @@ class AttentionImpl:
         self.window_left = sliding_window if sliding_window and sliding_window > 0 else -1
 
     def forward(self, md: AttentionMetadata, query, key, value, kv_cache: KVCache,
-                output: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, None]:
+                output: Optional[torch.Tensor] = None, kv_written: bool = False) -> Tuple[torch.Tensor, None]:
+        """kv_written: the caller already stored this step's K / V (ops.rotary_embedding_and_cache, the N1 fusion of RoPE
+        with the KV write) -- skip the reshape_paged_cache below"""
         T = query.size(0)
         q = query.view(T, self.num_heads, self.head_size) if query.dim() == 2 and query.is_contiguous() \
             else query.unflatten(-1, (self.num_heads, self.head_size))
         k = key.unflatten(-1, (self.num_kv_heads, self.head_size)) if key.dim() == 2 else key
         v = value.unflatten(-1, (self.num_kv_heads, self.head_size)) if value.dim() == 2 else value
         kc, vc = kv_cache.get_k_cache(), kv_cache.get_v_cache()
-        ops.reshape_paged_cache(md.slot_mapping, k, v, kc, vc)  # flash_attention.cpp:310-318
+        if not kv_written:
+            ops.reshape_paged_cache(md.slot_mapping, k, v, kc, vc)  # flash_attention.cpp:310-318
         if md.is_prefill:
             out = ops.prefill_attention(q, k, v, md.q_cu_seq_lens, md.kv_cu_seq_lens, md.max_query_len, self.scale,
                                         True, self.window_left, out=output)

@@ -205,6 +205,10 @@ class Qwen2DecoderLayer:
                 attn = ops.paged_attention(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache, kv_cache.v_cache, None,
                                            md.kv_seq_lens, md.block_table, 1, md.max_seq_len, self.attn.scale, False,
                                            self.attn.window_left)
+        elif self.fuse:  # prefill / chunked prefill: the same RoPE + KV-write fusion, then the attention kernel alone
+            ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
+                                           kv_cache.v_cache, self.d, True)
+            attn, _ = self.attn.forward(md, q, k, v, kv_cache, kv_written=True)
         else:
             ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)
             attn, _ = self.attn.forward(md, q, k, v, kv_cache)
