@@ -100,3 +100,34 @@ def test_moe_index_build_random(T, topk, E, seed):
     ref = orc.moe_compute_index(ids, E)
     for a, b in zip(got, ref):
         assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.gpu
+@settings(max_examples=8, **COMMON)
+@given(st.integers(1, 900), st.sampled_from([1, 2, 4]), st.sampled_from([2, 7, 32]), st.sampled_from([128, 384]),
+       st.sampled_from([8, 72, 256]), st.integers(0, 2 ** 16))
+def test_group_gemm_w8a8_random(T, topk, E, K, N, seed):
+    """W8A8 grouped GEMM (tile table + gather) == the oracle's scaled_matmul per expert, bit for bit, on random routing
+    (empty experts, experts smaller than a tile, N smaller than a tile)"""
+    from xllm_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    topk = min(topk, E)
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(T)]).to(torch.int32)
+    if E > 2:
+        ids[ids == 1] = 0                                   # expert 1 stays empty
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.cuda(), E)
+    xq = torch.randint(-127, 128, (T, K), generator=g, dtype=torch.int8)
+    xs = torch.rand(T, generator=g) * 0.05 + 0.001
+    wq = torch.randint(-127, 128, (E, N, K), generator=g, dtype=torch.int8)
+    ws = torch.rand(E, N, generator=g) * 0.02 + 0.001
+    tok = dst_src.cpu().long() // topk
+    ref = torch.empty(T * topk, N, dtype=torch.bfloat16)
+    off = 0
+    for e in range(E):
+        c = int(sizes[e])
+        if c:
+            ref[off:off + c] = orc.scaled_matmul(xq[tok[off:off + c]].contiguous(), wq[e], xs[tok[off:off + c]].contiguous(),
+                                                 ws[e], torch.bfloat16, None)
+        off += c
+    got = ops.group_gemm_w8a8(xq.cuda(), xs.cuda(), wq.cuda(), ws.cuda(), sizes, row_index=dst_src, index_div=topk)
+    assert torch.equal(got.cpu(), ref)
