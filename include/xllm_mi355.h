@@ -283,8 +283,9 @@ XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,
  * of each sequence (kv_lens [B], block_table [B, max_blocks]) -- call xllm_mi355_reshape_paged_cache with v = NULL
  * (store_latent_cache, :170-178) first -- out [T, H, 512].  causal != 0: query i of a sequence sees its first
  * kv_len - (q_len - 1 - i) keys (bottom-right alignment; identical to torch's is_causal when q_len == kv_len).
- * First version: every query token streams its keys like a decode entry (HBM/L2 traffic T*L/2 rows; the H heads of
- * a token share the stream).  workspace >= 8*T bytes (+ split-KV partials, see _mla_decode). */
+ * block_size % 64 == 0 and >= 128 workgroups of (4 query tokens x 16 heads): the four tokens of a workgroup share every
+ * DMA'd KV tile (no workspace beyond the index arrays); otherwise every query token streams its keys like a decode
+ * entry with split-KV.  workspace >= 8*T bytes (+ split-KV partials, see _mla_decode). */
 XM_API int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out, const int32_t* cu_q,
                                   const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks,
                                   int64_t batch, int64_t total_q_tokens, int64_t n_heads, int64_t head_dim,

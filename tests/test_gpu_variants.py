@@ -34,7 +34,10 @@ def test_gemm_parity_under_kernel_selector(env):
     {"XLLM_MI355_MLA_DMA": "0", "XLLM_MI355_MLA_SPLITS": "3"},
     {"XLLM_MI355_MLA_SPLITS": "3"},                          # LDS-DMA kernel with a forced split-KV (uneven slices)
     {"XLLM_MI355_MLA_SPLITS": "1"},
-], ids=["mla_regstaged", "mla_regstaged_split3", "mla_dma_split3", "mla_dma_nosplit"])
+    {"XLLM_MI355_MLA_PREFILL": "0"},                         # prefill: one decode-kernel entry per query token
+    {"XLLM_MI355_MLA_PREFILL": "1"},                         # prefill: the tile-sharing kernel on every batch size
+], ids=["mla_regstaged", "mla_regstaged_split3", "mla_dma_split3", "mla_dma_nosplit", "mla_prefill_per_token",
+        "mla_prefill_shared_forced"])
 def test_mla_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

@@ -504,6 +504,261 @@ __global__ __launch_bounds__(256, 1) void mla_decode_dma_kernel(
   }
 }
 
+__device__ __forceinline__ float mla_as_f32(unsigned v) { return __builtin_bit_cast(float, v); }
+
+// acc *= alpha on an accumulator that lives in AGPRs, inside the (rare) rescale branch. Written as asm because the
+// compiler's own AGPR -> VGPR copies for a plain `acc *= alpha` are hoisted OUT of the branch (128 v_accvgpr_read per tile
+// on the hot path). The MFMAs that last wrote / next read the accumulator are a whole QK^T phase / a P conversion away.
+__device__ __forceinline__ void mla_scale_acc(mf32x4_t& a, float alpha) {
+#ifdef XM_MLA_PLAIN_RESCALE
+  a *= alpha;
+#else
+  float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], t0, t1, t2, t3;
+  asm volatile(
+      "v_accvgpr_read_b32 %4, %0\n\tv_accvgpr_read_b32 %5, %1\n\tv_accvgpr_read_b32 %6, %2\n\tv_accvgpr_read_b32 %7, %3\n\t"
+      "v_mul_f32 %4, %8, %4\n\tv_mul_f32 %5, %8, %5\n\tv_mul_f32 %6, %8, %6\n\tv_mul_f32 %7, %8, %7\n\t"
+      "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+      : "+a"(x0), "+a"(x1), "+a"(x2), "+a"(x3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(alpha));
+  a = mf32x4_t{x0, x1, x2, x3};
+#endif
+}
+// MLA prefill / chunked prefill with the KV tile SHARED by four query tokens (block_size % 64 == 0).
+// The per-token decode kernels above re-read a sequence's whole latent cache once per query token; here a workgroup takes
+// four consecutive query tokens (flat index) x 16 heads, stages each 64-token tile ONCE by LDS-DMA (the same two 72 KB
+// buffers, swizzle and zero-fill as mla_decode_dma_kernel) and wave w works on query token 4 G + w alone:
+//   * S^T = K Q_w^T over all 64 tokens of the tile (72 MFMAs, K fragments rolling through 8 register slots);
+//   * softmax stays inside the wave: a lane holds 16 scores of one head, the maximum needs two permlane swaps, and the
+//     hi/lo 16-bit P operands of the PV MFMAs are exactly the lane's own registers (the K order of ds_read_b64_tr_b16
+//     matches the score layout), so there is no P exchange through LDS and no cross-wave reduction;
+//   * O_w^T = V^T P_w^T over all 512 value dims (128 MFMAs, accumulator 16 heads x 512 in 128 registers);
+//   * causal masks differ per wave (q_kvlen[token]); the tile loop runs to the longest of the four, rows past the
+//     sequence are zero-filled by the DMA bounds check, rows between a wave's own limit and the longest get p = 0.
+// Tokens of a group that belong to different sequences are handled in passes (one per distinct sequence, the other
+// waves' scores fully masked), so no host- or device-built group table is needed: q_seq / q_kvlen are the per-token
+// arrays mla_expand_queries_kernel already writes. Two barriers per tile (tile landed / buffer free); MFMA-bound:
+// 200 MFMAs per wave and tile against 544 KB of LDS reads per workgroup and tile (2176 of ~3200 cycles).
+template <typename T>
+__global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
+    const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, const int32_t* __restrict__ block_table,
+    int max_blocks, int n_heads, int block_size, float scale_log2, const int32_t* __restrict__ q_seq,
+    const int32_t* __restrict__ q_kvlen, int n_tokens, int n_groups) {
+  using TR = MlaTraits<T>;
+  using x8 = typename TR::x8;
+  using x4 = typename TR::x4;
+  using elem = typename TR::elem;
+  constexpr int KK = kMlaD / 32;                    // 18
+  constexpr int ROWB = kMlaD * 2;                   // 1152 bytes per row, unpadded
+  constexpr int BUFB = kMlaTile * ROWB;             // 73,728 bytes per tile buffer
+  constexpr int NDMA = BUFB / 1024 / 4;             // 18 DMA instructions (1 KB each) per wave per tile
+  constexpr int DB = kMlaDV / 16;                   // 32 output blocks of 16 dims
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUFB];
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, g = lane >> 4;
+  // workgroups i, i + 8, i + 16, ... run on the same XCD: give them the head blocks of one token group (shared L2 lines),
+  // groups in descending order (under a causal mask the late tokens are the long ones)
+  const int n_hb = (n_heads + 15) / 16;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int hb = slot % n_hb;
+  const int grp = n_groups - 1 - ((slot / n_hb) * 8 + xcd);
+  if (grp < 0) return;
+  const int tok0 = grp * 4;
+  const int my_tok = tok0 + wave;
+  const bool live = my_tok < n_tokens;
+  const int my_seq = live ? q_seq[my_tok] : -1;
+  const int my_kv = live ? q_kvlen[my_tok] : 0;
+  const int head = hb * 16 + p16;
+
+  x8 qf[KK];
+  {
+    const T* qp = q + ((int64_t)(live ? my_tok : tok0) * n_heads + (head < n_heads ? head : 0)) * kMlaD;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (head < n_heads && live) qf[kk] = *reinterpret_cast<const x8*>(qp + (kk * 4 + g) * 8);
+      else qf[kk] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  mf32x4_t acc_o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) acc_o[i] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kMlaNegBig, l_run = 0.0f;
+
+  int voff[NDMA];  // as in mla_decode_dma_kernel: lane's 16 bytes of DMA instruction i = (row, physical chunk)
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int c = (wave * NDMA + i) * 64 + lane, row = c / 72, pc = c % 72;
+    const int f = (row & 6) | ((row >> 3) & 1);
+    voff[i] = row * ROWB + ((pc ^ f) << 4);
+  }
+  const int fq = (p16 & 6) | ((p16 >> 3) & 1);          // f(row) of K row 16 tb + p16 (the same for every tb)
+  const int k_off = p16 * ROWB + ((g ^ fq) << 4);       // + tb * 16 rows + (kk >> 1) * 128, ^ 64 for odd kk
+  const int ft = (((p16 >> 3) & 1) << 1) | ((g & 1) << 2) | ((g >> 1) & 1);
+  const int v_x = ((((p16 >> 1) & 1) ^ ft) << 4) | ((p16 & 1) << 3);
+  const int v_row = (4 * g + (p16 >> 2)) * ROWB;
+  const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)lds3;
+
+  for (int pass = 0; pass < 4; ++pass) {
+    const int pt = tok0 + pass;
+    if (pt >= n_tokens) break;
+    const int seq = q_seq[pt];
+    if (pass > 0 && seq == q_seq[pt - 1]) continue;     // tokens are sorted by sequence: one pass per distinct sequence
+    int kv_hi = 0;
+    for (int j = pass; j < 4 && tok0 + j < n_tokens; ++j)
+      if (q_seq[tok0 + j] == seq) kv_hi = q_kvlen[tok0 + j] > kv_hi ? q_kvlen[tok0 + j] : kv_hi;
+    const int kv_w = my_seq == seq ? my_kv : 0;          // this wave's own causal limit inside the pass (0: masked out)
+    const int tile_hi = (kv_hi + kMlaTile - 1) / kMlaTile;
+    const int32_t* bt_row = block_table + (int64_t)seq * max_blocks;
+    auto stage = [&](int tile, int buf) {
+      int rows = 0;
+      int64_t row0 = 0;
+      if (tile < tile_hi) {
+        const int t0 = tile * kMlaTile;
+        rows = kv_hi - t0 < kMlaTile ? kv_hi - t0 : kMlaTile;
+        row0 = (int64_t)bt_row[t0 / block_size] * block_size + t0 % block_size;
+      }
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T*>(kc + row0 * kMlaD), 0, rows * ROWB, 0x00020000);
+      const lds_ptr_t dst = lds3 + buf * BUFB + wave * (NDMA * 1024);
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + i * 1024, 16, voff[i], 0, 0, 0);
+    };
+    if (tile_hi == 0) continue;
+    stage(0, 0);
+    stage(1, 1);
+    for (int tile = 0; tile < tile_hi; ++tile) {
+      const int buf = tile & 1;
+      asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // this wave's rows of `tile` have landed (tile + 1 still flies)
+      __builtin_amdgcn_s_barrier();                      // ... and so have the other waves' rows
+      const int t0 = tile * kMlaTile;
+      mf32x4_t s[4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) s[tb] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
+      {
+        const unsigned ke = lds_base + buf * BUFB + k_off, ko = lds_base + buf * BUFB + (k_off ^ 64);
+        mu32x4_t kf[8];
+        // item I: kk = I >> 2, token block tb = I & 3 (four independent accumulators back to back)
+#define MLP_K_RD(I_) MLA_DSR128(kf[(I_) & 7], (((I_) >> 2) & 1) ? ko : ke, ((I_) & 3) * 16 * ROWB + ((I_) >> 3) * 128);
+#define MLP_K_MM(I_, WAIT_)              \
+  MLA_LGKM1(WAIT_, kf[(I_) & 7]);        \
+  s[(I_) & 3] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[(I_) >> 2], s[(I_) & 3]);
+#define MLP_K_ST(I_) MLP_K_MM(I_, 7) MLP_K_RD((I_) + 8)
+#define MLP_K_ST8(B_) MLP_K_ST(B_) MLP_K_ST(B_ + 1) MLP_K_ST(B_ + 2) MLP_K_ST(B_ + 3) MLP_K_ST(B_ + 4) MLP_K_ST(B_ + 5) MLP_K_ST(B_ + 6) MLP_K_ST(B_ + 7)
+        MLP_K_RD(0) MLP_K_RD(1) MLP_K_RD(2) MLP_K_RD(3) MLP_K_RD(4) MLP_K_RD(5) MLP_K_RD(6) MLP_K_RD(7)
+        MLP_K_ST8(0) MLP_K_ST8(8) MLP_K_ST8(16) MLP_K_ST8(24) MLP_K_ST8(32) MLP_K_ST8(40) MLP_K_ST8(48) MLP_K_ST8(56)
+        MLP_K_MM(64, 7) MLP_K_MM(65, 6) MLP_K_MM(66, 5) MLP_K_MM(67, 4) MLP_K_MM(68, 3) MLP_K_MM(69, 2) MLP_K_MM(70, 1) MLP_K_MM(71, 0)
+#undef MLP_K_RD
+#undef MLP_K_MM
+#undef MLP_K_ST
+#undef MLP_K_ST8
+      }
+      // softmax of the wave's own 16 heads x 64 tokens: lane (p16, g) holds tokens t0 + 16 tb + 4 g + r of head p16
+      float mx = kMlaNegBig;
+      if (t0 + kMlaTile > kv_w) {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = s[tb][r] * scale_log2;
+            if (t0 + tb * 16 + g * 4 + r >= kv_w) v = -INFINITY;
+            s[tb][r] = v;
+            mx = fmaxf(mx, v);
+          }
+      } else {
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          s[tb] *= scale_log2;
+          mx = fmaxf(fmaxf(mx, fmaxf(s[tb][0], s[tb][1])), fmaxf(s[tb][2], s[tb][3]));
+        }
+      }
+      {  // xor-16 / xor-32 maximum by permlane swaps (VALU; see attention_prefill.hip)
+        unsigned u = __builtin_bit_cast(unsigned, mx), c;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+        const auto r16 = __builtin_amdgcn_permlane16_swap(u, c, false, false);
+        mx = fmaxf(mla_as_f32(r16[0]), mla_as_f32(r16[1]));
+        u = __builtin_bit_cast(unsigned, mx);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+        const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
+        mx = fmaxf(mla_as_f32(r32[0]), mla_as_f32(r32[1]));
+      }
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.0f;
+      x8 pf[2], pl[2];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[tb][r] - m_new);
+          psum += p;
+          const elem h = (elem)p;
+          pf[tb >> 1][(tb & 1) * 4 + r] = h;
+          pl[tb >> 1][(tb & 1) * 4 + r] = (elem)(p - (float)h);
+        }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i) mla_scale_acc(acc_o[i], alpha);
+      }
+      {
+        const unsigned vb = lds_base + buf * BUFB + v_row;
+        unsigned va[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = vb + (v_x ^ (j << 5));
+        mu32x2_t vt[8][2];
+        // item I: ks = I >> 5 (32-token half of the tile), db = I & 31; handled in pairs so that the hi / lo MFMAs on one
+        // accumulator are not back to back
+#define MLP_V_RD(I_)                                                                                           \
+  MLA_DSR64TR(vt[(I_) & 7][0], va[(I_) & 3], ((I_) >> 5) * 32 * ROWB + (((I_) & 31) >> 2) * 128);               \
+  MLA_DSR64TR(vt[(I_) & 7][1], va[(I_) & 3], ((I_) >> 5) * 32 * ROWB + (((I_) & 31) >> 2) * 128 + 16 * ROWB);
+#define MLP_V_MM2(I_, WAIT_)                                                                                   \
+  {                                                                                                            \
+    MLA_LGKM4(WAIT_, vt[(I_) & 7][0], vt[(I_) & 7][1], vt[((I_) + 1) & 7][0], vt[((I_) + 1) & 7][1]);          \
+    const x8 va8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[(I_) & 7][0]), __builtin_bit_cast(x4, vt[(I_) & 7][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+    const x8 vb8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[((I_) + 1) & 7][0]), __builtin_bit_cast(x4, vt[((I_) + 1) & 7][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+    acc_o[(I_) & 31] = TR::mfma(va8, pf[(I_) >> 5], acc_o[(I_) & 31]);                                         \
+    acc_o[((I_) + 1) & 31] = TR::mfma(vb8, pf[(I_) >> 5], acc_o[((I_) + 1) & 31]);                             \
+    acc_o[(I_) & 31] = TR::mfma(va8, pl[(I_) >> 5], acc_o[(I_) & 31]);                                         \
+    acc_o[((I_) + 1) & 31] = TR::mfma(vb8, pl[(I_) >> 5], acc_o[((I_) + 1) & 31]);                             \
+  }
+#define MLP_V_ST(I_) MLP_V_MM2(I_, 12) MLP_V_RD((I_) + 8) MLP_V_RD((I_) + 9)
+#define MLP_V_ST8(B_) MLP_V_ST(B_) MLP_V_ST(B_ + 2) MLP_V_ST(B_ + 4) MLP_V_ST(B_ + 6)
+        MLP_V_RD(0) MLP_V_RD(1) MLP_V_RD(2) MLP_V_RD(3) MLP_V_RD(4) MLP_V_RD(5) MLP_V_RD(6) MLP_V_RD(7)
+        MLP_V_ST8(0) MLP_V_ST8(8) MLP_V_ST8(16) MLP_V_ST8(24) MLP_V_ST8(32) MLP_V_ST8(40) MLP_V_ST8(48)
+        MLP_V_MM2(56, 12) MLP_V_MM2(58, 8) MLP_V_MM2(60, 4) MLP_V_MM2(62, 0)
+#undef MLP_V_RD
+#undef MLP_V_MM2
+#undef MLP_V_ST
+#undef MLP_V_ST8
+      }
+      __builtin_amdgcn_s_barrier();                      // every wave is done with this buffer
+      stage(tile + 2, buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two trailing (empty) prefetches
+  }
+
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (!live || head >= n_heads) return;
+  const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+  T* op = out + ((int64_t)my_tok * n_heads + head) * kMlaDV;
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    uint16_t hv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T t = from_f32<T>(acc_o[db][r] * inv);
+      __builtin_memcpy(&hv[r], &t, 2);
+    }
+    *reinterpret_cast<uint2*>(op + db * 16 + g * 4) =
+        make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+  }
+}
+
 template <typename T>
 __global__ void mla_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                  T* __restrict__ out, int nsplit) {
@@ -623,6 +878,23 @@ extern "C" int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(mla_expand_queries_kernel, dim3((unsigned)batch), dim3(256), 0, s, cu_q, kv_lens, causal, q_seq,
                      q_kvlen);
+  // enough query tokens to fill the chip without a split-KV: the kernel that shares every KV tile between four tokens
+  // (XLLM_MI355_MLA_PREFILL = 0: never, 1: whenever the page size allows it; default: by workgroup count)
+  static int share_mode = -2;
+  if (share_mode == -2) {
+    const char* e = getenv("XLLM_MI355_MLA_PREFILL");
+    share_mode = e ? atoi(e) : -1;
+  }
+  const int64_t n_groups = (total_q_tokens + 3) / 4, hblocks = (n_heads + 15) / 16;
+  if (block_size % kMlaTile == 0 && share_mode != 0 && (share_mode == 1 || n_groups * hblocks >= 128)) {
+    const dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * hblocks));
+    XM_DISPATCH_HALF(dtype, T, {
+      hipLaunchKernelGGL((mla_prefill_dma_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+                         block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale * 1.4426950408889634f, q_seq,
+                         q_kvlen, (int)total_q_tokens, (int)n_groups);
+    });
+    return hip_check_launch();
+  }
   return launch_mla(q, k_cache, out, kv_lens, q_seq, q_kvlen, block_table, max_blocks, total_q_tokens, n_heads,
                     block_size, max_kv_len, scale, dtype, reinterpret_cast<uint8_t*>(workspace) + idx_bytes,
                     workspace_bytes - idx_bytes, s);
