@@ -297,11 +297,22 @@ XM_API int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* out,
  * kernels/dcu/topk_gate.cpp:127-146): gating [T, E] (f32 / bf16 / f16) -> topk_weights [T, topk] f32, topk_ids
  * [T, topk] int32.  scoring 0 = softmax, 1 = sigmoid (+ optional fp32 correction_bias [E]: added for the selection,
  * removed from the returned weight); ties go to the lower expert index; renormalize divides by the selected sum.
- * E <= 512.  The grouped variant (moe_grouped_topk -> aiter::grouped_topk, an external library absent from the
- * reference tree) is not built. */
+ * E <= 512. */
 XM_API int xllm_mi355_moe_fused_topk(const void* gating, int dtype, int64_t n_tokens, int64_t n_experts,
                                      int64_t topk, int renormalize, const float* correction_bias, int scoring,
                                      float* topk_weights, int32_t* topk_ids, void* stream);
+
+/* dcu::moe_grouped_topk (kernels/dcu/topk_gate.cpp:59-125; what moe_active_topk :127-146 calls when num_expert_group > 1)
+ * -> aiter::native::grouped_topk / biased_grouped_topk (external library, not in the reference tree; the published
+ * DeepSeek-V2 / V3 gate is restated): score s = softmax | sigmoid; choice c = s (+ correction_bias, sigmoid only); group
+ * value = max c (no bias) | sum of the two largest c (bias); the topk_group best groups stay; topk experts by c among
+ * them (ties: lower index); weight = s (unbiased), / selected sum when renormalize, * routed_scaling_factor.
+ * Argument checks follow :67-98 (num_expert_group > 1, 0 < topk_group <= num_expert_group, bias needs sigmoid).
+ * E <= 512, E % num_expert_group == 0, num_expert_group <= 64, topk <= min(64, topk_group * E / num_expert_group). */
+XM_API int xllm_mi355_moe_grouped_topk(const void* gating, int dtype, int64_t n_tokens, int64_t n_experts,
+                                       int64_t topk, int64_t num_expert_group, int64_t topk_group, int renormalize,
+                                       const float* correction_bias, int scoring, float routed_scaling_factor,
+                                       float* topk_weights, int32_t* topk_ids, void* stream);
 
 /* ---- N3: sampler kernels of the decode step ---------------------------------------------------
  * dcu::random_sample (kernels/dcu/random_sample.hip:88-270; ops_api.h random_sample): probs [batch, vocab] fp32

@@ -373,3 +373,20 @@ def moe_fused_topk(gating, topk, renormalize, correction_bias=None, scoring_func
     lib().orc_moe_fused_topk(_p(g32), _i64(T), _i64(E), _i64(topk), C.c_int(int(renormalize)),
                              _p(b), C.c_int(int(scoring_func == "sigmoid")), _p(w), _p(ids))
     return w, ids
+
+
+def moe_grouped_topk(gating, topk, num_expert_group, topk_group, renormalize, correction_bias=None, scoring_func="softmax",
+                     routed_scaling_factor=1.0):
+    """dcu::moe_grouped_topk (kernels/dcu/topk_gate.cpp:59-125 -> aiter grouped_topk / biased_grouped_topk, an external
+    library absent from the reference tree): the published DeepSeek-V2 / V3 grouped gate; PARITY UNPINNED (see the C file)"""
+    T, E = gating.shape
+    assert E % num_expert_group == 0 and topk <= topk_group * (E // num_expert_group)
+    assert correction_bias is None or scoring_func == "sigmoid"
+    w = torch.empty(T, topk, dtype=torch.float32)
+    ids = torch.empty(T, topk, dtype=torch.int32)
+    b = correction_bias.float().contiguous() if correction_bias is not None else None
+    g32 = gating.float().contiguous()
+    lib().orc_moe_grouped_topk(_p(g32), _i64(T), _i64(E), _i64(topk), _i64(num_expert_group), _i64(topk_group),
+                               C.c_int(int(renormalize)), _p(b), C.c_int(int(scoring_func == "sigmoid")),
+                               C.c_float(float(routed_scaling_factor)), _p(w), _p(ids))
+    return w, ids

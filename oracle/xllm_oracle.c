@@ -855,3 +855,64 @@ ORC_API void orc_moe_fused_topk(const float* gating, int64_t T, int64_t E, int64
   }
   free(v);
 }
+
+
+/* Grouped gating top-k (DeepSeek-V2 / V3 device-limited routing). Reference call site: dcu::moe_grouped_topk
+ * (kernels/dcu/topk_gate.cpp:59-125) -> aiter::native::grouped_topk / biased_grouped_topk. aiter (ROCm/aiter) is an
+ * external library that is NOT in the reference tree (declared by hand at topk_gate.cpp:24-46, no pinned version), so this
+ * restates the PUBLISHED algorithm (DeepSeek-V2 / V3 gate, as in the open implementations of grouped_topk):
+ *   score   s[e] = softmax(x)[e] or sigmoid(x[e]);   choice score c[e] = s[e] + bias[e] (bias only with sigmoid)
+ *   group   value = max of c over the group (no bias)  |  sum of the two largest c of the group (with bias)
+ *   keep    the topk_group best groups (ties: lower group index); experts of the other groups are out of the race
+ *   pick    topk experts by c among the kept groups (ties: lower expert index); weight = s[e] (the UNBIASED score)
+ *   renormalize: weights /= their sum;  then weights *= routed_scaling_factor.
+ * PARITY UNPINNED: no in-tree test or golden vector covers this operator (closed library); expert ids are compared exactly,
+ * weights to 1e-6 relative. */
+ORC_API void orc_moe_grouped_topk(const float* gating, int64_t T, int64_t E, int64_t topk, int64_t G, int64_t topk_group,
+                                  int renormalize, const float* bias, int sigmoid, float route_scale, float* out_w,
+                                  int32_t* out_id) {
+  const int64_t EG = E / G;
+  float* s = (float*)malloc(sizeof(float) * (size_t)E);
+  float* c = (float*)malloc(sizeof(float) * (size_t)E);
+  float* gs = (float*)malloc(sizeof(float) * (size_t)G);
+  for (int64_t t = 0; t < T; ++t) {
+    const float* x = gating + t * E;
+    if (sigmoid) {
+      for (int64_t e = 0; e < E; ++e) s[e] = 1.0f / (1.0f + expf(-x[e]));
+    } else {
+      float mx = -INFINITY, sum = 0.0f;
+      for (int64_t e = 0; e < E; ++e) mx = fmaxf(mx, x[e]);
+      for (int64_t e = 0; e < E; ++e) { s[e] = expf(x[e] - mx); sum += s[e]; }
+      const float inv = 1.0f / sum;
+      for (int64_t e = 0; e < E; ++e) s[e] = s[e] * inv;
+    }
+    for (int64_t e = 0; e < E; ++e) c[e] = bias ? s[e] + bias[e] : s[e];
+    for (int64_t g = 0; g < G; ++g) {
+      float t1 = -INFINITY, t2 = -INFINITY;
+      for (int64_t i = 0; i < EG; ++i) {
+        const float v = c[g * EG + i];
+        if (v > t1) { t2 = t1; t1 = v; } else if (v > t2) t2 = v;
+      }
+      gs[g] = bias ? t1 + t2 : t1;
+    }
+    for (int64_t g = 0; g < G; ++g) {   /* rank of group g; groups outside the best topk_group lose their experts */
+      int64_t rank = 0;
+      for (int64_t h = 0; h < G; ++h) rank += (gs[h] > gs[g]) || (gs[h] == gs[g] && h < g);
+      if (rank >= topk_group)
+        for (int64_t i = 0; i < EG; ++i) c[g * EG + i] = -INFINITY;
+    }
+    float wsum = 0.0f;
+    for (int64_t k = 0; k < topk; ++k) {
+      int64_t best = 0;
+      for (int64_t e = 1; e < E; ++e)
+        if (c[e] > c[best]) best = e;
+      out_w[t * topk + k] = s[best];
+      out_id[t * topk + k] = (int32_t)best;
+      wsum += s[best];
+      c[best] = -INFINITY;
+    }
+    const float f = renormalize ? route_scale / wsum : route_scale;
+    for (int64_t k = 0; k < topk; ++k) out_w[t * topk + k] = out_w[t * topk + k] * f;
+  }
+  free(s); free(c); free(gs);
+}

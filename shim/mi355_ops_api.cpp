@@ -271,6 +271,43 @@ std::tuple<torch::Tensor, torch::Tensor> moe_fused_topk(const torch::Tensor& gat
   return {w, ids};
 }
 
+std::tuple<torch::Tensor, torch::Tensor> moe_grouped_topk(const torch::Tensor& gating_output, int64_t topk,
+                                                          int64_t num_expert_group, int64_t topk_group, bool renormalize,
+                                                          const std::optional<torch::Tensor>& correction_bias,
+                                                          const std::string& scoring_func, double routed_scaling_factor) {
+  TORCH_CHECK(gating_output.defined() && gating_output.dim() == 2, "moe_grouped_topk: input must be [num_tokens, num_experts]");
+  TORCH_CHECK(topk > 0, "moe_grouped_topk: topk must be positive");
+  TORCH_CHECK(num_expert_group > 1, "moe_grouped_topk requires num_expert_group > 1");
+  TORCH_CHECK(topk_group > 0 && topk_group <= num_expert_group, "moe_grouped_topk: 0 < topk_group <= num_expert_group");
+  TORCH_CHECK(scoring_func == "softmax" || scoring_func == "sigmoid", "moe_grouped_topk: unsupported scoring function ",
+              scoring_func);
+  const bool has_bias = correction_bias.has_value() && correction_bias->defined();
+  TORCH_CHECK(!has_bias || scoring_func == "sigmoid", "moe_grouped_topk: correction bias is supported only for sigmoid scoring");
+  DeviceGuard guard(gating_output.device());
+  const torch::Tensor g = gating_output.contiguous();
+  const int64_t T = g.size(0), E = g.size(1);
+  auto w = torch::empty({T, topk}, g.options().dtype(torch::kFloat32));
+  auto ids = torch::empty({T, topk}, g.options().dtype(torch::kInt32));
+  torch::Tensor bias;
+  if (has_bias) bias = correction_bias->to(torch::kFloat32).contiguous();
+  check(xllm_mi355_moe_grouped_topk(p(g), dt(g), T, E, topk, num_expert_group, topk_group, renormalize ? 1 : 0,
+                                    bias.defined() ? bias.data_ptr<float>() : nullptr, scoring_func == "softmax" ? 0 : 1,
+                                    static_cast<float>(routed_scaling_factor), w.data_ptr<float>(), ids.data_ptr<int32_t>(),
+                                    cur_stream()),
+        "moe_grouped_topk");
+  return {w, ids};
+}
+
+std::tuple<torch::Tensor, torch::Tensor> moe_active_topk(const torch::Tensor& gating_output, int64_t topk,
+                                                         int64_t num_expert_group, int64_t topk_group, bool renormalize,
+                                                         const std::optional<torch::Tensor>& correction_bias,
+                                                         const std::string& scoring_func, double routed_scaling_factor) {
+  if (num_expert_group > 1)
+    return moe_grouped_topk(gating_output, topk, num_expert_group, topk_group, renormalize, correction_bias, scoring_func,
+                            routed_scaling_factor);
+  return moe_fused_topk(gating_output, topk, renormalize, correction_bias, scoring_func);
+}
+
 std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t expert_num) {
   TORCH_CHECK(expert_id.dim() == 2 && expert_id.scalar_type() == torch::kInt32, "expert_id must be int32 [num_tokens, topk]");
   DeviceGuard guard(expert_id.device());

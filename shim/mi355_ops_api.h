@@ -71,6 +71,17 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
 std::tuple<torch::Tensor, torch::Tensor> moe_fused_topk(const torch::Tensor& gating_output, int64_t topk, bool renormalize,
                                                         const std::optional<torch::Tensor>& correction_bias,
                                                         const std::string& scoring_func);
+// dcu::moe_grouped_topk / dcu::moe_active_topk (kernels/dcu/dcu_ops_api.h, kernels/dcu/topk_gate.cpp:59-146): the
+// DeepSeek grouped gate (aiter grouped_topk / biased_grouped_topk in the reference) and the dispatcher the layer calls:
+// num_expert_group > 1 -> grouped, else moe_fused_topk (which ignores routed_scaling_factor, as in the reference)
+std::tuple<torch::Tensor, torch::Tensor> moe_grouped_topk(const torch::Tensor& gating_output, int64_t topk,
+                                                          int64_t num_expert_group, int64_t topk_group, bool renormalize,
+                                                          const std::optional<torch::Tensor>& correction_bias,
+                                                          const std::string& scoring_func, double routed_scaling_factor);
+std::tuple<torch::Tensor, torch::Tensor> moe_active_topk(const torch::Tensor& gating_output, int64_t topk,
+                                                         int64_t num_expert_group, int64_t topk_group, bool renormalize,
+                                                         const std::optional<torch::Tensor>& correction_bias,
+                                                         const std::string& scoring_func, double routed_scaling_factor);
 // kernel::moe_gen_idx (ops_api.h:73) -> {src_dst, dst_src, expert_sizes} (int32); stable inside an expert
 std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t expert_num);
 // kernel::moe_combine_result (ops_api.h:77; MoeCombineResultParams param.h:575-...): input [T*topk, H] in TOKEN order

@@ -15,6 +15,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("matmul", &k::matmul);
   m.def("random_sample", &k::random_sample);
   m.def("moe_fused_topk", &k::moe_fused_topk);
+  m.def("moe_grouped_topk", &k::moe_grouped_topk);
+  m.def("moe_active_topk", &k::moe_active_topk);
   m.def("moe_gen_idx", &k::moe_gen_idx);
   m.def("moe_combine_result", &k::moe_combine_result);
   m.def("moe_combine_result_sorted", &k::moe_combine_result_sorted);

@@ -992,6 +992,38 @@ def test_moe_fused_topk(E, topk, scoring, bias, renorm, dtype):
     torch.testing.assert_close(w.cpu(), w_ref, rtol=3e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("E,G,kg,topk,scoring,bias,renorm,scale,dtype", [
+    (256, 8, 4, 8, "sigmoid", True, True, 2.5, torch.float32),        # DeepSeek-V3: noaux_tc, 8 groups, 4 kept
+    (160, 8, 3, 6, "softmax", False, False, 16.0, torch.bfloat16),    # DeepSeek-V2: group_limited_greedy
+    (64, 4, 4, 2, "sigmoid", True, True, 1.0, torch.float16),         # the reference's moe_gate_test shape (all groups kept)
+    (512, 64, 5, 8, "softmax", False, True, 1.0, torch.float32),      # the widest supported table, 8 experts per group
+    (96, 2, 1, 7, "sigmoid", False, True, 0.5, torch.bfloat16)])
+def test_moe_grouped_topk(E, G, kg, topk, scoring, bias, renorm, scale, dtype):
+    """a16 / N4: dcu::moe_grouped_topk (topk_gate.cpp:59-125 -> aiter grouped_topk / biased_grouped_topk): ids bit-exact
+    vs the restated published algorithm (group limit, tie-breaks), weights to fp32 rounding; moe_active_topk dispatch"""
+    g = torch.Generator().manual_seed(E + G + topk)
+    T = 333
+    x = (torch.randn(T, E, generator=g) * 2).to(dtype)
+    x[0] = 0.25                                           # all scores equal: groups 0..kg-1, then the lowest experts
+    b = (torch.randn(E, generator=g) * 0.1) if bias else None
+    w_ref, id_ref = orc.moe_grouped_topk(x, topk, G, kg, renorm, b, scoring, scale)
+    w, ids = ops.moe_active_topk(x.to(DEV), topk, G, kg, renorm, b.to(DEV) if bias else None, scoring, scale)
+    assert torch.equal(ids.cpu(), id_ref)
+    torch.testing.assert_close(w.cpu(), w_ref, rtol=3e-6, atol=1e-7)
+    if not bias:
+        assert ids[0].tolist() == list(range(topk))
+    per = E // G
+    grp = (ids.cpu().long() // per)
+    assert all(len(set(r.tolist())) <= kg for r in grp)   # never more than topk_group distinct groups per token
+    if renorm:
+        torch.testing.assert_close(w.sum(-1).cpu(), torch.full((T,), scale), rtol=1e-5, atol=0)
+    with pytest.raises(ops.Mi355Error):
+        ops.moe_grouped_topk(x.to(DEV), topk, G, G + 1, renorm, None, scoring)            # topk_group > num_expert_group
+    if kg * per > 1:
+        with pytest.raises(ops.Mi355Error):
+            ops.moe_grouped_topk(x.to(DEV), kg * per + 1, G, kg, renorm, None, scoring)   # more picks than candidates
+
+
 def test_dual_micro_batch_decoder_equals_single_batch_step():
     """two micro-batches on two streams (attention of one half under the linear layers of the other) produce the bits
     of the single-batch step: per-sequence arithmetic is unchanged"""

@@ -374,6 +374,34 @@ def test_moe_helpers():
     torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("E,G,kg,topk,scoring,bias,renorm,scale", [
+    (256, 8, 4, 8, "sigmoid", True, True, 2.5), (160, 8, 3, 6, "softmax", False, False, 16.0),
+    (64, 4, 4, 2, "sigmoid", True, True, 1.0), (64, 4, 2, 4, "softmax", False, True, 1.0)])
+def test_grouped_topk_oracle_vs_tensorwise_published_gate(E, G, kg, topk, scoring, bias, renorm, scale):
+    """the C restatement of the grouped gate (oracle: orc_moe_grouped_topk) against the SAME published algorithm written
+    the way the open DeepSeek-V2 / V3 gates write it (view -> group max | top-2 sum -> topk groups -> mask -> topk)"""
+    g = torch.Generator().manual_seed(E * 3 + topk)
+    T = 200
+    x = torch.randn(T, E, generator=g) * 2
+    b = torch.randn(E, generator=g) * 0.1 if bias else None
+    w, ids = orc.moe_grouped_topk(x, topk, G, kg, renorm, b, scoring, scale)
+    s = torch.sigmoid(x) if scoring == "sigmoid" else torch.softmax(x, -1)
+    c = s + b if bias else s
+    gv = c.view(T, G, -1).topk(2, -1)[0].sum(-1) if bias else c.view(T, G, -1).max(-1)[0]
+    keep = torch.zeros(T, G).scatter_(1, gv.topk(kg, -1)[1], 1.0).bool()
+    cm = c.masked_fill(~keep[:, :, None].expand(T, G, E // G).reshape(T, E), float("-inf"))
+    ref_ids = cm.topk(topk, -1)[1]
+    ref_w = s.gather(1, ref_ids)
+    if renorm:
+        ref_w = ref_w / ref_w.sum(-1, keepdim=True)
+    ref_w = ref_w * scale
+    assert torch.equal(ids.long(), ref_ids)               # random floats: no ties, so torch.topk's order is the same
+    torch.testing.assert_close(w, ref_w, rtol=2e-5, atol=1e-7)
+    # tie-breaks and the group limit on a constructed row: all scores equal -> groups 0..kg-1, lowest experts first
+    w0, i0 = orc.moe_grouped_topk(torch.full((1, E), 0.25), topk, G, kg, renorm, None, scoring, scale)
+    assert i0[0].tolist() == list(range(topk))
+
+
 # ------------------------------------------------------------------------------------------- N3 sampler
 def test_philox4x32_10_known_answers():
     """Random123 known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution)"""

@@ -26,16 +26,16 @@ def test_shim_builds_and_exposes_reference_operator_names():
     m = _shim()
     for name in ("rms_norm", "fused_add_rms_norm", "act_and_mul", "reshape_paged_cache", "rotary_embedding", "matmul",
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
-                 "random_sample", "rejection_sample", "moe_fused_topk", "moe_gen_idx", "moe_combine_result",
-                 "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode"):
+                 "random_sample", "rejection_sample", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
+                 "moe_combine_result", "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode"):
         assert hasattr(m, name)
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
                 "static_scaled_fp8_quant", "fp8_scaled_quantize", "rms_norm_static_fp8_quant",
                 "fused_add_rms_norm_static_fp8_quant", "fp8_scaled_matmul", "fused_qk_norm_rope", "scaled_quantize",
                 "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
-                "update_llm_decode_metadata", "moe_fused_topk", "moe_gen_idx", "moe_combine_result", "group_gemm_gather",
-                "mla_decode"):
+                "update_llm_decode_metadata", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
+                "moe_combine_result", "group_gemm_gather", "mla_decode"):
         assert sym + "(" in hdr, sym
 
 
@@ -120,6 +120,14 @@ def test_shim_moe_and_mla_equal_the_ctypes_path():
     assert torch.equal(w, w2) and torch.equal(ids, ids2)
     with pytest.raises(RuntimeError):
         m.moe_fused_topk(logits, topk, True, None, "tanh")
+    bias = torch.randn(E, device=dev, generator=gd) * 0.1
+    wg, idg = m.moe_active_topk(logits, topk, 8, 3, True, bias, "sigmoid", 2.5)       # grouped (DeepSeek-V3 style)
+    wg2, idg2 = ops.moe_grouped_topk(logits, topk, 8, 3, True, bias, "sigmoid", 2.5)
+    assert torch.equal(wg, wg2) and torch.equal(idg, idg2)
+    wa, ida = m.moe_active_topk(logits, topk, 1, 1, True, None, "softmax", 2.5)        # one group: the plain fused top-k
+    assert torch.equal(wa, w) and torch.equal(ida, ids)
+    with pytest.raises(RuntimeError):
+        m.moe_grouped_topk(logits, topk, 8, 3, True, bias, "softmax", 1.0)             # bias needs sigmoid (topk_gate.cpp:96)
     src_dst, dst_src, sizes = m.moe_gen_idx(ids, E)
     r = ops.moe_compute_index(ids, E)
     assert torch.equal(src_dst, r[0]) and torch.equal(dst_src, r[1]) and torch.equal(sizes, r[2])

@@ -223,6 +223,109 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// a16 / N4: grouped gating top-k (DeepSeek-V2 / V3 device-limited routing). Reference call site: dcu::moe_grouped_topk
+// (kernels/dcu/topk_gate.cpp:59-125) -> aiter::native::grouped_topk / biased_grouped_topk -- an external library that is
+// not in the reference tree; the published DeepSeek-V2 / V3 gate algorithm:
+//   s = softmax(x) | sigmoid(x); choice score c = s (+ bias); group value = max c (no bias) | sum of the two largest c
+//   (bias); keep the topk_group best groups; topk experts by c among them (ties: lower index); weight = s (unbiased);
+//   renormalize by the selected sum; times routed_scaling_factor.
+// One wave per token as in moe_fused_topk_kernel; the choice scores go through 2 KB of LDS per wave once so that lane g
+// can walk group g's experts (a wave's own LDS writes are visible to its later reads: no barrier).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restrict__ gating, int n_tokens, int E, int topk,
+                                                               int G, int topk_group, int renormalize,
+                                                               const float* __restrict__ bias, int sigmoid,
+                                                               float route_scale, float* __restrict__ out_w,
+                                                               int32_t* __restrict__ out_id) {
+  __shared__ float choice[4][64 * kTopkMaxPerLane];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tok = blockIdx.x * 4 + wv;
+  if (tok >= n_tokens) return;
+  const T* row = gating + (int64_t)tok * E;
+  float sc[kTopkMaxPerLane], v[kTopkMaxPerLane];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    const int e = lane + 64 * j;
+    sc[j] = e < E ? to_f32(row[e]) : -INFINITY;
+    mx = fmaxf(mx, sc[j]);
+  }
+  if (sigmoid) {
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) sc[j] = lane + 64 * j < E ? 1.0f / (1.0f + expf(-sc[j])) : 0.0f;
+  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      sc[j] = lane + 64 * j < E ? expf(sc[j] - mx) : 0.0f;
+      sum += sc[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) sc[j] = sc[j] * inv;
+  }
+#pragma unroll
+  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    const int e = lane + 64 * j;
+    v[j] = e < E ? (bias ? sc[j] + bias[e] : sc[j]) : -INFINITY;
+    if (e < E) choice[wv][e] = v[j];
+  }
+  // group values (lane g walks group g), their ranks, the set of kept groups
+  const int EG = E / G;
+  float gs = -INFINITY;
+  if (lane < G) {
+    float t1 = -INFINITY, t2 = -INFINITY;
+    for (int i = 0; i < EG; ++i) {
+      const float x = choice[wv][lane * EG + i];
+      if (x > t1) { t2 = t1; t1 = x; } else if (x > t2) t2 = x;
+    }
+    gs = bias ? t1 + t2 : t1;
+  }
+  int rank = 0;
+  for (int h = 0; h < G; ++h) {
+    const float oh = __shfl(gs, h);
+    rank += (oh > gs) || (oh == gs && h < lane);
+  }
+  const unsigned long long kept = __ballot(lane < G && rank < topk_group);
+#pragma unroll
+  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    const int e = lane + 64 * j;
+    if (e < E && !((kept >> (e / EG)) & 1ull)) v[j] = -INFINITY;
+  }
+  float wsum = 0.0f;
+  float my_w = 0.0f;
+  for (int kk = 0; kk < topk; ++kk) {
+    float best = -INFINITY;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+      const int e = lane + 64 * j;
+      if (e < E && (v[j] > best || (v[j] == best && e < best_e))) { best = v[j]; best_e = e; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oe = __shfl_xor(best_e, o);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+    }
+    float ws = 0.0f;              // the owner retires the expert and supplies its unbiased score
+#pragma unroll
+    for (int j = 0; j < kTopkMaxPerLane; ++j)
+      if (lane + 64 * j == best_e) { ws = sc[j]; v[j] = -INFINITY; }
+    const float w = __shfl(ws, best_e & 63);
+    wsum += w;
+    if (lane == kk) my_w = w;
+    if (lane == 0) out_id[(int64_t)tok * topk + kk] = best_e;
+  }
+  if (lane < topk) out_w[(int64_t)tok * topk + lane] = my_w * (renormalize ? route_scale / wsum : route_scale);
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -300,6 +403,28 @@ extern "C" int xllm_mi355_moe_fused_topk(const void* gating, int dtype, int64_t 
     hipLaunchKernelGGL((moe_fused_topk_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,
                        (int)n_tokens, (int)n_experts, (int)topk, renormalize, correction_bias, scoring, topk_weights,
                        topk_ids);
+  });
+  return hip_check_launch();
+}
+
+extern "C" int xllm_mi355_moe_grouped_topk(const void* gating, int dtype, int64_t n_tokens, int64_t n_experts, int64_t topk,
+                                           int64_t num_expert_group, int64_t topk_group, int renormalize,
+                                           const float* correction_bias, int scoring, float routed_scaling_factor,
+                                           float* topk_weights, int32_t* topk_ids, void* stream) {
+  if (!gating || !topk_weights || !topk_ids || n_tokens < 0 || n_experts <= 0 || topk <= 0) return XM_ERR_INVALID;
+  if (scoring != 0 && scoring != 1) return XM_ERR_INVALID;
+  if (scoring == 0 && correction_bias) return XM_ERR_INVALID;  // topk_gate.cpp:96-98: the bias needs sigmoid scoring
+  if (num_expert_group <= 1 || topk_group <= 0 || topk_group > num_expert_group) return XM_ERR_INVALID;  // :73-80
+  if (n_experts % num_expert_group != 0) return XM_ERR_INVALID;
+  const int64_t per_group = n_experts / num_expert_group;
+  if (topk > topk_group * per_group || (correction_bias && per_group < 2)) return XM_ERR_INVALID;
+  if (n_experts > 64 * kTopkMaxPerLane || topk > 64 || num_expert_group > 64) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  const dim3 grid((unsigned)((n_tokens + 3) / 4));
+  XM_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((moe_grouped_topk_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,
+                       (int)n_tokens, (int)n_experts, (int)topk, (int)num_expert_group, (int)topk_group, renormalize,
+                       correction_bias, scoring, routed_scaling_factor, topk_weights, topk_ids);
   });
   return hip_check_launch();
 }

@@ -362,9 +362,12 @@ class FusedMoE:
 
     def __init__(self, hidden: int, inter: int, n_experts: int, topk: int, dtype, device, gen, renormalize: bool = True,
                  scoring_func: str = "softmax", correction_bias=None, tp: Optional[parallel.ProcessGroup] = None,
-                 fuse: bool = True, mode: str = "16bit"):
+                 fuse: bool = True, mode: str = "16bit", num_expert_group: int = 1, topk_group: int = 1,
+                 route_scale: float = 1.0):
         self.E, self.topk, self.renorm, self.scoring, self.bias, self.tp, self.fuse = (
             n_experts, topk, renormalize, scoring_func, correction_bias, tp, fuse)
+        # DeepSeek-style device-limited routing (fused_moe.cpp:155-166: num_expert_group / topk_group / route_scale)
+        self.n_group, self.topk_group, self.route_scale = num_expert_group, topk_group, route_scale
         self.mode = mode  # "16bit" = the reference's DCU path; "int8" = W8A8 experts (GroupGemmParams a_scale / b_scale)
         tp_size = tp.world_size() if tp is not None else 1
         assert inter % tp_size == 0
@@ -381,7 +384,8 @@ class FusedMoE:
     def forward_experts(self, hidden_states, router_logits):
         x = hidden_states.reshape(-1, hidden_states.size(-1))
         T = x.size(0)
-        weights, ids = ops.moe_fused_topk(router_logits.reshape(T, -1), self.topk, self.renorm, self.bias, self.scoring)
+        weights, ids = ops.moe_active_topk(router_logits.reshape(T, -1), self.topk, self.n_group, self.topk_group,
+                                           self.renorm, self.bias, self.scoring, self.route_scale)
         src_dst, dst_src, sizes = ops.moe_compute_index(ids, self.E)
         if self.mode == "int8":
             # each token is quantised ONCE; the expand happens inside the first grouped GEMM's A staging (scales follow)

@@ -645,3 +645,33 @@ def moe_fused_topk(gating_output, topk: int, renormalize: bool, correction_bias=
                                                0 if scoring_func == "softmax" else 1, _p(w), _p(ids), _stream()),
           "moe_fused_topk")
     return w, ids
+
+
+def moe_grouped_topk(gating_output, topk: int, num_expert_group: int, topk_group: int, renormalize: bool,
+                     correction_bias=None, scoring_func: str = "softmax", routed_scaling_factor: float = 1.0):
+    """dcu::moe_grouped_topk (kernels/dcu/topk_gate.cpp:59-125) -> (topk_weights f32, topk_ids int32)"""
+    _need_cuda(gating_output)
+    if scoring_func not in ("softmax", "sigmoid"):
+        raise Mi355Error(f"moe_grouped_topk: unsupported scoring function {scoring_func}")          # :81-82
+    if correction_bias is not None and scoring_func != "sigmoid":
+        raise Mi355Error("moe_grouped_topk: correction bias is supported only for sigmoid scoring")  # :96-98
+    T, E = gating_output.shape
+    g = gating_output.contiguous()
+    w = torch.empty(T, topk, dtype=torch.float32, device=g.device)
+    ids = torch.empty(T, topk, dtype=torch.int32, device=g.device)
+    bias = correction_bias.to(torch.float32).contiguous() if correction_bias is not None else None
+    check(_lib.lib().xllm_mi355_moe_grouped_topk(_p(g), _dt(g), T, E, topk, num_expert_group, topk_group, int(renormalize),
+                                                 _p(bias), 0 if scoring_func == "softmax" else 1,
+                                                 float(routed_scaling_factor), _p(w), _p(ids), _stream()),
+          "moe_grouped_topk")
+    return w, ids
+
+
+def moe_active_topk(gating_output, topk: int, num_expert_group: int, topk_group: int, renormalize: bool,
+                    correction_bias=None, scoring_func: str = "softmax", routed_scaling_factor: float = 1.0):
+    """dcu::moe_active_topk (kernels/dcu/topk_gate.cpp:127-146): grouped gate when num_expert_group > 1, else the plain
+    fused top-k (which, as in the reference, takes no routed_scaling_factor)"""
+    if num_expert_group > 1:
+        return moe_grouped_topk(gating_output, topk, num_expert_group, topk_group, renormalize, correction_bias,
+                                scoring_func, routed_scaling_factor)
+    return moe_fused_topk(gating_output, topk, renormalize, correction_bias, scoring_func)
