@@ -359,6 +359,15 @@ XM_API int xllm_mi355_moe_combine(void* out, const void* gemm2, const float* wei
 XM_API int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, const int32_t* src_dst,
                                          const float* weights, int64_t n_tokens, int64_t topk, int64_t hidden,
                                          int dtype, void* stream);
+/* Expert-parallel form of the same fusion (FusedMoEImpl::forward_experts on an EP rank, layers/dcu/fused_moe.cpp:236-303:
+ * only the rank's experts are computed, gemm2_full is ZERO elsewhere, the EP all-reduce adds the ranks): the caller sorts
+ * with expert ids rotated so that its own experts come first ((id - start_expert_id) mod E), runs the grouped GEMMs over
+ * local_expert_sizes = expert_sizes[0 .. n_local_experts), and this combine skips every sorted row at or past
+ * sum(local_expert_sizes) -- the reference's zero rows -- without a host read of the sizes (graph-capturable). */
+XM_API int xllm_mi355_moe_combine_sorted_local(void* out, const void* gemm2_sorted, const int32_t* src_dst,
+                                               const float* weights, const int32_t* local_expert_sizes,
+                                               int64_t n_local_experts, int64_t n_tokens, int64_t topk, int64_t hidden,
+                                               int dtype, void* stream);
 /* kernel::group_gemm (ops_api.h:57) -> dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74):
  * rows of `a` sorted by expert; out[off_e:off_e+M_e] = a[...] @ w[e]^T, w [E,N,K]; token_count is a
  * DEVICE int32 [E] (no host read). max_rows = a's row count. */

@@ -335,7 +335,8 @@ torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor
 }
 
 torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const torch::Tensor& reduce_weight,
-                                        const torch::Tensor& gather_ids) {
+                                        const torch::Tensor& gather_ids,
+                                        const std::optional<torch::Tensor>& local_expert_sizes) {
   TORCH_CHECK(input_sorted.dim() == 2 && reduce_weight.dim() == 2 && reduce_weight.numel() == input_sorted.size(0) &&
                   gather_ids.numel() == input_sorted.size(0) && gather_ids.scalar_type() == torch::kInt32 &&
                   reduce_weight.scalar_type() == torch::kFloat32,
@@ -344,6 +345,14 @@ torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const
   const torch::Tensor x = input_sorted.contiguous(), w = reduce_weight.contiguous(), g = gather_ids.contiguous();
   const int64_t T = w.size(0), topk = w.size(1), H = x.size(1);
   auto out = torch::empty({T, H}, x.options());
+  if (local_expert_sizes.has_value() && local_expert_sizes->defined()) {
+    TORCH_CHECK(local_expert_sizes->scalar_type() == torch::kInt32, "local_expert_sizes must be int32");
+    const torch::Tensor ls = local_expert_sizes->contiguous();
+    check(xllm_mi355_moe_combine_sorted_local(p(out), p(x), g.data_ptr<int32_t>(), w.data_ptr<float>(), ls.data_ptr<int32_t>(),
+                                              ls.numel(), T, topk, H, dt(x), cur_stream()),
+          "moe_combine_result_sorted");
+    return out;
+  }
   check(xllm_mi355_moe_combine_sorted(p(out), p(x), g.data_ptr<int32_t>(), w.data_ptr<float>(), T, topk, H, dt(x), cur_stream()),
         "moe_combine_result_sorted");
   return out;

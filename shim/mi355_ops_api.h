@@ -89,8 +89,11 @@ std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t e
 torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight);
 // the same with MoeCombineResultParams::gather_ids honoured: input stays in EXPERT order (the second grouped GEMM's
 // output) and row gather_ids[t*topk+k] is read for (t, k) -- index_copy_ + moe_combine_result in one pass
+// local_expert_sizes (int32 [E_local], EP rank whose experts were sorted to the front): rows at or past their sum are the
+// zero rows of the reference's gemm2_full (fused_moe.cpp:291-297) and are skipped -- no host read of the sizes
 torch::Tensor moe_combine_result_sorted(const torch::Tensor& input_sorted, const torch::Tensor& reduce_weight,
-                                        const torch::Tensor& gather_ids);
+                                        const torch::Tensor& gather_ids,
+                                        const std::optional<torch::Tensor>& local_expert_sizes = std::nullopt);
 // index_select(hidden, dst_src / topk) + group_gemm without the expanded copy (fused_moe.cpp:195-197, 250-262);
 // returns an undefined tensor when the 256x256 kernel cannot take the shape (the caller keeps the two reference calls)
 torch::Tensor group_gemm_gather(const torch::Tensor& input, const torch::Tensor& row_index, int64_t index_div,

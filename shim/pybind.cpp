@@ -19,7 +19,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("moe_active_topk", &k::moe_active_topk);
   m.def("moe_gen_idx", &k::moe_gen_idx);
   m.def("moe_combine_result", &k::moe_combine_result);
-  m.def("moe_combine_result_sorted", &k::moe_combine_result_sorted);
+  m.def("moe_combine_result_sorted", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& g, std::optional<torch::Tensor> ls) { return k::moe_combine_result_sorted(x, w, g, ls); }, pybind11::arg("input_sorted"), pybind11::arg("reduce_weight"), pybind11::arg("gather_ids"), pybind11::arg("local_expert_sizes") = std::nullopt);
   m.def("group_gemm", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& c) { return k::group_gemm(x, w, c, std::nullopt); });
   m.def("group_gemm_gather", &k::group_gemm_gather);
   m.def("group_gemm_w8a8", [](const torch::Tensor& x, const torch::Tensor& as, const torch::Tensor& w, const torch::Tensor& bs, const torch::Tensor& c, std::optional<torch::Tensor> idx, int64_t div) { return k::group_gemm_w8a8(x, as, w, bs, c, torch::kBFloat16, idx, div); });

@@ -713,6 +713,47 @@ def test_fused_moe_layer_w8a8_tracks_the_16bit_layer():
     assert ((out.float() - ref.float()).norm() / ref.float().norm()).item() <= 4e-2
 
 
+@pytest.mark.parametrize("mode,ep", [("16bit", 2), ("16bit", 4), ("int8", 4)])
+def test_fused_moe_expert_parallel_ranks_add_up(mode, ep):
+    """EP as in the reference's DCU layer (fused_moe.cpp:53-63, 236-315): a rank computes only its own experts, its output
+    holds zeros for the others, and the EP all-reduce (here: the sum over the ranks computed one after another on one GPU)
+    gives the all-experts layer. Per rank: fused path (ids rotated so the local experts sort first, combine skips the
+    rows of the other ranks, no host sync) == the reference's own sequence (zeros + index_copy_ of the local rows +
+    combine) bit for bit, also from a captured graph; the grouped gate and the shared experts ride along."""
+    from xllm_amd import layers
+    T, H, I, E, topk = 1024, 512, 384, 16, 4
+    mk = lambda **kw: layers.FusedMoE(H, I, E, topk, torch.bfloat16, DEV, torch.Generator(device=DEV).manual_seed(11),
+                                      mode=mode, num_expert_group=4, topk_group=2, scoring_func="sigmoid",
+                                      correction_bias=torch.linspace(-0.1, 0.1, E, device=DEV), route_scale=2.5, **kw)
+    gd = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    logits = torch.randn(T, E, device=DEV, generator=gd).bfloat16()
+    full = mk().forward_experts(x, logits).float()
+    total = torch.zeros_like(full)
+    for r in range(ep):
+        rank = mk(ep_rank=r, ep_size=ep)
+        assert rank.w13.size(0) == E // ep
+        part = rank.forward_experts(x, logits)
+        if mode == "16bit":
+            rank.fuse = False
+            assert torch.equal(rank.forward_experts(x, logits), part)
+            rank.fuse = True
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            captured = rank.forward_experts(x, logits)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, part)
+        total += part.float()
+    # every (token, expert) product is computed by exactly one rank with the same arithmetic; only the 16-bit rounding of
+    # the per-rank partial sums differs from the single-rank layer
+    assert ((total - full).norm() / full.norm()).item() <= 6e-3
+    shared = lambda t: (t.float() * 0.5).to(t.dtype)
+    with_shared = mk(ep_rank=0, ep_size=ep, shared_experts=shared).forward_experts(x, logits)
+    assert torch.equal(with_shared, mk(ep_rank=0, ep_size=ep).forward_experts(x, logits) + shared(x))
+
+
 @pytest.mark.parametrize("mode", ["16bit", "int8"])
 def test_fused_moe_layer_replays_from_a_hip_graph(mode):
     """the whole expert path (top-k, index build, tile-table plan, gathered grouped GEMMs, combine) has no host sync: one

@@ -144,6 +144,8 @@ def test_shim_moe_and_mla_equal_the_ctypes_path():
     out = m.moe_combine_result(full, w)
     assert torch.equal(out, ops.moe_combine_result(full, w, T, topk))
     assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst), out)
+    half = sizes[:E // 2].contiguous()                    # EP form: rows of the other experts count as zero rows
+    assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst, half), ops.moe_combine_sorted(g2, src_dst, w, T, topk, half))
     xq, xs = ops.scaled_quantize(x)
     w13q = torch.randint(-127, 128, (E, 2 * I, H), dtype=torch.int8, device=dev, generator=gd)
     w13s = torch.rand(E, 2 * I, device=dev, generator=gd) * 0.02 + 0.001

@@ -85,6 +85,7 @@ _OPTIONAL = {
     "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_moe_combine_sorted": ([vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_moe_combine_sorted_local": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_group_gemm": ([vp, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_group_gemm_w8a8": ([vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_group_gemm_gather": ([vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, i64, ci, vp], ci),

@@ -105,22 +105,36 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(T* __restrict__ out, c
 // N1-style fusion of the reference's index_copy_ + moe_combine_result (layers/dcu/fused_moe.cpp:296-303): the second
 // grouped GEMM's rows stay in expert order and are gathered through src_dst while they are combined:
 // out[t] = sum_k w[t, k] * gemm2_sorted[src_dst[t * topk + k]] (same fp32 sum, same order as the two operators).
+// EP form (local_sizes != nullptr): only the first sum(local_sizes[0 .. n_local)) sorted rows exist (the rank's own experts,
+// sorted to the front); the other rows are the ZERO rows of the reference's gemm2_full (fused_moe.cpp:291-297) and are
+// skipped instead of being materialised.
 template <typename T>
 __global__ __launch_bounds__(256) void moe_combine_sorted_kernel(T* __restrict__ out, const T* __restrict__ gemm2,
                                                                  const int32_t* __restrict__ src_dst,
-                                                                 const float* __restrict__ w, int topk, int H) {
+                                                                 const float* __restrict__ w, int topk, int H,
+                                                                 const int32_t* __restrict__ local_sizes, int n_local) {
   const int64_t t = blockIdx.x;
   constexpr int kMaxTopk = 16;
   __shared__ int rows[kMaxTopk];
   __shared__ float ws[kMaxTopk];
+  __shared__ int n_valid;
+  if (threadIdx.x == 0) n_valid = local_sizes ? 0 : 0x7fffffff;
+  __syncthreads();
+  if (local_sizes) {
+    int part = 0;
+    for (int e = threadIdx.x; e < n_local; e += blockDim.x) part += local_sizes[e];
+    if (part) atomicAdd(&n_valid, part);
+  }
   if (threadIdx.x < topk) {
     rows[threadIdx.x] = src_dst[t * topk + threadIdx.x];
     ws[threadIdx.x] = w[t * topk + threadIdx.x];
   }
   __syncthreads();
+  const int nv = n_valid;
   for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {  // H % 8 == 0: one 16-byte load per row and thread
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < topk; ++k) {
+      if (rows[k] >= nv) continue;
       const uint4 v = *reinterpret_cast<const uint4*>(gemm2 + (int64_t)rows[k] * H + i);
       const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll
@@ -384,7 +398,24 @@ int xllm_mi355_moe_combine_sorted(void* out, const void* gemm2_sorted, const int
   if (n_tokens == 0) return XM_OK;
   XM_DISPATCH_HALF(dtype, T,
                    hipLaunchKernelGGL((moe_combine_sorted_kernel<T>), dim3(n_tokens), dim3(256), 0, (hipStream_t)stream,
-                                      (T*)out, (const T*)gemm2_sorted, src_dst, weights, (int)topk, (int)hidden));
+                                      (T*)out, (const T*)gemm2_sorted, src_dst, weights, (int)topk, (int)hidden,
+                                      (const int32_t*)nullptr, 0));
+  return hip_check_launch();
+}
+
+int xllm_mi355_moe_combine_sorted_local(void* out, const void* gemm2_sorted, const int32_t* src_dst, const float* weights,
+                                        const int32_t* local_expert_sizes, int64_t n_local_experts, int64_t n_tokens,
+                                        int64_t topk, int64_t hidden, int dtype, void* stream) {
+  if (!out || !gemm2_sorted || !src_dst || !weights || !local_expert_sizes || n_local_experts <= 0 || n_tokens < 0 ||
+      topk <= 0 || hidden <= 0)
+    return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (topk > 16 || hidden % 8 != 0 || ((uintptr_t)gemm2_sorted % 16) || ((uintptr_t)out % 16)) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  XM_DISPATCH_HALF(dtype, T,
+                   hipLaunchKernelGGL((moe_combine_sorted_kernel<T>), dim3(n_tokens), dim3(256), 0, (hipStream_t)stream,
+                                      (T*)out, (const T*)gemm2_sorted, src_dst, weights, (int)topk, (int)hidden,
+                                      local_expert_sizes, (int)n_local_experts));
   return hip_check_launch();
 }
 

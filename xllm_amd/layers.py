@@ -363,9 +363,21 @@ class FusedMoE:
     def __init__(self, hidden: int, inter: int, n_experts: int, topk: int, dtype, device, gen, renormalize: bool = True,
                  scoring_func: str = "softmax", correction_bias=None, tp: Optional[parallel.ProcessGroup] = None,
                  fuse: bool = True, mode: str = "16bit", num_expert_group: int = 1, topk_group: int = 1,
-                 route_scale: float = 1.0):
+                 route_scale: float = 1.0, ep: Optional[parallel.ProcessGroup] = None, ep_rank: Optional[int] = None,
+                 ep_size: Optional[int] = None, shared_experts=None):
         self.E, self.topk, self.renorm, self.scoring, self.bias, self.tp, self.fuse = (
             n_experts, topk, renormalize, scoring_func, correction_bias, tp, fuse)
+        # expert parallelism as in the reference's DCU path (fused_moe.cpp:53-63, 236-315): every rank sees every token and
+        # routes over ALL experts, computes only experts [start, start + E / ep), and the EP all-reduce adds the ranks.
+        # (ep_rank / ep_size without a group: one rank's share computed alone, used by the single-GPU tests.)
+        self.ep = ep
+        self.ep_size = ep_size if ep_size is not None else (ep.world_size() if ep is not None else 1)
+        self.ep_rank = ep_rank if ep_rank is not None else (ep.rank() if ep is not None else 0)
+        assert n_experts % self.ep_size == 0
+        self.E_local = n_experts // self.ep_size
+        self.start = self.ep_rank * self.E_local
+        self.shared = shared_experts   # callable [T, H] -> [T, H] (the shared experts' dense MLP), added after the reduces
+        self._side = None
         # DeepSeek-style device-limited routing (fused_moe.cpp:155-166: num_expert_group / topk_group / route_scale)
         self.n_group, self.topk_group, self.route_scale = num_expert_group, topk_group, route_scale
         self.mode = mode  # "16bit" = the reference's DCU path; "int8" = W8A8 experts (GroupGemmParams a_scale / b_scale)
@@ -374,6 +386,9 @@ class FusedMoE:
         i_local = inter // tp_size
         self.w13 = (torch.randn(n_experts, 2 * i_local, hidden, device=device, generator=gen) / math.sqrt(hidden)).to(dtype)
         self.w2 = (torch.randn(n_experts, hidden, i_local, device=device, generator=gen) / math.sqrt(inter)).to(dtype)
+        if self.ep_size > 1:  # every rank draws the same full tensors and keeps its own experts
+            self.w13 = self.w13[self.start:self.start + self.E_local].contiguous()
+            self.w2 = self.w2[self.start:self.start + self.E_local].contiguous()
         if mode == "int8":  # symmetric per-output-channel int8 (what a W8A8 checkpoint carries)
             def q8(w):
                 sc = (w.float().abs().amax(-1) / 127.0).clamp_min(1e-12)
@@ -384,30 +399,56 @@ class FusedMoE:
     def forward_experts(self, hidden_states, router_logits):
         x = hidden_states.reshape(-1, hidden_states.size(-1))
         T = x.size(0)
+        shared_out, side = None, None
+        if self.shared is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # shared experts on a second stream next to the routed path (fused_moe.cpp:304-335)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=x.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                shared_out = self.shared(x)
         weights, ids = ops.moe_active_topk(router_logits.reshape(T, -1), self.topk, self.n_group, self.topk_group,
                                            self.renorm, self.bias, self.scoring, self.route_scale)
+        local = None
+        if self.ep_size > 1:
+            # rotate the expert ids so that this rank's experts sort to the front: their rows are then the first
+            # sum(sizes[:E_local]) sorted rows, at offset 0 -- no host read of the sizes (the reference's .item() calls)
+            ids = torch.remainder(ids - self.start, self.E).to(torch.int32)
         src_dst, dst_src, sizes = ops.moe_compute_index(ids, self.E)
+        if self.ep_size > 1:
+            sizes = sizes[:self.E_local]
+            local = sizes
         if self.mode == "int8":
             # each token is quantised ONCE; the expand happens inside the first grouped GEMM's A staging (scales follow)
             xq, xs = ops.scaled_quantize(x)
             h13 = ops.group_gemm_w8a8(xq, xs, self.w13_q, self.w13_s, sizes, x.dtype, row_index=dst_src, index_div=self.topk)
             aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu")
             h2 = ops.group_gemm_w8a8(aq, a_s, self.w2_q, self.w2_s, sizes, x.dtype)
-            out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk)
-            return parallel.reduce(out, self.tp).reshape(hidden_states.shape)
-        h13 = ops.group_gemm_gather(x, dst_src, self.topk, self.w13, sizes) if self.fuse else None
-        if h13 is None:  # reference order: expand with index_select, then the grouped GEMM
-            h13 = ops.group_gemm(x.index_select(0, (dst_src // self.topk).long()), self.w13, sizes)
-        act = torch.empty(h13.size(0), h13.size(1) // 2, dtype=h13.dtype, device=h13.device)
-        ops.act_and_mul(act, h13, "silu")
-        h2 = ops.group_gemm(act, self.w2, sizes)
-        if self.fuse:
-            out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk)
+            out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk, local)
         else:
-            full = torch.empty_like(h2)
-            full.index_copy_(0, dst_src.long(), h2)
-            out = ops.moe_combine_result(full, weights, T, self.topk)
-        return parallel.reduce(out, self.tp).reshape(hidden_states.shape)
+            h13 = ops.group_gemm_gather(x, dst_src, self.topk, self.w13, sizes) if self.fuse else None
+            if h13 is None:  # reference order: expand with index_select, then the grouped GEMM
+                h13 = ops.group_gemm(x.index_select(0, (dst_src // self.topk).long()), self.w13, sizes)
+            act = torch.empty(h13.size(0), h13.size(1) // 2, dtype=h13.dtype, device=h13.device)
+            ops.act_and_mul(act, h13, "silu")
+            h2 = ops.group_gemm(act, self.w2, sizes)
+            if self.fuse:
+                out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk, local)
+            else:  # the reference's own sequence: zeros, index_copy_ of the local rows (host read of their count), combine
+                n_local = int(sizes.sum().item()) if local is not None else h2.size(0)
+                full = torch.zeros_like(h2) if local is not None else torch.empty_like(h2)
+                full.index_copy_(0, dst_src[:n_local].long(), h2[:n_local])
+                out = ops.moe_combine_result(full, weights, T, self.topk)
+        out = parallel.reduce(out, self.ep)
+        out = parallel.reduce(out, self.tp)
+        if self.shared is not None:
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                shared_out = self.shared(x)
+            out = out + shared_out
+        return out.reshape(hidden_states.shape)
 
 
 class DualBatchDecoder:

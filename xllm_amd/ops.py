@@ -463,15 +463,23 @@ def moe_combine_result(gemm2, weights, n_tokens: int, topk: int):
     return out
 
 
-def moe_combine_sorted(gemm2_sorted, src_dst, weights, n_tokens: int, topk: int):
+def moe_combine_sorted(gemm2_sorted, src_dst, weights, n_tokens: int, topk: int, local_expert_sizes=None):
     """index_copy_ + kernel::moe_combine_result in one pass (layers/dcu/fused_moe.cpp:296-303): gemm2_sorted holds the rows
-    of the second grouped GEMM in expert order; out[t] = sum_k w[t,k] * gemm2_sorted[src_dst[t*topk+k]]."""
+    of the second grouped GEMM in expert order; out[t] = sum_k w[t,k] * gemm2_sorted[src_dst[t*topk+k]].
+    local_expert_sizes (int32 [E_local], device; EP rank): only the first sum(local_expert_sizes) sorted rows exist, the
+    others count as the zero rows of the reference's gemm2_full and are skipped."""
     _need_cuda(gemm2_sorted, src_dst, weights)
     H = gemm2_sorted.size(-1)
     out = torch.empty(n_tokens, H, dtype=gemm2_sorted.dtype, device=gemm2_sorted.device)
     gemm2_c = gemm2_sorted.contiguous()  # keep the (possibly new) tensors alive across the call
     src_dst_c = src_dst.contiguous()
     weights_c = weights.contiguous()
+    if local_expert_sizes is not None:
+        sizes_c = local_expert_sizes.contiguous()
+        check(_lib.lib().xllm_mi355_moe_combine_sorted_local(_p(out), _p(gemm2_c), _p(src_dst_c), _p(weights_c), _p(sizes_c),
+                                                            sizes_c.numel(), n_tokens, topk, H, _dt(gemm2_sorted), _stream()),
+              "moe_combine_sorted_local")
+        return out
     check(_lib.lib().xllm_mi355_moe_combine_sorted(_p(out), _p(gemm2_c), _p(src_dst_c), _p(weights_c), n_tokens, topk, H,
                                                   _dt(gemm2_sorted), _stream()), "moe_combine_sorted")
     return out
