@@ -109,6 +109,33 @@ def cases():
     bonus = torch.tensor([5, 6], dtype=torch.int32)
     c.update({"rej.draft": draft, "rej.n": n, "rej.cu": cun, "rej.dp": dp, "rej.tp": tp, "rej.ur": ur, "rej.up": up,
               "rej.bonus": bonus, "rej.out": orc.rejection_sample(draft, n, cun, dp, tp, bonus, ur, up)})
+    # --- (appended; the generator state above is untouched) MLA decode / prefill over a paged latent cache, page = 64
+    Hm, bsm = 16, 64
+    m_kv, m_q = [70, 130], [3, 6]
+    m_blocks = [[4, 1], [0, 5, 2]]
+    mdm = orc.build_batch_metadata(m_kv, m_q, m_blocks, bsm)
+    lat = (torch.randn(6, bsm, 1, 576, generator=g) * 0.5).to(bf)
+    qm = torch.randn(sum(m_q), Hm, 576, generator=g).to(bf)
+    m_scale = 192 ** -0.5
+    om = orc.paged_attention(qm, lat, lat, mdm["q_cu_seq_lens"], mdm["kv_seq_lens"], mdm["block_tables"], m_scale,
+                             causal=True, dv=512)
+    last = mdm["q_cu_seq_lens"][1:].long() - 1
+    c.update({"mla.cache": lat, "mla.q": qm, "mla.cu_q": mdm["q_cu_seq_lens"], "mla.kv_lens": mdm["kv_seq_lens"],
+              "mla.block_table": mdm["block_tables"], "mla.prefill_out": om, "mla.decode_out": om[last].contiguous()})
+    # --- grouped gating top-k (DeepSeek-V3 style: sigmoid + bias, 4 groups, 2 kept) and the softmax form
+    gg = torch.randn(7, 32, generator=g) * 2
+    gb = torch.randn(32, generator=g) * 0.1
+    w1, i1 = orc.moe_grouped_topk(gg, 4, 4, 2, True, gb, "sigmoid", 2.5)
+    w2, i2 = orc.moe_grouped_topk(gg, 3, 8, 3, False, None, "softmax", 1.0)
+    c.update({"gtopk.gating": gg, "gtopk.bias": gb, "gtopk.sig_w": w1, "gtopk.sig_ids": i1, "gtopk.soft_w": w2,
+              "gtopk.soft_ids": i2})
+    # --- MoE combine and the (bf16) grouped GEMM
+    g2 = torch.randn(10 * 2, 64, generator=g).to(bf)
+    cw = torch.rand(10, 2, generator=g)
+    c.update({"combine.gemm2": g2, "combine.w": cw, "combine.out": orc.moe_combine(g2, cw, 10, 2)})
+    xa = torch.randn(20, 64, generator=g).to(bf)
+    ww = (torch.randn(8, 48, 64, generator=g) / 8).to(bf)
+    c.update({"ggemm.a": xa, "ggemm.w": ww, "ggemm.out": orc.group_gemm(xa, ww, c["moe_index.sizes"])})
     return c
 
 

@@ -120,3 +120,19 @@ def test_hip_kernels_reproduce_the_committed_fixtures():
     rj = ops.rejection_sample(d("rej.draft"), d("rej.n"), d("rej.cu"), d("rej.dp"), d("rej.tp"), d("rej.bonus"),
                               d("rej.ur"), d("rej.up"))
     assert torch.equal(rj.cpu(), f["rej.out"])
+    # MLA over the paged latent cache: prefill (bottom-right causal) and decode of each sequence's last token
+    mq, mcache, m_scale = d("mla.q"), d("mla.cache"), 192 ** -0.5
+    mp = ops.mla_prefill(mq, mcache, d("mla.cu_q"), d("mla.kv_lens"), d("mla.block_table"), 512, m_scale, 130, is_causal=True)
+    assert _rel(mp, f["mla.prefill_out"]) <= 1e-3
+    last = f["mla.cu_q"][1:].long() - 1
+    mdc = ops.mla_decode(mq[last.to(DEV)].contiguous(), mcache, d("mla.kv_lens"), d("mla.block_table"), 512, m_scale, 130)
+    assert _rel(mdc, f["mla.decode_out"]) <= 1e-3
+    # grouped gate, combine, grouped GEMM
+    gw, gi = ops.moe_grouped_topk(d("gtopk.gating"), 4, 4, 2, True, d("gtopk.bias"), "sigmoid", 2.5)
+    assert torch.equal(gi.cpu(), f["gtopk.sig_ids"])
+    torch.testing.assert_close(gw.cpu(), f["gtopk.sig_w"], rtol=3e-6, atol=1e-7)
+    gw, gi = ops.moe_active_topk(d("gtopk.gating"), 3, 8, 3, False, None, "softmax", 1.0)
+    assert torch.equal(gi.cpu(), f["gtopk.soft_ids"])
+    torch.testing.assert_close(gw.cpu(), f["gtopk.soft_w"], rtol=3e-6, atol=1e-7)
+    _ulp_close(ops.moe_combine_result(d("combine.gemm2"), d("combine.w"), 10, 2), f["combine.out"])
+    _ulp_close(ops.group_gemm(d("ggemm.a"), d("ggemm.w"), d("moe_index.sizes")), f["ggemm.out"])
