@@ -123,10 +123,10 @@ def test_hip_kernels_reproduce_the_committed_fixtures():
     # MLA over the paged latent cache: prefill (bottom-right causal) and decode of each sequence's last token
     mq, mcache, m_scale = d("mla.q"), d("mla.cache"), 192 ** -0.5
     mp = ops.mla_prefill(mq, mcache, d("mla.cu_q"), d("mla.kv_lens"), d("mla.block_table"), 512, m_scale, 130, is_causal=True)
-    assert _rel(mp, f["mla.prefill_out"]) <= 1e-3
+    assert _rel(mp.view(mp.size(0), -1), f["mla.prefill_out"]) <= 1e-3
     last = f["mla.cu_q"][1:].long() - 1
     mdc = ops.mla_decode(mq[last.to(DEV)].contiguous(), mcache, d("mla.kv_lens"), d("mla.block_table"), 512, m_scale, 130)
-    assert _rel(mdc, f["mla.decode_out"]) <= 1e-3
+    assert _rel(mdc.view(mdc.size(0), -1), f["mla.decode_out"]) <= 1e-3
     # grouped gate, combine, grouped GEMM
     gw, gi = ops.moe_grouped_topk(d("gtopk.gating"), 4, 4, 2, True, d("gtopk.bias"), "sigmoid", 2.5)
     assert torch.equal(gi.cpu(), f["gtopk.sig_ids"])

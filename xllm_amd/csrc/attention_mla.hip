@@ -639,21 +639,36 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
       for (int tb = 0; tb < 4; ++tb) s[tb] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
       {
         const unsigned ke = lds_base + buf * BUFB + k_off, ko = lds_base + buf * BUFB + (k_off ^ 64);
-        mu32x4_t kf[8];
-        // item I: kk = I >> 2, token block tb = I & 3 (four independent accumulators back to back)
-#define MLP_K_RD(I_) MLA_DSR128(kf[(I_) & 7], (((I_) >> 2) & 1) ? ko : ke, ((I_) & 3) * 16 * ROWB + ((I_) >> 3) * 128);
-#define MLP_K_MM(I_, WAIT_)              \
-  MLA_LGKM1(WAIT_, kf[(I_) & 7]);        \
-  s[(I_) & 3] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[(I_) >> 2], s[(I_) & 3]);
-#define MLP_K_ST(I_) MLP_K_MM(I_, 7) MLP_K_RD((I_) + 8)
-#define MLP_K_ST8(B_) MLP_K_ST(B_) MLP_K_ST(B_ + 1) MLP_K_ST(B_ + 2) MLP_K_ST(B_ + 3) MLP_K_ST(B_ + 4) MLP_K_ST(B_ + 5) MLP_K_ST(B_ + 6) MLP_K_ST(B_ + 7)
-        MLP_K_RD(0) MLP_K_RD(1) MLP_K_RD(2) MLP_K_RD(3) MLP_K_RD(4) MLP_K_RD(5) MLP_K_RD(6) MLP_K_RD(7)
-        MLP_K_ST8(0) MLP_K_ST8(8) MLP_K_ST8(16) MLP_K_ST8(24) MLP_K_ST8(32) MLP_K_ST8(40) MLP_K_ST8(48) MLP_K_ST8(56)
-        MLP_K_MM(64, 7) MLP_K_MM(65, 6) MLP_K_MM(66, 5) MLP_K_MM(67, 4) MLP_K_MM(68, 3) MLP_K_MM(69, 2) MLP_K_MM(70, 1) MLP_K_MM(71, 0)
+        // item I: kk = I >> 2, token block tb = I & 3 (four independent accumulators back to back); KW fragment reads in flight
+        // (one wave per SIMD: the window has to cover the loaded LDS latency at 1 KB per 16-cycle MFMA)
+#ifndef XM_MLA_KW
+#define XM_MLA_KW 8
+#endif
+        constexpr int KW = XM_MLA_KW;
+        static_assert(KW >= 4 && KW <= 15, "lgkmcnt counts at most 15 outstanding reads");
+        mu32x4_t kf[KW];
+#define MLP_K_RD(I_) MLA_DSR128(kf[(I_) % KW], (((I_) >> 2) & 1) ? ko : ke, ((I_) & 3) * 16 * ROWB + ((I_) >> 3) * 128);
+#define MLP_K_IT(I_)                                                                             \
+  MLA_LGKM1(((I_) + KW < 72 ? KW - 1 : 71 - (I_)), kf[(I_) % KW]);                               \
+  s[(I_) & 3] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) % KW]), qf[(I_) >> 2], s[(I_) & 3]);     \
+  if ((I_) + KW < 72) { MLP_K_RD(((I_) + KW < 72 ? (I_) + KW : 71)) }
+#define MLP_K_IT8(B_) MLP_K_IT(B_) MLP_K_IT(B_ + 1) MLP_K_IT(B_ + 2) MLP_K_IT(B_ + 3) MLP_K_IT(B_ + 4) MLP_K_IT(B_ + 5) MLP_K_IT(B_ + 6) MLP_K_IT(B_ + 7)
+        MLP_K_RD(0) MLP_K_RD(1) MLP_K_RD(2) MLP_K_RD(3)
+        if (KW > 4) { MLP_K_RD(4 < KW ? 4 : 0) }
+        if (KW > 5) { MLP_K_RD(5 < KW ? 5 : 0) }
+        if (KW > 6) { MLP_K_RD(6 < KW ? 6 : 0) }
+        if (KW > 7) { MLP_K_RD(7 < KW ? 7 : 0) }
+        if (KW > 8) { MLP_K_RD(8 < KW ? 8 : 0) }
+        if (KW > 9) { MLP_K_RD(9 < KW ? 9 : 0) }
+        if (KW > 10) { MLP_K_RD(10 < KW ? 10 : 0) }
+        if (KW > 11) { MLP_K_RD(11 < KW ? 11 : 0) }
+        if (KW > 12) { MLP_K_RD(12 < KW ? 12 : 0) }
+        if (KW > 13) { MLP_K_RD(13 < KW ? 13 : 0) }
+        if (KW > 14) { MLP_K_RD(14 < KW ? 14 : 0) }
+        MLP_K_IT8(0) MLP_K_IT8(8) MLP_K_IT8(16) MLP_K_IT8(24) MLP_K_IT8(32) MLP_K_IT8(40) MLP_K_IT8(48) MLP_K_IT8(56) MLP_K_IT8(64)
 #undef MLP_K_RD
-#undef MLP_K_MM
-#undef MLP_K_ST
-#undef MLP_K_ST8
+#undef MLP_K_IT
+#undef MLP_K_IT8
       }
       // softmax of the wave's own 16 heads x 64 tokens: lane (p16, g) holds tokens t0 + 16 tb + 4 g + r of head p16
       float mx = kMlaNegBig;
