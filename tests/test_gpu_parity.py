@@ -755,6 +755,21 @@ def test_fused_moe_expert_parallel_ranks_add_up(mode, ep):
 
 
 @pytest.mark.parametrize("mode", ["16bit", "int8"])
+def test_fused_moe_alltoall_path_on_one_rank_equals_the_layer(mode):
+    """N4 all-to-all EP (parallel.ep_dispatch / ep_combine + forward_experts_alltoall): with one rank the exchange is the
+    identity, so the dispatched rows, the expert-local index build (topk = 1 over the arrival order), the grouped GEMMs
+    and the un-sort must reproduce forward_experts bit for bit (the 2-rank exchange itself runs in test_parallel_gloo.py)"""
+    from xllm_amd import layers
+    T, H, I, E, topk = 900, 512, 384, 16, 4
+    moe = layers.FusedMoE(H, I, E, topk, torch.bfloat16, DEV, torch.Generator(device=DEV).manual_seed(21), mode=mode,
+                          num_expert_group=4, topk_group=3)
+    gd = torch.Generator(device=DEV).manual_seed(22)
+    x = torch.randn(T, H, device=DEV, generator=gd).bfloat16()
+    logits = torch.randn(T, E, device=DEV, generator=gd).bfloat16()
+    assert torch.equal(moe.forward_experts_alltoall(x, logits), moe.forward_experts(x, logits))
+
+
+@pytest.mark.parametrize("mode", ["16bit", "int8"])
 def test_fused_moe_layer_replays_from_a_hip_graph(mode):
     """the whole expert path (top-k, index build, tile-table plan, gathered grouped GEMMs, combine) has no host sync: one
     captured graph, replayed on NEW inputs written into the static buffers, equals the eager layer bit for bit (the

@@ -111,3 +111,29 @@ def test_tp_sharded_equals_full():
         # partial sums are rounded to bf16 per rank before the SUM (as on the device path): 2 bf16 ulp
         assert (o - o_full).abs().max() <= 2 * 2.0 ** -8 * o_full.abs().max()
         assert (dn - dn_full).abs().max() <= 2 * 2.0 ** -8 * dn_full.abs().max()
+
+
+def _ep_alltoall(rank, world):
+    """all-to-all expert parallelism: every rank routes its OWN tokens; a stand-in expert e scales its rows by (e + 1)"""
+    from xllm_amd import parallel
+    pg, _ = parallel.make_tp_dp_groups(world, rank, world)
+    E, topk, Hd = 8, 3, 16
+    g = torch.Generator().manual_seed(100 + rank)
+    T = 5 + 4 * rank                                       # ragged: the ranks hold different numbers of tokens
+    x = torch.randn(T, Hd, generator=g)
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(T)]).to(torch.int32)
+    w = torch.rand(T, topk, generator=g)
+    rows, local_e, ctx = parallel.ep_dispatch(x, ids, E, pg)
+    e_local = E // world
+    assert rows.size(0) == local_e.numel() and int(local_e.min()) >= 0 and int(local_e.max()) < e_local
+    y = rows * (local_e.float() + rank * e_local + 1)[:, None]          # "expert" = scale by (global id + 1)
+    back = parallel.ep_combine(y, ctx, pg)
+    out = (back.view(T, topk, Hd) * w[..., None]).sum(1)
+    ref = (x[:, None, :] * (ids.float() + 1)[..., None] * w[..., None]).sum(1)
+    return bool(torch.allclose(out, ref, rtol=1e-6, atol=1e-6)), rows.size(0), T * topk
+
+
+def test_ep_alltoall_dispatch_combine_round_trip():
+    out = _run(_ep_alltoall)
+    assert all(ok for ok, _, _ in out)
+    assert sum(r for _, r, _ in out) == sum(n for _, _, n in out)      # every (token, k) row was computed exactly once

@@ -451,6 +451,43 @@ class FusedMoE:
         return out.reshape(hidden_states.shape)
 
 
+    def forward_experts_alltoall(self, hidden_states, router_logits):
+        """all-to-all expert parallelism (parallel.ep_dispatch / ep_combine; DeepEP-style, N4): this rank's OWN tokens are
+        routed over all experts, every (token, k) row travels to the rank that owns its expert, is computed there by the
+        same grouped GEMMs, and travels back for the weighted combine. Not graph-capturable (split sizes on the host)."""
+        x = hidden_states.reshape(-1, hidden_states.size(-1))
+        T = x.size(0)
+        pg = self.ep if self.ep is not None else parallel.ProcessGroup(None, 0, 1)
+        assert pg.world_size() == self.ep_size
+        weights, ids = ops.moe_active_topk(router_logits.reshape(T, -1), self.topk, self.n_group, self.topk_group,
+                                           self.renorm, self.bias, self.scoring, self.route_scale)
+        rows, local_e, ctx = parallel.ep_dispatch(x, ids, self.E, pg)
+        R = rows.size(0)
+        if R > 0:
+            src_dst, dst_src, sizes = ops.moe_compute_index(local_e.view(R, 1), self.E_local)
+            if self.mode == "int8":
+                xq, xs = ops.scaled_quantize(rows)
+                h13 = ops.group_gemm_w8a8(xq, xs, self.w13_q, self.w13_s, sizes, x.dtype, row_index=dst_src, index_div=1)
+                aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu")
+                h2 = ops.group_gemm_w8a8(aq, a_s, self.w2_q, self.w2_s, sizes, x.dtype)
+            else:
+                h13 = ops.group_gemm_gather(rows, dst_src, 1, self.w13, sizes)
+                if h13 is None:
+                    h13 = ops.group_gemm(rows.index_select(0, dst_src.long()), self.w13, sizes)
+                act = torch.empty(h13.size(0), h13.size(1) // 2, dtype=h13.dtype, device=h13.device)
+                ops.act_and_mul(act, h13, "silu")
+                h2 = ops.group_gemm(act, self.w2, sizes)
+            y = h2.index_select(0, src_dst.long())      # expert order -> arrival order
+        else:
+            y = rows.new_empty(0, x.size(-1))
+        back = parallel.ep_combine(y, ctx, pg)
+        out = ops.moe_combine_result(back, weights, T, self.topk)
+        out = parallel.reduce(out, self.tp)
+        if self.shared is not None:
+            out = out + self.shared(x)
+        return out.reshape(hidden_states.shape)
+
+
 class DualBatchDecoder:
     """Decode step of two micro-batches on two HIP streams (the reference's enable_multi_stream_parallel with
     micro_batch_num = 2, framework/config/parallel_config.h:83-85). The paged-attention kernel of a layer is bound by

@@ -35,6 +35,55 @@ class ProcessGroup:
         return out
 
 
+    def alltoall(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
+        """variable-size all-to-all over dim 0 (RCCL all-to-all over xGMI; gloo on the CPU tests): rows
+        [sum(send_counts[:r]), +send_counts[r]) of `send` go to rank r; returns the received rows, rank-major"""
+        if self._world == 1:
+            return send
+        out = send.new_empty((int(sum(recv_counts)),) + tuple(send.shape[1:]))
+        sc = send.contiguous()
+        _run_collective(lambda: dist.all_to_all_single(out, sc, list(recv_counts), list(send_counts), group=self.group))
+        return out
+
+
+# ---- all-to-all expert parallelism (SURVEY 8f N4; cfg5 names an RCCL all-to-all) ---------------------------------------
+# Reference: DeepEPImpl (layers/common/deep_ep.{h,cpp}: dispatch_step -> process_dispatch_result -> combine_step_*; MLU
+# only -- the CUDA / DCU layer combines EP ranks by all-reduce, fused_moe.cpp:308-315, which FusedMoE also mirrors).
+# Here every rank owns DIFFERENT tokens (data-parallel attention) and E / world experts:
+#   dispatch: the (token, k) pairs are grouped by destination rank (stable: token order inside a rank), the per-rank counts
+#             are exchanged, then the rows and their LOCAL expert ids travel in one all-to-all each;
+#   combine:  the expert outputs travel back through the mirrored all-to-all and are put back in (token, k) order, where the
+#             usual weighted combine (moe_combine_result) finishes the layer.
+# The split sizes are read on the host (one sync per layer, as DeepEP's normal mode does), so this path is for prefill;
+# decode under graph replay keeps the all-reduce form.
+def ep_dispatch(x: torch.Tensor, expert_ids: torch.Tensor, n_experts: int, pg: ProcessGroup):
+    world = pg.world_size()
+    e_local = n_experts // world
+    topk = expert_ids.size(1)
+    flat = expert_ids.reshape(-1).long()
+    dest = torch.div(flat, e_local, rounding_mode="floor")
+    order = torch.argsort(dest, stable=True)
+    send_counts = torch.bincount(dest, minlength=world)
+    if world == 1:
+        recv_counts = send_counts
+    else:
+        recv_counts = torch.empty_like(send_counts)
+        _run_collective(lambda: dist.all_to_all_single(recv_counts, send_counts, group=pg.group))
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    rows = x.index_select(0, torch.div(order, topk, rounding_mode="floor"))
+    local_e = (flat[order] - dest[order] * e_local).to(torch.int32)
+    return pg.alltoall(rows, sc, rc), pg.alltoall(local_e, sc, rc), (order, sc, rc)
+
+
+def ep_combine(y: torch.Tensor, ctx, pg: ProcessGroup) -> torch.Tensor:
+    """y: one output row per received row (arrival order) -> [T * topk, H] at the source, in (token, k) order"""
+    order, sc, rc = ctx
+    back = pg.alltoall(y, rc, sc)
+    out = torch.empty_like(back)
+    out[order] = back
+    return out
+
+
 _piecewise = None  # the PiecewiseGraph that is capturing, if any
 
 
