@@ -19,7 +19,9 @@ SELECT = "scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmu
     {"XLLM_MI355_P8N": "1", "XLLM_MI355_P8N_NB": "4"},       # narrow-tile decode kernel, 128 columns
     {"XLLM_MI355_P8": "0", "XLLM_MI355_SKINNY_DISABLE": "1"},  # 128x128 kernel only
     {"XLLM_MI355_SKINNY_BM128": "0"},                         # decode kernel on 256-row tiles for M <= 128 too
-], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256"])
+    {"XLLM_MI355_ASTAT": "1"},                                # activation-stationary decode kernel (gemm_astat.hip)
+    {"XLLM_MI355_ASTAT": "1", "XLLM_MI355_ASTAT_SPLITS": "3"},
+], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256", "astat", "astat_split3"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

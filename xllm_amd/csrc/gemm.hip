@@ -411,7 +411,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void gemm_skinny_kernel(cons
         if constexpr (KIND == kI8) {
           const int a = acc[t][j][r];
           if constexpr (SPLITK) {
+#ifdef XM_ABL_SK_STORE  /* ablation build (timing only, WRONG results): what the split-K atomics cost */
+            epi.acc_out[idx] = a;
+#else
             atomicAdd(epi.acc_out + idx, a);
+#endif
           } else {
             if (epi.acc_out) epi.acc_out[idx] = a;
             if (epi.out) store16(epi.out, idx, (float)a * epi.a_scale[m] * ws + bs, epi.out_bf16);
@@ -607,6 +611,35 @@ int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb
   const bool half_kind = KIND == kBF16 || KIND == kF16 || KIND == kFP8;  // kinds that split K through fp32 slabs
   const bool can_split = (KIND == kI8 || (half_kind && N % 4 == 0 && ((uintptr_t)epi.out % 8) == 0)) && workspace &&
                          ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
+  if constexpr (KIND == kI8) {
+    // few columns, M in (128, 256]: the activation-stationary kernel (gemm_astat.hip). XLLM_MI355_ASTAT = 0 off, 1 on for
+    // every legal shape; XLLM_MI355_ASTAT_SPLITS overrides the K split (tuning)
+    static int astat = -2, astat_splits = -2;
+    if (astat == -2) {
+      const char* e = getenv("XLLM_MI355_ASTAT");
+      astat = e ? atoi(e) : 0;
+      e = getenv("XLLM_MI355_ASTAT_SPLITS");
+      astat_splits = e ? atoi(e) : -1;
+    }
+    if (astat && can_split && M > 128 && M <= 256 && Kb % 256 == 0 && !epi.group_counts) {
+      const int64_t ranges = (N + 127) / 128;
+      const int slabs = (int)(Kb / 256);
+      int splits = (int)(256 / ranges);
+      const int by_k = slabs / 2 > 0 ? slabs / 2 : 1;
+      splits = splits > by_k ? by_k : splits;
+      splits = splits < 1 ? 1 : splits;
+      if (astat_splits > 0) splits = astat_splits;
+      const int rc = launch_gemm_astat_i8(A, W, M, N, Kb, reinterpret_cast<int32_t*>(workspace), splits, s);
+      if (rc != XM_ERR_UNSUPPORTED) {
+        if (rc != XM_OK || epi.defer) return rc;
+        int64_t blocks = (M * N + 255) / 256;
+        blocks = blocks > 1024 ? 1024 : blocks;
+        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
+        return hip_check_launch();
+      }
+    }
+  }
   SkinnyPlan p;
   if (half_kind) {  // one fp32 slab per K slice must fit the workspace
     const int64_t fit = can_split ? (int64_t)(ws_bytes / ((size_t)M * N * 4)) : 1;

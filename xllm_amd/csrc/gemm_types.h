@@ -184,4 +184,9 @@ template <int KIND>
 int launch_gemm_p8n(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int nb, int splits,
                     hipStream_t s);
 
+// activation-stationary int8 kernel for decode GEMMs with few columns (gemm_astat.hip): adds the exact int32 sums into the
+// zeroed split-K workspace acc_ws [M, N]; the caller runs the dequant epilogue (or defers it to the fused consumer)
+int launch_gemm_astat_i8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, int32_t* acc_ws, int splits,
+                         hipStream_t s);
+
 }  // namespace xm
