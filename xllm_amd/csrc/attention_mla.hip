@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
   s[(I_) & 3] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) % KW]), qf[(I_) >> 2], s[(I_) & 3]);     \
   if ((I_) + KW < 72) { MLP_K_RD(((I_) + KW < 72 ? (I_) + KW : 71)) }
 #define MLP_K_IT8(B_) MLP_K_IT(B_) MLP_K_IT(B_ + 1) MLP_K_IT(B_ + 2) MLP_K_IT(B_ + 3) MLP_K_IT(B_ + 4) MLP_K_IT(B_ + 5) MLP_K_IT(B_ + 6) MLP_K_IT(B_ + 7)
+#ifndef XM_ABL_MLP_NOQK  /* ablation builds (timing only, WRONG results): XM_ABL_MLP_NOQK / _NOPV / _NOSM drop a phase */
         MLP_K_RD(0) MLP_K_RD(1) MLP_K_RD(2) MLP_K_RD(3)
         if (KW > 4) { MLP_K_RD(4 < KW ? 4 : 0) }
         if (KW > 5) { MLP_K_RD(5 < KW ? 5 : 0) }
@@ -666,10 +667,23 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
         if (KW > 13) { MLP_K_RD(13 < KW ? 13 : 0) }
         if (KW > 14) { MLP_K_RD(14 < KW ? 14 : 0) }
         MLP_K_IT8(0) MLP_K_IT8(8) MLP_K_IT8(16) MLP_K_IT8(24) MLP_K_IT8(32) MLP_K_IT8(40) MLP_K_IT8(48) MLP_K_IT8(56) MLP_K_IT8(64)
+#endif
 #undef MLP_K_RD
 #undef MLP_K_IT
 #undef MLP_K_IT8
       }
+#ifdef XM_ABL_MLP_NOSM
+      x8 pf[2], pl[2];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[tb >> 1][(tb & 1) * 4 + r] = (elem)s[tb][r];
+          pl[tb >> 1][(tb & 1) * 4 + r] = (elem)s[tb][r];
+        }
+      l_run += 1.0f;
+      (void)kv_w; (void)t0;
+#else
       // softmax of the wave's own 16 heads x 64 tokens: lane (p16, g) holds tokens t0 + 16 tb + 4 g + r of head p16
       float mx = kMlaNegBig;
       if (t0 + kMlaTile > kv_w) {
@@ -719,6 +733,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
 #pragma unroll
         for (int i = 0; i < DB; ++i) mla_scale_acc(acc_o[i], alpha);
       }
+#endif
       {
         const unsigned vb = lds_base + buf * BUFB + v_row;
         unsigned va[4];
@@ -742,9 +757,13 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
   }
 #define MLP_V_ST(I_) MLP_V_MM2(I_, 12) MLP_V_RD((I_) + 8) MLP_V_RD((I_) + 9)
 #define MLP_V_ST8(B_) MLP_V_ST(B_) MLP_V_ST(B_ + 2) MLP_V_ST(B_ + 4) MLP_V_ST(B_ + 6)
+#ifndef XM_ABL_MLP_NOPV
         MLP_V_RD(0) MLP_V_RD(1) MLP_V_RD(2) MLP_V_RD(3) MLP_V_RD(4) MLP_V_RD(5) MLP_V_RD(6) MLP_V_RD(7)
         MLP_V_ST8(0) MLP_V_ST8(8) MLP_V_ST8(16) MLP_V_ST8(24) MLP_V_ST8(32) MLP_V_ST8(40) MLP_V_ST8(48)
         MLP_V_MM2(56, 12) MLP_V_MM2(58, 8) MLP_V_MM2(60, 4) MLP_V_MM2(62, 0)
+#else
+        asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pl[0]), "v"(pl[1]), "v"(va[0]));
+#endif
 #undef MLP_V_RD
 #undef MLP_V_MM2
 #undef MLP_V_ST
