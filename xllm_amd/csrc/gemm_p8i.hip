@@ -185,8 +185,19 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(W), 0, (int)((int64_t)N * Kb), 0x00020000);
   int voff_a[2][2], voff_w[2][2];  // [i][half]
   {
+#ifdef P8I_INTERLEAVE
+    // EXPERIMENT (-DP8I_INTERLEAVE, bit-exact, SLOWER: gate_up M = 8192 1157 vs 910 us, M = 256 65 vs 50 us): 8-row-interleaved
+    // slot layout [row >> 3][16-B chunk][row & 7]. ds_read_b128 runs at full rate only when 8 consecutive lanes read inside
+    // one aligned 128-B block (tools/lds_pattern_bench.hip: 5.3 vs 8 cycles per fragment read), so the 8 rows of a chunk
+    // are stored next to each other; but the DMA writes LDS lane-linearly, hence lane l must FETCH row (l & 7), chunk
+    // (l >> 3) of its 8-row group -- a 16-byte gather over 8 rows per 8 lanes that the load path serves far slower than
+    // the row-contiguous fetch, which costs more than the reads gain.
+    const int srow = wave * 8 + (lane & 7);
+    const int scol = (lane >> 3) << 4;
+#else
     const int srow = wave * 8 + (lane >> 3);
     const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -230,7 +241,11 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
     const int f = (lane & 15) >> 1;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+#ifdef P8I_INTERLEAVE
+      const unsigned o = base + ((lane & 15) >> 3) * 1024 + ((4 * kb + (lane >> 4)) << 7) + ((lane & 7) << 4) + 0 * f;
+#else
       const unsigned o = base + (lane & 15) * P8_BK + (((4 * kb + (lane >> 4)) ^ f) << 4);
+#endif
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         rd_w[b][kb] = o + b * 4 * P8_SLOT + wc * 32 * P8_BK;
