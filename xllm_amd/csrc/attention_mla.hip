@@ -713,7 +713,10 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
         const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
         mx = fmaxf(mla_as_f32(r32[0]), mla_as_f32(r32[1]));
       }
-      const float m_new = fmaxf(m_run, mx);
+      // lazy rescale: the reference maximum only moves when the tile's maximum exceeds it by more than 2^8 (scores are in
+      // the log2 domain), so P stays <= 256 -- exact in the fp32 sums, the same relative precision in the hi / lo parts --
+      // and the 128-register accumulator rescale (a third of all tiles under a causal mask otherwise) all but disappears
+      const float m_new = mx > m_run + 8.0f ? mx : m_run;
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       float psum = 0.0f;

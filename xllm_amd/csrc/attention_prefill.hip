@@ -462,7 +462,10 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
       mx = fmaxf(as_f32(r32[0]), as_f32(r32[1]));
     }
 #endif
-    const float m_new = fmaxf(m_run[nb], mx * scale_log2);
+    // lazy rescale: the reference maximum only moves when the tile's maximum exceeds it by more than 2^8 (log2 domain), so
+    // P stays <= 256 (exact in the fp32 sums, same relative precision in hi / lo) and the accumulator rescale all but vanishes
+    const float mxs = mx * scale_log2;
+    const float m_new = mxs > m_run[nb] + 8.0f ? mxs : m_run[nb];
     const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);  // v_exp_f32: results below 2^-126 flush to 0
     m_run[nb] = m_new;
     const pf32x4_t sc4 = {scale_log2, scale_log2, scale_log2, scale_log2}, nm4 = {-m_new, -m_new, -m_new, -m_new};
