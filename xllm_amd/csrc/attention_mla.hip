@@ -587,7 +587,23 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
   for (int i = 0; i < DB; ++i) acc_o[i] = mf32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = kMlaNegBig, l_run = 0.0f;
 
-  int voff[NDMA];  // as in mla_decode_dma_kernel: lane's 16 bytes of DMA instruction i = (row, physical chunk)
+  int voff[NDMA];
+#ifdef XM_MLA_INTERLEAVE
+  // 8-row-interleaved tile [row >> 3][16-B chunk (72)][row & 7][16 B] (9216 B per 8-row group): the K fragment reads
+  // (lane = (row, chunk)) then have 8 consecutive lanes inside one aligned 128-B block = full ds_read_b128 rate
+  // (tools/lds_pattern_bench.hip). DMA instruction n = 18 w + i fills LDS KB n = group n / 9, chunks 8 (n % 9) .. + 7:
+  // lane l fetches row 8 (n / 9) + (l & 7), chunk 8 (n % 9) + (l >> 3) -- a 16-byte gather over 8 rows.
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int n = wave * NDMA + i;
+    voff[i] = ((n / 9) * 8 + (lane & 7)) * ROWB + (((n % 9) * 8 + (lane >> 3)) << 4);
+  }
+  const int k_off = (p16 >> 3) * 9216 + g * 128 + (p16 & 7) * 16;   // + tb * 18432 + kk * 512
+  // V^T reads: row 32 ks + 16 hi + 4 g + (p16 >> 2), chunk 2 db + ((p16 >> 1) & 1), 8-byte half p16 & 1
+  const int v_row = (g >> 1) * 9216 + (4 * (g & 1) + (p16 >> 2)) * 16 + (p16 & 1) * 8 + ((p16 >> 1) & 1) * 128;
+  const int v_x = 0;
+#else
+  // as in mla_decode_dma_kernel: lane's 16 bytes of DMA instruction i = (row, physical chunk)
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int c = (wave * NDMA + i) * 64 + lane, row = c / 72, pc = c % 72;
@@ -599,6 +615,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
   const int ft = (((p16 >> 3) & 1) << 1) | ((g & 1) << 2) | ((g >> 1) & 1);
   const int v_x = ((((p16 >> 1) & 1) ^ ft) << 4) | ((p16 & 1) << 3);
   const int v_row = (4 * g + (p16 >> 2)) * ROWB;
+#endif
   const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)lds3;
 
   for (int pass = 0; pass < 4; ++pass) {
@@ -647,7 +664,11 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
         constexpr int KW = XM_MLA_KW;
         static_assert(KW >= 4 && KW <= 15, "lgkmcnt counts at most 15 outstanding reads");
         mu32x4_t kf[KW];
+#ifdef XM_MLA_INTERLEAVE
+#define MLP_K_RD(I_) MLA_DSR128(kf[(I_) % KW], ke, ((I_) & 3) * 18432 + ((I_) >> 2) * 512);
+#else
 #define MLP_K_RD(I_) MLA_DSR128(kf[(I_) % KW], (((I_) >> 2) & 1) ? ko : ke, ((I_) & 3) * 16 * ROWB + ((I_) >> 3) * 128);
+#endif
 #define MLP_K_IT(I_)                                                                             \
   MLA_LGKM1(((I_) + KW < 72 ? KW - 1 : 71 - (I_)), kf[(I_) % KW]);                               \
   s[(I_) & 3] = TR::mfma(__builtin_bit_cast(x8, kf[(I_) % KW]), qf[(I_) >> 2], s[(I_) & 3]);     \
@@ -745,9 +766,15 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
         mu32x2_t vt[8][2];
         // item I: ks = I >> 5 (32-token half of the tile), db = I & 31; handled in pairs so that the hi / lo MFMAs on one
         // accumulator are not back to back
+#ifdef XM_MLA_INTERLEAVE
+#define MLP_V_RD(I_)                                                                                           \
+  MLA_DSR64TR(vt[(I_) & 7][0], va[0], ((I_) >> 5) * 36864 + ((I_) & 31) * 256);                                 \
+  MLA_DSR64TR(vt[(I_) & 7][1], va[0], ((I_) >> 5) * 36864 + ((I_) & 31) * 256 + 18432);
+#else
 #define MLP_V_RD(I_)                                                                                           \
   MLA_DSR64TR(vt[(I_) & 7][0], va[(I_) & 3], ((I_) >> 5) * 32 * ROWB + (((I_) & 31) >> 2) * 128);               \
   MLA_DSR64TR(vt[(I_) & 7][1], va[(I_) & 3], ((I_) >> 5) * 32 * ROWB + (((I_) & 31) >> 2) * 128 + 16 * ROWB);
+#endif
 #define MLP_V_MM2(I_, WAIT_)                                                                                   \
   {                                                                                                            \
     MLA_LGKM4(WAIT_, vt[(I_) & 7][0], vt[(I_) & 7][1], vt[((I_) + 1) & 7][0], vt[((I_) + 1) & 7][1]);          \
