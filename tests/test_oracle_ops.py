@@ -402,6 +402,38 @@ def test_grouped_topk_oracle_vs_tensorwise_published_gate(E, G, kg, topk, scorin
     assert i0[0].tolist() == list(range(topk))
 
 
+def test_grouped_topk_oracle_invariants_over_random_geometries():
+    """size-independent properties of the grouped gate over random (E, groups, kept groups, topk) geometries: every pick
+    lies in one of at most topk_group groups, picks are distinct and ordered by choice score, weights are the unbiased
+    scores (renormalised sum = routed_scaling_factor), and a one-group problem degenerates to the plain top-k"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(2, 16), st.integers(1, 16), st.integers(1, 8), st.booleans(), st.booleans(), st.integers(0, 10 ** 6))
+    def run(G, per, topk, sigmoid, renorm, seed):
+        E = G * per
+        g = torch.Generator().manual_seed(seed)
+        kg = int(torch.randint(1, G + 1, (1,), generator=g))
+        topk_ = min(topk, kg * per)
+        x = torch.randn(9, E, generator=g) * 3
+        bias = torch.randn(E, generator=g) * 0.2 if (sigmoid and per >= 2 and seed % 2) else None
+        w, ids = orc.moe_grouped_topk(x, topk_, G, kg, renorm, bias, "sigmoid" if sigmoid else "softmax", 1.75)
+        s = torch.sigmoid(x) if sigmoid else torch.softmax(x, -1)
+        c = s + bias if bias is not None else s
+        for t in range(x.size(0)):
+            row = ids[t].long()
+            assert len(set(row.tolist())) == topk_
+            assert len(set((row // per).tolist())) <= kg
+            cs = c[t][row]
+            assert torch.all(cs[:-1] >= cs[1:])                       # descending choice score
+            ref_w = s[t][row]
+            ref_w = ref_w / ref_w.sum() * 1.75 if renorm else ref_w * 1.75
+            torch.testing.assert_close(w[t], ref_w, rtol=2e-5, atol=1e-7)
+        if kg == G and bias is None:                                    # every group kept: the plain top-k over all experts
+            assert torch.equal(ids.long(), c.topk(topk_, -1)[1])
+    run()
+
+
 # ------------------------------------------------------------------------------------------- N3 sampler
 def test_philox4x32_10_known_answers():
     """Random123 known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution)"""
