@@ -57,3 +57,17 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def test_every_kernel_source_is_built_and_tools_parse():
+    """hygiene: every .hip file under xllm_amd/csrc is in the Makefile's SRCS (so build() compiles it), and the python tools
+    at least parse (they only run on the GPU box)"""
+    import ast
+    import glob
+    csrc = os.path.join(ROOT, "xllm_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = [l for l in mk.splitlines() if l.startswith("SRCS")][0]
+    for f in glob.glob(os.path.join(csrc, "*.hip")):
+        assert os.path.basename(f) in srcs.split(), f"{os.path.basename(f)} is not in SRCS"
+    for f in glob.glob(os.path.join(ROOT, "tools", "*.py")) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        ast.parse(open(f).read(), filename=f)
