@@ -137,3 +137,46 @@ def test_ep_alltoall_dispatch_combine_round_trip():
     out = _run(_ep_alltoall)
     assert all(ok for ok, _, _ in out)
     assert sum(r for _, r, _ in out) == sum(n for _, _, n in out)      # every (token, k) row was computed exactly once
+
+
+def _ep_allreduce(rank, world):
+    """the reference's DCU expert parallelism (fused_moe.cpp:53-63, 236-315) with the index trick of layers.FusedMoE: ids
+    rotated by the rank's first expert so that its experts sort to the front, grouped GEMMs over expert_sizes[:E_local],
+    rows of the other ranks left at zero, EP all-reduce. Per-rank arithmetic with the CPU oracle, exchange over gloo."""
+    from xllm_amd import parallel
+    pg, _ = parallel.make_tp_dp_groups(world, rank, world)
+    T, topk, E, Hd, I = 40, 2, 8, 64, 32
+    g = torch.Generator().manual_seed(77)                      # the same tokens, routing and weights on every rank
+    x = torch.randn(T, Hd, generator=g).bfloat16()
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(T)]).to(torch.int32)
+    w = torch.rand(T, topk, generator=g)
+    w13 = (torch.randn(E, 2 * I, Hd, generator=g) / 8).bfloat16()
+    w2 = (torch.randn(E, Hd, I, generator=g) / 6).bfloat16()
+
+    def experts(ids_, w13_, w2_, n_local):
+        src_dst, dst_src, sizes = orc.moe_compute_index(ids_, E)
+        cnt = sizes[:n_local].contiguous()
+        rows = x.index_select(0, (dst_src // topk).long())
+        h = orc.group_gemm(rows, w13_, cnt)
+        act = torch.empty(h.size(0), I, dtype=torch.bfloat16)
+        orc.act_and_mul(act, h.contiguous(), "silu")
+        h2 = orc.group_gemm(act, w2_, cnt)                     # rows past sum(cnt) stay zero = the reference's gemm2_full
+        full = torch.zeros_like(h2)
+        n_valid = int(cnt.sum())
+        full[dst_src[:n_valid].long()] = h2[:n_valid]
+        return orc.moe_combine(full, w, T, topk)
+
+    e_local = E // world
+    start = rank * e_local
+    rot = torch.remainder(ids - start, E).to(torch.int32)
+    part = experts(rot, w13[start:start + e_local].contiguous(), w2[start:start + e_local].contiguous(), e_local).float()
+    parallel.reduce(part, pg)
+    whole = experts(ids, w13, w2, E).float()
+    return part, whole
+
+
+def test_ep_allreduce_ranks_add_up_to_the_all_experts_layer():
+    out = _run(_ep_allreduce)
+    for part, whole in out:
+        assert torch.equal(part, out[0][0])                                        # identical on every rank
+        assert ((part - whole).norm() / whole.norm()).item() <= 6e-3               # 16-bit rounding of the per-rank partials
