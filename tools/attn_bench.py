@@ -11,7 +11,7 @@ from xllm_amd import ops  # noqa: E402
 
 dev = "cuda"
 cases = [("tp1", 256, 28, 4, 4096), ("tp2", 256, 14, 2, 4096), ("tp4", 256, 7, 1, 4096), ("cfg2", 64, 28, 4, 2048),
-         ("tp4dp2", 128, 7, 1, 4096)]
+         ("tp4dp2", 128, 7, 1, 4096), ("dp2", 128, 28, 4, 4096), ("dp4", 64, 28, 4, 4096), ("dp8", 32, 28, 4, 4096)]
 if len(sys.argv) > 1:
     cases = [c for c in cases if c[0] in sys.argv[1].split(",")]
 tag = " ".join(f"{k[11:]}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355"))

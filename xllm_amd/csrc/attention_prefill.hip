@@ -321,6 +321,7 @@ typedef unsigned pu32x2_t __attribute__((ext_vector_type(2)));
 #define PF_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
 
 constexpr int kPf2Tile = 64;
+constexpr int kPfDefaultPMode = 2;                  // XLLM_MI355_PREFILL_P default (see launch_flash_prefill)
 constexpr int kPf2RowB = 256;                       // D = 128 16-bit elements per row, unpadded
 constexpr int kPf2TileB = kPf2Tile * kPf2RowB;      // 16 KB per operand and tile
 #ifdef XM_ABL_PF_TIMING  /* ablation build: shader-clock / wall-clock span of the tile loop of one workgroup */
@@ -367,7 +368,7 @@ __device__ __forceinline__ void pf2_qk(pf32x4_t (&s)[2][4], const unsigned (&ka)
 
 // O^T += V^T P^T of one tile (two 32-key halves, P = hi + lo). The reads of the second half roll into the registers of
 // the first: the pair of block db is complete when 14 younger reads are outstanding (first half) / 2 (7 - db) (second).
-template <typename T>
+template <typename T, bool P1>
 __device__ __forceinline__ void pf2_pv(pf32x4_t (&acc_o)[2][8], const typename PfTraits<T>::x8 (&pf)[2][2],
                                        const typename PfTraits<T>::x8 (&pl)[2][2], const unsigned (&va)[8]) {
   using TR = PfTraits<T>;
@@ -381,8 +382,10 @@ __device__ __forceinline__ void pf2_pv(pf32x4_t (&acc_o)[2][8], const typename P
 #define PF_V_LO(KS_, DB_)
 #else
 #define PF_V_LO(KS_, DB_)                                          \
-  acc_o[0][DB_] = TR::mfma(v8, pl[0][KS_], acc_o[0][DB_]);         \
-  acc_o[1][DB_] = TR::mfma(v8, pl[1][KS_], acc_o[1][DB_]);
+  if constexpr (!P1) {                                             \
+    acc_o[0][DB_] = TR::mfma(v8, pl[0][KS_], acc_o[0][DB_]);       \
+    acc_o[1][DB_] = TR::mfma(v8, pl[1][KS_], acc_o[1][DB_]);       \
+  }
 #endif
 #define PF_V_MM(KS_, DB_, WAIT_)                                                                                   \
   {                                                                                                                \
@@ -407,7 +410,7 @@ __device__ __forceinline__ void pf2_pv(pf32x4_t (&acc_o)[2][8], const typename P
 __device__ __forceinline__ float as_f32(unsigned v) { return __builtin_bit_cast(float, v); }
 
 // online softmax of one tile: masks, running max / sum, P = hi + lo 16-bit parts, rescale of O when the max moved
-template <typename T>
+template <typename T, bool P1>
 __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTraits<T>::x8 (&pf)[2][2],
                                             typename PfTraits<T>::x8 (&pl)[2][2], float (&m_run)[2], pf32x4_t (&l_run)[2],
                                             pf32x4_t (&acc_o)[2][8], bool need_mask, int t0, int kv_len, int causal,
@@ -477,7 +480,12 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
 #pragma unroll
       for (int r = 0; r < 4; ++r) p4[r] = __builtin_amdgcn_exp2f(e4[r]);
       l4 += p4;
-      if constexpr (__is_same(elem, __bf16)) {
+      if constexpr (P1) {
+        // one 16-bit P, rounded to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free f16 cast): what the reference's own
+        // attention kernels feed to PV (layers/cuda/flashinfer_attention.cpp:84-90 "attn @ V in bf16"); the row sum stays fp32
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf[nb][blk >> 1][(blk & 1) * 4 + r] = (elem)p4[r];
+      } else if constexpr (__is_same(elem, __bf16)) {
         // hi = p truncated to bf16 (two values packed by one v_perm), lo = bf16(p - hi): p - hi is exact in fp32
         const pu32x4_t pb = __builtin_bit_cast(pu32x4_t, p4);
         const pu32x4_t hb = pb & 0xffff0000u;
@@ -512,7 +520,7 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
 
 // NW = 8: ping-pong groups, 256 queries per workgroup, one workgroup per CU. NW = 4: one group, 128 queries per
 // workgroup, two workgroups per CU (short query blocks: no second group to alternate with).
-template <typename T, bool PAGED, int NW, bool MIDBAR>
+template <typename T, bool PAGED, int NW, bool MIDBAR, bool P1 = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, const int32_t* __restrict__ kv_lens,
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
         unsigned va[DB];
 #pragma unroll
         for (int db = 0; db < DB; ++db) va[db] = lds_base + ((i - 1) & 1) * TILEB + vofs[db];
-        pf2_pv<T>(acc_o, pf, pl, va);
+        pf2_pv<T, P1>(acc_o, pf, pl, va);
       }
       PF_MARK(1, acc_o[1][7][3])  // V reads + PV
       if (computes(i)) {
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
 #if defined(XM_ABL_PF_PRIO_VALU)
       __builtin_amdgcn_s_setprio(3);
 #endif
-      pf2_softmax<T>(s, pf, pl, m_run, l_run, acc_o, need_mask, t0, kv_len, causal, window_left, kvoff, qidx, g,
+      pf2_softmax<T, P1>(s, pf, pl, m_run, l_run, acc_o, need_mask, t0, kv_len, causal, window_left, kvoff, qidx, g,
                      scale_log2);
 #if defined(XM_ABL_PF_PRIO_VALU)
       __builtin_amdgcn_s_setprio(0);
@@ -764,6 +772,15 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
                              (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
                              (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
       } else {
+        // XLLM_MI355_PREFILL_P: 1 = one 16-bit P per score, 2 = P = hi + lo (two MFMAs per block; fp32-P accuracy)
+        static int p_mode = -1;
+        if (p_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_P"); p_mode = e ? atoi(e) : kPfDefaultPMode; }
+        if (p_mode == 1)
+          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3((unsigned)(nq * batch * qblocks)),
+                             dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table,
+                             (int)max_blocks, (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl,
+                             (int)batch, qblocks);
+        else
         hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
                            (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
                            (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch,
