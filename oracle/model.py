@@ -45,11 +45,17 @@ def export_weights(model) -> Dict[str, object]:
 
 
 class OracleQwen2:
-    def __init__(self, args, weights: Dict[str, object], dtype=torch.bfloat16, p_round: bool = False):
+    def __init__(self, args, weights: Dict[str, object], dtype=torch.bfloat16, p_round: bool = False, trace=None):
         self.args, self.w, self.dtype, self.p_round = args, weights, dtype, p_round
+        self.trace = trace    # optional list: (name, tensor copy) of every operator output, in order (diagnostics)
         self.nq, self.nkv, self.d = args.n_heads, args.n_kv_heads, args.head_dim
         self.q_size, self.kv_size = self.nq * self.d, self.nkv * self.d
         self.scale = math.sqrt(1.0 / self.d)          # qwen2_attention.cpp:70
+
+    def _t(self, name, t):
+        if self.trace is not None:
+            self.trace.append((name, t.clone()))
+        return t
 
     # ---- linear.cpp ------------------------------------------------------------------------------------------------
     def _linear(self, x, l):
@@ -72,12 +78,16 @@ class OracleQwen2:
 
     # ---- one decoder layer -----------------------------------------------------------------------------------------
     def _layer(self, lw, x, residual, positions, md, kc, vc, phase):
+        t = self._t
+        t("layer_in", x)
         x, residual = self._apply_norm(x, residual, lw["input_norm_w"])
-        qkv = self._linear(x, lw["qkv"])
+        t("input_norm", x); t("residual1", residual)
+        qkv = t("qkv", self._linear(x, lw["qkv"]))
         q = qkv[:, :self.q_size]
         k = qkv[:, self.q_size:self.q_size + self.kv_size]
         v = qkv[:, self.q_size + self.kv_size:]
         orc.rotary_embedding(positions, q, k, self.w["cos_sin"], self.d, True)
+        t("qkv_rope", qkv)
         T = q.shape[0]
         q3 = q.unflatten(-1, (self.nq, self.d))
         k3 = k.unflatten(-1, (self.nkv, self.d))
@@ -89,12 +99,15 @@ class OracleQwen2:
         else:
             attn = orc.paged_attention(q3, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"],
                                        self.scale, phase == "chunked", -1, self.p_round)
-        x = self._linear(attn.view(T, self.q_size), lw["o"])
+        t("attn", attn)
+        x = t("o_proj", self._linear(attn.view(T, self.q_size), lw["o"]))
         x, residual = self._apply_norm(x, residual, lw["post_norm_w"])
-        gate_up = self._linear(x, lw["gate_up"])
+        t("post_norm", x); t("residual2", residual)
+        gate_up = t("gate_up", self._linear(x, lw["gate_up"]))
         act = torch.empty(T, gate_up.shape[1] // 2, dtype=gate_up.dtype)
         orc.act_and_mul(act, gate_up, "silu")
-        return self._linear(act, lw["down"]), residual
+        t("act", act)
+        return t("down", self._linear(act, lw["down"])), residual
 
     # ---- llm_model_base.h ------------------------------------------------------------------------------------------
     def forward(self, tokens, positions, md, k_caches: List[torch.Tensor], v_caches: List[torch.Tensor], phase: str):
