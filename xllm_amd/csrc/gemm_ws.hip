@@ -1,0 +1,380 @@
+// gemm_ws.hip -- weight-stream int8 GEMM for decode-shaped problems (M <= 512 rows): out[M,N] = A[M,K] . W[N,K]^T
+// (kernel::scaled_matmul, kernels/dcu/scaled_matmul.cpp:103-300; exact int32 sums, the dequant epilogue of gemm_p8i.hip).
+//
+// Why another kernel (round-2 measurements, profiles/r02_gemm_ws.txt): a decode GEMM moves every weight byte exactly once,
+// a CU sustains only ~20-25 GB/s of an HBM stream, so the time of such a GEMM is set by HOW MANY CUs pull weights and
+// how deep their request queues are -- the 256 x 256 tiles of the 8-phase kernel put gate_up (N = 37888) on 148 of the 256
+// CUs (47 us at M = 32 and at M = 256 alike), the skinny kernel re-reads the activations from every workgroup.
+//
+// Design:
+//  * the weights are PRE-PACKED once (xllm_mi355_pack_weight_i8, at weight-load time) in MFMA-fragment order:
+//      [n16 group g][K tile kt (128 B)][k step ks (64 B)][lane l (64)][16 B],  lane l = row g*16 + (l & 15),
+//      bytes kt*128 + ks*64 + (l >> 4)*16 .. +16  -- one fragment = 1 KiB contiguous, a group = K*16 B contiguous;
+//  * a workgroup (4 waves, one per SIMD) owns (WM*MB*16 rows) x (WN*NG*16 columns) x one K slice. The W fragments of a K
+//    tile go HBM -> LDS by LDS-DMA, 1 KiB per instruction, source AND destination contiguous (a ring of AD + 1 slots, AD
+//    tiles in flight), and are read back lane-linearly with ds_read_b128 (full LDS rate, no bank conflicts, no swizzle);
+//  * the activations never touch the LDS: wave (wm, wn) loads the fragments of ITS OWN MB*16 rows straight from global /
+//    L2 into a register ring of the same depth (buffer_load_dwordx4, rows past M read as zeros);
+//  * v_mfma_i32_16x16x64_i8 with W as the row operand: D[n][m], lane & 15 = m, register r = n = 4*(lane >> 4) + r;
+//  * the column width of a tile is any even number of 16-column groups, so N = 37888 becomes 237 tiles of 160 columns
+//    (all CUs busy) instead of 148 of 256; few-column problems take K slices, whose exact int32 partial sums go to
+//    separate slabs with plain stores (no atomics, nothing to zero) and are summed by the consumer;
+//  * one barrier per K tile; LDS-DMA and activation loads retire in order on vmcnt, so both run AD tiles ahead.
+#include <stdlib.h>
+
+#include "gemm_types.h"
+
+namespace xm {
+
+constexpr int WS_BK = 128;     // K tile in bytes
+constexpr int WS_FRAG = 1024;  // one 16 x 64-byte fragment
+
+// ------------------------------------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weight_i8_kernel(const uint8_t* __restrict__ W, uint8_t* __restrict__ Wp,
+                                                             int64_t N, int64_t K) {
+  const int64_t chunks_per_row = K / 16, total = N * chunks_per_row;
+  const int64_t KT = K / WS_BK;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / chunks_per_row, c = i - n * chunks_per_row;
+    const int64_t g = n >> 4, r = n & 15, kt = c >> 3, ks = (c >> 2) & 1, kq = c & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(W + n * K + c * 16);
+    *reinterpret_cast<uint4*>(Wp + ((g * KT + kt) * 2 + ks) * WS_FRAG + (kq * 16 + r) * 16) = v;
+  }
+}
+
+#define WS_BUFLOAD(DST, VOFF, RSRC, SOFF, IMM)                                             \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                        \
+               : "=v"(DST) : "v"(VOFF), "s"(RSRC), "s"(SOFF), "n"(IMM) : "memory")
+
+template <int N_>
+struct WsWait;  // s_waitcnt lgkmcnt(CNT) that "produces" N_ fragment registers (orders their uses behind the wait)
+
+// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; AD K tiles in flight
+template <int WM, int WN, int MB, int NG, int AD>
+__global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
+                                                            int M, int N, int64_t K, int m_tiles, int n_tiles,
+                                                            int kt_per_slice, int n_slices, GemmEpi epi,
+                                                            int32_t* __restrict__ slabs) {
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int G = WN * NG;             // 16-column groups of a workgroup tile
+  constexpr int RA = AD + 1;             // ring depth: LDS slots and activation register sets
+  constexpr int SLOT = G * 2 * WS_FRAG;  // bytes of W per K tile
+  constexpr int ND = (2 * G) / 4;        // LDS-DMA instructions per wave and K tile
+  constexpr int NA = 2 * MB;             // activation loads per wave and K tile
+  static_assert((2 * G) % 4 == 0, "an even number of column groups per workgroup");
+  static_assert(RA * SLOT <= 160 * 1024, "LDS ring");
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[RA * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  // block -> (m tile, n tile, K slice): the m tiles of one column range sit on the same XCD (block b runs on XCD b % 8)
+  // next to each other in dispatch order, so the second one finds the weights in that XCD's L2
+  int mt, nt, slice;
+  {
+    const int b = blockIdx.x, x = b & 7, y = b >> 3;
+    mt = y % m_tiles;
+    const int rest = (y / m_tiles) * 8 + x;
+    if (rest >= n_tiles * n_slices) return;
+    nt = rest % n_tiles;
+    slice = rest / n_tiles;
+  }
+  const int KT = (int)(K / WS_BK);
+  const int kt0 = slice * kt_per_slice;
+  int kt1 = kt0 + kt_per_slice;
+  kt1 = kt1 > KT ? KT : kt1;
+  const int nk = kt1 - kt0;  // >= 1 (the planner never makes an empty slice)
+  const int n_groups = N >> 4;
+  const int g0 = nt * G;
+  int g_live = n_groups - g0;
+  g_live = g_live > G ? G : g_live;
+  const int m_base = mt * (WM * MB * 16) + wm * (MB * 16);
+
+  // ---- sources
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(Wp) + (int64_t)g0 * KT * (2 * WS_FRAG), 0, (int)((int64_t)g_live * KT * (2 * WS_FRAG)), 0x00020000);
+  int voff_a[MB], voff_w[ND];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) voff_a[mb] = (m_base + mb * 16 + (lane & 15)) * (int)K + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int f = wave * ND + i;  // fragment of the tile: group f / 2, k step f % 2
+    voff_w[i] = (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16;
+  }
+  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  const unsigned rd_base = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
+
+  u32x4 afr[RA][MB][2];  // activation fragments [ring set][row block][k step]
+  i32x4_t acc[MB][NG];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+
+  // tile t of the slice (clamped: the tail re-loads the last tile, every load is unconditional so vmcnt is static)
+  auto issue = [&](auto SET_, int t) {
+    constexpr int SET = decltype(SET_)::value;
+    const int kt = kt0 + (t < nk ? t : nk - 1);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      WS_BUFLOAD(afr[SET][mb][0], voff_a[mb], rsrc_a, kt * WS_BK, 0);
+      WS_BUFLOAD(afr[SET][mb][1], voff_a[mb], rsrc_a, kt * WS_BK, 64);
+    }
+    const lds_ptr_t dst = lds3 + SET * SLOT + wave * ND * WS_FRAG;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + i * WS_FRAG, 16, voff_w[i], kt * (2 * WS_FRAG), 0, 0);
+  };
+
+  auto ktile = [&](auto SET_, int t) {
+    constexpr int SET = decltype(SET_)::value;
+    constexpr int NEXT = (SET + AD) % RA;
+    // this wave's loads of tile t (issued AD iterations ago) have landed; AD - 1 younger tiles stay in flight
+    if constexpr (MB == 4)
+      asm volatile("s_waitcnt vmcnt(%8)"
+                   : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]), "+v"(afr[SET][1][0]), "+v"(afr[SET][1][1]),
+                     "+v"(afr[SET][2][0]), "+v"(afr[SET][2][1]), "+v"(afr[SET][3][0]), "+v"(afr[SET][3][1])
+                   : "n"((AD - 1) * (NA + ND)) : "memory");
+    else if constexpr (MB == 2)
+      asm volatile("s_waitcnt vmcnt(%4)"
+                   : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]), "+v"(afr[SET][1][0]), "+v"(afr[SET][1][1])
+                   : "n"((AD - 1) * (NA + ND)) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]) : "n"((AD - 1) * (NA + ND)) : "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's slices of tile t are in the LDS; tile t - 1 has been read by everybody
+    issue(std::integral_constant<int, NEXT>{}, t + AD);
+    u32x4 fw[2][NG];
+    const unsigned ra = rd_base + SET * SLOT;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ks][ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG + ks * WS_FRAG));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // the k step's NG fragments are complete when at most (1 - ks) * NG younger reads are outstanding
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[0][ng]) : "n"(NG < 16 ? NG : 15));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[1][ng]));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ks][ng]),
+                                                             __builtin_bit_cast(i32x4_t, afr[SET][mb][ks]), acc[mb][ng],
+                                                             0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  // ---- prologue: AD tiles in flight
+  static_for<AD>([&](auto i) { issue(i, decltype(i)::value); });
+  for (int t = 0; t < nk; t += RA) {
+    bool done = false;
+    static_for<RA>([&](auto r) {
+      constexpr int R = decltype(r)::value;
+      if (!done) {
+        if (t + R < nk) ktile(r, t + R);
+        else done = true;
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
+
+  // ---- epilogue: lane & 15 = m inside the row block, registers = four consecutive n
+  const int g4 = lane >> 4, ml = lane & 15;
+  if (n_slices > 1) {  // exact int32 partial sums of this K slice -> its slab (plain 16-byte stores)
+    int32_t* const slab = slabs + (int64_t)slice * M * N;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = m_base + mb * 16 + ml;
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        const int g = g0 + wn * NG + ng;
+        if (m < M && g < n_groups) *reinterpret_cast<i32x4_t*>(slab + (int64_t)m * N + g * 16 + 4 * g4) = acc[mb][ng];
+      }
+    }
+    return;
+  }
+  const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
+  const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int g = g0 + wn * NG + ng;
+    if (g >= n_groups) continue;
+    const int n = g * 16 + 4 * g4;
+    float wsv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.out) {
+      const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+      wsv[0] = w4.x; wsv[1] = w4.y; wsv[2] = w4.z; wsv[3] = w4.w;
+    }
+    if (has_bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bsv[e] = load16(bias16, n + e, out_bf16);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = m_base + mb * 16 + ml;
+      if (m >= M) continue;
+      if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + (int64_t)m * N + n) = acc[mb][ng];  // raw sums (tests)
+      if (!epi.out) continue;
+      const float as = epi.a_scale[m];
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * as * wsv[e] + bsv[e];
+      uint2 pk;
+      if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
+      else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)m * N + n) = pk;
+    }
+  }
+}
+
+// sum of the K-slice slabs (exact int32) + the dequant epilogue of scaled_matmul; nothing is zeroed
+__global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __restrict__ slabs, int n_slices, int64_t M,
+                                                               int64_t N, GemmEpi epi) {
+  const int64_t total = M * N;
+  for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x * 4) {
+    i32x4_t a = *reinterpret_cast<const i32x4_t*>(slabs + idx);
+    for (int s = 1; s < n_slices; ++s) a += *reinterpret_cast<const i32x4_t*>(slabs + (int64_t)s * total + idx);
+    const int64_t m = idx / N, n = idx - m * N;
+    if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = a;
+    if (!epi.out) continue;
+    const float as = epi.a_scale[m];
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = (float)a[e] * as * epi.w_scale[n + e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+    uint2 pk;
+    if (epi.out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
+    else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + idx) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ planner + launch
+struct WsPlan { int wm, wn, mb, ng, slices; };
+
+template <int WM, int WN, int MB, int NG, int AD>
+static int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
+                         int32_t* slabs, hipStream_t s) {
+  constexpr int G = WN * NG;
+  const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
+  const int n_groups = (int)(N / 16), n_tiles = (n_groups + G - 1) / G;
+  const int KT = (int)(K / WS_BK);
+  int per = (KT + slices - 1) / slices;
+  slices = (KT + per - 1) / per;  // no empty slice
+  const int rest = n_tiles * slices;
+  const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
+  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, AD>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
+                     (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+  return slices;
+}
+
+// (M, N, K) -> tile shape and K slices. The tile height follows M; the width and the slice count are chosen so that the
+// grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
+// with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
+static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes) {
+  static int f_ng = -2, f_sl = -2;
+  if (f_ng == -2) {
+    const char* e = getenv("XLLM_MI355_WS_NG");
+    f_ng = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_WS_SLICES");
+    f_sl = e ? atoi(e) : -1;
+  }
+  WsPlan p;
+  if (M <= 16) { p.wm = 1; p.wn = 4; p.mb = 1; }
+  else if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
+  else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
+  else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
+  else { p.wm = 4; p.wn = 1; p.mb = 4; }
+  const int rows = p.wm * p.mb * 16;
+  const int m_tiles = (int)((M + rows - 1) / rows);
+  const int n_groups = (int)(N / 16), KT = (int)(K / WS_BK);
+  static const int ngs_w1[] = {10, 8, 6, 4, 2}, ngs_w2[] = {5, 4, 3, 2, 1}, ngs_w4[] = {3, 2, 1};
+  const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);
+  const int n_ngs = p.wn == 4 ? 3 : 5;
+  double best = 1e30;
+  p.ng = ngs[n_ngs - 1];
+  p.slices = 1;
+  for (int i = 0; i < n_ngs; ++i) {
+    const int ng = ngs[i], G = p.wn * ng;
+    const int n_tiles = (n_groups + G - 1) / G;
+    const int resident = (p.mb * ng <= 8) ? 2 : 1;  // small accumulator tiles: two workgroups per CU
+    for (int sl = 1; sl <= 8; ++sl) {
+      if (sl > 1 && (!can_slice || (size_t)sl * M * N * 4 > ws_bytes || KT / sl < 4)) break;
+      const int64_t wgs = (int64_t)m_tiles * n_tiles * sl;
+      const double rounds = (double)((wgs + 256 * resident - 1) / (256 * resident));
+      const int nk = (KT + sl - 1) / sl;
+      // per K tile and workgroup: matrix-pipe cycles of a wave vs the cycles its CU needs to pull the tile's weights
+      // (~12 B / clk / CU of HBM stream, shared by the resident workgroups)
+      const double mfma = p.mb * ng * 2 * 17.0, hbm = G * 2048.0 / 12.0 * resident;
+      double t = rounds * (nk * (mfma > hbm ? mfma : hbm) + 2500.0);
+      if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 2000.0;  // slab write + read-back, spread over the chip
+      if (t < best) { best = t; p.ng = ng; p.slices = sl; }
+    }
+  }
+  if (f_ng > 0) p.ng = f_ng;
+  if (f_sl > 0 && can_slice) p.slices = f_sl;
+  return p;
+}
+
+#define WS_CASE(WM_, WN_, MB_, NG_, AD_)                                                                              \
+  if (p.wm == WM_ && p.wn == WN_ && p.mb == MB_ && p.ng == NG_)                                                       \
+    return ws_launch_cfg<WM_, WN_, MB_, NG_, AD_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
+
+static int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi,
+                       int32_t* slabs, hipStream_t s) {
+  WS_CASE(4, 1, 4, 10, 3) WS_CASE(4, 1, 4, 8, 3) WS_CASE(4, 1, 4, 6, 3) WS_CASE(4, 1, 4, 4, 3) WS_CASE(4, 1, 4, 2, 3)
+  WS_CASE(2, 2, 4, 5, 3) WS_CASE(2, 2, 4, 4, 3) WS_CASE(2, 2, 4, 3, 3) WS_CASE(2, 2, 4, 2, 3) WS_CASE(2, 2, 4, 1, 3)
+  WS_CASE(1, 4, 4, 3, 4) WS_CASE(1, 4, 4, 2, 4) WS_CASE(1, 4, 4, 1, 4)
+  WS_CASE(1, 4, 2, 3, 4) WS_CASE(1, 4, 2, 2, 4) WS_CASE(1, 4, 2, 1, 4)
+  WS_CASE(1, 4, 1, 3, 4) WS_CASE(1, 4, 1, 2, 4) WS_CASE(1, 4, 1, 1, 4)
+  return -1;
+}
+
+// Returns XM_ERR_UNSUPPORTED when the shape is outside the envelope. With epi.defer the exact int32 sums are left in
+// `workspace` as *n_slabs slabs of M*N (the fused consumer adds them); otherwise the 16-bit result is written to epi.out.
+int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                      size_t ws_bytes, int* n_slabs, hipStream_t s) {
+  if (M <= 0 || M > 512 || N % 16 != 0 || K % WS_BK != 0 || K / WS_BK < 4 || M * K >= (1ll << 31) || epi.group_counts ||
+      ((uintptr_t)A % 16) || ((uintptr_t)Wp % 16) || (epi.out && (uintptr_t)epi.out % 8) || (epi.w_scale && (uintptr_t)epi.w_scale % 16))
+    return XM_ERR_UNSUPPORTED;
+  if (N * K >= (1ll << 31) * 16ll) return XM_ERR_UNSUPPORTED;
+  const bool need_slab = epi.defer != 0;
+  if (need_slab && (!workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
+  const bool can_slice = workspace && ws_bytes >= (size_t)2 * M * N * 4;
+  WsPlan p = ws_plan(M, N, K, can_slice, ws_bytes);
+  int32_t* const slabs = reinterpret_cast<int32_t*>(workspace);
+  GemmEpi e2 = epi;
+  if (need_slab && p.slices == 1) {  // one slab = the kernel's raw-accumulator output
+    e2.acc_out = slabs;
+    e2.out = nullptr;
+  }
+  const int slices = ws_dispatch(p, A, Wp, M, N, K, e2, slabs, s);
+  if (slices < 0) return XM_ERR_UNSUPPORTED;
+  if (n_slabs) *n_slabs = slices;
+  if (slices > 1 && !need_slab) {
+    int64_t blocks = (M * N / 4 + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(ws_slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, slices, M, N, epi);
+  }
+  return hip_check_launch();
+}
+
+int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s) {
+  if (N % 16 != 0 || K % WS_BK != 0 || ((uintptr_t)W % 16) || ((uintptr_t)Wp % 16)) return XM_ERR_UNSUPPORTED;
+  int64_t blocks = (N * (K / 16) + 255) / 256;
+  blocks = blocks > 65536 ? 65536 : blocks;
+  hipLaunchKernelGGL(pack_weight_i8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t*)W, (uint8_t*)Wp, N, K);
+  return hip_check_launch();
+}
+
+}  // namespace xm
