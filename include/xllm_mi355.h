@@ -183,6 +183,33 @@ XM_API int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const floa
                                     const float* w_scale, const void* bias, void* out, int32_t* acc_out,
                                     int64_t M, int64_t N, int64_t K, int out_dtype, void* stream);
 
+/* ---- pre-packed int8 weights (decode-shaped GEMMs, M <= 512) -------------------------------------------------
+ * A decode GEMM streams every weight byte once; the weight-stream kernel (xllm_amd/csrc/gemm_ws.hip) wants them in
+ * MFMA-fragment order so that a fragment is 1 KiB contiguous in HBM and in the LDS:
+ *   packed[((g * K/128 + kt) * 2 + ks) * 1024 + lane * 16 + j] = w[g*16 + (lane & 15)][kt*128 + ks*64 + (lane >> 4)*16 + j]
+ * Packed once at weight-load time -- where the reference's loaders re-lay weights for a backend, e.g.
+ * layers/common/linear.cpp:572-583 (fp8 scale handling at load) and the NPU / MLU weight formats. N % 16 == 0,
+ * K % 128 == 0; `packed` has N*K bytes and must not alias `w`. */
+XM_API int xllm_mi355_pack_weight_i8(const int8_t* w, int8_t* packed, int64_t N, int64_t K, void* stream);
+/* kernel::scaled_matmul on packed weights. Same arithmetic and results as xllm_mi355_scaled_matmul (exact int32 sums,
+ * the same dequant expression: bit-identical outputs). The scratch is EXPLICIT and caller-owned: `workspace` /
+ * `ws_bytes` may be NULL / 0 (then K is never sliced); when given, K slices write their exact partial sums to
+ * separate M*N int32 slabs with plain stores -- nothing has to be zero beforehand, nothing is left to clean up, and two
+ * calls may share one buffer as long as they are ordered on a stream. XM_ERR_UNSUPPORTED outside the envelope
+ * (M > 512, N % 16, K % 128, K < 512): callers fall back to xllm_mi355_scaled_matmul on the row-major weights. */
+XM_API int xllm_mi355_scaled_matmul_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,
+                                           const float* w_scale, const void* bias, void* out, int32_t* acc_out,
+                                           int64_t M, int64_t N, int64_t K, int out_dtype, void* workspace,
+                                           size_t ws_bytes, void* stream);
+/* xllm_mi355_scaled_matmul_add_rms_norm on packed weights with the explicit workspace (>= 4*M*N bytes required,
+ * XM_ERR_WORKSPACE otherwise; more lets the planner slice K). Bit-identical to the unfused operator sequence. */
+XM_API int xllm_mi355_scaled_matmul_add_rms_norm_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,
+                                                        const float* w_scale, const void* bias, void* residual,
+                                                        const void* norm_weight, float eps, void* out_norm,
+                                                        int8_t* out_q, float* out_q_scale, int64_t M, int64_t N,
+                                                        int64_t K, int dtype, void* workspace, size_t ws_bytes,
+                                                        void* stream);
+
 /* optional scratch for the int8 split-K path of scaled_matmul (>= M*N*4 bytes; the reference operator
  * has no workspace argument, so it is registered once per stream owner; NULL disables split-K). */
 XM_API int xllm_mi355_set_gemm_workspace(void* workspace, size_t bytes);

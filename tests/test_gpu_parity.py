@@ -1309,3 +1309,121 @@ def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):
     assert torch.equal(torch.stack(ref), runs[0][0])
     for a, b in zip(caches, runs[0][1]):
         assert torch.equal(a.k_cache, b.k_cache) and torch.equal(a.v_cache, b.v_cache)
+
+
+# ------------------------------------------------------------------------------------------- weight-stream decode GEMM
+def _ws_plan(ng, slices):
+    from xllm_amd import _lib
+    _lib.lib().xllm_mi355_debug_ws_plan(int(ng), int(slices))
+
+
+def _packed_gemm(a, wp, a_s, w_s, bias, M, N, K, want_acc=False, ws_bytes=64 << 20):
+    """straight through the C ABI (no fallback): returns (out, acc or None)"""
+    import ctypes as C
+    from xllm_amd import _lib
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    acc = torch.empty(M, N, dtype=torch.int32, device=DEV) if want_acc else None
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+    ws.fill_(0x5a)   # the slabs need no zeroing: poison them
+    rc = _lib.lib().xllm_mi355_scaled_matmul_packed(
+        a.data_ptr(), wp.data_ptr(), a_s.data_ptr(), w_s.data_ptr(), 0 if bias is None else bias.data_ptr(), out.data_ptr(),
+        0 if acc is None else acc.data_ptr(), M, N, K, 1, ws.data_ptr() if ws_bytes else 0, ws_bytes,
+        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return rc, out, acc
+
+
+def test_pack_weight_i8_layout():
+    """packed[((g*K/128 + kt)*2 + ks)*1024 + lane*16 + j] = w[g*16 + (lane & 15)][kt*128 + ks*64 + (lane >> 4)*16 + j]"""
+    g = torch.Generator().manual_seed(1)
+    N, K = 48, 384
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    wp = ops.pack_weight_i8(w.to(DEV)).cpu().reshape(-1)
+    exp = w.view(N // 16, 16, K // 128, 2, 4, 16).permute(0, 2, 3, 4, 1, 5).reshape(-1)   # [g][kt][ks][kq][r][16]
+    assert torch.equal(wp, exp)
+    assert ops.pack_weight_i8(torch.zeros(40, 384, dtype=torch.int8, device=DEV)) is None       # N % 16
+    assert ops.pack_weight_i8(torch.zeros(48, 320, dtype=torch.int8, device=DEV)) is None       # K % 128
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 32, 33, 64, 65, 100, 128, 129, 250, 256, 257, 400, 512])
+def test_packed_gemm_exact_over_tile_shapes(M):
+    """every wave-tile family (M decides it) x every tile width x K slices: exact int32 sums (vs an fp64 product) and an
+    output bit-identical to the row-major kernel's; ragged N (a tail tile with fewer live column groups), poisoned slabs"""
+    g = torch.Generator().manual_seed(M)
+    N, K = 1936, 1152          # 121 column groups (odd: every width leaves a tail), 9 K tiles
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.02 + 0.001).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.02 + 0.001).to(DEV)
+    bias = torch.randn(N, generator=g).bfloat16().to(DEV)
+    wp = ops.pack_weight_i8(w)
+    ref_acc = (a.double() @ w.double().T).to(torch.int32)
+    ref_out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias)
+    ran = 0
+    try:
+        for ng in (1, 2, 3, 4, 5, 6, 8, 10):
+            for slices in (1, 2, 3):
+                _ws_plan(ng, slices)
+                rc, out, acc = _packed_gemm(a, wp, a_s, w_s, bias, M, N, K, want_acc=True)
+                if rc == -2:
+                    continue          # this width does not exist for this tile family
+                assert rc == 0
+                ran += 1
+                assert torch.equal(acc, ref_acc), (ng, slices)
+                assert torch.equal(out, ref_out), (ng, slices)
+    finally:
+        _ws_plan(0, 0)
+    assert ran >= 6
+    rc, out, _ = _packed_gemm(a, wp, a_s, w_s, None, M, N, K, ws_bytes=0)          # no scratch: never sliced, still right
+    assert rc == 0 and torch.equal(out, ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None))
+
+
+@pytest.mark.parametrize("M", [32, 64, 128, 256])
+def test_packed_gemm_qwen2_7b_shapes_planner(M):
+    """the four linears of a Qwen2-7B layer through the planner's own choice: exact sums, outputs bit-identical to the
+    row-major kernels (ops.scaled_matmul dispatches to the packed kernel when b_packed is given)"""
+    g = torch.Generator().manual_seed(7 + M)
+    for N, K in ((4608, 3584), (3584, 3584), (37888, 3584), (3584, 18944)):
+        a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+        w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+        a_s = (torch.rand(M, generator=g) * 0.02 + 0.001).to(DEV)
+        w_s = (torch.rand(N, generator=g) * 0.02 + 0.001).to(DEV)
+        wp = ops.pack_weight_i8(w)
+        rc, out, acc = _packed_gemm(a, wp, a_s, w_s, None, M, N, K, want_acc=True)
+        assert rc == 0
+        assert torch.equal(acc, (a.double() @ w.double().T).to(torch.int32)), (N, K)
+        assert torch.equal(out, ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None)), (N, K)
+        assert torch.equal(out, ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None, b_packed=wp))
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(256, 3584, 3584, False), (256, 3584, 18944, False), (37, 512, 1024, True),
+                                        (300, 1024, 512, True), (64, 3584, 18944, False)])
+def test_packed_gemm_add_norm_fusion_equals_separate_ops(M, N, K, bias):
+    """scaled_matmul_add_rms_norm on packed weights (K slices summed by the consumer) == scaled_matmul ->
+    fused_add_rms_norm (-> int8 quant), bit for bit; twice in a row on the same scratch (nothing to re-zero)"""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.02 + 0.001).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.02 + 0.001).to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV) if bias else None
+    res0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    nw = (torch.rand(N, generator=g) + 0.5).bfloat16().to(DEV)
+    wp = ops.pack_weight_i8(w)
+    y = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, b)
+    res_ref = res0.clone()
+    q_ref, s_ref = ops.rms_norm_dynamic_int8_quant(y.clone(), nw, 1e-6, residual=res_ref)
+    res_ref2, y2 = res0.clone(), y.clone()
+    ops.fused_add_rms_norm(y2, res_ref2, nw, 1e-6)
+    for slices in (0, 1, 2, 4):
+        try:
+            _ws_plan(0, slices)
+            for _ in range(2):
+                res_a = res0.clone()
+                q, qs = ops.scaled_matmul_add_rms_norm(a, w, a_s, w_s, res_a, nw, 1e-6, b, quantize=True, b_packed=wp)
+                assert torch.equal(q, q_ref) and torch.equal(qs, s_ref) and torch.equal(res_a, res_ref), slices
+            res_b = res0.clone()
+            n16 = ops.scaled_matmul_add_rms_norm(a, w, a_s, w_s, res_b, nw, 1e-6, b, quantize=False, b_packed=wp)
+            assert torch.equal(n16, y2) and torch.equal(res_b, res_ref2), slices
+        finally:
+            _ws_plan(0, 0)

@@ -13,7 +13,7 @@ dev = "cuda"
 shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
 Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
 kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k == "GEMM_DIST")
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED"))
 for M in Ms:
     for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
         copies = max(2, min(8, int(600e6 // (N * K)) + 1))
@@ -29,7 +29,11 @@ for M in Ms:
                 a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
             a_s = torch.rand(M, device=dev)
             w_s = torch.rand(N, device=dev)
-            fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)
+            if os.environ.get("GEMM_PACKED", "0") == "1":
+                wps = [ops.pack_weight_i8(x) for x in ws]
+                fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])
+            else:
+                fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)
             bytes_ = N * K + M * K + M * N * 2
         else:
             ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(copies)]

@@ -57,6 +57,10 @@ _SIGS = {
     "xllm_mi355_set_gemm_workspace": ([vp, sz], ci),
     "xllm_mi355_set_gemm_workspace_for_stream": ([vp, vp, sz], ci),
     "xllm_mi355_scaled_matmul_add_rms_norm": ([vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_pack_weight_i8": ([vp, vp, i64, i64, vp], ci),
+    "xllm_mi355_scaled_matmul_packed": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, sz, vp], ci),
+    "xllm_mi355_scaled_matmul_add_rms_norm_packed": ([vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, i64, i64, ci, vp, sz,
+                                                      vp], ci),
     "xllm_mi355_static_scaled_fp8_quant": ([vp, vp, vp, i64, ci, vp], ci),
     "xllm_mi355_fp8_scaled_quantize": ([vp, vp, vp, vp, i64, ci, vp], ci),
     "xllm_mi355_fp8_scaled_matmul": ([vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, i64, ci, vp], ci),

@@ -108,7 +108,7 @@ inline int hip_check_launch() {
 void xm_moe_scratch(void** ws, size_t* bytes);
 int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
                             const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
-                            int dtype, int quant, hipStream_t s);
+                            int dtype, int quant, hipStream_t s, int n_slabs = 0);
 
 }  // namespace xm
 

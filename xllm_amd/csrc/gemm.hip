@@ -910,6 +910,43 @@ int xllm_mi355_scaled_matmul_add_rms_norm(const int8_t* a, const int8_t* w, cons
                                  (hipStream_t)stream);
 }
 
+int xllm_mi355_pack_weight_i8(const int8_t* w, int8_t* packed, int64_t N, int64_t K, void* stream) {
+  if (!w || !packed || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  return launch_pack_weight_i8(w, packed, N, K, (hipStream_t)stream);
+}
+
+int xllm_mi355_scaled_matmul_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale, const float* w_scale,
+                                    const void* bias, void* out, int32_t* acc_out, int64_t M, int64_t N, int64_t K,
+                                    int out_dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (out && (!a_scale || !w_scale)) return XM_ERR_INVALID;
+  if (!out && !acc_out) return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0 || N == 0) return XM_OK;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
+  return launch_gemm_ws_i8(a, w_packed, M, N, K, epi, workspace, ws_bytes, nullptr, (hipStream_t)stream);
+}
+
+int xllm_mi355_scaled_matmul_add_rms_norm_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,
+                                                 const float* w_scale, const void* bias, void* residual,
+                                                 const void* norm_weight, float eps, void* out_norm, int8_t* out_q,
+                                                 float* out_q_scale, int64_t M, int64_t N, int64_t K, int dtype,
+                                                 void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || !a_scale || !w_scale || !residual || !norm_weight || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if ((out_q != nullptr) == (out_norm != nullptr)) return XM_ERR_INVALID;  // exactly one output form
+  if (out_q && !out_q_scale) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  if (!workspace || ws_bytes < (size_t)M * N * 4) return XM_ERR_WORKSPACE;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0, 1};
+  int n_slabs = 1;
+  const int rc = launch_gemm_ws_i8(a, w_packed, M, N, K, epi, workspace, ws_bytes, &n_slabs, (hipStream_t)stream);
+  if (rc != XM_OK) return rc;
+  return launch_acc_add_rms_norm(out_q ? (void*)out_q : out_norm, out_q_scale, reinterpret_cast<int32_t*>(workspace),
+                                 a_scale, w_scale, bias, residual, norm_weight, eps, M, N, dtype, out_q != nullptr,
+                                 (hipStream_t)stream, n_slabs);
+}
+
 int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale, int64_t a_scale_numel,
                                  const float* w_scale, int64_t w_scale_numel, const void* bias, void* out, int64_t M,
                                  int64_t N, int64_t K, int out_dtype, void* stream) {

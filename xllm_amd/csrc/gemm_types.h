@@ -189,4 +189,9 @@ int launch_gemm_p8n(const void* A, const void* W, int64_t M, int64_t N, int64_t 
 int launch_gemm_astat_i8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, int32_t* acc_ws, int splits,
                          hipStream_t s);
 
+// weight-stream decode kernel on pre-packed int8 weights (gemm_ws.hip)
+int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                      size_t ws_bytes, int* n_slabs, hipStream_t s);
+int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s);
+
 }  // namespace xm

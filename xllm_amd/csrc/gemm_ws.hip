@@ -46,24 +46,82 @@ __global__ __launch_bounds__(256) void pack_weight_i8_kernel(const uint8_t* __re
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"                        \
                : "=v"(DST) : "v"(VOFF), "s"(RSRC), "s"(SOFF), "n"(IMM) : "memory")
 
-template <int N_>
-struct WsWait;  // s_waitcnt lgkmcnt(CNT) that "produces" N_ fragment registers (orders their uses behind the wait)
+// ---- pieces of the K loop as plain device functions (hipcc drops the host stub of a kernel whose lambdas nest or capture
+// arrays of template-dependent size, so the kernel body below uses no lambda at all)
+template <int MB>
+__device__ __forceinline__ void ws_issue_a(u32x4 (&dst)[MB][2], const int (&voff_a)[MB], const __amdgpu_buffer_rsrc_t rsrc_a,
+                                           int so) {
+  // compiler-visible loads: hipcc's wait-count pass counts them and the LDS-DMA operations on the same in-order vmcnt
+  // and puts the counted wait in front of the first MFMA that uses them (never a vmcnt(0): no LDS access is visible)
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    dst[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[mb], so, 0);
+    dst[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[mb] + 64, so, 0);
+  }
+}
 
-// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; AD K tiles in flight
-template <int WM, int WN, int MB, int NG, int AD>
+typedef __attribute__((address_space(3))) uint8_t* ws_lds_ptr_t;
+
+// the MFMAs of one K tile: W fragments from the LDS slot at `ra` (lane-linear), activation fragments `a`.
+// One fragment register set for both k steps: the k-step-1 read of group ng is issued right behind the k-step-0 MFMAs of
+// that group (its data returns tens of cycles after they have read their operands). LDS operations retire in order:
+//   R0_0 .. R0_{NG-1}, R1_0, .., R1_{NG-1};  group (0, ng) needs R0_ng: NG-1-ng later R0s + ng R1s = NG - 1 outstanding;
+//   group (1, ng) needs R1_ng: NG - 1 - ng outstanding.
+template <int MB, int NG, int NG_LEFT>
+__device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG], const u32x4 (&a)[MB][2]) {
+  if constexpr (NG_LEFT > 0) {
+    constexpr int ng = NG - NG_LEFT;
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG_LEFT - 1));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ng]),
+                                                         __builtin_bit_cast(i32x4_t, a[mb][1]), acc[mb][ng], 0, 0, 0);
+    ws_kstep1<MB, NG, NG_LEFT - 1>(acc, fw, a);
+  }
+}
+template <int MB, int NG>
+__device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], const u32x4 (&a)[MB][2], unsigned ra) {
+  u32x4 fw[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG));
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG - 1));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ng]),
+                                                         __builtin_bit_cast(i32x4_t, a[mb][0]), acc[mb][ng], 0, 0, 0);
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG + WS_FRAG));
+  }
+  ws_kstep1<MB, NG, NG>(acc, fw, a);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; DA activation tiles and DW > DA weight
+// tiles in flight. vmcnt retires in order, and a wave issues [activation loads of tile t + DA, LDS-DMA of tile t + DW] per
+// iteration: when tile t is needed, everything up to its activation loads has to be back, i.e. all but the last
+// ND + (DA - 1) (NA + ND) operations -- the weight tiles t + 1 .. t + DW stay in flight across the wait.
+template <int WM, int WN, int MB, int NG, int DA, int DW>
 __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
                                                             int M, int N, int64_t K, int m_tiles, int n_tiles,
                                                             int kt_per_slice, int n_slices, GemmEpi epi,
                                                             int32_t* __restrict__ slabs) {
   static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(DW > DA && DA >= 1, "weights run further ahead than the activations");
   constexpr int G = WN * NG;             // 16-column groups of a workgroup tile
-  constexpr int RA = AD + 1;             // ring depth: LDS slots and activation register sets
+  constexpr int RA = DA + 1;             // activation register sets
+  constexpr int NS = DW + 1;             // LDS slots
   constexpr int SLOT = G * 2 * WS_FRAG;  // bytes of W per K tile
   constexpr int ND = (2 * G) / 4;        // LDS-DMA instructions per wave and K tile
   constexpr int NA = 2 * MB;             // activation loads per wave and K tile
+  constexpr int VMCNT = ND + (DA - 1) * (NA + ND);
   static_assert((2 * G) % 4 == 0, "an even number of column groups per workgroup");
-  static_assert(RA * SLOT <= 160 * 1024, "LDS ring");
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[RA * SLOT];
+  static_assert(NS * SLOT <= 160 * 1024, "LDS ring");
+  static_assert(VMCNT < 64, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * SLOT];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,7 +153,8 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * K), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(Wp) + (int64_t)g0 * KT * (2 * WS_FRAG), 0, (int)((int64_t)g_live * KT * (2 * WS_FRAG)), 0x00020000);
-  int voff_a[MB], voff_w[ND];
+  int voff_a[MB], voff_w[8];  // [ND] used: an array of template-dependent size next to the LDS-DMA builtin makes hipcc drop the kernel's host stub
+  static_assert(ND <= 8, "voff_w");
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) voff_a[mb] = (m_base + mb * 16 + (lane & 15)) * (int)K + (lane >> 4) * 16;
 #pragma unroll
@@ -103,8 +162,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
     const int f = wave * ND + i;  // fragment of the tile: group f / 2, k step f % 2
     voff_w[i] = (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16;
   }
-  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
-  const lds_ptr_t lds3 = (lds_ptr_t)lds;
+  const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
   const unsigned rd_base = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
 
   u32x4 afr[RA][MB][2];  // activation fragments [ring set][row block][k step]
@@ -114,77 +172,53 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
 #pragma unroll
     for (int j = 0; j < NG; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
 
-  // tile t of the slice (clamped: the tail re-loads the last tile, every load is unconditional so vmcnt is static)
-  auto issue = [&](auto SET_, int t) {
-    constexpr int SET = decltype(SET_)::value;
-    const int kt = kt0 + (t < nk ? t : nk - 1);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      WS_BUFLOAD(afr[SET][mb][0], voff_a[mb], rsrc_a, kt * WS_BK, 0);
-      WS_BUFLOAD(afr[SET][mb][1], voff_a[mb], rsrc_a, kt * WS_BK, 64);
-    }
-    const lds_ptr_t dst = lds3 + SET * SLOT + wave * ND * WS_FRAG;
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst + i * WS_FRAG, 16, voff_w[i], kt * (2 * WS_FRAG), 0, 0);
-  };
-
-  auto ktile = [&](auto SET_, int t) {
-    constexpr int SET = decltype(SET_)::value;
-    constexpr int NEXT = (SET + AD) % RA;
-    // this wave's loads of tile t (issued AD iterations ago) have landed; AD - 1 younger tiles stay in flight
-    if constexpr (MB == 4)
-      asm volatile("s_waitcnt vmcnt(%8)"
-                   : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]), "+v"(afr[SET][1][0]), "+v"(afr[SET][1][1]),
-                     "+v"(afr[SET][2][0]), "+v"(afr[SET][2][1]), "+v"(afr[SET][3][0]), "+v"(afr[SET][3][1])
-                   : "n"((AD - 1) * (NA + ND)) : "memory");
-    else if constexpr (MB == 2)
-      asm volatile("s_waitcnt vmcnt(%4)"
-                   : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]), "+v"(afr[SET][1][0]), "+v"(afr[SET][1][1])
-                   : "n"((AD - 1) * (NA + ND)) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(afr[SET][0][0]), "+v"(afr[SET][0][1]) : "n"((AD - 1) * (NA + ND)) : "memory");
-    __builtin_amdgcn_s_barrier();  // every wave's slices of tile t are in the LDS; tile t - 1 has been read by everybody
-    issue(std::integral_constant<int, NEXT>{}, t + AD);
-    u32x4 fw[2][NG];
-    const unsigned ra = rd_base + SET * SLOT;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ks][ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG + ks * WS_FRAG));
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // the k step's NG fragments are complete when at most (1 - ks) * NG younger reads are outstanding
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[0][ng]) : "n"(NG < 16 ? NG : 15));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[1][ng]));
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-          acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ks][ng]),
-                                                             __builtin_bit_cast(i32x4_t, afr[SET][mb][ks]), acc[mb][ng],
-                                                             0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
-  // ---- prologue: AD tiles in flight
-  static_for<AD>([&](auto i) { issue(i, decltype(i)::value); });
-  for (int t = 0; t < nk; t += RA) {
-    bool done = false;
-    static_for<RA>([&](auto r) {
-      constexpr int R = decltype(r)::value;
-      if (!done) {
-        if (t + R < nk) ktile(r, t + R);
-        else done = true;
-      }
-    });
+  // tiles past the end of the slice re-load its last tile: every load is unconditional, so the vmcnt arithmetic is static
+#define WS_KT(T_) (kt0 + ((T_) < nk ? (T_) : nk - 1))
+#define WS_ISSUE_A(SET_, T_) ws_issue_a<MB>(afr[SET_], voff_a, rsrc_a, WS_KT(T_) * WS_BK)
+#define WS_ISSUE_W(T_)                                                                                              \
+  {                                                                                                                  \
+    const ws_lds_ptr_t dst_ = lds3 + ((T_) % NS) * SLOT + wave * ND * WS_FRAG;                                       \
+    const int so_ = WS_KT(T_) * (2 * WS_FRAG);                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < ND; ++i_)                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst_ + i_ * WS_FRAG, 16, voff_w[i_], so_, 0, 0);           \
   }
+  // one K tile: ring set SET_ holds its activations, LDS slot t % NS its weights
+#define WS_KTILE(SET_, T_)                                                                                             \
+  {                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory"); /* this wave's LDS-DMA slices of the tile have landed */ \
+    __builtin_amdgcn_s_barrier(); /* every wave's slices are in the LDS; the previous tile has been read by everybody */ \
+    __builtin_amdgcn_sched_barrier(0); /* (the scheduler must not lift the loads below over the counted wait above) */  \
+    WS_ISSUE_A(((SET_) + DA) % RA, (T_) + DA);                                                                         \
+    WS_ISSUE_W((T_) + DW) /* into the slot of the previous tile */                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    ws_compute<MB, NG>(acc, afr[SET_], rd_base + ((T_) % NS) * SLOT);                                                   \
+  }
+
+  // ---- prologue in the issue order of the steady state (virtual iterations -DW .. -1): W(0 .. DW-DA-1) alone, then
+  // [A(i), W(DW-DA+i)] for i < DA -- so the same vmcnt is right from the first iteration on
+#pragma unroll
+  for (int i = 0; i < DW - DA; ++i) WS_ISSUE_W(i)
+  WS_ISSUE_A(0, 0);
+  WS_ISSUE_W(DW - DA)
+  if constexpr (DA == 2) {
+    WS_ISSUE_A(1, 1);
+    WS_ISSUE_W(DW - DA + 1)
+  }
+  static_assert(DA <= 2 && (RA == 2 || RA == 3), "ring of two or three activation sets");
+  for (int t = 0; t < nk; t += RA) {  // (the plain break form keeps the accumulators in place across the back edge)
+    WS_KTILE(0, t)
+    if (t + 1 >= nk) break;
+    WS_KTILE(1, t + 1)
+    if constexpr (RA == 3) {
+      if (t + 2 >= nk) break;
+      WS_KTILE(2, t + 2)
+    }
+  }
+#undef WS_KTILE
+#undef WS_ISSUE_W
+#undef WS_ISSUE_A
+#undef WS_KT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
 
   // ---- epilogue: lane & 15 = m inside the row block, registers = four consecutive n
@@ -262,8 +296,8 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
 // ------------------------------------------------------------------------------------------------ planner + launch
 struct WsPlan { int wm, wn, mb, ng, slices; };
 
-template <int WM, int WN, int MB, int NG, int AD>
-static int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
+template <int WM, int WN, int MB, int NG, int DA, int DW>
+int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
   constexpr int G = WN * NG;
   const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
@@ -273,7 +307,7 @@ static int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, in
   slices = (KT + per - 1) / per;  // no empty slice
   const int rest = n_tiles * slices;
   const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
-  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, AD>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
+  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, DA, DW>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
                      (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
   return slices;
 }
@@ -281,8 +315,8 @@ static int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, in
 // (M, N, K) -> tile shape and K slices. The tile height follows M; the width and the slice count are chosen so that the
 // grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
+static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
 static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes) {
-  static int f_ng = -2, f_sl = -2;
   if (f_ng == -2) {
     const char* e = getenv("XLLM_MI355_WS_NG");
     f_ng = e ? atoi(e) : -1;
@@ -326,17 +360,19 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   return p;
 }
 
-#define WS_CASE(WM_, WN_, MB_, NG_, AD_)                                                                              \
+#define WS_CASE(WM_, WN_, MB_, NG_, DA_, DW_)                                                                         \
   if (p.wm == WM_ && p.wn == WN_ && p.mb == MB_ && p.ng == NG_)                                                       \
-    return ws_launch_cfg<WM_, WN_, MB_, NG_, AD_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
+    return ws_launch_cfg<WM_, WN_, MB_, NG_, DA_, DW_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
 
-static int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi,
+int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi,
                        int32_t* slabs, hipStream_t s) {
-  WS_CASE(4, 1, 4, 10, 3) WS_CASE(4, 1, 4, 8, 3) WS_CASE(4, 1, 4, 6, 3) WS_CASE(4, 1, 4, 4, 3) WS_CASE(4, 1, 4, 2, 3)
-  WS_CASE(2, 2, 4, 5, 3) WS_CASE(2, 2, 4, 4, 3) WS_CASE(2, 2, 4, 3, 3) WS_CASE(2, 2, 4, 2, 3) WS_CASE(2, 2, 4, 1, 3)
-  WS_CASE(1, 4, 4, 3, 4) WS_CASE(1, 4, 4, 2, 4) WS_CASE(1, 4, 4, 1, 4)
-  WS_CASE(1, 4, 2, 3, 4) WS_CASE(1, 4, 2, 2, 4) WS_CASE(1, 4, 2, 1, 4)
-  WS_CASE(1, 4, 1, 3, 4) WS_CASE(1, 4, 1, 2, 4) WS_CASE(1, 4, 1, 1, 4)
+  WS_CASE(4, 1, 4, 10, 1, 2) WS_CASE(4, 1, 4, 8, 1, 2) WS_CASE(4, 1, 4, 6, 1, 3) WS_CASE(4, 1, 4, 4, 2, 4)
+  WS_CASE(4, 1, 4, 2, 2, 4)
+  WS_CASE(2, 2, 4, 5, 1, 2) WS_CASE(2, 2, 4, 4, 1, 3) WS_CASE(2, 2, 4, 3, 2, 4) WS_CASE(2, 2, 4, 2, 2, 4)
+  WS_CASE(2, 2, 4, 1, 2, 4)
+  WS_CASE(1, 4, 4, 3, 2, 4) WS_CASE(1, 4, 4, 2, 2, 4) WS_CASE(1, 4, 4, 1, 2, 4)
+  WS_CASE(1, 4, 2, 3, 2, 4) WS_CASE(1, 4, 2, 2, 2, 4) WS_CASE(1, 4, 2, 1, 2, 4)
+  WS_CASE(1, 4, 1, 3, 2, 4) WS_CASE(1, 4, 1, 2, 2, 4) WS_CASE(1, 4, 1, 1, 2, 4)
   return -1;
 }
 
@@ -378,3 +414,9 @@ int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStre
 }
 
 }  // namespace xm
+
+// tests / tuning: force the tile width (16-column groups per wave) and the K-slice count of the next launches; <= 0 = planner
+extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan(int ng, int slices) {
+  xm::f_ng = ng > 0 ? ng : -1;
+  xm::f_sl = slices > 0 ? slices : -1;
+}

@@ -189,7 +189,9 @@ template <typename T, int QUANT>
 __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
     void* __restrict__ out, float* __restrict__ q_scale, int32_t* __restrict__ acc, const float* __restrict__ a_scale,
     const float* __restrict__ w_scale, const T* __restrict__ bias, T* __restrict__ residual,
-    const T* __restrict__ weight, float eps, int hidden) {
+    const T* __restrict__ weight, float eps, int hidden, int n_slabs, int64_t slab_stride) {
+  // n_slabs == 0: the zero-at-rest split-K workspace of gemm.hip (read, then re-zeroed); n_slabs >= 1: that many K-slice
+  // slabs of exact int32 partial sums written by gemm_ws.hip (summed here, left as they are)
   static_assert(sizeof(T) == 2, "16-bit activations");
   constexpr int N = 8;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -205,9 +207,15 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
   for (int i = 0; i < kMaxVec; ++i) {
     const int c = threadIdx.x + i * kRowThreads;
     if (c < nvec) {
-      const i32x4 a0 = reinterpret_cast<const i32x4*>(acc_row)[2 * c], a1 = reinterpret_cast<const i32x4*>(acc_row)[2 * c + 1];
-      reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
-      reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
+      i32x4 a0 = reinterpret_cast<const i32x4*>(acc_row)[2 * c], a1 = reinterpret_cast<const i32x4*>(acc_row)[2 * c + 1];
+      if (n_slabs == 0) {
+        reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
+        reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
+      }
+      for (int sl = 1; sl < n_slabs; ++sl) {
+        a0 += reinterpret_cast<const i32x4*>(acc_row + sl * slab_stride)[2 * c];
+        a1 += reinterpret_cast<const i32x4*>(acc_row + sl * slab_stride)[2 * c + 1];
+      }
       const float4 w0 = reinterpret_cast<const float4*>(w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
       const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -271,17 +279,17 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
 // launcher used by gemm.hip (declared in common.h)
 int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
                             const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
-                            int dtype, int quant, hipStream_t s) {
+                            int dtype, int quant, hipStream_t s, int n_slabs) {
   if (N % 8 != 0 || N > (int64_t)kRowThreads * kMaxVec * 8) return XM_ERR_UNSUPPORTED;
   if (((uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)w_scale | (uintptr_t)acc) % 16)
     return XM_ERR_UNSUPPORTED;
   XM_DISPATCH_HALF(dtype, T, {
     if (quant)
       hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 2>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
-                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N);
+                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N, n_slabs, M * N);
     else
       hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 0>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
-                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N);
+                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N, n_slabs, M * N);
   });
   return hip_check_launch();
 }

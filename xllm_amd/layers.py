@@ -55,11 +55,25 @@ def build_cos_sin_cache(args: ModelArgs, dtype, device, max_pos: Optional[int] =
     return torch.cat([fr.cos(), fr.sin()], -1).to(dtype).to(device)
 
 
-class QuantLinear:
-    """Column/Row-parallel linear, w8a8-dynamic (int8) / fp8 / 16-bit, weight [N_local, K_local]."""
+def _shard(t: torch.Tensor, dim: int, rank: int, world: int) -> torch.Tensor:
+    n = t.size(dim) // world
+    return t.narrow(dim, rank * n, n).contiguous()
 
-    def __init__(self, n: int, k: int, bias: bool, mode: str, dtype, device, gen, row_parallel_pg=None):
+
+class QuantLinear:
+    """Column/Row-parallel linear, w8a8-dynamic (int8) / fp8 / 16-bit, weight [N_local, K_local].
+
+    Parameters are drawn for the FULL layer from `gen` (every rank of a TP group passes a generator in the same state, so
+    every rank draws the same tensors) and then cut: `shard=("col", rank, world)` keeps output rows (ColumnParallelLinear,
+    linear.cpp:616-716; `col_blocks` = the fused projections [q; k; v] / [gate; up] whose blocks are sharded one by one,
+    with `kv_replicas` for kv heads shared by several ranks, qwen2_attention.cpp:57-65), `shard=("row", rank, world)` keeps
+    input columns (RowParallelLinear, linear.cpp:1405-1522: bias only on rank 0 so that the all-reduce adds it once).
+    int8 scales are per output channel over the FULL K (a checkpoint is quantised before it is sharded)."""
+
+    def __init__(self, n: int, k: int, bias: bool, mode: str, dtype, device, gen, row_parallel_pg=None, shard=None,
+                 col_blocks=None):
         self.mode, self.dtype, self.pg = mode, dtype, row_parallel_pg
+        self.weight_packed = None
         if mode == "int8":
             # random-init weights of the architecture (N(0, initializer_range = 0.02), models/llm/qwen2.h) put through
             # the symmetric per-output-channel int8 quantisation a W8A8 checkpoint carries: w_q = round(w / s),
@@ -74,11 +88,34 @@ class QuantLinear:
         else:
             self.weight = (torch.randn(n, k, device=device, generator=gen) / math.sqrt(k)).to(dtype)
         self.bias = (torch.randn(n, device=device, generator=gen) * 0.1).to(dtype) if bias else None
+        if shard is not None and shard[2] > 1:
+            kind, rank, world = shard
+            if kind == "col":
+                blocks = col_blocks or [(n, world, rank)]          # (rows of the block, ways it is cut, this rank's piece)
+                rows, off = [], 0
+                for size, ways, piece in blocks:
+                    step = size // ways
+                    rows.append(torch.arange(off + piece * step, off + (piece + 1) * step, device=device))
+                    off += size
+                idx = torch.cat(rows)
+                self.weight = self.weight.index_select(0, idx).contiguous()
+                if self.bias is not None:
+                    self.bias = self.bias.index_select(0, idx).contiguous()
+                if mode == "int8":
+                    self.w_scale = self.w_scale.index_select(0, idx).contiguous()
+            else:
+                self.weight = _shard(self.weight, 1, rank, world)
+                if self.bias is not None and rank != 0:
+                    self.bias = torch.zeros_like(self.bias)
+        if mode == "int8" and self.weight.is_cuda:
+            # decode-shaped GEMMs stream the weights in MFMA-fragment order (xllm_mi355_pack_weight_i8, once at load time);
+            # the row-major copy stays for the prefill kernels
+            self.weight_packed = ops.pack_weight_i8(self.weight)
 
     def forward(self, x, pre_quant=None):
         if self.mode == "int8":
             q, s = pre_quant if pre_quant is not None else ops.scaled_quantize(x)
-            y = ops.scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias)
+            y = ops.scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
         elif self.mode == "fp8":
             q, s = pre_quant if pre_quant is not None else ops.fp8_scaled_quantize(x)
             y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias)
@@ -94,24 +131,31 @@ class Qwen2DecoderLayer:
     def __init__(self, args: ModelArgs, mode: str, dtype, device, gen, tp: Optional[parallel.ProcessGroup] = None,
                  fuse: bool = True):
         tp_size = tp.world_size() if tp else 1
+        tp_rank = tp.rank() if tp else 0
         assert args.n_heads % tp_size == 0  # qwen2_attention.cpp:54
         self.nq = args.n_heads // tp_size
         if args.n_kv_heads >= tp_size:       # qwen2_attention.cpp:57-65
             assert args.n_kv_heads % tp_size == 0
-            self.nkv = args.n_kv_heads // tp_size
-        else:
+            self.nkv, kv_ways, kv_piece = args.n_kv_heads // tp_size, tp_size, tp_rank
+        else:                                # kv heads replicated: rank r holds kv head r / (tp / n_kv_heads)
             assert tp_size % args.n_kv_heads == 0
-            self.nkv = 1
+            self.nkv, kv_ways, kv_piece = 1, args.n_kv_heads, tp_rank // (tp_size // args.n_kv_heads)
         self.d, self.args, self.mode, self.fuse, self.dtype = args.head_dim, args, mode, fuse and mode == "int8", dtype
         self.q_size, self.kv_size = self.nq * self.d, self.nkv * self.d
-        H, I = args.hidden_size, args.intermediate_size // tp_size
+        H, I_full = args.hidden_size, args.intermediate_size
+        I = I_full // tp_size
         self.I = I
+        # replicated parameters and the full tensors of the sharded ones: the same draws on every rank of the TP group
         w = lambda: (torch.rand(H, device=device, generator=gen) + 0.5).to(dtype)
         self.input_norm_w, self.post_norm_w = w(), w()
-        self.qkv_proj = QuantLinear(self.q_size + 2 * self.kv_size, H, True, mode, dtype, device, gen)
-        self.o_proj = QuantLinear(H, self.q_size, False, mode, dtype, device, gen, row_parallel_pg=tp)
-        self.gate_up_proj = QuantLinear(2 * I, H, False, mode, dtype, device, gen)
-        self.down_proj = QuantLinear(H, I, False, mode, dtype, device, gen, row_parallel_pg=tp)
+        qf, kvf = args.n_heads * self.d, args.n_kv_heads * self.d
+        col, row = ("col", tp_rank, tp_size), ("row", tp_rank, tp_size)
+        self.qkv_proj = QuantLinear(qf + 2 * kvf, H, True, mode, dtype, device, gen, shard=col,
+                                    col_blocks=[(qf, tp_size, tp_rank), (kvf, kv_ways, kv_piece), (kvf, kv_ways, kv_piece)])
+        self.o_proj = QuantLinear(H, qf, False, mode, dtype, device, gen, row_parallel_pg=tp, shard=row)
+        self.gate_up_proj = QuantLinear(2 * I_full, H, False, mode, dtype, device, gen, shard=col,
+                                        col_blocks=[(I_full, tp_size, tp_rank), (I_full, tp_size, tp_rank)])
+        self.down_proj = QuantLinear(H, I_full, False, mode, dtype, device, gen, row_parallel_pg=tp, shard=row)
         self.attn = AttentionImpl(self.nq, self.d, math.sqrt(1.0 / self.d), self.nkv)
 
     def weight_bytes(self) -> int:
@@ -137,7 +181,7 @@ class Qwen2DecoderLayer:
         if not self.fuse or lin.pg is not None or lin.mode != "int8" or residual is None or norm_w is None:
             return None
         return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
-                                              self.args.rms_norm_eps, lin.bias, quantize=quantize)
+                                              self.args.rms_norm_eps, lin.bias, quantize=quantize, b_packed=lin.weight_packed)
 
     # ---- the decode step cut at the attention kernel (dual micro-batch executor, DualBatchDecoder below) ----------
     def pre_attention(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin, h_in=None):
@@ -245,13 +289,14 @@ class Qwen2Model:
 
     def __init__(self, args: ModelArgs, mode: str = "int8", dtype=torch.bfloat16, device="cuda", seed: int = 0,
                  tp: Optional[parallel.ProcessGroup] = None, fuse: bool = True, n_layers: Optional[int] = None):
-        gen = torch.Generator(device=device).manual_seed(seed + (tp.rank() if tp else 0))
+        gen = torch.Generator(device=device).manual_seed(seed)   # the SAME stream on every rank: full tensors, then shards
         self.args, self.tp, self.dtype, self.device = args, tp, dtype, device
         tp_size = tp.world_size() if tp else 1
         self.layers = [Qwen2DecoderLayer(args, mode, dtype, device, gen, tp, fuse)
                        for _ in range(n_layers if n_layers is not None else args.n_layers)]
         self.norm_w = (torch.rand(args.hidden_size, device=device, generator=gen) + 0.5).to(dtype)
-        self.lm_head = QuantLinear(args.vocab_size // tp_size, args.hidden_size, False, "16bit", dtype, device, gen)
+        self.lm_head = QuantLinear(args.vocab_size, args.hidden_size, False, "16bit", dtype, device, gen,
+                                   shard=("col", tp.rank() if tp else 0, tp_size))
         self.embed = (torch.randn(args.vocab_size, args.hidden_size, device=device, generator=gen)).to(dtype)
         self.cos_sin = build_cos_sin_cache(args, dtype, device, 8192)
 

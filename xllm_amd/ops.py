@@ -215,14 +215,50 @@ def scaled_quantize(x, output=None, output_scale=None) -> Tuple[torch.Tensor, to
 
 
 _gemm_ws = {}
+_GEMM_WS_BYTES = 64 << 20
 
 
-def _ensure_gemm_workspace(device, nbytes):
+def _ensure_gemm_workspace(device, nbytes=0):
+    """the zero-at-rest split-K scratch of the row-major GEMM kernels: ONE fixed-size buffer per device, allocated on first
+    use and never replaced (a captured HIP graph has its address baked in, and the int8 split-K path relies on it being zero
+    between calls). Problems whose M*N*4 exceeds it simply do not split K (the C side checks ws_bytes). Returns its size."""
     ws = _gemm_ws.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("GEMM workspace must exist before a graph capture: run one eager step first")
+        ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
         _gemm_ws[device] = ws
         check(_lib.lib().xllm_mi355_set_gemm_workspace(ws.data_ptr(), ws.numel()), "set_gemm_workspace")
+    return ws.numel()
+
+
+_slab_ws = {}
+_SLAB_WS_BYTES = 64 << 20
+
+
+def _slab_workspace(device):
+    """explicit scratch of the packed-weight GEMMs (K-slice slabs; no invariant: nothing to zero, calls on one stream may
+    share it). One fixed buffer per (device, stream), never replaced."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _slab_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("GEMM slab workspace must exist before a graph capture: run one eager step first")
+        ws = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=device)
+        _slab_ws[key] = ws
+    return ws
+
+
+def pack_weight_i8(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """xllm_mi355_pack_weight_i8: [N, K] int8 row-major -> MFMA-fragment order for the weight-stream decode GEMM (done once,
+    at weight-load time). None when the shape is outside the packed kernel's envelope (N % 16, K % 128)."""
+    _need_cuda(w)
+    N, K = w.shape
+    if w.dtype != torch.int8 or not w.is_contiguous() or N % 16 or K % 128:
+        return None
+    out = torch.empty_like(w)
+    check(_lib.lib().xllm_mi355_pack_weight_i8(_p(w), _p(out), N, K, _stream()), "pack_weight_i8")
+    return out
 
 
 _stream_ws = {}
@@ -237,7 +273,7 @@ def set_gemm_workspace_for_stream(stream: "torch.cuda.Stream", nbytes: int) -> N
 
 
 def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, acc_out=None,
-                  quant_bit_size: int = 8, a_quant_bit_size: int = 8):
+                  quant_bit_size: int = 8, a_quant_bit_size: int = 8, b_packed=None):
     """dcu::scaled_matmul (dcu_ops_api.h, scaled_matmul.cpp:103-300): a [M,K] int8, b [N,K] int8,
     a_scale [M]/[M,1] f32, b_scale [N]/[N,1] f32, optional bias [N] (output dtype)."""
     _need_cuda(a, b, a_scale, b_scale)
@@ -251,8 +287,16 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
     M, K = a.shape
     N = b.size(0)
     out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+    if b_packed is not None and M <= 512:   # decode-shaped: the weight-stream kernel on the pre-packed weights
+        ws = _slab_workspace(a.device)
+        rc = _lib.lib().xllm_mi355_scaled_matmul_packed(_p(a), _p(b_packed), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)),
+                                                        _p(bias), _p(out), _p(acc_out), M, N, K, _DT[output_dtype],
+                                                        ws.data_ptr(), ws.numel(), _stream())
+        if rc != -2:
+            check(rc, "scaled_matmul_packed")
+            return out
     if acc_out is None:
-        _ensure_gemm_workspace(a.device, M * N * 4)
+        _ensure_gemm_workspace(a.device)
     check(_lib.lib().xllm_mi355_scaled_matmul(_p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias),
                                              _p(out), _p(acc_out), M, N, K, _DT[output_dtype], _stream()),
           "scaled_matmul")
@@ -261,7 +305,7 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
 
 # ------------------------------------------------------------------------------------------------ fp8
 def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, eps: float, bias=None,
-                               quantize: bool = True):
+                               quantize: bool = True, b_packed=None):
     """N1 fusion across the GEMM boundary: scaled_matmul (dcu::scaled_matmul) -> residual add + RMSNorm
     (kernel::fused_layernorm) [-> scaled_quantize]. `residual` [M, N] is updated in place to r16(y + residual);
     returns (q int8 [M, N], scale [M]) when `quantize`, else the 16-bit norm [M, N]. Bit-identical to the separate
@@ -271,7 +315,6 @@ def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, ep
     N = b.size(0)
     if not (a.is_contiguous() and b.is_contiguous() and residual.is_contiguous() and residual.shape == (M, N)):
         raise Mi355Error("scaled_matmul_add_rms_norm: contiguous a [M,K], b [N,K], residual [M,N]")
-    _ensure_gemm_workspace(a.device, M * N * 4)
     if quantize:
         q = torch.empty(M, N, dtype=torch.int8, device=a.device)
         qs = torch.empty(M, dtype=torch.float32, device=a.device)
@@ -279,9 +322,18 @@ def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, ep
     else:
         q = qs = None
         out = torch.empty(M, N, dtype=residual.dtype, device=a.device)
-    rc = _lib.lib().xllm_mi355_scaled_matmul_add_rms_norm(
-        _p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias), _p(residual), _p(norm_weight), eps,
-        _p(out), _p(q), _p(qs), M, N, K, _dt(residual), _stream())
+    rc = -2
+    if b_packed is not None and M <= 512:
+        ws = _slab_workspace(a.device)
+        rc = _lib.lib().xllm_mi355_scaled_matmul_add_rms_norm_packed(
+            _p(a), _p(b_packed), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias), _p(residual), _p(norm_weight),
+            eps, _p(out), _p(q), _p(qs), M, N, K, _dt(residual), ws.data_ptr(), ws.numel(), _stream())
+    if rc == -2:
+        if _ensure_gemm_workspace(a.device) < M * N * 4:
+            return None
+        rc = _lib.lib().xllm_mi355_scaled_matmul_add_rms_norm(
+            _p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias), _p(residual), _p(norm_weight), eps,
+            _p(out), _p(q), _p(qs), M, N, K, _dt(residual), _stream())
     if rc == -2:  # XM_ERR_UNSUPPORTED: not a decode-shaped problem
         return None
     check(rc, "scaled_matmul_add_rms_norm")
@@ -349,13 +401,21 @@ def matmul(a, b, bias=None):
 
 # ------------------------------------------------------------------------------------------------ attention
 _attn_ws = {}
+_retired_ws = []   # outgrown scratch buffers stay allocated: a captured HIP graph may still launch kernels that write them
 
 
 def _attn_workspace(device, nbytes):
-    ws = _attn_ws.get(device)
+    """split-KV partials: transient per launch, one buffer per (device, stream) so that two streams never share partials;
+    grows by replacement outside captures only (the old buffer is retired, not freed)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _attn_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        _attn_ws[device] = ws
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("attention workspace too small inside a graph capture: run one eager step of this shape first")
+        if ws is not None:
+            _retired_ws.append(ws)
+        ws = torch.empty(max(nbytes, 16 << 20), dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
     return ws
 
 
@@ -439,6 +499,10 @@ def moe_compute_index(expert_id, num_experts: int):
     need = 4 * ((T * topk + 1023) // 1024 + 1) * num_experts
     ws = _moe_ws.get(dev)
     if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("MoE workspace too small inside a graph capture: run one eager step of this shape first")
+        if ws is not None:
+            _retired_ws.append(ws)
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dev)
         _moe_ws[dev] = ws
         check(_lib.lib().xllm_mi355_set_moe_workspace(ws.data_ptr(), ws.numel()), "set_moe_workspace")
@@ -524,6 +588,8 @@ def group_gemm_w8a8(a, a_scale, weight, w_scale, token_count, output_dtype=torch
     rows = row_index.numel() if row_index is not None else a.size(0)
     need = 16 * (rows // 256 + E) + 64
     ws = _moe_ws.get(a.device)
+    if ws is not None and ws.numel() < need:
+        _retired_ws.append(ws)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=a.device)
         _moe_ws[a.device] = ws
