@@ -1317,6 +1317,15 @@ def _ws_plan(ng, slices):
     _lib.lib().xllm_mi355_debug_ws_plan(int(ng), int(slices))
 
 
+@pytest.fixture
+def packed_everywhere():
+    """ops dispatches to the packed kernel by a measured per-shape policy; these tests want it wherever it is legal"""
+    old = ops._PACKED_POLICY
+    ops._PACKED_POLICY = "1"
+    yield
+    ops._PACKED_POLICY = old
+
+
 def _packed_gemm(a, wp, a_s, w_s, bias, M, N, K, want_acc=False, ws_bytes=64 << 20):
     """straight through the C ABI (no fallback): returns (out, acc or None)"""
     import ctypes as C
@@ -1379,7 +1388,7 @@ def test_packed_gemm_exact_over_tile_shapes(M):
 
 
 @pytest.mark.parametrize("M", [32, 64, 128, 256])
-def test_packed_gemm_qwen2_7b_shapes_planner(M):
+def test_packed_gemm_qwen2_7b_shapes_planner(M, packed_everywhere):
     """the four linears of a Qwen2-7B layer through the planner's own choice: exact sums, outputs bit-identical to the
     row-major kernels (ops.scaled_matmul dispatches to the packed kernel when b_packed is given)"""
     g = torch.Generator().manual_seed(7 + M)
@@ -1398,7 +1407,7 @@ def test_packed_gemm_qwen2_7b_shapes_planner(M):
 
 @pytest.mark.parametrize("M,N,K,bias", [(256, 3584, 3584, False), (256, 3584, 18944, False), (37, 512, 1024, True),
                                         (300, 1024, 512, True), (64, 3584, 18944, False)])
-def test_packed_gemm_add_norm_fusion_equals_separate_ops(M, N, K, bias):
+def test_packed_gemm_add_norm_fusion_equals_separate_ops(M, N, K, bias, packed_everywhere):
     """scaled_matmul_add_rms_norm on packed weights (K slices summed by the consumer) == scaled_matmul ->
     fused_add_rms_norm (-> int8 quant), bit for bit; twice in a row on the same scratch (nothing to re-zero)"""
     g = torch.Generator().manual_seed(M + N + K)

@@ -44,11 +44,28 @@ for M in Ms:
             fn(i)
         n = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(n):
-            fn(i)
-        e1.record()
-        torch.cuda.synchronize()
+        if os.environ.get("GEMM_GRAPH", "1") == "1":   # n launches replayed from ONE HIP graph: no host launch cost in the figure
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                fn(0)   # (per-stream scratch buffers are created outside the capture)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for i in range(n):
+                        fn(i)
+                g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                g.replay()
+                e1.record()
+            torch.cuda.synchronize()
+        else:
+            e0.record()
+            for i in range(n):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         print(f"[gemm {kind}] {tag:40s} M={M:5d} {name:8s} N={N:6d} K={K:6d}  {us:8.1f} us  {bytes_ / us / 1e3:7.1f} GB/s  "
               f"{2 * M * N * K / us / 1e6:7.1f} TOP/s")

@@ -28,6 +28,9 @@ namespace xm {
 
 constexpr int WS_BK = 128;     // K tile in bytes
 constexpr int WS_FRAG = 1024;  // one 16 x 64-byte fragment
+#ifndef WS_W_AUX
+#define WS_W_AUX 2  // cache policy of the weight stream: nt (every byte is read once)
+#endif
 
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ __launch_bounds__(256) void pack_weight_i8_kernel(const uint8_t* __restrict__ W, uint8_t* __restrict__ Wp,
@@ -48,77 +51,87 @@ __global__ __launch_bounds__(256) void pack_weight_i8_kernel(const uint8_t* __re
 
 // ---- pieces of the K loop as plain device functions (hipcc drops the host stub of a kernel whose lambdas nest or capture
 // arrays of template-dependent size, so the kernel body below uses no lambda at all)
-template <int MB>
-__device__ __forceinline__ void ws_issue_a(u32x4 (&dst)[MB][2], const int (&voff_a)[MB], const __amdgpu_buffer_rsrc_t rsrc_a,
-                                           int so) {
-  // compiler-visible loads: hipcc's wait-count pass counts them and the LDS-DMA operations on the same in-order vmcnt
-  // and puts the counted wait in front of the first MFMA that uses them (never a vmcnt(0): no LDS access is visible)
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    dst[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[mb], so, 0);
-    dst[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[mb] + 64, so, 0);
-  }
-}
-
 typedef __attribute__((address_space(3))) uint8_t* ws_lds_ptr_t;
 
-// the MFMAs of one K tile: W fragments from the LDS slot at `ra` (lane-linear), activation fragments `a`.
-// One fragment register set for both k steps: the k-step-1 read of group ng is issued right behind the k-step-0 MFMAs of
-// that group (its data returns tens of cycles after they have read their operands). LDS operations retire in order:
-//   R0_0 .. R0_{NG-1}, R1_0, .., R1_{NG-1};  group (0, ng) needs R0_ng: NG-1-ng later R0s + ng R1s = NG - 1 outstanding;
-//   group (1, ng) needs R1_ng: NG - 1 - ng outstanding.
+// The accumulators are pinned to AGPRs and updated in place by an asm MFMA: with the builtin, hipcc (512-register budget,
+// AGPR form) gives vdst and srcC different registers across unrolled tile bodies and copies ~2 accumulator registers
+// per MFMA back and forth inside the loop. Hazards the compiler can no longer see: srcC == vdst back-to-back is forwarded by
+// the hardware (and every accumulator is touched once per MB * NG MFMAs here); the MFMA -> VALU read of the epilogue gets
+// explicit s_nops after the loop; operands come from waited ds_reads.
+#ifdef WS_ABL_NOMFMA
+#define WS_MFMA(ACC, W_, A_) asm volatile("" : "+a"(ACC) : "v"(W_), "v"(A_))
+#else
+#define WS_MFMA(ACC, W_, A_) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(W_), "v"(A_))
+#endif
+#define WS_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+
+// k step 1 of a tile, group by group (compile-time recursion: the wait counts are immediates)
 template <int MB, int NG, int NG_LEFT>
-__device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG], const u32x4 (&a)[MB][2]) {
+__device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG], const u32x4 (&a1)[MB]) {
   if constexpr (NG_LEFT > 0) {
     constexpr int ng = NG - NG_LEFT;
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG_LEFT - 1));
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ng]),
-                                                         __builtin_bit_cast(i32x4_t, a[mb][1]), acc[mb][ng], 0, 0, 0);
-    ws_kstep1<MB, NG, NG_LEFT - 1>(acc, fw, a);
+    for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], fw[ng], a1[mb]);
+    ws_kstep1<MB, NG, NG_LEFT - 1>(acc, fw, a1);
   }
 }
+// The MFMAs of one K tile. `rw`: this lane's address of the wave's first W fragment in the LDS slot (lane-linear 1-KiB
+// blocks, [group][k step]); `ra0` / `ra1`: its address in the wave's first row block of the row-major, swizzled activation
+// tile for k step 0 / 1. LDS operations retire in order; they are issued as
+//   A0_0..A0_{MB-1}, A1_0..A1_{MB-1}, W0_0..W0_{NG-1}, then W1_ng right behind the k-step-0 MFMAs of group ng (into the SAME
+//   register: its data returns tens of cycles after those MFMAs have read their operands).
+//   group (0, ng) needs W0_ng: NG-1-ng later W0s + ng W1s = NG - 1 outstanding; group (1, ng) needs W1_ng: NG - 1 - ng.
 template <int MB, int NG>
-__device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], const u32x4 (&a)[MB][2], unsigned ra) {
-  u32x4 fw[NG];
+__device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, unsigned ra0, unsigned ra1) {
+  u32x4 a0[MB], a1[MB], fw[NG];
 #pragma unroll
-  for (int ng = 0; ng < NG; ++ng)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG));
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a0[mb], ra0, mb * 16 * WS_BK);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a1[mb], ra1, mb * 16 * WS_BK);
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) WS_DSR(fw[ng], rw, ng * 2 * WS_FRAG);
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG - 1));
+    if (ng == 0) {
+      if constexpr (MB == 4)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(fw[0]) : "n"(NG - 1));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(fw[0]) : "n"(NG - 1));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG - 1));
+    }
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-      acc[mb][ng] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4_t, fw[ng]),
-                                                         __builtin_bit_cast(i32x4_t, a[mb][0]), acc[mb][ng], 0, 0, 0);
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ng]) : "v"(ra), "n"(ng * 2 * WS_FRAG + WS_FRAG));
+    for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], fw[ng], a0[mb]);
+    WS_DSR(fw[ng], rw, ng * 2 * WS_FRAG + WS_FRAG);
   }
-  ws_kstep1<MB, NG, NG>(acc, fw, a);
+  if constexpr (MB == 4) asm volatile("" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));  // (older than every W read)
+  else asm volatile("" : "+v"(a1[0]), "+v"(a1[1]));
+  ws_kstep1<MB, NG, NG>(acc, fw, a1);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; DA activation tiles and DW > DA weight
-// tiles in flight. vmcnt retires in order, and a wave issues [activation loads of tile t + DA, LDS-DMA of tile t + DW] per
-// iteration: when tile t is needed, everything up to its activation loads has to be back, i.e. all but the last
-// ND + (DA - 1) (NA + ND) operations -- the weight tiles t + 1 .. t + DW stay in flight across the wait.
-template <int WM, int WN, int MB, int NG, int DA, int DW>
+// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; DW K tiles in flight. BOTH operands go
+// HBM / L2 -> LDS by LDS-DMA in fragment order, so that every VMEM operation of a wave is an LDS-DMA with the same prefetch
+// distance: vmcnt retires in order, and with activation loads into registers next to the weight DMAs the weights could never
+// run further ahead than the (register-bound) activations -- measured: 2.1-3.0 TB/s. A wave issues its share of the
+// tile's NDW weight + NDA activation fragments per iteration and waits for all but the (DW - 1) newest tiles.
+template <int WM, int WN, int MB, int NG, int DW>
 __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
                                                             int M, int N, int64_t K, int m_tiles, int n_tiles,
                                                             int kt_per_slice, int n_slices, GemmEpi epi,
                                                             int32_t* __restrict__ slabs) {
   static_assert(WM * WN == 4, "four waves per workgroup");
-  static_assert(DW > DA && DA >= 1, "weights run further ahead than the activations");
-  constexpr int G = WN * NG;             // 16-column groups of a workgroup tile
-  constexpr int RA = DA + 1;             // activation register sets
-  constexpr int NS = DW + 1;             // LDS slots
-  constexpr int SLOT = G * 2 * WS_FRAG;  // bytes of W per K tile
-  constexpr int ND = (2 * G) / 4;        // LDS-DMA instructions per wave and K tile
-  constexpr int NA = 2 * MB;             // activation loads per wave and K tile
-  constexpr int VMCNT = ND + (DA - 1) * (NA + ND);
-  static_assert((2 * G) % 4 == 0, "an even number of column groups per workgroup");
+  static_assert(MB == 2 || MB == 4, "row blocks per wave");
+  constexpr int G = WN * NG;              // 16-column groups of a workgroup tile
+  constexpr int NS = DW + 1;              // LDS slots
+  constexpr int SLOT_W = G * 2 * WS_FRAG, SLOT_A = WM * MB * 2 * WS_FRAG, SLOT = SLOT_W + SLOT_A;
+  constexpr int NDW = (2 * G) / 4;        // weight LDS-DMA instructions per wave and K tile
+  constexpr int NDA = (2 * WM * MB) / 4;  // activation LDS-DMA instructions per wave and K tile
+  constexpr int VMCNT = (DW - 1) * (NDW + NDA);
+  static_assert((2 * G) % 4 == 0 && (2 * WM * MB) % 4 == 0, "fragments per tile divide over the four waves");
   static_assert(NS * SLOT <= 160 * 1024, "LDS ring");
   static_assert(VMCNT < 64, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * SLOT];
@@ -143,83 +156,97 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
   kt1 = kt1 > KT ? KT : kt1;
   const int nk = kt1 - kt0;  // >= 1 (the planner never makes an empty slice)
   const int n_groups = N >> 4;
-  const int g0 = nt * G;
-  int g_live = n_groups - g0;
-  g_live = g_live > G ? G : g_live;
-  const int m_base = mt * (WM * MB * 16) + wm * (MB * 16);
+  // balanced column split: tile nt owns groups [nt * n_groups / n_tiles, (nt + 1) * n_groups / n_tiles) -- at most G of them
+  // (the launcher guarantees it), so that 2368 groups over 256 workgroups become 9 or 10 groups each instead of 197 x 12 + 4
+  const int g0 = (int)((int64_t)nt * n_groups / n_tiles);
+  const int g_live = (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
+  const int m_tile0 = mt * (WM * MB * 16), m_base = m_tile0 + wm * (MB * 16);
 
-  // ---- sources
+  // ---- sources (rows past M and column groups past N read as zeros: buffer range check)
   const __amdgpu_buffer_rsrc_t rsrc_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * K), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(Wp) + (int64_t)g0 * KT * (2 * WS_FRAG), 0, (int)((int64_t)g_live * KT * (2 * WS_FRAG)), 0x00020000);
-  int voff_a[MB], voff_w[8];  // [ND] used: an array of template-dependent size next to the LDS-DMA builtin makes hipcc drop the kernel's host stub
-  static_assert(ND <= 8, "voff_w");
+  int voff_a[8], voff_w[8];  // [NDA] / [NDW] used: an array of template-dependent size next to the LDS-DMA builtin makes hipcc drop the kernel's host stub
+  static_assert(NDW <= 8 && NDA <= 8, "voff arrays");
+  // activations: the tile sits in the LDS ROW-MAJOR (128 B per row), one DMA instruction = 8 rows x 128 B with lane j <->
+  // (row j / 8, physical 16-B chunk j % 8): 8 lanes fetch one 128-B row segment (coalesced; a fragment-order gather of 16-B
+  // pieces from 16 rows per instruction ran at 16 GB/s per CU, measured). The chunk index is XOR-swizzled by (row / 2) % 8 on
+  // the SOURCE side so that the fragment reads (16 rows, one chunk) are free of bank conflicts.
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) voff_a[mb] = (m_base + mb * 16 + (lane & 15)) * (int)K + (lane >> 4) * 16;
+  for (int i = 0; i < NDA; ++i) {
+    const int row = (wave * NDA + i) * 8 + (lane >> 3);
+    voff_a[i] = (m_tile0 + row) * (int)K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
 #pragma unroll
-  for (int i = 0; i < ND; ++i) {
-    const int f = wave * ND + i;  // fragment of the tile: group f / 2, k step f % 2
+  for (int i = 0; i < NDW; ++i) {
+    const int f = wave * NDW + i;  // weight fragment of the tile: group f / 2, k step f % 2
     voff_w[i] = (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16;
   }
   const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
-  const unsigned rd_base = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
+  const unsigned rd_w = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
+  // fragment (row block mb, k step ks): lane l reads row mb*16 + (l & 15), logical chunk ks*4 + (l >> 4)
+  const unsigned rd_a_base = (unsigned)(__UINTPTR_TYPE__)lds3 + SLOT_W + (wm * MB * 16 + (lane & 15)) * WS_BK;
+  const unsigned rd_a0 = rd_a_base + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
+  const unsigned rd_a1 = rd_a_base + (((4 + (lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
 
-  u32x4 afr[RA][MB][2];  // activation fragments [ring set][row block][k step]
   i32x4_t acc[MB][NG];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
     for (int j = 0; j < NG; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
 
-  // tiles past the end of the slice re-load its last tile: every load is unconditional, so the vmcnt arithmetic is static
-#define WS_KT(T_) (kt0 + ((T_) < nk ? (T_) : nk - 1))
-#define WS_ISSUE_A(SET_, T_) ws_issue_a<MB>(afr[SET_], voff_a, rsrc_a, WS_KT(T_) * WS_BK)
-#define WS_ISSUE_W(T_)                                                                                              \
+  // tile T_ of the slice -> LDS slot T_ % NS (tiles past the end re-load the last tile: every load is unconditional, so
+  // the vmcnt arithmetic is static; nobody reads them)
+#define WS_ISSUE(T_)                                                                                                 \
   {                                                                                                                  \
-    const ws_lds_ptr_t dst_ = lds3 + ((T_) % NS) * SLOT + wave * ND * WS_FRAG;                                       \
-    const int so_ = WS_KT(T_) * (2 * WS_FRAG);                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < ND; ++i_)                                                                \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst_ + i_ * WS_FRAG, 16, voff_w[i_], so_, 0, 0);           \
-  }
-  // one K tile: ring set SET_ holds its activations, LDS slot t % NS its weights
-#define WS_KTILE(SET_, T_)                                                                                             \
-  {                                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory"); /* this wave's LDS-DMA slices of the tile have landed */ \
-    __builtin_amdgcn_s_barrier(); /* every wave's slices are in the LDS; the previous tile has been read by everybody */ \
-    __builtin_amdgcn_sched_barrier(0); /* (the scheduler must not lift the loads below over the counted wait above) */  \
-    WS_ISSUE_A(((SET_) + DA) % RA, (T_) + DA);                                                                         \
-    WS_ISSUE_W((T_) + DW) /* into the slot of the previous tile */                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    ws_compute<MB, NG>(acc, afr[SET_], rd_base + ((T_) % NS) * SLOT);                                                   \
+    const int kt_ = kt0 + ((T_) < nk ? (T_) : nk - 1);                                                               \
+    const ws_lds_ptr_t dw_ = lds3 + ((T_) % NS) * SLOT + wave * NDW * WS_FRAG;                                       \
+    const ws_lds_ptr_t da_ = lds3 + ((T_) % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDA; ++i_)                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_A, da_ + i_ * WS_FRAG, 16, voff_a[i_], kt_ * WS_BK, 0, 0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_)                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_W, dw_ + i_ * WS_FRAG, 16, voff_w[i_], kt_ * (2 * WS_FRAG), 0, \
+                                                 WS_W_AUX);                                                          \
   }
 
-  // ---- prologue in the issue order of the steady state (virtual iterations -DW .. -1): W(0 .. DW-DA-1) alone, then
-  // [A(i), W(DW-DA+i)] for i < DA -- so the same vmcnt is right from the first iteration on
+  // ablation builds (tools/build_ablations.sh; timing only, WRONG results): an empty buffer descriptor makes every DMA of
+  // that operand an out-of-range access (no memory request, zeros to the LDS) at unchanged instruction counts
+#ifdef WS_ABL_NOADMA
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, 0, 0x00020000);
+#define WS_ABL_RSRC_A rsrc_a0
+#else
+#define WS_ABL_RSRC_A rsrc_a
+#endif
+#ifdef WS_ABL_NOWDMA
+  const __amdgpu_buffer_rsrc_t rsrc_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(Wp), 0, 0, 0x00020000);
+#define WS_ABL_RSRC_W rsrc_w0
+#else
+#define WS_ABL_RSRC_W rsrc_w
+#endif
 #pragma unroll
-  for (int i = 0; i < DW - DA; ++i) WS_ISSUE_W(i)
-  WS_ISSUE_A(0, 0);
-  WS_ISSUE_W(DW - DA)
-  if constexpr (DA == 2) {
-    WS_ISSUE_A(1, 1);
-    WS_ISSUE_W(DW - DA + 1)
+  for (int i = 0; i < DW; ++i) WS_ISSUE(i)
+  for (int t = 0; t < nk; ++t) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");  // this wave's fragments of tile t have landed
+    __builtin_amdgcn_s_barrier();  // everybody's have; and everybody has finished reading tile t - 1
+    __builtin_amdgcn_sched_barrier(0);
+    WS_ISSUE(t + DW)               // into the slot of tile t - 1
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned so = (t % NS) * SLOT;
+#ifndef WS_ABL_NOCOMPUTE
+    ws_compute<MB, NG>(acc, rd_w + so, rd_a0 + so, rd_a1 + so);
+#endif
   }
-  static_assert(DA <= 2 && (RA == 2 || RA == 3), "ring of two or three activation sets");
-  for (int t = 0; t < nk; t += RA) {  // (the plain break form keeps the accumulators in place across the back edge)
-    WS_KTILE(0, t)
-    if (t + 1 >= nk) break;
-    WS_KTILE(1, t + 1)
-    if constexpr (RA == 3) {
-      if (t + 2 >= nk) break;
-      WS_KTILE(2, t + 2)
-    }
-  }
-#undef WS_KTILE
-#undef WS_ISSUE_W
-#undef WS_ISSUE_A
-#undef WS_KT
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
+#undef WS_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail prefetches have landed before the LDS is released
+  // MFMA -> VALU read hazard of the asm MFMAs: the accumulators of the LAST column group were written by the last MB MFMAs;
+  // the nops carry them as operands so that the epilogue's reads of exactly those registers are ordered behind the nops
+  // (every other accumulator was written >= MB * 16 cycles before the loop ended)
+  if constexpr (MB == 4)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
+  else
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]));
 
   // ---- epilogue: lane & 15 = m inside the row block, registers = four consecutive n
   const int g4 = lane >> 4, ml = lane & 15;
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
 #pragma unroll
       for (int ng = 0; ng < NG; ++ng) {
         const int g = g0 + wn * NG + ng;
-        if (m < M && g < n_groups) *reinterpret_cast<i32x4_t*>(slab + (int64_t)m * N + g * 16 + 4 * g4) = acc[mb][ng];
+        if (m < M && wn * NG + ng < g_live) *reinterpret_cast<i32x4_t*>(slab + (int64_t)m * N + g * 16 + 4 * g4) = acc[mb][ng];
       }
     }
     return;
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int g = g0 + wn * NG + ng;
-    if (g >= n_groups) continue;
+    if (wn * NG + ng >= g_live) continue;
     const int n = g * 16 + 4 * g4;
     float wsv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi.out) {
@@ -296,18 +323,22 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
 // ------------------------------------------------------------------------------------------------ planner + launch
 struct WsPlan { int wm, wn, mb, ng, slices; };
 
-template <int WM, int WN, int MB, int NG, int DA, int DW>
+template <int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
   constexpr int G = WN * NG;
   const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
-  const int n_groups = (int)(N / 16), n_tiles = (n_groups + G - 1) / G;
+  const int n_groups = (int)(N / 16);
   const int KT = (int)(K / WS_BK);
   int per = (KT + slices - 1) / slices;
   slices = (KT + per - 1) / per;  // no empty slice
+  // at least ceil(n_groups / G) column tiles; more (narrower, balanced) ones while the grid still fits one round of 256 CUs
+  int n_tiles = (n_groups + G - 1) / G;
+  const int fit = 256 / (m_tiles * slices);
+  if (fit > n_tiles) n_tiles = fit < n_groups ? fit : n_groups;
   const int rest = n_tiles * slices;
   const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
-  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, DA, DW>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
+  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, DW>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
                      (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
   return slices;
 }
@@ -324,55 +355,58 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     f_sl = e ? atoi(e) : -1;
   }
   WsPlan p;
-  if (M <= 16) { p.wm = 1; p.wn = 4; p.mb = 1; }
-  else if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
+  if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
   else { p.wm = 4; p.wn = 1; p.mb = 4; }
   const int rows = p.wm * p.mb * 16;
   const int m_tiles = (int)((M + rows - 1) / rows);
   const int n_groups = (int)(N / 16), KT = (int)(K / WS_BK);
-  static const int ngs_w1[] = {10, 8, 6, 4, 2}, ngs_w2[] = {5, 4, 3, 2, 1}, ngs_w4[] = {3, 2, 1};
+  // candidates of the family, narrowest first (a narrower ring slot = more tiles in flight in the same LDS)
+  static const int ngs_w1[] = {2, 4, 6, 8, 10}, ngs_w2[] = {1, 2, 3, 4, 5}, ngs_w4[] = {1, 2, 3};
   const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);
   const int n_ngs = p.wn == 4 ? 3 : 5;
+  const int g_max = p.wn * ngs[n_ngs - 1];
   double best = 1e30;
   p.ng = ngs[n_ngs - 1];
   p.slices = 1;
-  for (int i = 0; i < n_ngs; ++i) {
-    const int ng = ngs[i], G = p.wn * ng;
-    const int n_tiles = (n_groups + G - 1) / G;
-    const int resident = (p.mb * ng <= 8) ? 2 : 1;  // small accumulator tiles: two workgroups per CU
-    for (int sl = 1; sl <= 8; ++sl) {
-      if (sl > 1 && (!can_slice || (size_t)sl * M * N * 4 > ws_bytes || KT / sl < 4)) break;
-      const int64_t wgs = (int64_t)m_tiles * n_tiles * sl;
-      const double rounds = (double)((wgs + 256 * resident - 1) / (256 * resident));
-      const int nk = (KT + sl - 1) / sl;
-      // per K tile and workgroup: matrix-pipe cycles of a wave vs the cycles its CU needs to pull the tile's weights
-      // (~12 B / clk / CU of HBM stream, shared by the resident workgroups)
-      const double mfma = p.mb * ng * 2 * 17.0, hbm = G * 2048.0 / 12.0 * resident;
-      double t = rounds * (nk * (mfma > hbm ? mfma : hbm) + 2500.0);
-      if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 2000.0;  // slab write + read-back, spread over the chip
-      if (t < best) { best = t; p.ng = ng; p.slices = sl; }
-    }
+  for (int sl = 1; sl <= 8; ++sl) {
+    if (sl > 1 && (!can_slice || (size_t)sl * M * N * 4 > ws_bytes || KT / sl < 4)) break;
+    int fit = 256 / (m_tiles * sl);
+    fit = fit < 1 ? 1 : fit;
+    int nt = fit < n_groups ? fit : n_groups;              // column tiles per (m tile, slice), balanced split
+    int gl = (n_groups + nt - 1) / nt;                     // live groups of the widest tile
+    if (gl > g_max) { gl = g_max; nt = (n_groups + g_max - 1) / g_max; }
+    int ng = ngs[n_ngs - 1];
+    for (int i = 0; i < n_ngs; ++i)
+      if (p.wn * ngs[i] >= gl) { ng = ngs[i]; break; }
+    const double rounds = (double)(((int64_t)m_tiles * nt * sl + 255) / 256);
+    const int nk = (KT + sl - 1) / sl;
+    // per K tile and workgroup: matrix-pipe cycles of a wave against the cycles its CU needs to pull the tile's weights
+    // (~12 B / clk of HBM stream per CU) and activations (L2, ~40 B / clk)
+    const double mfma = p.mb * ng * 2 * 17.0, mem = gl * 2048.0 / 12.0 + p.wm * p.mb * 2048.0 / 40.0;
+    double t = rounds * (nk * (mfma > mem ? mfma : mem) + 4000.0);
+    if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 2000.0;  // slab write + read-back, spread over the chip
+    if (t < best) { best = t; p.ng = ng; p.slices = sl; }
   }
   if (f_ng > 0) p.ng = f_ng;
   if (f_sl > 0 && can_slice) p.slices = f_sl;
   return p;
 }
 
-#define WS_CASE(WM_, WN_, MB_, NG_, DA_, DW_)                                                                         \
+#define WS_CASE(WM_, WN_, MB_, NG_, DW_)                                                                              \
   if (p.wm == WM_ && p.wn == WN_ && p.mb == MB_ && p.ng == NG_)                                                       \
-    return ws_launch_cfg<WM_, WN_, MB_, NG_, DA_, DW_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
+    return ws_launch_cfg<WM_, WN_, MB_, NG_, DW_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
 
 int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi,
                        int32_t* slabs, hipStream_t s) {
-  WS_CASE(4, 1, 4, 10, 1, 2) WS_CASE(4, 1, 4, 8, 1, 2) WS_CASE(4, 1, 4, 6, 1, 3) WS_CASE(4, 1, 4, 4, 2, 4)
-  WS_CASE(4, 1, 4, 2, 2, 4)
-  WS_CASE(2, 2, 4, 5, 1, 2) WS_CASE(2, 2, 4, 4, 1, 3) WS_CASE(2, 2, 4, 3, 2, 4) WS_CASE(2, 2, 4, 2, 2, 4)
-  WS_CASE(2, 2, 4, 1, 2, 4)
-  WS_CASE(1, 4, 4, 3, 2, 4) WS_CASE(1, 4, 4, 2, 2, 4) WS_CASE(1, 4, 4, 1, 2, 4)
-  WS_CASE(1, 4, 2, 3, 2, 4) WS_CASE(1, 4, 2, 2, 2, 4) WS_CASE(1, 4, 2, 1, 2, 4)
-  WS_CASE(1, 4, 1, 3, 2, 4) WS_CASE(1, 4, 1, 2, 2, 4) WS_CASE(1, 4, 1, 1, 2, 4)
+  // (WM, WN, MB, NG, DW): the ring of DW + 1 slots fills most of the 160 KiB of LDS (a CU needs of the order of 100 KiB of
+  // requests in flight to pull its share of the HBM stream, MI355X_MICROARCH.md "ldsdma-fill"); a slot holds the tile's
+  // weight fragments (2 KiB per column group) and activation fragments (2 KiB per 16-row block)
+  WS_CASE(4, 1, 4, 10, 2) WS_CASE(4, 1, 4, 8, 2) WS_CASE(4, 1, 4, 6, 2) WS_CASE(4, 1, 4, 4, 3) WS_CASE(4, 1, 4, 2, 3)
+  WS_CASE(2, 2, 4, 5, 3) WS_CASE(2, 2, 4, 4, 4) WS_CASE(2, 2, 4, 3, 4) WS_CASE(2, 2, 4, 2, 5) WS_CASE(2, 2, 4, 1, 6)
+  WS_CASE(1, 4, 4, 3, 4) WS_CASE(1, 4, 4, 2, 5) WS_CASE(1, 4, 4, 1, 8)
+  WS_CASE(1, 4, 2, 3, 4) WS_CASE(1, 4, 2, 2, 6) WS_CASE(1, 4, 2, 1, 8)
   return -1;
 }
 

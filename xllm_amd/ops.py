@@ -11,6 +11,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import ctypes as C
+import os
 
 import torch
 
@@ -249,6 +250,21 @@ def _slab_workspace(device):
     return ws
 
 
+_PACKED_POLICY = os.environ.get("XLLM_MI355_PACKED", "auto")   # "0" never, "1" wherever legal, "auto" = measured policy
+
+
+def _prefer_packed(M: int, N: int, K: int) -> bool:
+    """which int8 kernel serves a decode-shaped GEMM (profiles/r02_gemm_ws.txt): the weight-stream kernel on packed weights
+    wins wherever the weight stream is the bound -- every shape at M <= 128, and the few-column / long-K problems (down_proj)
+    up to M = 512; at M = 256 the wide problems stay on the 256 x 256 8-phase kernel (the activation tile then takes most of
+    the LDS ring)."""
+    if _PACKED_POLICY == "0":
+        return False
+    if _PACKED_POLICY == "1":
+        return M <= 512
+    return M <= 128 or (M <= 512 and N <= 8192 and K >= 8192)
+
+
 def pack_weight_i8(w: torch.Tensor) -> Optional[torch.Tensor]:
     """xllm_mi355_pack_weight_i8: [N, K] int8 row-major -> MFMA-fragment order for the weight-stream decode GEMM (done once,
     at weight-load time). None when the shape is outside the packed kernel's envelope (N % 16, K % 128)."""
@@ -287,7 +303,7 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
     M, K = a.shape
     N = b.size(0)
     out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
-    if b_packed is not None and M <= 512:   # decode-shaped: the weight-stream kernel on the pre-packed weights
+    if b_packed is not None and _prefer_packed(M, N, K):   # decode-shaped: the weight-stream kernel on the pre-packed weights
         ws = _slab_workspace(a.device)
         rc = _lib.lib().xllm_mi355_scaled_matmul_packed(_p(a), _p(b_packed), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)),
                                                         _p(bias), _p(out), _p(acc_out), M, N, K, _DT[output_dtype],
@@ -323,7 +339,7 @@ def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, ep
         q = qs = None
         out = torch.empty(M, N, dtype=residual.dtype, device=a.device)
     rc = -2
-    if b_packed is not None and M <= 512:
+    if b_packed is not None and _prefer_packed(M, N, K):
         ws = _slab_workspace(a.device)
         rc = _lib.lib().xllm_mi355_scaled_matmul_add_rms_norm_packed(
             _p(a), _p(b_packed), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias), _p(residual), _p(norm_weight),
