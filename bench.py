@@ -7,10 +7,15 @@ argmax) over a synthetic fixed-shape batch: bs=256 sequences with ctx=4096 cache
 the reference's op order (xllm_amd/layers.py) through the C ABI of include/xllm_mi355.h -- hand-written
 gfx950 kernels only; the oracle is used for the cpu_baseline leg alone.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): tensor parallel over RCCL/xGMI with the
-reference's sharding (heads / columns, all-reduce after o_proj and down_proj, all-gather of logits).
-Qwen2-7B has 28 heads, so valid TP is {1,2,4} (qwen2_attention.cpp:54-65): N=8 runs TP=4 x DP=2 with the
-global batch split across the two replicas.  Total work is fixed => "scaling": "strong".
+Multi-GPU (one process per GPU; launched by torch.distributed.run, or by this script itself when WORLD_SIZE is not set):
+the global batch of 256 sequences is FIXED ("scaling": "strong") and the layout decides how N GPUs share it:
+  dp     (default) N replicas of the model (7.6 GB of int8 weights fit a 288 GB GPU many times over), 256 / N sequences each,
+         NO data-path exchange -- the decode path shards by sequences; only the timing barrier crosses ranks;
+  tp     the reference's tensor parallelism over RCCL / xGMI (heads / columns, all-reduce after o_proj and down_proj,
+         all-gather of logits); Qwen2-7B has 28 heads, so TP is 1, 2 or 4 (qwen2_attention.cpp:54-65);
+  tp4dp2 TP = 4 inside two replicas (what the reference would run on 8 GPUs).
+Measured per-replica steps on one GPU (--emulate-dp, profiles/r02_layouts.txt) put dp ahead of tp at every N: the weight
+stream of a replica does not shrink with N, but neither does a TP rank's 57 collectives per step, and DP has none.
 
 Prints ONE JSON line on rank 0.
 """
@@ -53,6 +58,8 @@ def parse():
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
     p.add_argument("--no-engine", action="store_true", help="skip the step-level harness leg (xllm_amd.engine.DecodeEngine)")
+    p.add_argument("--layout", default="auto", choices=["auto", "dp", "tp", "tp4dp2"],
+                   help="how N GPUs share the fixed global batch (auto = dp; see the module docstring)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
@@ -141,12 +148,69 @@ def cpu_baseline(args_model, mode, ctx, block_size):
                       f"t_layer={t_layer:.3f}s t_lm_head={t_head:.3f}s"}
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU, and relay its
+    output (the reference forks one worker per device the same way, runtime/worker_server.cpp:285-326). Never reports a
+    one-GPU number for an N-GPU request."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if a.backend == "nccl" and ndev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline_cfg1():
+    """BASELINE.json configs[0]: Qwen2-0.5B fp32, bs = 1, ctx = 128, greedy decode "on the reference CPU path". The reference
+    has no CPU backend, so the path is the end-to-end oracle model (oracle/model.py: the restated operators in the
+    reference's order, pinned on the HuggingFace Qwen2 implementation) run in fp32 on this host's cores: prefill of 128
+    tokens, then 16 greedy decode steps, timed whole (no sampling of layers, no extrapolation)."""
+    from oracle import model as omodel
+    from oracle import oracle as orc
+    from xllm_amd import layers
+    # bs = 1: every operator is a matrix-VECTOR product of at most 4864 x 896; 16 threads is where the oracle's OpenMP loops
+    # stop scaling on such sizes (with 256 threads a decode step takes 35 s instead of 0.1 s: fork / join and spinning)
+    cores = min(os.cpu_count() or 1, 16)
+    orc.lib().orc_set_num_threads(cores)
+    args = layers.ModelArgs.qwen2_0_5b()
+    w = omodel.export_weights(layers.Qwen2Model(args, "16bit", torch.float32, "cpu", seed=1))
+    om = omodel.OracleQwen2(args, w, torch.float32)
+    prompt = torch.randint(0, args.vocab_size, (128,), generator=torch.Generator().manual_seed(0))
+    t0 = time.perf_counter()
+    omodel.greedy_generate(om, prompt, 1, 128, collect_logits=False)          # prefill + first token
+    t_prefill = time.perf_counter() - t0
+    if t_prefill > 40.0:   # a starved host: do not spend minutes of the bench run on the reported baseline
+        orc.lib().orc_set_num_threads(os.cpu_count() or 1)
+        return {"value": None, "unit": "tokens/s", "cores": cores, "kind": "port",
+                "sample": f"oracle model, Qwen2-0.5B fp32 bs=1: prefill of 128 tokens took {t_prefill:.1f}s on this host; "
+                          f"decode leg skipped", "prefill_tokens_per_s": round(128 / t_prefill, 2)}
+    n_new = 17
+    t0 = time.perf_counter()
+    omodel.greedy_generate(om, prompt, n_new, 128, collect_logits=False)
+    t_all = time.perf_counter() - t0
+    t_decode = max(t_all - t_prefill, 1e-9)
+    orc.lib().orc_set_num_threads(os.cpu_count() or 1)
+    return {"value": round((n_new - 1) / t_decode, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle model (OpenMP, {cores} threads), Qwen2-0.5B fp32 bs=1: prefill of 128 tokens {t_prefill:.2f}s, "
+                      f"{n_new - 1} greedy decode steps {t_decode:.2f}s; whole model, nothing extrapolated",
+            "prefill_tokens_per_s": round(128 / t_prefill, 2)}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
@@ -169,10 +233,23 @@ def main():
     model_name, mode, gbatch, ctx = CONFIGS[a.config]
     margs = getattr(layers.ModelArgs, model_name)()
     block_size = 128
-    tp_size = world if world in (1, 2, 4) else 4
-    if margs.n_heads % tp_size:
-        tp_size = 2 if margs.n_heads % 2 == 0 and world % 2 == 0 else 1
+    layout = a.layout if a.layout != "auto" else "dp"
+    if world == 1:
+        tp_size = 1
+    elif layout == "dp":
+        tp_size = 1
+    elif layout == "tp":
+        tp_size = world
+        if margs.n_heads % tp_size:
+            raise SystemExit(f"--layout tp: {margs.n_heads} heads do not divide over {world} ranks "
+                             f"(qwen2_attention.cpp:54); use dp or tp4dp2")
+    else:
+        tp_size = 4
+        if world % 4:
+            raise SystemExit("--layout tp4dp2 needs a multiple of 4 GPUs")
     dp_size = world // tp_size
+    if gbatch % dp_size:
+        raise SystemExit(f"global batch {gbatch} does not divide over {dp_size} replicas")
     tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_size) if world > 1 else (None, 0))
     B = gbatch // dp_size
     if a.emulate_dp > 1 and world == 1:
@@ -250,8 +327,9 @@ def main():
     # decode runs under HIP-graph replay in the reference (runtime/dcu_graph_executor_impl.h): capture one step
     # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
     graph = None
-    use_graph = (not a.no_graph) and (world == 1 or a.graph) and a.backend == "nccl"
-    piecewise = (not a.no_graph) and world > 1 and not use_graph
+    # no collective inside the step (one GPU, or data-parallel replicas): ONE graph; tensor parallel: piecewise graphs
+    use_graph = (not a.no_graph) and (tp_size == 1 or (a.graph and a.backend == "nccl"))
+    piecewise = (not a.no_graph) and tp_size > 1 and not use_graph
     if piecewise:
         # TP > 1: one graph per run of kernels between two collectives, collectives eager in between
         # (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo never run inside a capture
@@ -294,6 +372,23 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / a.steps * 1e3
     tok_s = gbatch * a.steps / elapsed
+    # exchange accounting (reference: 2 all-reduces per layer + the logits all-gather, linear.cpp:1518-1520, 712-714)
+    collectives_per_step = (2 * len(model.layers) + 1) if tp_size > 1 else 0
+    exposed_comm_ms = 0.0 if tp_size == 1 else None
+    if piecewise and graph is not None:
+        # the same piecewise replay with the collectives left out (results are then wrong, timing only): the difference is
+        # the communication time that is NOT hidden under compute
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay(skip_collectives=True)
+        sync_all()
+        t_nc = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([t_nc], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_nc = float(t.item())
+        exposed_comm_ms = round(max(ms_per_step - t_nc / a.steps * 1e3, 0.0), 4)
 
     # roofline leg: per-launch HIP events around the dominant kernel (paged decode attention) on the launch
     # stream, over eager steps of the same workload (events cannot be read back from inside a replayed graph)
@@ -337,7 +432,11 @@ def main():
             "config": {"workload": f"{model_name} {'W8A8 int8' if mode == 'int8' else 'bf16'} decode step, "
                                    f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
-                       "global_batch": gbatch, "ctx": ctx, "parallelism": f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else ""),
+                       "global_batch": gbatch, "ctx": ctx, "per_gpu_batch": B,
+                       "parallelism": (f"dp{dp_size}" if tp_size == 1 and dp_size > 1 else
+                                       f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else "")),
+                       "layout": layout if world > 1 else "single", "collectives_per_step": collectives_per_step,
+                       "exposed_comm_ms": exposed_comm_ms,
                        "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,
                        "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ split-KV merge when the launch splits)",
@@ -352,6 +451,8 @@ def main():
             out["engine"] = engine_info
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
+            if a.config == "cfg3":
+                out["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -499,6 +499,11 @@ ORC_API void orc_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const flo
   free(af);
 }
 
+/* thread count of the OpenMP regions (bench.py: small per-call work drowns in fork / join with hundreds of threads) */
+#include <omp.h>
+ORC_API void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+ORC_API int orc_get_max_threads(void) { return omp_get_max_threads(); }
+
 /* ------------------------------------------------------------------------- */
 /* Attention (all modes): layers/dcu/torch_attention.cpp:40-345 (GQA expand,  */
 /* per-sequence SDPA, page gather with last_page_len) and the eager variant   */

@@ -238,15 +238,18 @@ _SLAB_WS_BYTES = 64 << 20
 
 
 def _slab_workspace(device):
-    """explicit scratch of the packed-weight GEMMs (K-slice slabs; no invariant: nothing to zero, calls on one stream may
-    share it). One fixed buffer per (device, stream), never replaced."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _slab_ws.get(key)
+    """explicit scratch of the packed-weight GEMMs (K-slice slabs; no invariant: nothing to zero, calls ordered on a stream may
+    share it). One fixed buffer per device, never replaced; a stream that runs GEMMs CONCURRENTLY with another one (the dual
+    micro-batch executor) registers its own with set_gemm_workspace_for_stream."""
+    own = _slab_ws.get((device, torch.cuda.current_stream(device).cuda_stream))
+    if own is not None:
+        return own
+    ws = _slab_ws.get(device)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
             raise Mi355Error("GEMM slab workspace must exist before a graph capture: run one eager step first")
         ws = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=device)
-        _slab_ws[key] = ws
+        _slab_ws[device] = ws
     return ws
 
 
@@ -284,6 +287,7 @@ def set_gemm_workspace_for_stream(stream: "torch.cuda.Stream", nbytes: int) -> N
     """register a private split-K workspace for GEMMs launched on `stream` (micro-batches on concurrent streams)"""
     ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=stream.device)
     _stream_ws[stream.cuda_stream] = ws
+    _slab_ws[(stream.device, stream.cuda_stream)] = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=stream.device)
     check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, ws.data_ptr(), ws.numel()),
           "set_gemm_workspace_for_stream")
 

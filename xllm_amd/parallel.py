@@ -144,11 +144,12 @@ class PiecewiseGraph:
         cur.wait_stream(self._stream)
         return out
 
-    def replay(self) -> None:
+    def replay(self, skip_collectives: bool = False) -> None:
+        """skip_collectives: timing aid (bench.py's exposed-communication figure): the graphs alone, wrong results"""
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
-            else:
+            elif not skip_collectives:
                 it()
 
 
