@@ -65,15 +65,40 @@ typedef __attribute__((address_space(3))) uint8_t* ws_lds_ptr_t;
 #endif
 #define WS_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 
+// the LDS-DMA instructions a wave issues for ONE K tile (NDA activation + NDW weight pieces of 1 KiB), handed to the compute
+// routine so that it can spread them between its MFMA groups: issuing a piece costs the wave 60-180 cycles (MI355X_MICROARCH.md),
+// 13 pieces in a row in front of the MFMAs of a 256-row tile were as long as the MFMAs themselves (measured: the tile time was
+// their SUM); between MFMA groups the matrix pipe keeps running underneath
+struct WsDma {
+  __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
+  ws_lds_ptr_t dst_a, dst_w;  // this wave's first piece in the destination slot
+  int so_a, so_w;             // scalar offsets of the K tile
+};
+template <int NDA, int NDW>
+__device__ __forceinline__ void ws_dma_piece(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int j) {
+  if (j < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_a, d.dst_a + j * WS_FRAG, 16, voff_a[j], d.so_a, 0, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, d.dst_w + (j - NDA) * WS_FRAG, 16, voff_w[j - NDA], d.so_w, 0, WS_W_AUX);
+}
+// pieces due after MFMA group `slot` of 2 * NG (an even spread of ND pieces over the groups)
+template <int NDA, int NDW, int NG>
+__device__ __forceinline__ void ws_dma_slot(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int slot) {
+  constexpr int ND = NDA + NDW;
+  const int lo = slot * ND / (2 * NG), hi = (slot + 1) * ND / (2 * NG);
+#pragma unroll
+  for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW>(d, voff_a, voff_w, j);
+}
+
 // k step 1 of a tile, group by group (compile-time recursion: the wait counts are immediates)
-template <int MB, int NG, int NG_LEFT>
-__device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG], const u32x4 (&a1)[MB]) {
+template <int MB, int NG, int NDA, int NDW, int NG_LEFT>
+__device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG], const u32x4 (&a1)[MB], const WsDma& d,
+                                          const int (&voff_a)[8], const int (&voff_w)[8]) {
   if constexpr (NG_LEFT > 0) {
     constexpr int ng = NG - NG_LEFT;
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fw[ng]) : "n"(NG_LEFT - 1));
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], fw[ng], a1[mb]);
-    ws_kstep1<MB, NG, NG_LEFT - 1>(acc, fw, a1);
+    ws_dma_slot<NDA, NDW, NG>(d, voff_a, voff_w, NG + ng);
+    ws_kstep1<MB, NG, NDA, NDW, NG_LEFT - 1>(acc, fw, a1, d, voff_a, voff_w);
   }
 }
 // The MFMAs of one K tile. `rw`: this lane's address of the wave's first W fragment in the LDS slot (lane-linear 1-KiB
@@ -82,8 +107,10 @@ __device__ __forceinline__ void ws_kstep1(i32x4_t (&acc)[MB][NG], u32x4 (&fw)[NG
 //   A0_0..A0_{MB-1}, A1_0..A1_{MB-1}, W0_0..W0_{NG-1}, then W1_ng right behind the k-step-0 MFMAs of group ng (into the SAME
 //   register: its data returns tens of cycles after those MFMAs have read their operands).
 //   group (0, ng) needs W0_ng: NG-1-ng later W0s + ng W1s = NG - 1 outstanding; group (1, ng) needs W1_ng: NG - 1 - ng.
-template <int MB, int NG>
-__device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, unsigned ra0, unsigned ra1) {
+// (LDS-DMA pieces count on vmcnt, not lgkmcnt: interleaving them does not disturb these counts.)
+template <int MB, int NG, int NDA, int NDW>
+__device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, unsigned ra0, unsigned ra1, const WsDma& d,
+                                           const int (&voff_a)[8], const int (&voff_w)[8]) {
   u32x4 a0[MB], a1[MB], fw[NG];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) WS_DSR(a0[mb], ra0, mb * 16 * WS_BK);
@@ -91,7 +118,6 @@ __device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, 
   for (int mb = 0; mb < MB; ++mb) WS_DSR(a1[mb], ra1, mb * 16 * WS_BK);
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) WS_DSR(fw[ng], rw, ng * 2 * WS_FRAG);
-  __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     if (ng == 0) {
@@ -105,11 +131,11 @@ __device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, 
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], fw[ng], a0[mb]);
     WS_DSR(fw[ng], rw, ng * 2 * WS_FRAG + WS_FRAG);
+    ws_dma_slot<NDA, NDW, NG>(d, voff_a, voff_w, ng);
   }
   if constexpr (MB == 4) asm volatile("" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));  // (older than every W read)
   else asm volatile("" : "+v"(a1[0]), "+v"(a1[1]));
-  ws_kstep1<MB, NG, NG>(acc, fw, a1);
-  __builtin_amdgcn_s_setprio(0);
+  ws_kstep1<MB, NG, NDA, NDW, NG>(acc, fw, a1, d, voff_a, voff_w);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -228,14 +254,23 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
   for (int i = 0; i < DW; ++i) WS_ISSUE(i)
   for (int t = 0; t < nk; ++t) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");  // this wave's fragments of tile t have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");  // this wave's pieces of tile t have landed
     __builtin_amdgcn_s_barrier();  // everybody's have; and everybody has finished reading tile t - 1
     __builtin_amdgcn_sched_barrier(0);
-    WS_ISSUE(t + DW)               // into the slot of tile t - 1
-    __builtin_amdgcn_sched_barrier(0);
+    // tile t + DW goes into the slot of tile t - 1, piece by piece between the MFMA groups of tile t
+    const int tn = t + DW, ktn = kt0 + (tn < nk ? tn : nk - 1);
+    WsDma d;
+    d.rsrc_a = WS_ABL_RSRC_A;
+    d.rsrc_w = WS_ABL_RSRC_W;
+    d.dst_w = lds3 + (tn % NS) * SLOT + wave * NDW * WS_FRAG;
+    d.dst_a = lds3 + (tn % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;
+    d.so_a = ktn * WS_BK;
+    d.so_w = ktn * (2 * WS_FRAG);
     const unsigned so = (t % NS) * SLOT;
 #ifndef WS_ABL_NOCOMPUTE
-    ws_compute<MB, NG>(acc, rd_w + so, rd_a0 + so, rd_a1 + so);
+    ws_compute<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
+#else
+    WS_ISSUE(tn)
 #endif
   }
 #undef WS_ISSUE
