@@ -558,6 +558,18 @@ class DualBatchDecoder:
         for st, (b, e) in zip(self.streams, self.cut):   # split-K partial sums of the two halves must not mix
             ops.set_gemm_workspace_for_stream(st, 32 << 20)
 
+    def close(self):
+        """give the per-stream scratch buffers back (the C side keeps at most 8 registered streams)"""
+        for st in self.streams:
+            ops.release_stream_workspaces(st)
+        self.streams = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def forward(self, tokens, positions, kv_caches):
         m = self.model
         main = torch.cuda.current_stream()

@@ -288,6 +288,16 @@ def set_gemm_workspace_for_stream(stream: "torch.cuda.Stream", nbytes: int) -> N
     ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=stream.device)
     _stream_ws[stream.cuda_stream] = ws
     _slab_ws[(stream.device, stream.cuda_stream)] = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=stream.device)
+    _private_streams.add(stream.cuda_stream)
+
+
+def release_stream_workspaces(stream: "torch.cuda.Stream") -> None:
+    """undo set_gemm_workspace_for_stream (the C side has 8 slots; stream handles are recycled by torch's pool)"""
+    _stream_ws.pop(stream.cuda_stream, None)
+    _slab_ws.pop((stream.device, stream.cuda_stream), None)
+    _attn_ws.pop((stream.device, stream.cuda_stream), None)
+    _private_streams.discard(stream.cuda_stream)
+    check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, 0, 0), "release gemm workspace")
     check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, ws.data_ptr(), ws.numel()),
           "set_gemm_workspace_for_stream")
 
@@ -422,12 +432,16 @@ def matmul(a, b, bias=None):
 # ------------------------------------------------------------------------------------------------ attention
 _attn_ws = {}
 _retired_ws = []   # outgrown scratch buffers stay allocated: a captured HIP graph may still launch kernels that write them
+_private_streams = set()   # streams registered with set_gemm_workspace_for_stream: they get scratch buffers of their own
 
 
 def _attn_workspace(device, nbytes):
-    """split-KV partials: transient per launch, one buffer per (device, stream) so that two streams never share partials;
-    grows by replacement outside captures only (the old buffer is retired, not freed)"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    """split-KV partials: transient per launch. One buffer per device (launches ordered on a stream, or across streams that
+    wait on each other, may share it); a stream registered as running CONCURRENTLY with others (set_gemm_workspace_for_stream:
+    the dual micro-batch executor) gets its own. Grows by replacement outside captures only (the old buffer is retired, not
+    freed, so a captured graph that still points at it stays valid)."""
+    sid = torch.cuda.current_stream(device).cuda_stream
+    key = (device, sid) if sid in _private_streams else device
     ws = _attn_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
