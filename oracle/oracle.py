@@ -378,7 +378,8 @@ def moe_fused_topk(gating, topk, renormalize, correction_bias=None, scoring_func
 def moe_grouped_topk(gating, topk, num_expert_group, topk_group, renormalize, correction_bias=None, scoring_func="softmax",
                      routed_scaling_factor=1.0):
     """dcu::moe_grouped_topk (kernels/dcu/topk_gate.cpp:59-125 -> aiter grouped_topk / biased_grouped_topk, an external
-    library absent from the reference tree): the published DeepSeek-V2 / V3 grouped gate; PARITY UNPINNED (see the C file)"""
+    library absent from the reference tree): the published DeepSeek-V2 / V3 grouped gate, pinned on the statistics of
+    tests/core/layers/mlu/moe_gate_test.cpp:143-272 (tests/test_reference_fixtures.py)"""
     T, E = gating.shape
     assert E % num_expert_group == 0 and topk <= topk_group * (E // num_expert_group)
     assert correction_bias is None or scoring_func == "sigmoid"

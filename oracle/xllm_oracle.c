@@ -11,10 +11,15 @@
  * so this is a "port"; it is pinned against
  *   - the golden vectors of tests/core/layers/mlu/qwen2_attention_test.cpp:254-328
  *     (prefill B=2,S=128 and paged decode B=4,S=257, seeded_tensor inputs),
+ *     -- the decode vector to the last printed digit once P is rounded to bf16 before PV (p_round), the reference's own
+ *     eager spec (layers/cuda/flashinfer_attention.cpp:84-90),
+ *   - the statistics / values hard-coded in tests/core/layers/mlu/{moe_gate,dense_mlp,fused_moe}_test.cpp (grouped gate:
+ *     min / max / sum of weights and ids for three seeded cases; W8A8 MLP = 1105920.0; W8A8 MoE layer = 992.0): reproduced
+ *     exactly, tests/test_reference_fixtures.py -- these pin the per-token int8 quantiser, the int32 GEMM + scale
+ *     epilogue, SiLU * mul's cast points, the grouped gate and the weighted combine,
  *   - the in-test CPU references of tests/core/kernels/dcu/ (the _test.cpp files) (torch CPU
- *     ops with the reference's tolerances), see tests/test_oracle_*.py.
- * int8 scaled_quantize/scaled_matmul have no reference test at all
- * ("parity unpinned" for those two; they are checked against float64 closed forms).
+ *     ops with the reference's tolerances), see tests/test_oracle_*.py,
+ *   - end to end: oracle/model.py against the HuggingFace Qwen2 implementation (tests/test_oracle_model.py).
  *
  * Plain C99 + OpenMP.  dtype codes: 0 = f32, 1 = bf16, 2 = f16.
  */
@@ -871,8 +876,9 @@ ORC_API void orc_moe_fused_topk(const float* gating, int64_t T, int64_t E, int64
  *   keep    the topk_group best groups (ties: lower group index); experts of the other groups are out of the race
  *   pick    topk experts by c among the kept groups (ties: lower expert index); weight = s[e] (the UNBIASED score)
  *   renormalize: weights /= their sum;  then weights *= routed_scaling_factor.
- * PARITY UNPINNED: no in-tree test or golden vector covers this operator (closed library); expert ids are compared exactly,
- * weights to 1e-6 relative. */
+ * PINNED on the reference's own fixtures (tests/core/layers/mlu/moe_gate_test.cpp:143-272: min / max / sum of weights and
+ * expert ids for sigmoid + correction bias, softmax and the all-ties topk_group = 1 case, seeded inputs): reproduced exactly
+ * by tests/test_reference_fixtures.py, which also settles the tie rules (lower index wins). */
 ORC_API void orc_moe_grouped_topk(const float* gating, int64_t T, int64_t E, int64_t topk, int64_t G, int64_t topk_group,
                                   int renormalize, const float* bias, int sigmoid, float route_scale, float* out_w,
                                   int32_t* out_id) {

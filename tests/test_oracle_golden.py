@@ -45,7 +45,7 @@ def _caches():
     return kc, vc
 
 
-def _layer(hidden, positions, w, kc, vc, slots, mode, **kw):
+def _layer(hidden, positions, w, kc, vc, slots, mode, p_round=False, **kw):
     q_size, kv_size = NQ * D, NKV * D
     qkv = orc.matmul(hidden, w["qkv"], w["qkv_b"])
     q, k, v = qkv[:, :q_size], qkv[:, q_size:q_size + kv_size], qkv[:, q_size + kv_size:]
@@ -56,10 +56,11 @@ def _layer(hidden, positions, w, kc, vc, slots, mode, **kw):
     orc.reshape_paged_cache(slots, k3, v3, kc, vc)
     scale = math.sqrt(1.0 / D)
     if mode == "prefill":
-        attn = orc.attention_varlen(q.unflatten(-1, (NQ, D)), k3, v3, kw["cu"], kw["cu"], scale, causal=True)
+        attn = orc.attention_varlen(q.unflatten(-1, (NQ, D)), k3, v3, kw["cu"], kw["cu"], scale, causal=True,
+                                    p_round=p_round)
     else:
         attn = orc.paged_attention(q.unflatten(-1, (NQ, D)), kc, vc, kw["cu_q"], kw["kv_lens"],
-                                   kw["block_table"], scale, causal=False)
+                                   kw["block_table"], scale, causal=False, p_round=p_round)
     return orc.matmul(attn, w["o"])
 
 
@@ -89,9 +90,12 @@ def test_prefill_golden():
 
 
 def test_decode_golden():
+    """With P rounded to the tensor dtype before PV (oracle p_round: the reference's eager spec,
+    layers/cuda/flashinfer_attention.cpp:84-90, and evidently what the MLU kernel behind this golden does) the ten values are
+    reproduced to the last printed digit; with P kept in fp32 the vector is 2.4e-3 away -- the size of the effect of that one
+    rounding on a 257-key softmax (round 1 asserted 3 %, which pinned nothing)."""
     B, S = 4, 256
     w = _weights()
-    kc, vc = _caches()
     hidden = orc.make_noise(PFX + "decode.hidden_states", (B, H), 0.02)
     positions = torch.full((B,), S)
     kv = S + 1
@@ -99,12 +103,29 @@ def test_decode_golden():
     per = nblk * BS
     slots = torch.tensor([b * per + (kv - 1) for b in range(B)], dtype=torch.int32)
     table = torch.arange(B * nblk, dtype=torch.int32).view(B, nblk)
-    out = _layer(hidden, positions, w, kc, vc, slots, "decode", cu_q=torch.arange(B + 1, dtype=torch.int32),
-                 kv_lens=torch.full((B,), kv, dtype=torch.int32), block_table=table)
-    expected = GOLD["qwen2_attention_decode"]["first10"]
-    got = out.flatten()[:10].float()
-    exp = torch.tensor(expected)
-    # outputs are sums of ~2048 mean-zero terms of size 1e-5: compare on the vector, 3% of its norm
-    assert (got - exp).norm() / exp.norm() < 3e-2, (got, exp)
-    assert torch.all((got - exp).abs() <= 4e-5), (got, exp)
+    exp = torch.tensor(GOLD["qwen2_attention_decode"]["first10"])
+    errs = {}
+    for p_round in (True, False):
+        kc, vc = _caches()
+        out = _layer(hidden, positions, w, kc, vc, slots, "decode", p_round=p_round,
+                     cu_q=torch.arange(B + 1, dtype=torch.int32), kv_lens=torch.full((B,), kv, dtype=torch.int32),
+                     block_table=table)
+        got = out.flatten()[:10].float()
+        errs[p_round] = ((got - exp).norm() / exp.norm()).item()
+        if p_round:
+            _assert_close_bf16(got, exp.tolist(), ulps=1)
+    assert errs[True] < 1e-5 and 1e-3 < errs[False] < 5e-3, errs
 
+
+def test_prefill_golden_with_rounded_p():
+    """the prefill golden is reproduced by both P modes (128 keys, near-constant outputs: it cannot tell them apart)"""
+    B, S = 2, 128
+    w = _weights()
+    kc, vc = _caches()
+    hidden = orc.make_noise(PFX + "prefill.hidden_states", (B * S, H), 0.02)
+    positions = torch.arange(S).repeat(B)
+    per = _block_num(S) * BS
+    slots = torch.tensor([b * per + i for b in range(B) for i in range(S)], dtype=torch.int32)
+    cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32)
+    out = _layer(hidden, positions, w, kc, vc, slots, "prefill", p_round=True, cu=cu)
+    _assert_close_bf16(out.flatten()[:10], GOLD["qwen2_attention_prefill"]["first10"], ulps=2)

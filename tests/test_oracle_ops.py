@@ -1,7 +1,8 @@
 """Checks the CPU oracle against the same in-test references the reference's kernel tests use
 (tests/core/kernels/dcu/*_test.cpp compare device kernels with torch CPU ops), with the reference's
 tolerances as the floor, plus float64 closed forms for the ops the reference never tests
-(int8 scaled_quantize / scaled_matmul: "parity unpinned" by the reference)."""
+(int8 scaled_quantize / scaled_matmul have no kernel-level reference test; the reference's LAYER fixtures
+that run through them are reproduced in tests/test_reference_fixtures.py)."""
 import math
 
 import pytest
