@@ -17,12 +17,15 @@ def main():
     name = "xllm_mi355_shim"
     out = os.path.join(HERE, name + sysconfig.get_config_var("EXT_SUFFIX"))
     srcs = [os.path.join(HERE, f) for f in ("mi355_ops_api.cpp", "mi355_attention.cpp", "pybind.cpp")]
+    stub = os.path.join(HERE, "stub")   # stand-ins for the two reference headers mi355_attention.h includes
     deps = srcs + [os.path.join(HERE, "mi355_ops_api.h"), os.path.join(HERE, "mi355_attention.h"),
-                   os.path.join(ROOT, "include", "xllm_mi355.h")]
+                   os.path.join(ROOT, "include", "xllm_mi355.h"),
+                   os.path.join(stub, "layers", "common", "attention_metadata.h"),
+                   os.path.join(stub, "framework", "kv_cache", "kv_cache.h")]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     inc = ce.include_paths("cuda") if hasattr(ce, "include_paths") else []
-    inc += ["/opt/rocm/include", sysconfig.get_paths()["include"]]
+    inc += ["/opt/rocm/include", sysconfig.get_paths()["include"], stub]
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
     kern = os.path.join(ROOT, "xllm_amd", "lib")
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",

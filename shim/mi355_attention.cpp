@@ -1,8 +1,34 @@
 #include "mi355_attention.h"
 
+#include <type_traits>
+
 #include "mi355_ops_api.h"
 
-namespace xllm::layer::mi355 {
+namespace xllm {
+namespace layer {
+
+// every member of the reference's types this file touches, with the type it is used as
+// (layers/common/attention_metadata.h:73-186, framework/kv_cache/kv_cache.h:46-47)
+#define MI355_CHECK_FIELD(S, F, T) static_assert(std::is_same_v<decltype(S::F), T>, #S "::" #F " is not a " #T)
+MI355_CHECK_FIELD(AttentionMetadata, q_cu_seq_lens, torch::Tensor);
+MI355_CHECK_FIELD(AttentionMetadata, kv_cu_seq_lens, torch::Tensor);
+MI355_CHECK_FIELD(AttentionMetadata, kv_seq_lens, torch::Tensor);
+MI355_CHECK_FIELD(AttentionMetadata, block_table, torch::Tensor);
+MI355_CHECK_FIELD(AttentionMetadata, slot_mapping, torch::Tensor);
+MI355_CHECK_FIELD(AttentionMetadata, max_query_len, int64_t);
+MI355_CHECK_FIELD(AttentionMetadata, max_seq_len, int64_t);
+MI355_CHECK_FIELD(AttentionMetadata, is_prefill, bool);
+MI355_CHECK_FIELD(AttentionMetadata, is_chunked_prefill, bool);
+MI355_CHECK_FIELD(AttentionMetadata, is_causal, bool);
+#undef MI355_CHECK_FIELD
+static_assert(std::is_same_v<decltype(std::declval<const KVCache&>().get_k_cache()), torch::Tensor> &&
+                  std::is_same_v<decltype(std::declval<const KVCache&>().get_v_cache()), torch::Tensor>,
+              "KVCache accessors");
+
+AttentionImpl::AttentionImpl(int64_t num_heads, int64_t head_size, float scale, int64_t num_kv_heads,
+                             int64_t sliding_window)
+    : num_heads_(num_heads), head_size_(head_size), scale_(scale), num_kv_heads_(num_kv_heads),
+      window_left_(sliding_window > 0 ? sliding_window : -1) {}  // flash_attention.cpp:257
 
 std::tuple<torch::Tensor, std::optional<torch::Tensor>> AttentionImpl::forward(const AttentionMetadata& md,
                                                                                torch::Tensor& query, torch::Tensor& key,
@@ -14,17 +40,18 @@ std::tuple<torch::Tensor, std::optional<torch::Tensor>> AttentionImpl::forward(c
   auto kc = kv_cache.get_k_cache(), vc = kv_cache.get_v_cache();
   k::reshape_paged_cache(md.slot_mapping, kk, vv, kc, vc);  // flash_attention.cpp:310-318
   torch::Tensor out;
-  if (md.is_prefill) {
-    out = k::prefill_attention(q, kk, vv, md.q_cu_seq_lens, md.kv_cu_seq_lens, md.max_query_len, scale_, true,
+  if (md.is_prefill) {          // causal by construction: attention_metadata_builder.cpp:240-241 sets is_causal with it
+    out = k::prefill_attention(q, kk, vv, md.q_cu_seq_lens, md.kv_cu_seq_lens, md.max_query_len, scale_, md.is_causal,
                                window_left_);
   } else if (md.is_chunked_prefill) {
     out = k::paged_attention(q, kc, vc, md.q_cu_seq_lens, md.kv_seq_lens, md.block_table, md.max_query_len,
-                             md.max_seq_len, scale_, true, window_left_);
-  } else {
+                             md.max_seq_len, scale_, md.is_causal, window_left_);
+  } else {                      // decode: one query per sequence, nothing to mask (flash_attention.cpp:220-288)
     out = k::paged_attention(q, kc, vc, std::nullopt, md.kv_seq_lens, md.block_table, 1, md.max_seq_len, scale_, false,
                              window_left_);
   }
   return {out, std::nullopt};
 }
 
-}  // namespace xllm::layer::mi355
+}  // namespace layer
+}  // namespace xllm

@@ -1,42 +1,35 @@
-// layers/mi355/attention.h of a USE_MI355 build: the xllm::layer::AttentionImpl contract of
-// xllm/core/layers/dcu/attention.h:31-51 implemented on xllm::kernel::mi355 (dispatch as
-// layers/dcu/flash_attention.cpp:291-376). Self-contained mirror types are used here because the reference's
-// AttentionMetadata / KVCache headers pull in the whole framework; field names are the reference's.
+// layers/mi355/attention.h of a USE_MI355 build: xllm::layer::AttentionImpl with the declaration of
+// xllm/core/layers/dcu/attention.h:31-51 (same constructor, same forward), implemented on xllm::kernel::mi355 with the
+// dispatch of layers/dcu/flash_attention.cpp:291-376. It is written against the reference's OWN types: inside xLLM the two
+// includes below resolve to the real headers; outside (this repository's build and tests) shim/stub/ provides field-for-field
+// stand-ins, and mi355_attention.cpp static_asserts the members it uses against whichever header it sees.
 #pragma once
 #include <torch/torch.h>
 
 #include <optional>
 #include <tuple>
 
-namespace xllm::layer::mi355 {
+#include "framework/kv_cache/kv_cache.h"
+#include "layers/common/attention_metadata.h"
 
-struct AttentionMetadata {  // layers/common/attention_metadata.h:73-186 (subset used on CUDA/DCU)
-  torch::Tensor q_cu_seq_lens, kv_cu_seq_lens, kv_seq_lens, slot_mapping, block_table;
-  int64_t max_query_len = 1, max_seq_len = 0;
-  bool is_prefill = false, is_chunked_prefill = false;
-  bool is_causal() const { return is_prefill || is_chunked_prefill; }  // attention_metadata_builder.cpp:240-241
-};
+namespace xllm {
+namespace layer {
 
-struct KVCache {  // framework/kv_cache: [n_blocks, block_size, n_kv_heads_local, head_dim]
-  torch::Tensor k_cache, v_cache;
-  torch::Tensor get_k_cache() const { return k_cache; }
-  torch::Tensor get_v_cache() const { return v_cache; }
-};
-
-class AttentionImpl {
+class AttentionImpl final : public torch::nn::Module {
  public:
-  AttentionImpl(int64_t num_heads, int64_t head_size, float scale, int64_t num_kv_heads, int64_t sliding_window)
-      : num_heads_(num_heads), head_size_(head_size), scale_(scale), num_kv_heads_(num_kv_heads),
-        window_left_(sliding_window > 0 ? sliding_window : -1) {}  // flash_attention.cpp:257
+  AttentionImpl() = default;
+  AttentionImpl(int64_t num_heads, int64_t head_size, float scale, int64_t num_kv_heads, int64_t sliding_window);
 
-  std::tuple<torch::Tensor, std::optional<torch::Tensor>> forward(const AttentionMetadata& md, torch::Tensor& query,
-                                                                  torch::Tensor& key, torch::Tensor& value,
-                                                                  KVCache& kv_cache);
+  std::tuple<torch::Tensor, std::optional<torch::Tensor>> forward(const AttentionMetadata& attn_metadata,
+                                                                  torch::Tensor& query, torch::Tensor& key,
+                                                                  torch::Tensor& value, KVCache& kv_cache);
 
  private:
-  int64_t num_heads_, head_size_;
-  float scale_;
-  int64_t num_kv_heads_, window_left_;
+  int64_t num_heads_ = 0, head_size_ = 0;
+  float scale_ = 1.0f;
+  int64_t num_kv_heads_ = 0, window_left_ = -1;
 };
+TORCH_MODULE(Attention);
 
-}  // namespace xllm::layer::mi355
+}  // namespace layer
+}  // namespace xllm

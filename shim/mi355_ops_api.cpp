@@ -322,6 +322,20 @@ std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t e
   return {src_dst, dst_src, sizes};
 }
 
+// the CUDA-header spellings the reference's USE_DCU branches of ops_api.cpp call (kernels/cuda/cuda_ops_api.h:
+// moe_compute_index -> (src_dst, dst_src, expert_sizes); moe_combine_result(input, weights, N, topk)); with
+// patches/xllm-use-mi355.patch those branches run on this backend through `namespace cuda = mi355`
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> moe_compute_index(const torch::Tensor& expert_id, int64_t expert_num) {
+  auto v = moe_gen_idx(expert_id, expert_num);
+  return {v[0], v[1], v[2]};
+}
+
+torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight, int64_t num_tokens,
+                                 int32_t topk) {
+  TORCH_CHECK(reduce_weight.size(0) == num_tokens && reduce_weight.size(1) == topk, "moe_combine_result: weights [N, topk]");
+  return moe_combine_result(input, reduce_weight);
+}
+
 torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight) {
   TORCH_CHECK(input.dim() == 2 && reduce_weight.dim() == 2 && reduce_weight.numel() == input.size(0) &&
                   reduce_weight.scalar_type() == torch::kFloat32,

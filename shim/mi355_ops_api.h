@@ -87,6 +87,10 @@ std::vector<torch::Tensor> moe_gen_idx(const torch::Tensor& expert_id, int64_t e
 // kernel::moe_combine_result (ops_api.h:77; MoeCombineResultParams param.h:575-...): input [T*topk, H] in TOKEN order
 // (after the caller's index_copy_), reduce_weight [T, topk] float32
 torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight);
+// the spellings of kernels/cuda/cuda_ops_api.h that the USE_DCU branches of ops_api.cpp (:629-633, :679-689) call
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> moe_compute_index(const torch::Tensor& expert_id, int64_t expert_num);
+torch::Tensor moe_combine_result(const torch::Tensor& input, const torch::Tensor& reduce_weight, int64_t num_tokens,
+                                 int32_t topk);
 // the same with MoeCombineResultParams::gather_ids honoured: input stays in EXPERT order (the second grouped GEMM's
 // output) and row gather_ids[t*topk+k] is read for (t, k) -- index_copy_ + moe_combine_result in one pass
 // local_expert_sizes (int32 [E_local], EP rank whose experts were sorted to the front): rows at or past their sum are the

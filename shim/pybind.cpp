@@ -18,7 +18,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("moe_grouped_topk", &k::moe_grouped_topk);
   m.def("moe_active_topk", &k::moe_active_topk);
   m.def("moe_gen_idx", &k::moe_gen_idx);
-  m.def("moe_combine_result", &k::moe_combine_result);
+  m.def("moe_combine_result", [](const torch::Tensor& x, const torch::Tensor& w) { return k::moe_combine_result(x, w); });
+  m.def("moe_combine_result4", [](const torch::Tensor& x, const torch::Tensor& w, int64_t n, int64_t topk) { return k::moe_combine_result(x, w, n, (int32_t)topk); });
+  m.def("moe_compute_index", &k::moe_compute_index);
   m.def("moe_combine_result_sorted", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& g, std::optional<torch::Tensor> ls) { return k::moe_combine_result_sorted(x, w, g, ls); }, pybind11::arg("input_sorted"), pybind11::arg("reduce_weight"), pybind11::arg("gather_ids"), pybind11::arg("local_expert_sizes") = std::nullopt);
   m.def("group_gemm", [](const torch::Tensor& x, const torch::Tensor& w, const torch::Tensor& c) { return k::group_gemm(x, w, c, std::nullopt); });
   m.def("group_gemm_gather", &k::group_gemm_gather);
@@ -36,10 +38,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     return k::paged_attention(q, kc, vc, std::nullopt, kv_lens, bt, 1, max_kv, scale, false, -1);
   });
   m.def("attention_forward", [](torch::Tensor q, torch::Tensor kk, torch::Tensor v, torch::Tensor kc, torch::Tensor vc, torch::Tensor slots, torch::Tensor kv_lens, torch::Tensor bt, int64_t nq, int64_t nkv, int64_t d, int64_t max_kv) {
-    xllm::layer::mi355::AttentionImpl attn(nq, d, 1.0f / std::sqrt((float)d), nkv, -1);
-    xllm::layer::mi355::AttentionMetadata md;
+    xllm::layer::Attention attn(nq, d, 1.0f / std::sqrt((float)d), nkv, -1);   // TORCH_MODULE holder, as the layers use it
+    xllm::layer::AttentionMetadata md{};
     md.kv_seq_lens = kv_lens; md.block_table = bt; md.slot_mapping = slots; md.max_seq_len = max_kv;
-    xllm::layer::mi355::KVCache cache{kc, vc};
-    return std::get<0>(attn.forward(md, q, kk, v, cache));
+    md.max_query_len = 1; md.is_prefill = false; md.is_chunked_prefill = false; md.is_dummy = false; md.is_causal = false;
+    xllm::KVCache cache(kc, vc);
+    return std::get<0>(attn->forward(md, q, kk, v, cache));
   });
 }

@@ -43,6 +43,25 @@ def assert_attn_close(got, ref, rel=1e-3):
     assert ((got - ref).abs() <= 2 * 2.0 ** -8 * scale + 1e-30).all(), f"max abs {(got - ref).abs().max()}"
 
 
+def assert_prefill_close(out, q, k, v, cu, scale):
+    """flash prefill against the oracle. The default kernel feeds ONE 16-bit P per score to PV, as the reference does
+    (flashinfer_attention.cpp:84-90; oracle p_round); that rounding alone moves the result by e_ref ~ 2.5e-3 from the fp32-P
+    result, so the bars are relative to it: no further from the exact result than the reference's own spec (x1.25), and
+    within 2 e_ref of that spec (the two round P at different points: un-normalised vs normalised). With
+    XLLM_MI355_PREFILL_P=2 (P = hi + lo) the fp32-P bar of 1e-3 applies."""
+    import os
+    ref0 = orc.attention_varlen(q, k, v, cu, cu, scale, causal=True)
+    if os.environ.get("XLLM_MI355_PREFILL_P") == "2" or q.shape[-1] != 128:
+        assert_attn_close(out, ref0)
+        return
+    ref1 = orc.attention_varlen(q, k, v, cu, cu, scale, causal=True, p_round=True)
+    r = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    e_ref = r(ref1, ref0)
+    assert torch.isfinite(out.float()).all()
+    assert r(out, ref0) <= max(1e-3, 1.25 * e_ref), (r(out, ref0), e_ref)
+    assert r(out, ref1) <= max(1e-3, 2.0 * e_ref), (r(out, ref1), e_ref)
+
+
 # ------------------------------------------------------------------------------------------- probes
 def test_library_loaded_is_hip_path():
     from xllm_amd import _lib
@@ -422,11 +441,10 @@ def test_prefill_attention(nq, nkv, d, lens):
     k = qkv[:, nq * d:(nq + nkv) * d].unflatten(-1, (nkv, d))
     v = qkv[:, (nq + nkv) * d:].unflatten(-1, (nkv, d))
     scale = d ** -0.5
-    ref = orc.attention_varlen(q, k, v, cu, cu, scale, causal=True)
     qd = qkv.to(DEV)
     out = ops.prefill_attention(qd[:, :nq * d].unflatten(-1, (nq, d)), qd[:, nq * d:(nq + nkv) * d].unflatten(-1, (nkv, d)),
                                 qd[:, (nq + nkv) * d:].unflatten(-1, (nkv, d)), cu.to(DEV), cu.to(DEV), max(lens), scale)
-    assert_attn_close(out, ref)
+    assert_prefill_close(out, q, k, v, cu, scale)
 
 
 @pytest.mark.parametrize("bs", [128, 16])

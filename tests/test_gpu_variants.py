@@ -53,7 +53,8 @@ def test_mla_parity_under_kernel_selector(env):
     {"XLLM_MI355_PREFILL_DMA": "0"},                         # register-staged flash prefill kernel for head dim 128 too
     {"XLLM_MI355_PREFILL_DMA": "2"},                         # ping-pong wave groups (256 queries per workgroup)
     {"XLLM_MI355_PREFILL_DMA": "3"},                         # the same two groups, offset by half a tile, one barrier per tile
-], ids=["prefill_regstaged", "prefill_pingpong", "prefill_pingpong_free"])
+    {"XLLM_MI355_PREFILL_P": "2"},                           # P = hi + lo on the default kernel (fp32-P accuracy, 1e-3 bar)
+], ids=["prefill_regstaged", "prefill_pingpong", "prefill_pingpong_free", "prefill_p_hi_lo"])
 def test_prefill_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

@@ -71,3 +71,86 @@ def test_every_kernel_source_is_built_and_tools_parse():
         assert os.path.basename(f) in srcs.split(), f"{os.path.basename(f)} is not in SRCS"
     for f in glob.glob(os.path.join(ROOT, "tools", "*.py")) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
         ast.parse(open(f).read(), filename=f)
+
+
+def _struct_members(path, struct):
+    """(type, name) of every data member of `struct` in a C++ header, in order, outside #if ... #endif blocks"""
+    import re
+    src = open(path).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = src[src.index("struct " + struct + " {") + len("struct " + struct + " {"):]
+    depth, end = 1, 0
+    for i, ch in enumerate(body):
+        depth += ch == "{"
+        depth -= ch == "}"
+        if depth == 0:
+            end = i
+            break
+    body = body[:end]
+    body = re.sub(r"#if.*?#endif", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        m = re.match(r"^(.*?)\s+(\w+)(\s*=\s*[^;]+)?$", decl)
+        if m and "(" not in m.group(1):
+            out.append((m.group(1), m.group(2)))
+    return out
+
+
+def test_shim_stub_headers_mirror_the_reference_field_for_field():
+    """shim/mi355_attention.* is written against the reference's AttentionMetadata / KVCache; outside the xLLM tree it builds
+    against shim/stub/. Where the reference is present (this container), the stub must list exactly the reference's members
+    (names, types, order) outside its USE_CUDA / USE_NPU blocks, and KVCache's accessors must exist with the same signature."""
+    ref_root = "/root/reference/xllm/core"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present")
+    stub = _struct_members(os.path.join(ROOT, "shim", "stub", "layers", "common", "attention_metadata.h"), "AttentionMetadata")
+    ref = _struct_members(os.path.join(ref_root, "layers", "common", "attention_metadata.h"), "AttentionMetadata")
+    assert stub == ref, [x for x in zip(stub, ref) if x[0] != x[1]][:3]
+    kv = open(os.path.join(ref_root, "framework", "kv_cache", "kv_cache.h")).read()
+    assert "torch::Tensor get_k_cache() const;" in kv and "torch::Tensor get_v_cache() const;" in kv
+    dcu = " ".join(open(os.path.join(ref_root, "layers", "dcu", "attention.h")).read().split())
+    ours = " ".join(open(os.path.join(ROOT, "shim", "mi355_attention.h")).read().split())
+    for sig in ("AttentionImpl(int64_t num_heads, int64_t head_size, float scale, int64_t num_kv_heads, int64_t sliding_window);",
+                "std::tuple<torch::Tensor, std::optional<torch::Tensor>> forward( const AttentionMetadata& attn_metadata, "
+                "torch::Tensor& query, torch::Tensor& key, torch::Tensor& value, KVCache& kv_cache);"):
+        assert sig in dcu, sig
+        assert sig.replace("forward( const", "forward(const") in ours, sig
+
+
+def test_reference_patch_applies_and_every_call_it_enables_is_declared(tmp_path):
+    """patches/xllm-use-mi355.patch is the reference-side binding: it must apply to the reference as it stands here, and every
+    cuda:: / dcu:: function the patched ops_api.cpp calls from a branch that compiles under USE_MI355 must be declared in
+    shim/mi355_ops_api.h (the two namespaces are aliased to xllm::kernel::mi355 by the patch)."""
+    import shutil
+    import subprocess
+    ref_root = "/root/reference"
+    patch = os.path.join(ROOT, "patches", "xllm-use-mi355.patch")
+    assert os.path.isfile(patch)
+    files = re.findall(r"^\+\+\+ b/(\S+)", open(patch).read(), flags=re.M)
+    assert "xllm/core/kernels/ops_api.cpp" in files and len(files) >= 8
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present")
+    for rel in files:
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        shutil.copy(os.path.join(ref_root, rel), tmp_path / rel)
+    subprocess.check_call(["git", "init", "-q"], cwd=tmp_path)
+    subprocess.check_call(["git", "apply", patch], cwd=tmp_path)
+    src = open(tmp_path / "xllm/core/kernels/ops_api.cpp").read()
+    declared = set(re.findall(r"\b(\w+)\s*\(", open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()))
+    called, live, depth = set(), [], 0
+    for line in src.splitlines():                         # walk the #if chains: which branches compile under USE_MI355?
+        s = line.strip()
+        if s.startswith("#if"):
+            live.append("USE_MI355" in s)
+        elif s.startswith("#elif"):
+            live[-1] = "USE_MI355" in s
+        elif s.startswith("#else"):
+            live[-1] = False
+        elif s.startswith("#endif"):
+            live.pop()
+        elif live and live[-1]:
+            called.update(re.findall(r"\b(?:cuda|dcu)::(\w+)\s*\(", s))
+    assert len(called) >= 15 and {"scaled_matmul", "rms_norm", "moe_compute_index"} <= called, called
+    assert called <= declared, sorted(called - declared)

@@ -131,6 +131,8 @@ def test_shim_moe_and_mla_equal_the_ctypes_path():
     src_dst, dst_src, sizes = m.moe_gen_idx(ids, E)
     r = ops.moe_compute_index(ids, E)
     assert torch.equal(src_dst, r[0]) and torch.equal(dst_src, r[1]) and torch.equal(sizes, r[2])
+    t3 = m.moe_compute_index(ids, E)                      # the cuda_ops_api.h spelling ops_api.cpp:629 calls under the patch
+    assert isinstance(t3, tuple) and all(torch.equal(a, b) for a, b in zip(t3, r))
     x = torch.randn(T, H, device=dev, generator=gd).bfloat16()
     w13 = (torch.randn(E, 2 * I, H, device=dev, generator=gd) / 22).bfloat16()
     xs = x.index_select(0, (dst_src // topk).long())
@@ -143,6 +145,9 @@ def test_shim_moe_and_mla_equal_the_ctypes_path():
     full.index_copy_(0, dst_src.long(), g2)
     out = m.moe_combine_result(full, w)
     assert torch.equal(out, ops.moe_combine_result(full, w, T, topk))
+    assert torch.equal(m.moe_combine_result4(full, w, T, topk), out)                  # ops_api.cpp:679 four-argument call
+    with pytest.raises(RuntimeError):
+        m.moe_combine_result4(full, w, T + 1, topk)
     assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst), out)
     half = sizes[:E // 2].contiguous()                    # EP form: rows of the other experts count as zero rows
     assert torch.equal(m.moe_combine_result_sorted(g2, w, src_dst, half), ops.moe_combine_sorted(g2, src_dst, w, T, topk, half))

@@ -321,7 +321,7 @@ typedef unsigned pu32x2_t __attribute__((ext_vector_type(2)));
 #define PF_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
 
 constexpr int kPf2Tile = 64;
-constexpr int kPfDefaultPMode = 2;                  // XLLM_MI355_PREFILL_P default (see launch_flash_prefill)
+constexpr int kPfDefaultPMode = 1;                  // XLLM_MI355_PREFILL_P default (see launch_flash_prefill)
 constexpr int kPf2RowB = 256;                       // D = 128 16-bit elements per row, unpadded
 constexpr int kPf2TileB = kPf2Tile * kPf2RowB;      // 16 KB per operand and tile
 #ifdef XM_ABL_PF_TIMING  /* ablation build: shader-clock / wall-clock span of the tile loop of one workgroup */
@@ -772,7 +772,11 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
                              (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
                              (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
       } else {
-        // XLLM_MI355_PREFILL_P: 1 = one 16-bit P per score, 2 = P = hi + lo (two MFMAs per block; fp32-P accuracy)
+        // XLLM_MI355_PREFILL_P: 1 (default) = one 16-bit P per score, rounded to nearest even: the reference's semantics --
+        // its eager spec casts P to the tensor dtype before PV (layers/cuda/flashinfer_attention.cpp:84-90) and its MLU decode
+        // golden vector is reproduced to the last digit only with that rounding; the output is then
+        // 2.1e-3 from the fp32-P result where the reference's own spec is 2.5e-3 away (profiles/r02_prefill_p.txt).
+        // 2 = P = hi + lo (two MFMAs per block: fp32-P accuracy, 1e-4, at 1.34x the time)
         static int p_mode = -1;
         if (p_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_P"); p_mode = e ? atoi(e) : kPfDefaultPMode; }
         if (p_mode == 1)
