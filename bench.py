@@ -35,6 +35,9 @@ CONFIGS = {
     "cfg3": ("qwen2_7b", "int8", 256, 4096),   # BASELINE.json metric config (configs[2])
     "cfg2": ("qwen2_7b", "16bit", 64, 2048),   # configs[1]
     "tiny": ("qwen2_0_5b", "int8", 8, 512),    # CPU-sized smoke shape
+    # one rank's layer of the TP=8 configurations (configs[3], configs[4]) on one GPU: bench_slices.py
+    "cfg4-slice": ("deepseek_v3", "fp8", 128, 8192),
+    "cfg5-slice": ("qwen3_moe", "int8", 8192, 4096),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -230,6 +233,12 @@ def main():
     from xllm_amd import layers, parallel
     from xllm_amd.attention import KVCache
 
+    if a.config.endswith("-slice"):
+        if world != 1:
+            raise SystemExit(f"--config {a.config} is a one-GPU slice of a TP=8 job: run it with --gpus 1")
+        import bench_slices
+        print(json.dumps(bench_slices.run(a, dev)), flush=True)
+        return
     model_name, mode, gbatch, ctx = CONFIGS[a.config]
     margs = getattr(layers.ModelArgs, model_name)()
     block_size = 128

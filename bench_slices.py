@@ -1,0 +1,182 @@
+"""bench_slices.py -- the single-GPU slices of BASELINE.json's TP=8 configurations (bench.py --config cfg4-slice | cfg5-slice).
+
+configs[3] (DeepSeek-V3 MLA fp8 TP=8, bs=128 ctx=8192) and configs[4] (Qwen3-MoE W8A8 TP=8, T=8192 chunked prefill) do not
+fit the metric's one-GPU line; what one rank of those jobs runs per layer does, and that is what is timed here, with the shard
+shapes of rank 0 of 8 and no exchange (the exchanges are counted and reported, not timed -- a 1-GPU box has no peer):
+
+  cfg4-slice  one DeepSeek-V3 decoder layer of one TP=8 rank, decode step of 128 sequences with 8191 cached tokens each:
+              DeepseekV2Attention (16 of 128 heads, q_lora 1536, kv_lora 512, rope 64; q_b_proj / o_proj fp8 e4m3 with dynamic
+              per-token activation scales; paged latent cache [n_blocks, 64, 1, 576] bf16, shuffled pages) + the routed experts
+              (256 experts, top-8 of 4-of-8 groups, sigmoid scores + correction bias, intermediate 2048 / 8 per rank, 16-bit
+              like the reference's DCU path, fused_moe.cpp:217-337).  roofline: mla_decode kernel against HBM.
+  cfg5-slice  the routed experts of one Qwen3-MoE layer (H 2048, 128 experts top-8, intermediate 768) on one expert-parallel
+              rank of 8 (16 local experts; every rank routes all T = 8192 tokens of the chunk, fused_moe.cpp:236-315), W8A8:
+              per-token int8 quantisation, grouped GEMM w13 with the expand fused in, SiLU*mul + requantisation, grouped GEMM
+              w2, weighted combine.  roofline: the w13 grouped GEMM against the dense int8 MFMA rate.
+
+The product path only (xllm_amd.layers over the C ABI); nothing under oracle/ is touched.
+"""
+import time
+
+import torch
+
+HBM_PEAK_GBS = 8000.0
+I8_PEAK_TOPS = 5000.0   # dense int8 MFMA (2x the bf16 rate), MI355X_MICROARCH.md
+
+
+def _timed_calls(fn_holder, name, events):
+    """wrap module attribute `name` so that every call is bracketed by HIP events on the launch stream"""
+    orig = getattr(fn_holder, name)
+
+    def wrapped(*args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(*args, **kw)
+        e1.record()
+        events.append((e0, e1))
+        return out
+
+    setattr(fn_holder, name, wrapped)
+    return orig
+
+
+def _time_steps(step, steps, warmup, sync):
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def cfg4_slice(a, dev):
+    from xllm_amd import attention, layers, ops
+    from xllm_amd.attention import KVCache
+    H, heads, tp = 7168, 128, 8
+    q_lora, kv_lora, nope, rope, v_dim = 1536, 512, 128, 64, 128
+    E, topk, n_group, topk_group, moe_i = 256, 8, 8, 4, 2048
+    B, ctx, bs = 128, 8192, 64
+    gen = torch.Generator(device=dev).manual_seed(4)
+    attn = layers.DeepseekV2Attention(H, heads // tp, q_lora, kv_lora, nope, rope, v_dim, 1e-6, torch.bfloat16, dev, gen,
+                                      max_pos=ctx, quant="fp8")
+    bias = torch.randn(E, device=dev, generator=gen) * 0.1
+    moe = layers.FusedMoE(H, moe_i // tp, E, topk, torch.bfloat16, dev, gen, renormalize=True, scoring_func="sigmoid",
+                          correction_bias=bias, num_expert_group=n_group, topk_group=topk_group, route_scale=2.5)
+    gate_w = (torch.randn(E, H, device=dev, generator=gen) / H ** 0.5).bfloat16()
+    pages = ctx // bs
+    n_blocks = int(B * pages * 1.1) + 1
+    perm = torch.randperm(n_blocks, generator=torch.Generator().manual_seed(5))[: B * pages].to(torch.int32).view(B, pages)
+    bi = attention.build_batch_input([ctx - 1] * B, [ctx] * B, perm.tolist(), bs)
+    md = attention.build_attention_metadata(bi, is_prefill=False, is_chunked_prefill=False, device=dev)
+    cache = KVCache(torch.empty(n_blocks, bs, 1, kv_lora + rope, dtype=torch.bfloat16, device=dev).normal_(generator=gen), None)
+    x = torch.randn(B, H, device=dev, generator=gen).bfloat16()
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+
+    def step():
+        h = attn.forward(pos, x, md, cache)                 # (all-reduce over the 8 ranks here)
+        return moe.forward_experts(h, ops.matmul(h, gate_w))   # (all-reduce over the 8 ranks here)
+
+    sync = torch.cuda.synchronize
+    step()
+    sync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    dt = _time_steps(g.replay, a.steps, a.warmup, sync)
+    # dominant kernel, per launch, eagerly on the same stream with events (a replayed graph has no host-visible launches)
+    ev, fp8_ev = [], []
+    orig = _timed_calls(ops, "mla_decode", ev)
+    orig8 = _timed_calls(ops, "fp8_scaled_matmul", fp8_ev)
+    for _ in range(max(a.steps, 5)):
+        step()
+    sync()
+    ops.mla_decode, ops.fp8_scaled_matmul = orig, orig8
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    attn_ms = sum(ms) / len(ms)
+    h_l = heads // tp
+    nbytes = B * (ctx * (kv_lora + rope) * 2 + h_l * (kv_lora + rope) * 2 + h_l * kv_lora * 2)
+    achieved = nbytes / (attn_ms * 1e-3) / 1e9
+    f8 = [e0.elapsed_time(e1) for e0, e1 in fp8_ev]
+    qb_ms, o_ms = sum(f8[0::2]) / len(f8[0::2]), sum(f8[1::2]) / len(f8[1::2])
+    qb_bytes, o_bytes = h_l * (nope + rope) * q_lora, H * h_l * v_dim
+    return {
+        "metric": "decode tokens/s through one DeepSeek-V3 layer of one TP=8 rank (cfg4-slice)",
+        "value": round(B / dt, 1), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "fp8",
+        "config": {"workload": "deepseek_v3 layer slice: MLA decode (16 heads/rank, fp8 q_b/o projections) + 256-expert top-8 "
+                               "routed MoE (intermediate 2048/8), bs=128 ctx=8192, paged latent cache block=64 bf16, "
+                               "random-init weights", "global_batch": B, "ctx": ctx, "per_gpu_batch": B,
+                   "parallelism": "rank 0 of tp8 (shard shapes, no exchange timed)", "collectives_per_step": 2,
+                   "hip_graph": True},
+        "roofline": {"bound": "hbm", "kernel": "mla_decode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
+                     "avg_launch_ms": round(attn_ms, 4), "launches_timed": len(ms)},
+        "fp8_linears": {"q_b_proj": {"M": B, "N": h_l * (nope + rope), "K": q_lora, "us": round(qb_ms * 1e3, 2),
+                                      "weight_gbs": round(qb_bytes / (qb_ms * 1e-3) / 1e9, 1)},
+                        "o_proj": {"M": B, "N": H, "K": h_l * v_dim, "us": round(o_ms * 1e3, 2),
+                                   "weight_gbs": round(o_bytes / (o_ms * 1e-3) / 1e9, 1)}},
+    }
+
+
+def cfg5_slice(a, dev):
+    from xllm_amd import layers, ops
+    H, E, topk, moe_i, ep = 2048, 128, 8, 768, 8
+    T = 8192
+    gen = torch.Generator(device=dev).manual_seed(5)
+    moe = layers.FusedMoE(H, moe_i, E, topk, torch.bfloat16, dev, gen, renormalize=True, mode="int8", ep_rank=0, ep_size=ep)
+    gate_w = (torch.randn(E, H, device=dev, generator=gen) / H ** 0.5).bfloat16()
+    x = torch.randn(T, H, device=dev, generator=gen).bfloat16()
+
+    def step():
+        return moe.forward_experts(x, ops.matmul(x, gate_w))   # (EP all-reduce over the 8 ranks here)
+
+    sync = torch.cuda.synchronize
+    step()
+    sync()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    dt = _time_steps(g.replay, a.steps, a.warmup, sync)
+    ev = []
+    orig = _timed_calls(ops, "group_gemm_w8a8", ev)
+    sizes_seen = []
+    orig_idx = ops.moe_compute_index
+
+    def idx(*args, **kw):
+        r = orig_idx(*args, **kw)
+        sizes_seen.append(r[2])
+        return r
+
+    ops.moe_compute_index = idx
+    for _ in range(max(a.steps, 5)):
+        step()
+    sync()
+    ops.group_gemm_w8a8, ops.moe_compute_index = orig, orig_idx
+    rows = int(sizes_seen[-1][:E // ep].sum().item())       # rows of this rank's 16 experts (host read AFTER the timed region)
+    w13 = [e0.elapsed_time(e1) for e0, e1 in ev[0::2]]
+    w2 = [e0.elapsed_time(e1) for e0, e1 in ev[1::2]]
+    w13_ms, w2_ms = sum(w13) / len(w13), sum(w2) / len(w2)
+    ops13 = 2.0 * rows * (2 * moe_i) * H
+    ops2 = 2.0 * rows * H * moe_i
+    ach = ops13 / (w13_ms * 1e-3) / 1e12
+    return {
+        "metric": "prefill tokens/s through the routed experts of one Qwen3-MoE layer on one EP=8 rank (cfg5-slice)",
+        "value": round(T / dt, 1), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "int8",
+        "config": {"workload": "qwen3_moe routed-expert slice: gate + top-8 of 128 + W8A8 grouped GEMMs (16 local experts, "
+                               "intermediate 768) + combine over a chunk of 8192 tokens, random-init weights",
+                   "global_batch": T, "ctx": 4096, "per_gpu_batch": T, "rows_on_this_rank": rows,
+                   "parallelism": "rank 0 of ep8 (all-reduce EP: every rank routes the whole chunk; no exchange timed)",
+                   "collectives_per_step": 1, "hip_graph": True},
+        "roofline": {"bound": "mfma", "kernel": "group_gemm_w8a8 (w13, expand fused)", "achieved": round(ach, 1),
+                     "peak": I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(ach / I8_PEAK_TOPS, 4), "traffic": None,
+                     "ops_per_launch": ops13, "avg_launch_ms": round(w13_ms, 4), "launches_timed": len(w13)},
+        "w2_gemm": {"tops": round(ops2 / (w2_ms * 1e-3) / 1e12, 1), "avg_launch_ms": round(w2_ms, 4)},
+    }
+
+
+def run(a, dev):
+    out = (cfg4_slice if a.config == "cfg4-slice" else cfg5_slice)(a, dev)
+    out.update({"n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "data": "synthetic"})
+    return out

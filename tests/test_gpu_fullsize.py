@@ -121,6 +121,40 @@ def test_int8_gemm_full_size_checksums(M, N, K):
         assert torch.equal(out[rows].cpu(), ref)
 
 
+@pytest.mark.parametrize("M,N,K,scales", [
+    (256, 2 * I, H, "tc"), (256, H, I, "tc"), (8192, 2 * I, H, "tc"), (8192, H, I, "tensor"), (8192, 4608, H, "tc"),
+    (128, 16 * 192, 1536, "tc"), (128, 7168, 16 * 128, "tensor"), (128, 7168, 18432 // 8, "tc"),   # DeepSeek-V3, one TP=8 rank
+])
+def test_fp8_gemm_full_size_against_fp64(M, N, K, scales):
+    """fp8 e4m3 GEMM at the full Qwen2-7B and DeepSeek-V3 (one TP=8 rank) shapes. e4m3 x e4m3 products are exact in fp32, so
+    the only freedom is the fp32 summation order: sampled rows against the fp64 product of the dequantised operands within a
+    few fp32-accumulation ulps + one bf16 rounding (bar 2e-2 of BASELINE far away), and linear checksums of the WHOLE output
+    (per column and per row) against fp64 sums computed without forming the reference product."""
+    gd = torch.Generator(device=DEV).manual_seed(M * 7 + N)
+    a = (torch.randn(M, K, device=DEV, generator=gd) * 2).to(torch.float8_e4m3fn)
+    w = (torch.randn(N, K, device=DEV, generator=gd) * 0.5).to(torch.float8_e4m3fn)
+    per = scales == "tc"                                   # per-token + per-channel, or one scale per tensor
+    a_s = torch.rand(M if per else 1, device=DEV, generator=gd) * 0.05 + 0.01
+    w_s = torch.rand(N if per else 1, device=DEV, generator=gd) * 0.02 + 0.01
+    out = ops.fp8_scaled_matmul(a, w, a_s, w_s, torch.bfloat16)
+    a64 = a.double() * (a_s.double()[:, None] if per else a_s.double())
+    w64 = w.double() * (w_s.double()[:, None] if per else w_s.double())
+    rows = torch.randint(0, M, (32,), device=DEV, generator=gd)
+    ref = a64[rows] @ w64.T
+    mag = (a64[rows].abs() @ w64.abs().T)                  # the error scale of a length-K fp32 sum
+    err = (out[rows].double() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2.0 ** -20 * mag).all(), float((err / mag).max())
+    assert rel_l2(out[rows], ref) <= 3e-3                  # bf16 output rounding only
+    # whole-output checksums: sum_m out[m, n] = (sum_m a[m]) . w[n];  sum_n out[m, n] = a[m] . (sum_n w[n])
+    col = a64.sum(0) @ w64.T
+    row = a64 @ w64.sum(0)
+    o64 = out.double()                                     # independent bf16 roundings add in quadrature (6 x 2^-9 rms > 6 sigma) + fp32 sums
+    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -20 * (a64.abs().sum(0) @ w64.abs().T) + 1e-9
+    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -20 * (a64.abs() @ w64.abs().sum(0)) + 1e-9
+    assert ((o64.sum(0) - col).abs() <= tol_c).all()
+    assert ((o64.sum(1) - row).abs() <= tol_r).all()
+
+
 def test_silu_mul_quant_full_size():
     gd = torch.Generator(device=DEV).manual_seed(7)
     M = 8192

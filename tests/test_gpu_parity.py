@@ -1075,6 +1075,51 @@ def test_random_sample(B, V):
     assert torch.equal(got_rng, got_u)
 
 
+def test_random_sample_on_segment_boundaries_stays_next_to_the_crossing():
+    """u placed within an ulp of the running sum at the kernel's segment boundaries (multiples of 1024): whichever way the
+    two summation orders round, the sampled index has to sit on the crossing of the exact CDF, never far away."""
+    V, g = 32768, torch.Generator().manual_seed(77)
+    probs = torch.softmax(torch.randn(1, V, generator=g) * 2, -1)
+    probs[probs < 1e-6] = 0.0
+    cdf = torch.cumsum(probs.double(), -1)[0]
+    us, rows = [], []
+    for k in range(1, V // 1024):
+        c = cdf[k * 1024 - 1].float()
+        for uu in (c, torch.nextafter(c, torch.tensor(0.0)), torch.nextafter(c, torch.tensor(2.0))):
+            us.append(uu)
+    u = torch.stack(us)
+    got = ops.random_sample(probs.expand(len(us), V).contiguous().to(DEV), uniform=u.to(DEV)).cpu()
+    for b in range(len(us)):
+        i = int(got[b])
+        assert probs[0, i] > 0 and cdf[i] > u[b] - 1e-5 and (i == 0 or cdf[i - 1] <= u[b] + 1e-5), (b, i, float(u[b]))
+
+
+def test_moe_index_ignores_ids_outside_the_expert_range():
+    """padding rows (-1) or ids >= E are not counted (the reference's histogram guard, moe_compute_index.cu:41-60); their
+    src_dst entry is -1 and the sorted combine treats them as absent."""
+    T, topk, E, H = 70, 2, 8, 64
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, E, (T, topk), generator=g, dtype=torch.int32)
+    ids[3, 1] = -1
+    ids[40, 0] = E + 5
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.to(DEV), E)
+    flat = ids.flatten()
+    ok = (flat >= 0) & (flat < E)
+    assert torch.equal(sizes.cpu(), torch.bincount(flat[ok].long(), minlength=E).to(torch.int32))
+    sd = src_dst.cpu().flatten()
+    assert torch.equal(sd[~ok], torch.full((2,), -1, dtype=torch.int32))
+    n_ok = int(ok.sum())
+    assert sorted(sd[ok].tolist()) == list(range(n_ok))
+    assert torch.equal(dst_src.cpu()[:n_ok][sd[ok].long()], ok.nonzero().flatten().to(torch.int32))
+    w = torch.rand(T, topk, generator=g)
+    rows = torch.randn(T * topk, H, generator=g).bfloat16()
+    got = ops.moe_combine_sorted(rows.to(DEV), src_dst, w.to(DEV), T, topk).cpu()
+    gathered = torch.zeros(T * topk, H)
+    gathered[ok] = rows.float()[sd[ok].long()]
+    ref = (gathered.view(T, topk, H) * w[..., None]).sum(1)
+    assert torch.allclose(got.float(), ref, rtol=1e-2, atol=1e-2)
+
+
 def test_rejection_sample_bit_exact():
     g = torch.Generator().manual_seed(77)
     B, V = 48, 4099

@@ -20,7 +20,12 @@ __global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kMoeChunk;
   for (int i = threadIdx.x; i < kMoeChunk; i += blockDim.x)
-    if (base + i < n) atomicAdd(&h[expert_id[base + i]], 1);
+    if (base + i < n) {
+      // ids outside [0, E) (padding rows, -1) are not counted, as in the reference's histogram
+      // (kernels/cuda/moe/moe_compute_index.cu: `eid >= 0 && eid < num_experts`); the place pass marks them below
+      const int32_t e = expert_id[base + i];
+      if (e >= 0 && e < E) atomicAdd(&h[e], 1);
+    }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += blockDim.x) chunk_cnt[(int64_t)blockIdx.x * E + e] = h[e];
 }
@@ -83,12 +88,15 @@ __global__ __launch_bounds__(1024) void moe_place_kernel(const int32_t* __restri
     }
   }
 #pragma unroll
-  for (int r = 0; r < kMoeChunk / 64; ++r)
+  for (int r = 0; r < kMoeChunk / 64; ++r) {
+    const int64_t i = base + r * 64 + lane;
     if (pos[r] >= 0) {
-      const int64_t i = base + r * 64 + lane;
       src_dst[i] = pos[r];
       dst_src[pos[r]] = (int32_t)i;
+    } else if (i < n) {
+      src_dst[i] = -1;  // a row whose id is outside [0, E) has no sorted position: the sorted combine skips it
     }
+  }
 }
 
 template <typename T>
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256) void moe_combine_sorted_kernel(T* __restrict__
   for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {  // H % 8 == 0: one 16-byte load per row and thread
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < topk; ++k) {
-      if (rows[k] >= nv) continue;
+      if (rows[k] < 0 || rows[k] >= nv) continue;
       const uint4 v = *reinterpret_cast<const uint4*>(gemm2 + (int64_t)rows[k] * H + i);
       const T* e = reinterpret_cast<const T*>(&v);
 #pragma unroll

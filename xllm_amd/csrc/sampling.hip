@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kRsThreads) void random_sample_kernel(const float* 
   __shared__ float part[kRsMaxSeg][kRsWaves];
   __shared__ float wave_tot[kRsWaves];
   __shared__ int wave_last[kRsWaves];
-  __shared__ int s_seg, s_sampled, s_last;
+  __shared__ int s_seg, s_sampled, s_last, s_seg_last;
   __shared__ float s_prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row = blockIdx.x;
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kRsThreads) void random_sample_kernel(const float* 
     s_prefix = agg;
     s_last = lv;
     s_sampled = d;
+    s_seg_last = -1;
   }
   __syncthreads();
   const int seg = s_seg;
@@ -141,11 +142,19 @@ __global__ __launch_bounds__(kRsThreads) void random_sample_kernel(const float* 
     for (int j = 3; j >= 0; --j)
       if (v[j] > 0.0f && pre + c[j] > u) cand = base + j;
     if (cand < d) atomicMin(&s_sampled, cand);
+    // the segment was chosen from the wave-tree sums, the crossing is looked for with the sequential scan: when u falls in
+    // the rounding gap between the two orders no index crosses, and the answer is the segment's own last p > 0 index
+    int seg_last = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] > 0.0f) seg_last = base + j;
+    if (seg_last >= 0) atomicMax(&s_seg_last, seg_last);
     __syncthreads();
   }
   if (tid == 0) {
     int r = s_sampled;
-    if (r >= d) r = s_last >= 0 ? s_last : 0;  // sum(probs) <= u (u ~ 1 or rounding): last valid index (reference :231-235)
+    if (r >= d) r = s_seg_last >= 0 ? s_seg_last : (s_last >= 0 ? s_last : 0);  // sum(probs) <= u (u ~ 1): last valid index of
+                                                                                // the row (reference :231-235)
     out[row] = r;
   }
 }

@@ -342,8 +342,9 @@ class DeepseekV2Attention:
 
     def __init__(self, hidden: int, n_heads: int, q_lora: int, kv_lora: int, nope: int, rope: int, v_dim: int, eps: float,
                  dtype, device, gen, tp: Optional[parallel.ProcessGroup] = None, rope_theta: float = 1e4,
-                 max_pos: int = 8192, mscale: float = 1.0):
+                 max_pos: int = 8192, mscale: float = 1.0, quant: str = "16bit"):
         tp_size = tp.world_size() if tp is not None else 1
+        self.quant = quant   # "fp8": q_b_proj and o_proj carry QuantArgs (deepseek_v2_attention.cpp:96-118); the others never do
         assert n_heads % tp_size == 0, "num_heads must be divisible by tensor parallel size"   # :64-65
         self.h, self.q_lora, self.kv_lora, self.nope, self.rope, self.v_dim = n_heads // tp_size, q_lora, kv_lora, nope, rope, v_dim
         self.eps, self.dtype, self.tp = eps, dtype, tp
@@ -358,6 +359,11 @@ class DeepseekV2Attention:
         self.w_kc = kv_b[:, :nope].contiguous()                       # [h, nope, kv_lora]
         self.w_vc = kv_b[:, nope:].transpose(1, 2).contiguous()       # [h, kv_lora, v]  (load_state_dict :335-339)
         self.o_w = rnd(hidden, self.h * v_dim)
+        if quant != "16bit":
+            assert q_lora > 0 and quant == "fp8"
+            self.q_b_lin = QuantLinear(self.h * (nope + rope), q_lora, False, quant, dtype, device, gen)
+            self.o_lin = QuantLinear(hidden, self.h * v_dim, False, quant, dtype, device, gen)
+            self.q_b_w = self.o_w = None
         self.scale = float((nope + rope) ** -0.5) * mscale * mscale   # :148-154
         inv_freq = 1.0 / torch.pow(torch.tensor(rope_theta), torch.arange(0, rope, 2, dtype=torch.float32) / rope)
         fr = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv_freq)
@@ -378,7 +384,8 @@ class DeepseekV2Attention:
         latent_normed = torch.cat([c_kv_normed, k_pe.squeeze(1)], -1)
         ops.store_latent_cache(latent_normed, md.slot_mapping, kv_cache.get_k_cache())
         if self.q_lora > 0:                                                                       # prepare_query :156-168
-            q = ops.matmul(self._norm(ops.matmul(hidden_states, self.q_a_w), self.q_a_norm_w), self.q_b_w)
+            q_a = self._norm(ops.matmul(hidden_states, self.q_a_w), self.q_a_norm_w)
+            q = self.q_b_lin.forward(q_a) if self.quant != "16bit" else ops.matmul(q_a, self.q_b_w)
         else:
             q = ops.matmul(hidden_states, self.q_w)
         q = q.view(T, self.h, self.nope + self.rope)
@@ -394,6 +401,8 @@ class DeepseekV2Attention:
             attn = ops.mla_decode(q_in, kv_cache.get_k_cache(), md.kv_seq_lens, md.block_table, self.kv_lora, self.scale,
                                   md.max_seq_len)
         out = torch.bmm(attn.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)            # project_output :180-187
+        if self.quant != "16bit":
+            return self.o_lin.forward(out)
         return ops.matmul(out, self.o_w)   # partial sums under TP: the decoder layer reduces
 
 
