@@ -128,7 +128,7 @@ def test_int8_gemm_full_size_checksums(M, N, K):
 def test_fp8_gemm_full_size_against_fp64(M, N, K, scales):
     """fp8 e4m3 GEMM at the full Qwen2-7B and DeepSeek-V3 (one TP=8 rank) shapes. e4m3 x e4m3 products are exact in fp32, so
     the only freedom is the fp32 summation order: sampled rows against the fp64 product of the dequantised operands within a
-    few fp32-accumulation ulps + one bf16 rounding (bar 2e-2 of BASELINE far away), and linear checksums of the WHOLE output
+    few accumulation ulps + one bf16 rounding (bar 2e-2 of BASELINE far away), and linear checksums of the WHOLE output
     (per column and per row) against fp64 sums computed without forming the reference product."""
     gd = torch.Generator(device=DEV).manual_seed(M * 7 + N)
     a = (torch.randn(M, K, device=DEV, generator=gd) * 2).to(torch.float8_e4m3fn)
@@ -143,14 +143,16 @@ def test_fp8_gemm_full_size_against_fp64(M, N, K, scales):
     ref = a64[rows] @ w64.T
     mag = (a64[rows].abs() @ w64.abs().T)                  # the error scale of a length-K fp32 sum
     err = (out[rows].double() - ref).abs()
-    assert (err <= 2.0 ** -8 * ref.abs() + 2.0 ** -20 * mag).all(), float((err / mag).max())
+    # measured (tools/fp8_fullsize_diag.py): the fp8 MFMA's running sum is a little coarser than a chain of fp32 FMAs -- worst
+    # entry 2^-19.3 * sum|a||w| over 10^7 outputs (torch's fp32 product: 2^-27) -- still four orders below the 2e-2 bar
+    assert (err <= 2.0 ** -8 * ref.abs() + 2.0 ** -17 * mag).all(), float((err / mag).max())
     assert rel_l2(out[rows], ref) <= 3e-3                  # bf16 output rounding only
     # whole-output checksums: sum_m out[m, n] = (sum_m a[m]) . w[n];  sum_n out[m, n] = a[m] . (sum_n w[n])
     col = a64.sum(0) @ w64.T
     row = a64 @ w64.sum(0)
     o64 = out.double()                                     # independent bf16 roundings add in quadrature (6 x 2^-9 rms > 6 sigma) + fp32 sums
-    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -20 * (a64.abs().sum(0) @ w64.abs().T) + 1e-9
-    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -20 * (a64.abs() @ w64.abs().sum(0)) + 1e-9
+    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -17 * (a64.abs().sum(0) @ w64.abs().T) / math.sqrt(M) + 1e-9
+    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -17 * (a64.abs() @ w64.abs().sum(0)) / math.sqrt(N) + 1e-9
     assert ((o64.sum(0) - col).abs() <= tol_c).all()
     assert ((o64.sum(1) - row).abs() <= tol_r).all()
 

@@ -180,3 +180,25 @@ def test_ep_allreduce_ranks_add_up_to_the_all_experts_layer():
     for part, whole in out:
         assert torch.equal(part, out[0][0])                                        # identical on every rank
         assert ((part - whole).norm() / whole.norm()).item() <= 6e-3               # 16-bit rounding of the per-rank partials
+
+
+def _async_reduce(rank, world):
+    from xllm_amd import parallel
+    pg, _ = parallel.make_tp_dp_groups(world, rank, world)
+    x = torch.arange(12, dtype=torch.float32).view(3, 4) * (rank + 1)
+    ctx = parallel.launch_reduce(x, pg)                       # in flight ...
+    independent = torch.full((2, 2), float(rank)) @ torch.eye(2)   # ... while unrelated work runs
+    y = parallel.finish_reduce(ctx)
+    again = parallel.finish_reduce(ctx)                       # idempotent: the Work is consumed once
+    single = parallel.finish_reduce(parallel.launch_reduce(torch.ones(2), None))
+    return y.tolist(), again.tolist(), single.tolist(), independent.tolist(), y.data_ptr() == x.data_ptr()
+
+
+def test_launch_reduce_finish_reduce_pair():
+    """parallel_state::launch_reduce / finish_reduce (parallel_state_async.cpp:72-84, parallel_state.cpp:176-181): the sum is
+    there after finish, in place, and world 1 / no group is a pass-through"""
+    out = _run(_async_reduce)
+    want = (torch.arange(12, dtype=torch.float32).view(3, 4) * 3).tolist()
+    for r, (y, again, single, ind, in_place) in enumerate(out):
+        assert y == want and again == want and single == [1.0, 1.0] and in_place
+        assert ind == [[float(r)] * 2] * 2

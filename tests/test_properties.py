@@ -84,7 +84,13 @@ def test_paged_attention_random_geometry(case, heads):
         ref = orc.paged_attention(qt, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale, causal=causal)
         out = ops.paged_attention(qt.cuda(), kc.cuda(), vc.cuda(), md["q_cu_seq_lens"].cuda() if causal else None,
                                   md["kv_seq_lens"].cuda(), md["block_tables"].cuda(), max(mode_q), max(lens), scale, causal)
-        assert _rel(out.view(T, -1), ref.view(T, -1)) <= 1e-3
+        if causal:   # chunked prefill keeps one 16-bit P like the reference: bars relative to the p_round oracle
+            from _bars import assert_p16_attention_close
+            ref16 = orc.paged_attention(qt, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
+                                        causal=True, p_round=True)
+            assert_p16_attention_close(out.view(T, -1), ref.view(T, -1), ref16.view(T, -1))
+        else:
+            assert _rel(out.view(T, -1), ref.view(T, -1)) <= 1e-3
 
 
 @pytest.mark.gpu

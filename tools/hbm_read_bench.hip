@@ -98,10 +98,36 @@ void run(const u32x4* buf, size_t bytes, int blocks_per_cu, unsigned* sink) {
          UNROLL, ms * 1e3, bytes / ms / 1e9);
 }
 
-int main() {
+// short launches (the 268 MB of KV a cfg2 / one-DP-replica-of-8 decode attention launch reads): 8 launches back to back, each
+// over its own eighth of the buffer (nothing comes from the 256 MB Infinity Cache), average time per launch
+template <int UNROLL, bool PRIVATE>
+void run_small(const u32x4* buf, size_t bytes_total, int blocks_per_cu, unsigned* sink) {
+  const int grid = 256 * blocks_per_cu;
+  const size_t each = bytes_total / 8 / 4096 * 4096;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int r = 0; r < 8; ++r) k<UNROLL><<<grid, 256>>>(buf + (size_t)r * each / 16, each / 16, sink);
+  hipEventRecord(e0);
+  for (int r = 0; r < 8; ++r) {
+    if (PRIVATE) kp<UNROLL><<<grid, 256>>>(buf + (size_t)r * each / 16, each / 16, sink);
+    else k<UNROLL><<<grid, 256>>>(buf + (size_t)r * each / 16, each / 16, sink);
+  }
+  hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 8;
+  printf("short launch, %zu MB each, %s: blocks/CU=%2d loads_in_flight/lane=%2d  %7.1f us  %5.2f TB/s\n", each >> 20,
+         PRIVATE ? "private regions" : "interleaved walk", blocks_per_cu, UNROLL, ms * 1e3, each / ms / 1e9);
+}
+
+int main(int argc, char** argv) {
   const size_t bytes = 2151153664ull / 4096 * 4096;
   u32x4* buf; unsigned* sink;
   hipMalloc(&buf, bytes); hipMalloc(&sink, 4); hipMemset(buf, 1, bytes);
+  if (argc > 1) {  // "small": the short-launch ceiling only
+    for (int b : {1, 2, 4}) {
+      run_small<8, false>(buf, bytes, b, sink); run_small<16, false>(buf, bytes, b, sink);
+      run_small<8, true>(buf, bytes, b, sink); run_small<16, true>(buf, bytes, b, sink);
+    }
+    return 0;
+  }
   for (int b : {1, 2, 4, 8}) { run<4>(buf, bytes, b, sink); run<8>(buf, bytes, b, sink); run<16>(buf, bytes, b, sink); }
   for (int b : {1, 2, 4}) { run_private<8>(buf, bytes, b, sink); run_private<16>(buf, bytes, b, sink); }
   run_strided<8, 4, true>(buf, bytes, 256, sink);

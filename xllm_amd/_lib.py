@@ -52,6 +52,7 @@ _SIGS = {
     "xllm_mi355_fused_qk_norm_rope": ([vp, i64, i64, i64, i64, i64, f32, vp, vp, vp, ci, ci, vp, ci, vp], ci),
     "xllm_mi355_act_and_mul": ([vp, vp, i64, i64, ci, ci, vp], ci),
     "xllm_mi355_act_and_mul_dynamic_int8_quant": ([vp, vp, vp, i64, i64, ci, ci, vp], ci),
+    "xllm_mi355_act_and_mul_dynamic_int8_quant_live": ([vp, vp, vp, i64, i64, ci, ci, vp, i64, vp], ci),
     "xllm_mi355_scaled_quantize": ([vp, vp, vp, i64, i64, ci, vp], ci),
     "xllm_mi355_scaled_matmul": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_set_gemm_workspace": ([vp, sz], ci),

@@ -56,6 +56,32 @@ bool decode_deep_prefetch() {
   return g_deep != 0;
 }
 
+// heads per workgroup of the decode kernel (4 waves = hpw kv heads x 4/hpw sub-ranges of the token range, merged in LDS).
+// All kv heads of a token in one workgroup (hpw = 4) read whole token rows and allow the fused int8 epilogue, but give only
+// batch * nkv / 4 workgroups; below ~one workgroup per CU the parallelism has to come from somewhere, and sub-ranges inside
+// the workgroup are free (LDS merge) while grid-level splits pay partial writes + a merge launch. So: the largest hpw that
+// still yields >= 192 workgroups, else hpw = 1 and the rest through grid-level splits.
+static int g_hpw_override = -2;
+int decode_heads_per_wg(int64_t batch, int64_t nkv) {
+  if (g_hpw_override == -2) {
+    const char* e = getenv("XLLM_MI355_DECODE_HPW");
+    g_hpw_override = e ? atoi(e) : -1;
+  }
+  if (g_hpw_override > 0 && 4 % g_hpw_override == 0 && nkv % g_hpw_override == 0) return g_hpw_override;
+  for (int hpw = 4; hpw > 1; hpw >>= 1)
+    if (nkv % hpw == 0 && batch * (nkv / hpw) >= 192) return hpw;
+  return 1;
+}
+
+static int g_excl = -2;
+int decode_exclusive_cu() {
+  if (g_excl == -2) {
+    const char* e = getenv("XLLM_MI355_DECODE_EXCL");
+    g_excl = e ? atoi(e) : 0;
+  }
+  return g_excl;
+}
+
 }  // namespace xm
 
 using namespace xm;

@@ -406,6 +406,8 @@ __global__ void paged_decode_merge_kernel(const float* __restrict__ part_o, cons
 
 int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len);
 bool decode_deep_prefetch();
+int decode_heads_per_wg(int64_t batch, int64_t nkv);
+int decode_exclusive_cu();
 
 template <typename T, int D>
 int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out, const int32_t* cu_q,
@@ -413,7 +415,7 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
                         int64_t nq, int64_t nkv, int64_t block_size, int64_t q_stride, int64_t max_kv_len,
                         float scale, int64_t window_left, void* workspace, size_t ws_bytes, hipStream_t s,
                         int8_t* out_q, float* out_scale) {
-  int hpw = nkv >= 4 && nkv % 4 == 0 ? 4 : (nkv % 2 == 0 ? 2 : 1);
+  const int hpw = decode_heads_per_wg(batch, nkv);
   int nsplit = decode_num_splits(batch, nkv, hpw, max_kv_len);
   // the fused int8 epilogue needs the whole token in one workgroup: decline shapes that want split-KV or have
   // more than one head group (the caller then runs paged_attention + scaled_quantize)
@@ -428,12 +430,15 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(batch * (nkv / hpw) * nsplit));
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
+  // A/B switch (XLLM_MI355_DECODE_EXCL=1): grids of at most one workgroup per CU reserve enough extra LDS that two
+  // workgroups cannot share a CU, so the dispatcher has to spread them over all 256
+  const size_t dyn = (decode_exclusive_cu() && grid.x <= 256) ? 48 * 1024 : 0;
   if (block_size % kTile == 0 && decode_deep_prefetch())
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
   else if (block_size % kTile == 0)
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
   else

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(1024) void moe_place_kernel(const int32_t* __restri
     if (pos[r] >= 0) {
       src_dst[i] = pos[r];
       dst_src[pos[r]] = (int32_t)i;
-    } else if (i < n) {
-      src_dst[i] = -1;  // a row whose id is outside [0, E) has no sorted position: the sorted combine skips it
+    } else if (wave == 0 && i < n && (eid[r] < 0 || eid[r] >= E)) {
+      src_dst[i] = -1;  // a row whose id is outside [0, E) has no sorted position (no wave owns it): the sorted combine skips it
     }
   }
 }

@@ -606,11 +606,19 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_reg_kernel(int8_t* __restr
 // leaves 7 of 8 waves idle at d = 768 and the launch becomes row-count bound (65536 rows: 405 us; this kernel: ~50 us)
 template <typename T, int MODE, int VPT>
 __global__ __launch_bounds__(512) void act_and_mul_i8_wave_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
-                                                                  const T* __restrict__ in, int d, int64_t n_rows) {
+                                                                  const T* __restrict__ in, int d, int64_t n_rows,
+                                                                  const int32_t* __restrict__ live_sizes, int n_sizes) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
   if (t >= n_rows) return;
+  if (live_sizes) {  // expert-parallel rank: only the first sum(live_sizes) sorted rows exist (device-side count, no host read)
+    int part = 0;
+    for (int e = lane; e < n_sizes; e += 64) part += live_sizes[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (t >= part) return;
+  }
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(in + t * 2 * (int64_t)d);
   const u32x4* y = x + nvec;
@@ -1113,15 +1121,15 @@ static int launch_act(void* out, const void* input, int64_t n_tokens, int64_t d,
 
 template <typename T>
 static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64_t n_tokens, int64_t d,
-                       int act_mode, hipStream_t s) {
+                       int act_mode, hipStream_t s, const int32_t* live_sizes = nullptr, int n_sizes = 0) {
   if (sizeof(T) == 2 && act_mode == XM_ACT_SILU && d % 8 == 0 && d <= 1024 && n_tokens >= 512) {  // MoE expert widths
     const unsigned blocks = (unsigned)((n_tokens + 7) / 8);
     if (d <= 512)
       hipLaunchKernelGGL((act_and_mul_i8_wave_kernel<T, XM_ACT_SILU, 1>), dim3(blocks), dim3(512), 0, s, out_q, out_scale,
-                         (const T*)input, (int)d, n_tokens);
+                         (const T*)input, (int)d, n_tokens, live_sizes, n_sizes);
     else
       hipLaunchKernelGGL((act_and_mul_i8_wave_kernel<T, XM_ACT_SILU, 2>), dim3(blocks), dim3(512), 0, s, out_q, out_scale,
-                         (const T*)input, (int)d, n_tokens);
+                         (const T*)input, (int)d, n_tokens, live_sizes, n_sizes);
     return hip_check_launch();
   }
   if (sizeof(T) == 2 && act_mode == XM_ACT_SILU && d % 8 == 0 && d <= 20480) {  // the hot-path configuration
@@ -1171,6 +1179,18 @@ int xllm_mi355_act_and_mul_dynamic_int8_quant(int8_t* out_q, float* out_scale, c
   if (d % 8 != 0 || d * 2 > 65536 || (uintptr_t)input % 16 || (uintptr_t)out_q % 8) return XM_ERR_UNSUPPORTED;
   XM_DISPATCH_HALF(dtype, T,
                    return launch_actq<T>(out_q, out_scale, input, n_tokens, d, act_mode, (hipStream_t)stream));
+  return XM_OK;
+}
+
+int xllm_mi355_act_and_mul_dynamic_int8_quant_live(int8_t* out_q, float* out_scale, const void* input,
+                                                   int64_t n_tokens, int64_t d, int act_mode, int dtype,
+                                                   const int32_t* live_sizes, int64_t n_sizes, void* stream) {
+  if (!out_q || !out_scale || !input || n_tokens < 0 || d <= 0 || (live_sizes && n_sizes <= 0)) return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  if (d % 8 != 0 || d * 2 > 65536 || (uintptr_t)input % 16 || (uintptr_t)out_q % 8) return XM_ERR_UNSUPPORTED;
+  XM_DISPATCH_HALF(dtype, T,
+                   return launch_actq<T>(out_q, out_scale, input, n_tokens, d, act_mode, (hipStream_t)stream, live_sizes,
+                                         (int)n_sizes));
   return XM_OK;
 }
 

@@ -477,7 +477,7 @@ class FusedMoE:
             # each token is quantised ONCE; the expand happens inside the first grouped GEMM's A staging (scales follow)
             xq, xs = ops.scaled_quantize(x)
             h13 = ops.group_gemm_w8a8(xq, xs, self.w13_q, self.w13_s, sizes, x.dtype, row_index=dst_src, index_div=self.topk)
-            aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu")
+            aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu", live_sizes=local)   # EP: the rank's own rows only
             h2 = ops.group_gemm_w8a8(aq, a_s, self.w2_q, self.w2_s, sizes, x.dtype)
             out = ops.moe_combine_sorted(h2, src_dst, weights, T, self.topk, local)
         else:
@@ -495,12 +495,18 @@ class FusedMoE:
                 full.index_copy_(0, dst_src[:n_local].long(), h2[:n_local])
                 out = ops.moe_combine_result(full, weights, T, self.topk)
         out = parallel.reduce(out, self.ep)
-        out = parallel.reduce(out, self.tp)
+        if self.shared is not None and side is None:
+            # no second stream (graph capture / CPU): the TP all-reduce of the routed output is started first and the shared
+            # experts run while it is in flight (the reference's launch_reduce / finish_reduce pair,
+            # deepseek_v2_sparse_moe_block.cpp:208-260)
+            pending = parallel.launch_reduce(out, self.tp)
+            shared_out = self.shared(x)
+            out = parallel.finish_reduce(pending)
+        else:
+            out = parallel.reduce(out, self.tp)
         if self.shared is not None:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
-            else:
-                shared_out = self.shared(x)
             out = out + shared_out
         return out.reshape(hidden_states.shape)
 

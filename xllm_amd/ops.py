@@ -190,13 +190,20 @@ def act_and_mul(out, input, act_mode: str = "silu") -> None:
           "act_and_mul")
 
 
-def act_and_mul_dynamic_int8_quant(input, act_mode: str = "silu"):
-    """N1 fusion (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815)."""
+def act_and_mul_dynamic_int8_quant(input, act_mode: str = "silu", live_sizes=None):
+    """N1 fusion (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815). live_sizes (int32, device): the expert sizes of an
+    expert-parallel rank -- only the first sum(live_sizes) sorted rows exist; rows past them are left untouched."""
     _need_cuda(input)
     d = input.size(-1) // 2
     T = input.numel() // (2 * d)
     q = torch.empty(T, d, dtype=torch.int8, device=input.device)
     s = torch.empty(T, dtype=torch.float32, device=input.device)
+    if live_sizes is not None:
+        _need_cuda(live_sizes)
+        check(_lib.lib().xllm_mi355_act_and_mul_dynamic_int8_quant_live(
+            _p(q), _p(s), _p(input), T, d, _ACT[act_mode], _dt(input), _p(live_sizes), live_sizes.numel(), _stream()),
+            "act_and_mul_int8_live")
+        return q, s
     check(_lib.lib().xllm_mi355_act_and_mul_dynamic_int8_quant(_p(q), _p(s), _p(input), T, d, _ACT[act_mode],
                                                               _dt(input), _stream()), "act_and_mul_int8")
     return q, s

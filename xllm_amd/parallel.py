@@ -26,6 +26,13 @@ class ProcessGroup:
     def allreduce(self, x: torch.Tensor) -> None:
         _run_collective(lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
 
+    def allreduce_async(self, x: torch.Tensor):
+        """ProcessGroup::allreduce_async (process_group.cpp:103-108): returns the c10d Work. With RCCL the collective runs on
+        the process group's own HIP stream, fenced against the CURRENT stream by events on both sides (enqueue: the RCCL
+        stream waits for what the current stream has queued; Work.wait(): the current stream waits for the collective), so
+        every kernel launched between allreduce_async and wait() overlaps the transfer over xGMI."""
+        return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def allgather(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self._world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         xc = x.contiguous()
@@ -159,6 +166,36 @@ def reduce(x: torch.Tensor, pg: Optional[ProcessGroup]) -> torch.Tensor:
         return x
     pg.allreduce(x)
     return x
+
+
+class ReduceAsyncCtx:
+    """parallel_state.h:37-40: the tensor being reduced in place + the pending Work (None: nothing in flight)"""
+    __slots__ = ("tensor", "work")
+
+    def __init__(self, tensor, work=None):
+        self.tensor, self.work = tensor, work
+
+
+def launch_reduce(x: torch.Tensor, pg: Optional[ProcessGroup]) -> ReduceAsyncCtx:
+    """parallel_state::launch_reduce (parallel_state_async.cpp:72-84): start the SUM all-reduce of `x` and return at once;
+    the caller keeps launching independent work (the next GEMM of the other micro-batch, the shared experts) and calls
+    finish_reduce where it needs the sum. Inside a piecewise-graph capture there is nothing to overlap with on the host
+    side (the collective sits between two graph launches), so the collective is issued in place."""
+    if pg is None or pg.world_size() == 1:
+        return ReduceAsyncCtx(x)
+    xc = x.contiguous()
+    if _piecewise is not None:
+        pg.allreduce(xc)
+        return ReduceAsyncCtx(xc)
+    return ReduceAsyncCtx(xc, pg.allreduce_async(xc))
+
+
+def finish_reduce(ctx: ReduceAsyncCtx) -> torch.Tensor:
+    """parallel_state::finish_reduce (parallel_state.cpp:176-181)"""
+    if ctx.work is not None:
+        ctx.work.wait()
+        ctx.work = None
+    return ctx.tensor
 
 
 def gather(x: torch.Tensor, pg: Optional[ProcessGroup], dim: int = -1) -> torch.Tensor:
