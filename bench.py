@@ -63,6 +63,9 @@ def parse():
     p.add_argument("--no-engine", action="store_true", help="skip the step-level harness leg (xllm_amd.engine.DecodeEngine)")
     p.add_argument("--layout", default="auto", choices=["auto", "dp", "tp", "tp4dp2"],
                    help="how N GPUs share the fixed global batch (auto = dp; see the module docstring)")
+    p.add_argument("--oneshot-allreduce", action="store_true",
+                   help="tensor parallel: the one-shot xGMI all-reduce of csrc/allreduce.hip for the per-layer sums (a kernel, "
+                        "captured into the step's graphs) instead of RCCL; opt-in until validated on a multi-GPU node")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
@@ -260,6 +263,8 @@ def main():
     if gbatch % dp_size:
         raise SystemExit(f"global batch {gbatch} does not divide over {dp_size} replicas")
     tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_size) if world > 1 else (None, 0))
+    if a.oneshot_allreduce and tp_pg is not None and tp_size > 1:
+        tp_pg.enable_oneshot(dev, 8 << 20)
     B = gbatch // dp_size
     if a.emulate_dp > 1 and world == 1:
         B = gbatch // a.emulate_dp
@@ -445,6 +450,7 @@ def main():
                        "parallelism": (f"dp{dp_size}" if tp_size == 1 and dp_size > 1 else
                                        f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else "")),
                        "layout": layout if world > 1 else "single", "collectives_per_step": collectives_per_step,
+                       "allreduce": (("oneshot-xgmi" if a.oneshot_allreduce else "rccl") if tp_size > 1 and world > 1 else None),
                        "exposed_comm_ms": exposed_comm_ms,
                        "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,
                        "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},

@@ -466,6 +466,34 @@ XM_API int xllm_mi355_host_build_batch(const int32_t* n_kv_cache_tokens, const i
                                        const int32_t* block_indptr, const int32_t* block_ids, int64_t num_sequences,
                                        int64_t block_size, xllm_mi355_host_batch_t* out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * One-shot SUM all-reduce over peer-mapped buffers (xGMI), for the small tensor-parallel messages of a decode step.
+ * Replaces, for messages <= max_message_bytes, parallel_state::reduce -> ProcessGroup::allreduce -> ProcessGroupNCCL
+ * (framework/parallel_state/parallel_state.cpp:183-192, process_group.cpp:98-108). Opt-in; RCCL stays the default.
+ *
+ * Set-up, once per rank (one process per GPU): allocate the shared buffer with xllm_mi355_ipc_alloc
+ * (xllm_mi355_oneshot_allreduce_buffer_bytes(max_message_bytes) bytes, zeroed; *kind in: the first memory kind to try,
+ * out: the kind obtained -- 0 fine-grained, 1 uncached, 2 plain hipMalloc), export it (xllm_mi355_ipc_get_handle: XLLM_MI355_IPC_HANDLE_BYTES opaque bytes that
+ * travel to the peers over any host channel), open every peer's handle (xllm_mi355_ipc_open_handle), keep
+ * peer_buffers[world] with peer_buffers[rank] = the rank's own buffer. epoch_state: 2 zero-initialised uint32 in the
+ * rank's own device memory; status: 1 zero-initialised int (set to 1 if a wait exceeded timeout_s -- the result of that
+ * launch is undefined; a peer died or did not issue the same sequence of all-reduces).
+ *
+ * xllm_mi355_oneshot_allreduce: inout[count] (XM_F32 / XM_BF16 / XM_F16, 16-byte aligned, count * size % 16 == 0) becomes
+ * the sum over ranks, accumulated in fp32 in rank order -- bit-identical on every rank. Every rank must call it with the
+ * same count, in the same order. A plain kernel on `stream`: no host synchronisation, HIP-graph capturable.
+ * XM_ERR_WORKSPACE: message larger than max_message_bytes (fall back to RCCL). */
+#define XLLM_MI355_IPC_HANDLE_BYTES 64
+XM_API size_t xllm_mi355_oneshot_allreduce_buffer_bytes(size_t max_message_bytes);
+XM_API int xllm_mi355_ipc_alloc(size_t bytes, void** ptr, int* kind);
+XM_API int xllm_mi355_ipc_free(void* ptr);
+XM_API int xllm_mi355_ipc_get_handle(void* dev_ptr, void* handle64);
+XM_API int xllm_mi355_ipc_open_handle(const void* handle64, void** ptr);
+XM_API int xllm_mi355_ipc_close_handle(void* ptr);
+XM_API int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* const* peer_buffers, int rank,
+                                        int world, size_t max_message_bytes, uint32_t* epoch_state, int* status,
+                                        double timeout_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

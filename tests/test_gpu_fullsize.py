@@ -151,8 +151,8 @@ def test_fp8_gemm_full_size_against_fp64(M, N, K, scales):
     col = a64.sum(0) @ w64.T
     row = a64 @ w64.sum(0)
     o64 = out.double()                                     # independent bf16 roundings add in quadrature (6 x 2^-9 rms > 6 sigma) + fp32 sums
-    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -17 * (a64.abs().sum(0) @ w64.abs().T) / math.sqrt(M) + 1e-9
-    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -17 * (a64.abs() @ w64.abs().sum(0)) / math.sqrt(N) + 1e-9
+    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -19 * (a64.abs().sum(0) @ w64.abs().T) + 1e-9
+    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -19 * (a64.abs() @ w64.abs().sum(0)) + 1e-9
     assert ((o64.sum(0) - col).abs() <= tol_c).all()
     assert ((o64.sum(1) - row).abs() <= tol_r).all()
 

@@ -1,0 +1,107 @@
+"""One-shot all-reduce protocol test: TWO processes on ONE GPU (the only multi-process shape a 1-GPU box offers). It exercises
+everything except the xGMI hop itself: IPC export / import of the shared buffers, the flag protocol across processes, slot
+reuse over many epochs (odd / even), mixed message sizes, dtypes, HIP-graph replay of the collective, the bit-identical
+rank-ordered fp32 sum, and the bounded wait (a rank whose peer never calls gets status = 1 instead of a hung queue).
+Reference semantics: parallel_state::reduce = in-place SUM all-reduce (framework/parallel_state/parallel_state.cpp:183-192)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _msg(rank, i, n, dtype):
+    g = torch.Generator().manual_seed(1000 * i + rank)
+    return (torch.randn(n, generator=g) * (1 + rank)).to(dtype)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xllm_amd import parallel
+    pg = parallel.ProcessGroup(dist.group.WORLD, rank, world)
+    res = {"ok": True, "log": []}
+    try:
+        ar = pg.enable_oneshot("cuda:0", max_bytes=4 << 20)
+        res["kind"] = ar.kind
+        sizes = [8, 3584, 256 * 3584, 917504, 24, 2 << 20, 256 * 3584, 8, 4096, 1 << 20, 40, 256 * 3584]
+        for i, n in enumerate(sizes):
+            dtype = (torch.bfloat16, torch.float16, torch.float32)[i % 3]
+            if n * (4 if dtype == torch.float32 else 2) > ar.max_bytes:
+                dtype = torch.bfloat16
+            x = _msg(rank, i, n, dtype).cuda()
+            want = sum(_msg(r, i, n, dtype).float() for r in range(world)).to(dtype)   # fp32 sum in rank order, one rounding
+            parallel.reduce(x, pg)
+            if not torch.equal(x.cpu(), want):
+                res["ok"] = False
+                res["log"].append(f"mismatch at message {i} (n={n}, {dtype}): max abs {(x.cpu().float() - want.float()).abs().max()}")
+        # bigger than the shared slot: falls back to the group's own all-reduce (gloo here, RCCL on a node)
+        big = torch.ones(3 << 20, dtype=torch.bfloat16)
+        assert not ar.takes(big.cuda())
+        # graph replay: the collective is a plain kernel
+        static = _msg(rank, 99, 256 * 3584, torch.bfloat16).cuda()
+        src = [_msg(rank, 100 + k, 256 * 3584, torch.bfloat16).cuda() for k in range(3)]
+        static.copy_(src[0])
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            parallel.reduce(static.clone(), pg)            # warm-up on the capture stream (both ranks: one epoch)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                y = static * 1.0
+                parallel.reduce(y, pg)
+        for k in range(3):
+            static.copy_(src[k])
+            g.replay()
+            torch.cuda.synchronize()
+            want = sum(_msg(r, 100 + k, 256 * 3584, torch.bfloat16).float() for r in range(world)).bfloat16()
+            if not torch.equal(y.cpu(), want):
+                res["ok"] = False
+                res["log"].append(f"graph replay {k} mismatch")
+        ar.check()
+        # bounded wait: only rank 0 calls; it must come back with status = 1, not hang
+        dist.barrier()
+        if rank == 0:
+            ar.timeout_s = 0.2
+            lonely = torch.ones(4096, dtype=torch.bfloat16, device="cuda")
+            ar.allreduce(lonely)
+            torch.cuda.synchronize()
+            try:
+                ar.check()
+                res["ok"] = False
+                res["log"].append("a lonely all-reduce did not report a timeout")
+            except Exception as e:   # noqa: BLE001
+                res["timeout_reported"] = "timed out" in str(e)
+        dist.barrier()
+        ar.close()
+    except Exception as e:   # noqa: BLE001
+        res["ok"] = False
+        res["log"].append(repr(e))
+    ret[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_processes_one_gpu_protocol():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret[r]["ok"], ret[r]["log"]
+    assert ret[0].get("timeout_reported") is True

@@ -41,6 +41,13 @@ _SIGS = {
     "xllm_mi355_host_cache_slots": ([vp, i64, i64, i64, i64, vp], ci),
     "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_oneshot_allreduce_buffer_bytes": ([sz], sz),
+    "xllm_mi355_ipc_alloc": ([sz, C.POINTER(vp), C.POINTER(ci)], ci),
+    "xllm_mi355_ipc_free": ([vp], ci),
+    "xllm_mi355_ipc_get_handle": ([vp, vp], ci),
+    "xllm_mi355_ipc_open_handle": ([vp, C.POINTER(vp)], ci),
+    "xllm_mi355_ipc_close_handle": ([vp], ci),
+    "xllm_mi355_oneshot_allreduce": ([vp, i64, ci, C.POINTER(vp), ci, ci, sz, vp, vp, C.c_double, vp], ci),
     "xllm_mi355_decode_metadata_update": ([C.POINTER(DecodeMetadata), vp], ci),
     "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_build_block_table_from_paged_kv": ([vp, vp, i32, i32, vp, vp], ci),

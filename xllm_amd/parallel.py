@@ -7,6 +7,7 @@ cuda_process_group.h:24-53 -- on ROCm torch "nccl" IS RCCL) and the helpers para
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -16,6 +17,14 @@ import torch.distributed as dist
 class ProcessGroup:
     def __init__(self, group: Optional[dist.ProcessGroup] = None, rank: int = 0, world_size: int = 1):
         self.group, self._rank, self._world = group, rank, world_size
+        self.oneshot: Optional["OneShotAllReduce"] = None
+
+    def enable_oneshot(self, device, max_bytes: int = 8 << 20) -> "OneShotAllReduce":
+        """opt in to the one-shot xGMI all-reduce (csrc/allreduce.hip) for CUDA messages of at most max_bytes; larger
+        messages, other dtypes and CPU tensors keep going through RCCL / gloo. Collective: every rank of the group calls it."""
+        if self._world > 1 and self.oneshot is None:
+            self.oneshot = OneShotAllReduce(self, device, max_bytes)
+        return self.oneshot
 
     def rank(self) -> int:
         return self._rank
@@ -24,6 +33,9 @@ class ProcessGroup:
         return self._world
 
     def allreduce(self, x: torch.Tensor) -> None:
+        if self.oneshot is not None and self.oneshot.takes(x):
+            self.oneshot.allreduce(x)     # a plain kernel: also inside a graph capture, no eager piece needed
+            return
         _run_collective(lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
 
     def allreduce_async(self, x: torch.Tensor):
@@ -51,6 +63,84 @@ class ProcessGroup:
         sc = send.contiguous()
         _run_collective(lambda: dist.all_to_all_single(out, sc, list(recv_counts), list(send_counts), group=self.group))
         return out
+
+
+class OneShotAllReduce:
+    """One-shot SUM all-reduce over peer-mapped buffers (include/xllm_mi355.h, csrc/allreduce.hip): every rank copies its
+    message into its own shared slot, raises a flag in every peer's buffer and sums all slots in rank order (fp32, one
+    rounding), so the result is bit-identical on every rank and costs ONE xGMI hop instead of the ring's 2 (W - 1).
+    The handles travel over the group's object all-gather (host side, once). Opt-in: ProcessGroup.enable_oneshot."""
+
+    _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+    def __init__(self, pg: "ProcessGroup", device, max_bytes: int = 8 << 20, timeout_s: float = 2.0):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        l = _lib.lib()
+        self.pg, self.max_bytes, self.timeout_s = pg, int(max_bytes), float(timeout_s)
+        self.device = torch.device(device)
+        world, rank = pg.world_size(), pg.rank()
+        total = l.xllm_mi355_oneshot_allreduce_buffer_bytes(self.max_bytes)
+        handle = None
+        with torch.cuda.device(self.device):
+            for first_kind in (0, 1, 2):            # fine-grained, uncached, plain: the first kind that can be exported
+                ptr, kind = C.c_void_p(), C.c_int(first_kind)
+                _lib.check(l.xllm_mi355_ipc_alloc(total, C.byref(ptr), C.byref(kind)), "ipc_alloc")
+                buf = C.create_string_buffer(64)
+                if l.xllm_mi355_ipc_get_handle(ptr, buf) == 0:
+                    handle = bytes(buf.raw)
+                    break
+                l.xllm_mi355_ipc_free(ptr)
+                if kind.value >= 2:
+                    break
+            if handle is None:
+                raise _lib.Mi355Error("one-shot all-reduce: hipIpcGetMemHandle failed for every memory kind")
+            self.own, self.kind = ptr, kind.value
+            everyone = [None] * world
+            dist.all_gather_object(everyone, (os.getpid(), handle), group=pg.group)
+            self.peers = (C.c_void_p * world)()
+            self._opened = []
+            for r, (pid, h) in enumerate(everyone):
+                if r == rank:
+                    self.peers[r] = self.own.value
+                    continue
+                p = C.c_void_p()
+                _lib.check(l.xllm_mi355_ipc_open_handle(h, C.byref(p)), f"ipc_open_handle(rank {r})")
+                self.peers[r] = p.value
+                self._opened.append(p)
+        self.state = torch.zeros(2, dtype=torch.int32, device=self.device)     # epoch, blocks-done counter
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=pg.group)    # every rank has every buffer mapped before the first launch
+
+    def takes(self, x: torch.Tensor) -> bool:
+        n = x.numel() * x.element_size()
+        return (x.is_cuda and x.is_contiguous() and x.dtype in self._DT and 0 < n <= self.max_bytes and n % 16 == 0
+                and x.data_ptr() % 16 == 0)
+
+    def allreduce(self, x: torch.Tensor) -> None:
+        l = self._lib.lib()
+        self._lib.check(l.xllm_mi355_oneshot_allreduce(
+            x.data_ptr(), x.numel(), self._DT[x.dtype], self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes,
+            self.state.data_ptr(), self.status.data_ptr(), self.timeout_s, torch.cuda.current_stream().cuda_stream),
+            "oneshot_allreduce")
+
+    def check(self) -> None:
+        """host-side look at the status word (synchronises): raises if any launch gave up waiting for a peer"""
+        if int(self.status.item()) != 0:
+            raise self._lib.Mi355Error("one-shot all-reduce: a wait for a peer's flag timed out (result undefined)")
+
+    def close(self) -> None:
+        l = self._lib.lib()
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.pg.group)   # nobody unmaps while a peer may still read
+        for p in self._opened:
+            l.xllm_mi355_ipc_close_handle(p)
+        self._opened = []
+        if self.own is not None:
+            l.xllm_mi355_ipc_free(self.own)
+            self.own = None
 
 
 # ---- all-to-all expert parallelism (SURVEY 8f N4; cfg5 names an RCCL all-to-all) ---------------------------------------
