@@ -593,21 +593,28 @@ def test_mla_prefill_and_latent_store(H, bs, lens):
                               causal=True, dv=512)
     out = ops.mla_prefill(q.to(DEV), kc_dev, md["q_cu_seq_lens"].to(DEV), md["kv_seq_lens"].to(DEV),
                           md["block_tables"].to(DEV), 512, scale, max(kv_lens), is_causal=True)
-    assert_attn_close(out.view(T, -1), ref)
+    # the tile-sharing kernel keeps ONE 16-bit P per score like prefill_sdpa (torch SDPA) does: bars relative to the p_round
+    # oracle (tests/_bars.py); the per-token path (decode kernel, P = hi + lo) meets the same bars with room to spare
+    from _bars import assert_p16_attention_close
+    ref16 = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
+                                causal=True, dv=512, p_round=True)
+    assert_p16_attention_close(out.view(T, -1), ref.view(T, -1), ref16.view(T, -1))
     if T >= 256:                                                       # the unmasked form of the same entry
         ref_nc = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
                                      causal=False, dv=512)
+        ref_nc16 = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
+                                       causal=False, dv=512, p_round=True)
         out_nc = ops.mla_prefill(q.to(DEV), kc_dev, md["q_cu_seq_lens"].to(DEV), md["kv_seq_lens"].to(DEV),
                                  md["block_tables"].to(DEV), 512, scale, max(kv_lens), is_causal=False)
-        assert_attn_close(out_nc.view(T, -1), ref_nc)
+        assert_p16_attention_close(out_nc.view(T, -1), ref_nc.view(T, -1), ref_nc16.view(T, -1))
     # decode through the same cache agrees with the last query row of every sequence
     dec = ops.mla_decode(q[md["q_cu_seq_lens"][1:].long() - 1].contiguous().to(DEV), kc_dev, md["kv_seq_lens"].to(DEV),
                          md["block_tables"].to(DEV), 512, scale, max(kv_lens))
     last = out.cpu()[md["q_cu_seq_lens"][1:].long() - 1]
     if T * ((H + 15) // 16) < 4 * 128 and os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "1":
         assert torch.equal(dec.cpu(), last)             # the per-token path IS the decode kernel: bit-equal
-    else:                                               # tile-sharing kernel: another summation order, one bf16 ulp
-        assert_attn_close(dec.view(B, -1), last.view(B, -1), rel=3e-3)
+    else:                                               # tile-sharing kernel: one 16-bit P (decode: hi + lo), another sum order
+        assert_attn_close(dec.view(B, -1), last.view(B, -1), rel=6e-3)
 
 
 def test_moe_index_combine_group_gemm():

@@ -38,8 +38,9 @@ def test_gemm_parity_under_kernel_selector(env):
     {"XLLM_MI355_MLA_SPLITS": "1"},
     {"XLLM_MI355_MLA_PREFILL": "0"},                         # prefill: one decode-kernel entry per query token
     {"XLLM_MI355_MLA_PREFILL": "1"},                         # prefill: the tile-sharing kernel on every batch size
+    {"XLLM_MI355_MLA_PREFILL": "1", "XLLM_MI355_MLA_PREFILL_P": "2"},   # ... with P = hi + lo (fp32-P accuracy)
 ], ids=["mla_regstaged", "mla_regstaged_split3", "mla_dma_split3", "mla_dma_nosplit", "mla_prefill_per_token",
-        "mla_prefill_shared_forced"])
+        "mla_prefill_shared_forced", "mla_prefill_shared_p_hi_lo"])
 def test_mla_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

@@ -538,7 +538,10 @@ __device__ __forceinline__ void mla_scale_acc(mf32x4_t& a, float alpha) {
 // waves' scores fully masked), so no host- or device-built group table is needed: q_seq / q_kvlen are the per-token
 // arrays mla_expand_queries_kernel already writes. Two barriers per tile (tile landed / buffer free); MFMA-bound:
 // 200 MFMAs per wave and tile against 544 KB of LDS reads per workgroup and tile (2176 of ~3200 cycles).
-template <typename T>
+// P1: ONE RNE-rounded 16-bit P per score in front of PV, as the reference's prefill computes it (prefill_sdpa, layers/dcu/
+// deepseek_v2_attention.cpp:212-262: torch SDPA rounds the probabilities to the tensor dtype) -- half the PV MFMAs of the
+// hi + lo form, which remains selectable (XLLM_MI355_MLA_PREFILL_P=2)
+template <typename T, bool P1>
 __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, const int32_t* __restrict__ block_table,
     int max_blocks, int n_heads, int block_size, float scale_log2, const int32_t* __restrict__ q_seq,
@@ -750,7 +753,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
           psum += p;
           const elem h = (elem)p;
           pf[tb >> 1][(tb & 1) * 4 + r] = h;
-          pl[tb >> 1][(tb & 1) * 4 + r] = (elem)(p - (float)h);
+          if constexpr (!P1) pl[tb >> 1][(tb & 1) * 4 + r] = (elem)(p - (float)h);
         }
       l_run = l_run * alpha + psum;
       if (__any(alpha != 1.0f)) {
@@ -782,8 +785,10 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_dma_kernel(
     const x8 vb8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[((I_) + 1) & 7][0]), __builtin_bit_cast(x4, vt[((I_) + 1) & 7][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
     acc_o[(I_) & 31] = TR::mfma(va8, pf[(I_) >> 5], acc_o[(I_) & 31]);                                         \
     acc_o[((I_) + 1) & 31] = TR::mfma(vb8, pf[(I_) >> 5], acc_o[((I_) + 1) & 31]);                             \
-    acc_o[(I_) & 31] = TR::mfma(va8, pl[(I_) >> 5], acc_o[(I_) & 31]);                                         \
-    acc_o[((I_) + 1) & 31] = TR::mfma(vb8, pl[(I_) >> 5], acc_o[((I_) + 1) & 31]);                             \
+    if constexpr (!P1) {                                                                                       \
+      acc_o[(I_) & 31] = TR::mfma(va8, pl[(I_) >> 5], acc_o[(I_) & 31]);                                       \
+      acc_o[((I_) + 1) & 31] = TR::mfma(vb8, pl[(I_) >> 5], acc_o[((I_) + 1) & 31]);                           \
+    }                                                                                                          \
   }
 #define MLP_V_ST(I_) MLP_V_MM2(I_, 12) MLP_V_RD((I_) + 8) MLP_V_RD((I_) + 9)
 #define MLP_V_ST8(B_) MLP_V_ST(B_) MLP_V_ST(B_ + 2) MLP_V_ST(B_ + 4) MLP_V_ST(B_ + 6)
@@ -952,11 +957,24 @@ extern "C" int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* 
   const int64_t n_groups = (total_q_tokens + 3) / 4, hblocks = (n_heads + 15) / 16;
   if (block_size % kMlaTile == 0 && share_mode != 0 && (share_mode == 1 || n_groups * hblocks >= 128)) {
     const dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * hblocks));
-    XM_DISPATCH_HALF(dtype, T, {
-      hipLaunchKernelGGL((mla_prefill_dma_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
-                         block_table, (int)max_blocks, (int)n_heads, (int)block_size, scale * 1.4426950408889634f, q_seq,
-                         q_kvlen, (int)total_q_tokens, (int)n_groups);
-    });
+    static int p_mode = -2;
+    if (p_mode == -2) {
+      const char* e = getenv("XLLM_MI355_MLA_PREFILL_P");
+      p_mode = e ? atoi(e) : 1;
+    }
+    if (p_mode == 2) {
+      XM_DISPATCH_HALF(dtype, T, {
+        hipLaunchKernelGGL((mla_prefill_dma_kernel<T, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache,
+                           (T*)out, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                           scale * 1.4426950408889634f, q_seq, q_kvlen, (int)total_q_tokens, (int)n_groups);
+      });
+    } else {
+      XM_DISPATCH_HALF(dtype, T, {
+        hipLaunchKernelGGL((mla_prefill_dma_kernel<T, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache,
+                           (T*)out, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                           scale * 1.4426950408889634f, q_seq, q_kvlen, (int)total_q_tokens, (int)n_groups);
+      });
+    }
     return hip_check_launch();
   }
   return launch_mla(q, k_cache, out, kv_lens, q_seq, q_kvlen, block_table, max_blocks, total_q_tokens, n_heads,
