@@ -1222,10 +1222,18 @@ def test_dual_micro_batch_decoder_equals_single_batch_step():
     positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
     ref = model.forward(tokens, positions, md, caches).clone()
     dual = layers.DualBatchDecoder(model, md, B)
-    for _ in range(3):   # repeated runs: stream ordering must hold every time
+    for it in range(3):   # repeated runs: stream ordering must hold every time
         out = dual.forward(tokens, positions, caches)
         torch.cuda.synchronize()
-        assert torch.equal(out, ref)
+        bad = ((out.float() - ref.float()).abs().amax(-1) > 0).nonzero().flatten().tolist()
+        assert not bad, (it, len(bad), bad[:6], bad[-3:])
+    dual.close()
+    for _ in range(6):   # the library keeps 8 per-stream scratch slots: decoders that come and go must give theirs back
+        d2 = layers.DualBatchDecoder(model, md, B)
+        d2.close()
+    d3 = layers.DualBatchDecoder(model, md, B)
+    assert torch.equal(d3.forward(tokens, positions, caches), ref)
+    d3.close()
 
 
 def test_deepseek_v2_attention_layer_matches_a_plain_restatement():

@@ -30,27 +30,46 @@ __global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict
   for (int e = threadIdx.x; e < E; e += blockDim.x) chunk_cnt[(int64_t)blockIdx.x * E + e] = h[e];
 }
 
-// pass 2 (one workgroup, one thread per expert): expert sizes, expert offsets (exclusive scan over experts), and
-// per-chunk bases chunk_cnt[c][e] <- offset[e] + sum_{c' < c} cnt[c'][e]
+// pass 2 (one workgroup): expert sizes, expert offsets (exclusive scan over experts), and per-chunk bases
+// chunk_cnt[c][e] <- offset[e] + sum_{c' < c} cnt[c'][e]. The 1024 threads are (expert, part): 1024 / Epad parts share the
+// chunks of an expert, so the chain of dependent loads per thread is nchunks / parts long instead of nchunks (64 chunks at
+// T * topk = 65536, E = 128: 8 instead of 64 -- the kernel is pure latency).
 __global__ __launch_bounds__(1024) void moe_scan_kernel(int32_t* __restrict__ chunk_cnt, int nchunks, int E,
                                                         int32_t* __restrict__ expert_sizes) {
   __shared__ int32_t incl[kMaxExperts];
-  const int e = threadIdx.x;
+  __shared__ int32_t part_sum[kMaxExperts];   // [part][e], parts * Epad == 1024
+  int epad = 1;
+  while (epad < E) epad <<= 1;
+  const int parts = kMaxExperts / epad;
+  const int e = threadIdx.x & (epad - 1), part = threadIdx.x / epad;
+  const int per = (nchunks + parts - 1) / parts;
+  const int c0 = part * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
   int32_t s = 0;
   if (e < E)
-    for (int c = 0; c < nchunks; ++c) s += chunk_cnt[(int64_t)c * E + e];
-  if (e < E) expert_sizes[e] = s;
-  incl[e] = s;
+    for (int c = c0; c < c1; ++c) s += chunk_cnt[(int64_t)c * E + e];
+  part_sum[part * epad + e] = s;
+  __syncthreads();
+  int32_t tot = 0, before = 0;   // the expert's size and the rows of the parts in front of this one
+  for (int p = 0; p < parts; ++p) {
+    const int32_t v = part_sum[p * epad + e];
+    tot += v;
+    before += p < part ? v : 0;
+  }
+  const int t = threadIdx.x;     // the scan over experts runs on threads 0 .. 1023 = expert index (part 0 holds the sizes)
+  if (part == 0 && e < E) expert_sizes[e] = tot;
+  __syncthreads();
+  incl[t] = 0;
+  if (part == 0) incl[e] = e < E ? tot : 0;
   __syncthreads();
   for (int d = 1; d < kMaxExperts; d <<= 1) {  // Hillis-Steele inclusive scan over the experts
-    const int32_t v = e >= d ? incl[e - d] : 0;
+    const int32_t v = t >= d ? incl[t - d] : 0;
     __syncthreads();
-    incl[e] += v;
+    incl[t] += v;
     __syncthreads();
   }
   if (e < E) {
-    int32_t run = incl[e] - s;
-    for (int c = 0; c < nchunks; ++c) {
+    int32_t run = incl[e] - tot + before;
+    for (int c = c0; c < c1; ++c) {
       const int32_t v = chunk_cnt[(int64_t)c * E + e];
       chunk_cnt[(int64_t)c * E + e] = run;
       run += v;

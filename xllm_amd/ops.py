@@ -237,6 +237,7 @@ def _ensure_gemm_workspace(device, nbytes=0):
         ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
         _gemm_ws[device] = ws
         check(_lib.lib().xllm_mi355_set_gemm_workspace(ws.data_ptr(), ws.numel()), "set_gemm_workspace")
+        torch.cuda.synchronize(device)          # the zeroing memset runs on the null stream
     return ws.numel()
 
 
@@ -296,6 +297,9 @@ def set_gemm_workspace_for_stream(stream: "torch.cuda.Stream", nbytes: int) -> N
     _stream_ws[stream.cuda_stream] = ws
     _slab_ws[(stream.device, stream.cuda_stream)] = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=stream.device)
     _private_streams.add(stream.cuda_stream)
+    check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, ws.data_ptr(), ws.numel()),
+          "set_gemm_workspace_for_stream")     # (the C side zeroes it: the int8 split-K scratch is zero at rest)
+    torch.cuda.synchronize(stream.device)       # that memset runs on the null stream; side streams do not wait for it
 
 
 def release_stream_workspaces(stream: "torch.cuda.Stream") -> None:
@@ -305,8 +309,6 @@ def release_stream_workspaces(stream: "torch.cuda.Stream") -> None:
     _attn_ws.pop((stream.device, stream.cuda_stream), None)
     _private_streams.discard(stream.cuda_stream)
     check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, 0, 0), "release gemm workspace")
-    check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, ws.data_ptr(), ws.numel()),
-          "set_gemm_workspace_for_stream")
 
 
 def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, acc_out=None,
