@@ -27,15 +27,16 @@ def _msg(rank, i, n, dtype):
     return (torch.randn(n, generator=g) * (1 + rank)).to(dtype)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, distinct):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(0)
+    dev = rank if distinct else 0
+    torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from xllm_amd import parallel
     pg = parallel.ProcessGroup(dist.group.WORLD, rank, world)
     res = {"ok": True, "log": []}
     try:
-        ar = pg.enable_oneshot("cuda:0", max_bytes=4 << 20)
+        ar = pg.enable_oneshot(f"cuda:{dev}", max_bytes=4 << 20)
         res["kind"] = ar.kind
         sizes = [8, 3584, 256 * 3584, 917504, 24, 2 << 20, 256 * 3584, 8, 4096, 1 << 20, 40, 256 * 3584]
         for i, n in enumerate(sizes):
@@ -79,7 +80,7 @@ def _worker(rank, world, port, ret):
         dist.barrier()
         if rank == 0:
             ar.timeout_s = 0.2
-            lonely = torch.ones(4096, dtype=torch.bfloat16, device="cuda")
+            lonely = torch.ones(4096, dtype=torch.bfloat16, device=f"cuda:{dev}")
             ar.allreduce(lonely)
             torch.cuda.synchronize()
             try:
@@ -98,10 +99,14 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(300)
-def test_two_processes_one_gpu_protocol():
+@pytest.mark.parametrize("distinct", [False, True], ids=["two_processes_one_gpu", "one_gpu_per_rank"])
+def test_oneshot_allreduce_protocol(distinct):
+    """`one_gpu_per_rank` is the real thing (flags and data cross xGMI) and needs a node with >= 2 GPUs"""
+    if distinct and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ret, distinct), nprocs=2, join=True)
     for r in range(2):
         assert ret[r]["ok"], ret[r]["log"]
     assert ret[0].get("timeout_reported") is True
