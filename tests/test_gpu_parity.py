@@ -337,6 +337,45 @@ def test_matmul_16bit(dtype):
     assert_ulp_close(out, ref, dtype, ulps=2.0, min_exact=0.95)  # MFMA block-sum order vs serial fp32 sum
 
 
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 32, 33, 48, 64])
+@pytest.mark.parametrize("N,K,dtype", [(256, 512, torch.bfloat16), (4608, 3584, torch.bfloat16), (3584, 2048, torch.float16)])
+def test_matmul_weight_stream_rows(M, N, K, dtype):
+    """the weight-stream kernel of the 16-bit decode linears (gemm_wsb.hip: M <= 64, N % 64 == 0): every row-block count,
+    K slices through fp32 slabs (few columns) and none (many), bias, against the oracle (fp32 sum in another order) and the
+    fp64 product; identical bits run to run"""
+    g = torch.Generator().manual_seed(M * 31 + N)
+    a = (torch.randn(M, K, generator=g) * 0.7).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g).to(dtype)
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    out = ops.matmul(ad, wd, bd)
+    assert torch.equal(out, ops.matmul(ad, wd, bd))
+    assert_ulp_close(out, orc.matmul(a, w, b), dtype, ulps=1.0, min_exact=0.97)
+    ref64 = (a.double() @ w.double().T + b.double())
+    assert ((out.cpu().double() - ref64).abs() <= ULP[dtype] * (ref64.abs() * 2 + 0.5 * ref64.abs().mean())).all()
+    assert torch.equal(ops.matmul(ad, wd), ops.matmul(ad, wd, torch.zeros_like(bd)))      # no bias == zero bias
+
+
+def test_group_gemm_few_rows_per_expert():
+    """MoE decode shape: a handful of rows per expert (gemm_wsb.hip grouped form): experts without a row, experts with more
+    than one 16-row pass, the expand fused as an index (group_gemm_gather == index_select + group_gemm bit for bit)"""
+    T, topk, E, H, N = 24, 4, 32, 512, 384
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(0, E, (T, topk), generator=g, dtype=torch.int32)
+    ids[:20, 0] = 5                                           # expert 5 gets >= 20 rows: two passes of 16
+    ids[ids == 7] = 8                                         # expert 7 gets none
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids.to(DEV), E)
+    assert int(sizes[5]) >= 20 and int(sizes[7]) == 0
+    x = torch.randn(T, H, generator=g).bfloat16()
+    w = (torch.randn(E, N, H, generator=g) / math.sqrt(H)).bfloat16()
+    xs = x[(dst_src.cpu().long() // topk)]
+    got = ops.group_gemm(xs.to(DEV), w.to(DEV), sizes)
+    ref = orc.group_gemm(xs, w, sizes.cpu())
+    assert_ulp_close(got, ref, torch.bfloat16, ulps=1.0, min_exact=0.97)
+    fused = ops.group_gemm_gather(x.to(DEV), dst_src, topk, w.to(DEV), sizes)
+    assert fused is not None and torch.equal(fused, got)
+
+
 # ------------------------------------------------------------------------------------------- attention
 def _paged_case(B, nq, nkv, d, bs, kv_lens, q_lens, dtype, seed, noise=1.0):
     g = torch.Generator().manual_seed(seed)

@@ -8,7 +8,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmul_16bit or gemm_add_norm"
+SELECT = ("scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmul_16bit or gemm_add_norm or group_gemm "
+          "or matmul_weight_stream")
 
 
 @pytest.mark.parametrize("env", [
@@ -21,7 +22,10 @@ SELECT = "scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matmu
     {"XLLM_MI355_SKINNY_BM128": "0"},                         # decode kernel on 256-row tiles for M <= 128 too
     {"XLLM_MI355_ASTAT": "1"},                                # activation-stationary decode kernel (gemm_astat.hip)
     {"XLLM_MI355_ASTAT": "1", "XLLM_MI355_ASTAT_SPLITS": "3"},
-], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256", "astat", "astat_split3"])
+    {"XLLM_MI355_WSB": "0"},                                  # 16-bit decode linears / few-row experts on the tiled kernels
+    {"XLLM_MI355_WSB_SLICES": "3"},                           # weight-stream 16-bit kernel with a forced K-slice count
+], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256", "astat", "astat_split3",
+        "wsb_off", "wsb_slices3"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

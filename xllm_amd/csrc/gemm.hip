@@ -972,6 +972,12 @@ int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out,
   void* ws = nullptr;
   size_t ws_bytes = 0;
   gemm_ws_for(stream, &ws, &ws_bytes);
+  if (M <= 64) {  // one pass over the weights: the weight-stream kernel (gemm_wsb.hip); declines shapes that are not its own
+    const int rc = dtype == XM_BF16
+                       ? launch_gemm_wsb_dense<bf16_t>(a, w, bias, out, M, N, K, ws, ws_bytes, (hipStream_t)stream)
+                       : launch_gemm_wsb_dense<f16_t>(a, w, bias, out, M, N, K, ws, ws_bytes, (hipStream_t)stream);
+    if (rc != XM_ERR_UNSUPPORTED) return rc;
+  }
   if (dtype == XM_BF16) return launch_gemm<kBF16>(a, w, M, N, K * 2, epi, ws, ws_bytes, (hipStream_t)stream);
   return launch_gemm<kF16>(a, w, M, N, K * 2, epi, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -986,6 +992,13 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   if (max_rows == 0) return XM_OK;
   GemmEpi epi{nullptr, 0, nullptr, 0, nullptr, out, nullptr, dtype == XM_BF16, token_count, (int)n_experts};
   hipStream_t s = (hipStream_t)stream;
+  if (max_rows <= 16 * n_experts) {  // a handful of rows per expert (MoE decode): one pass over the live experts' weights
+    const int rc = dtype == XM_BF16 ? launch_gemm_wsb_grouped<bf16_t>(a, w, token_count, out, max_rows, n_experts, N, K,
+                                                                      gather_rows, gather_div, s)
+                                    : launch_gemm_wsb_grouped<f16_t>(a, w, token_count, out, max_rows, n_experts, N, K,
+                                                                     gather_rows, gather_div, s);
+    if (rc != XM_ERR_UNSUPPORTED) return rc;
+  }
   // 256x256 8-phase kernel behind a device-built tile table (kept in the tail of the MoE scratch); the 128x128 kernel
   // with its per-workgroup expert walk is the fallback (no scratch registered, shape outside the 8-phase envelope)
   static int p8_mode = -2;  // XLLM_MI355_GROUP_P8=0: 128x128 kernel only (A/B), read once

@@ -194,4 +194,13 @@ int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64
                       size_t ws_bytes, int* n_slabs, hipStream_t s);
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s);
 
+// gemm_wsb.hip: weight-stream GEMM for 16-bit weights at decode shapes (dense M <= 64, grouped with few rows per expert)
+template <typename T>
+int launch_gemm_wsb_dense(const void* x, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                          void* workspace, size_t ws_bytes, hipStream_t s);
+template <typename T>
+int launch_gemm_wsb_grouped(const void* x, const void* w, const int32_t* counts, void* out, int64_t max_rows,
+                            int64_t n_experts, int64_t N, int64_t K, const int32_t* row_index, int64_t index_div,
+                            hipStream_t s);
+
 }  // namespace xm

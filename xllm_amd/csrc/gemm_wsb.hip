@@ -1,0 +1,335 @@
+// gemm_wsb.hip -- weight-stream GEMM for 16-bit weights at decode shapes (M <= 64 rows per problem), dense and grouped.
+//
+// Operators served: kernel::matmul (ops_api.h:48 -> kernels/dcu/matmul.cpp:20-25, F::linear) for the bf16 / f16 linears of a
+// decode step (cfg2: Qwen2-7B bf16, B = 64), and kernel::group_gemm (ops_api.h:77 -> kernels/dcu/group_gemm.cpp:25-74) when
+// the experts hold a handful of rows each (MoE decode: 128 tokens x top-8 over 256 experts = 4 rows per expert).
+//
+// At these shapes the problem is ONE pass over the weights: out[m][n] = sum_k x[m][k] w[n][k] with every byte of w used
+// once. So there is no LDS stage and no barrier in the K loop -- the structure of the paged-decode attention kernel:
+//   * workgroup = 64 output columns x all rows x one K slice; its 4 waves split the K steps of the slice round-robin, each
+//     wave owns ALL 64 columns and ALL rows for its steps (no operand is loaded twice inside a workgroup);
+//   * w goes HBM -> VGPR directly in MFMA-operand order: w is the MFMA *row* operand (D[n][m]), lane (n = l & 15,
+//     kq = l >> 4) loads the 32 contiguous bytes w[n][64 s + 16 kq .. +16) of K step s -- four lanes cover one 128-byte line
+//     of a row -- and feeds two v_mfma_f32_16x16x32 (k permutation identical on both operands); x (<= 64 rows, L2-resident)
+//     is loaded the same way as the column operand;
+//   * one K step (16 KiB of operands per wave at 64 rows) is in flight in registers underneath the previous step's 32 MFMAs;
+//   * the four waves' fp32 partial tiles meet in LDS once, at the end, and are summed in wave order; K slices (few-column
+//     problems: qkv / o / down) leave fp32 slabs that a second kernel adds in slice order -- deterministic, no atomics.
+// A lane of the accumulator holds 4 consecutive n of one row, so partial tiles move as 16-byte LDS stores and the 16-bit
+// result leaves as 8-byte stores of whole 128-byte row segments.
+//
+// Grouped form: blockIdx.y = expert; the workgroup finds its expert's rows from the device-side sizes (prefix sum over
+// <= 1024 experts in registers), leaves at once when the expert has no row (its weights are never read), and walks the
+// expert's rows 16 at a time; the expand of the reference (index_select(hidden, dst_src / topk)) is an index on the x rows.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace xm {
+
+typedef __bf16 wsb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wsb_f16x8 __attribute__((ext_vector_type(8)));
+typedef float wsb_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wsb_u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct WsbTraits;
+template <>
+struct WsbTraits<bf16_t> {
+  static __device__ __forceinline__ wsb_f32x4 mfma(wsb_u32x4 a, wsb_u32x4 b, wsb_f32x4 c) {
+    wsb_bf16x8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+  }
+};
+template <>
+struct WsbTraits<f16_t> {
+  static __device__ __forceinline__ wsb_f32x4 mfma(wsb_u32x4 a, wsb_u32x4 b, wsb_f32x4 c) {
+    wsb_f16x8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+  }
+};
+
+constexpr int kWsbCols = 64;        // output columns per workgroup = 4 MFMA column blocks
+constexpr int kWsbK = 64;           // k elements per step = two MFMAs
+constexpr int kWsbPad = 64;         // floats per LDS row of a partial tile; the 16 float4 of a row are XOR-swizzled by the row
+                                    // (lanes of one store hold 16 different rows: without it a 16-way bank conflict)
+
+struct WsbGroup {
+  const int32_t* counts;      // rows per expert (device), null = dense
+  const int32_t* row_index;   // sorted row r reads x row row_index[r] / index_div (null: x row r)
+  int n_experts, index_div;
+};
+
+// hipcc moves plain loads of a software pipeline next to their use (below a mid-loop exit, or behind the compute of a
+// counted loop: both seen in the ISA of the first two versions of this kernel), so the operand loads are inline asm, retired by
+// counted s_waitcnt that carry the stage's registers as operands (the MFMAs cannot be scheduled above them)
+#define WSB_LD(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
+
+template <typename T, int MB>
+__device__ __forceinline__ void wsb_issue(wsb_u32x4 (&wr)[4][2], wsb_u32x4 (&xr)[MB][2], const T* const (&wrow)[4],
+                                          const T* const (&xrow)[MB], int64_t koff) {
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const T* p = wrow[nb] + koff;
+    WSB_LD(wr[nb][0], p, 0);
+    WSB_LD(wr[nb][1], p, 16);
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const T* p = xrow[mb] + koff;
+    WSB_LD(xr[mb][0], p, 0);
+    WSB_LD(xr[mb][1], p, 16);
+  }
+}
+
+// wait until at most CNT vector loads are outstanding; the stage's registers are in/out operands
+template <int MB, int CNT>
+__device__ __forceinline__ void wsb_wait(wsb_u32x4 (&wr)[4][2], wsb_u32x4 (&xr)[MB][2]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(wr[0][0]), "+v"(wr[0][1]), "+v"(wr[1][0]), "+v"(wr[1][1]), "+v"(wr[2][0]), "+v"(wr[2][1]),
+                 "+v"(wr[3][0]), "+v"(wr[3][1])
+               : "n"(CNT));
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) asm volatile("" : "+v"(xr[mb][0]), "+v"(xr[mb][1]));
+}
+
+template <typename T, int MB, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                       T* __restrict__ out, float* __restrict__ slabs,
+                                                       const T* __restrict__ bias, int M, int N, int K, int steps_per_slice,
+                                                       WsbGroup grp) {
+  using TR = WsbTraits<T>;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][16 MB rows][kWsbPad]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * kWsbCols;
+  const int n_steps = K / kWsbK;
+
+  int row0 = 0, cnt = M, slice = 0;
+  const T* wb = w;
+  if constexpr (GROUPED) {
+    const int e = blockIdx.y;
+    int before = 0;
+    for (int i = lane; i < e; i += 64) before += grp.counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    row0 = __builtin_amdgcn_readfirstlane(before);
+    cnt = grp.counts[e];
+    if (cnt <= 0) return;                       // the expert's weights are never touched
+    wb = w + (int64_t)e * N * K;
+  } else {
+    slice = blockIdx.y;
+  }
+  const int s_lo = slice * steps_per_slice;
+  int s_hi = s_lo + steps_per_slice;
+  s_hi = s_hi < n_steps ? s_hi : n_steps;
+  // this wave's steps: s_lo + wave, + 4, ... (a wave without a step adds a zero tile)
+  const int my_first = s_lo + wave;
+  const int my_n = my_first < s_hi ? (s_hi - my_first + 3) / 4 : 0;
+
+  // per-lane row pointers of w: 4 column blocks
+  const T* wrow[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) wrow[nb] = wb + (int64_t)(n0 + nb * 16 + p16) * K + kq * 16;
+
+  for (int rb0 = 0; rb0 < cnt; rb0 += 16 * MB) {
+    const T* xrow[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      int r = rb0 + mb * 16 + p16;
+      r = r < cnt ? r : cnt - 1;               // rows past the end re-read the last row; their results are not stored
+      int64_t src = row0 + r;
+      if constexpr (GROUPED) {
+        if (grp.row_index) src = grp.row_index[src] / grp.index_div;
+      }
+      xrow[mb] = x + src * (int64_t)K + kq * 16;
+    }
+    wsb_f32x4 acc[4][MB];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = wsb_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // two named register stages; every load is unconditional: a step past the wave's range re-loads its last step
+    wsb_u32x4 w0[4][2], x0[MB][2], w1[4][2], x1[MB][2];
+    constexpr int kLoads = 8 + 2 * MB;   // vector loads per stage
+    auto koff_of = [&](int i) -> int64_t {
+      i = i < my_n ? i : my_n - 1;
+      return (int64_t)(my_first + 4 * i) * kWsbK;
+    };
+    if (my_n > 0) {
+      wsb_issue<T, MB>(w0, x0, wrow, xrow, koff_of(0));
+      for (int i = 0; i < my_n; i += 2) {
+        wsb_issue<T, MB>(w1, x1, wrow, xrow, koff_of(i + 1));
+        wsb_wait<MB, kLoads>(w0, x0);                     // stage 0 has landed, stage 1 stays in flight
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = TR::mfma(w0[nb][h], x0[mb][h], acc[nb][mb]);
+        wsb_issue<T, MB>(w0, x0, wrow, xrow, koff_of(i + 2));
+        wsb_wait<MB, kLoads>(w1, x1);
+        if (i + 1 < my_n) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+              for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = TR::mfma(w1[nb][h], x1[mb][h], acc[nb][mb]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (redundant) prefetch
+    }
+
+    // partial tiles -> LDS: lane holds D[n = nb*16 + 4 kq + r][m = mb*16 + p16]: 4 consecutive n of one row
+    float* mine = red + wave * (16 * MB * kWsbPad);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        *reinterpret_cast<wsb_f32x4*>(mine + (mb * 16 + p16) * kWsbPad + (((nb * 4 + kq) ^ p16) << 2)) = acc[nb][mb];
+    __syncthreads();
+    int rows = cnt - rb0;
+    rows = rows < 16 * MB ? rows : 16 * MB;
+    for (int idx = threadIdx.x; idx < rows * 16; idx += 256) {
+      const int m = idx >> 4, c4 = (idx & 15) * 4;
+      const int sw = ((idx & 15) ^ (m & 15)) << 2;
+      wsb_f32x4 v = *reinterpret_cast<const wsb_f32x4*>(red + m * kWsbPad + sw);
+#pragma unroll
+      for (int wv = 1; wv < 4; ++wv) {
+        const wsb_f32x4 t = *reinterpret_cast<const wsb_f32x4*>(red + wv * (16 * MB * kWsbPad) + m * kWsbPad + sw);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      }
+      const int64_t o = (int64_t)(row0 + rb0 + m) * N + n0 + c4;
+      if (slabs) {
+        *reinterpret_cast<wsb_f32x4*>(slabs + (int64_t)slice * M * N + o) = v;
+      } else {
+        uint16_t hv[4];
+        T bv[4];
+        if (bias) {
+          const uint2 braw = *reinterpret_cast<const uint2*>(bias + n0 + c4);   // 8-byte aligned (checked on the host)
+          __builtin_memcpy(bv, &braw, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = bias ? to_f32<T>(bv[j]) : 0.0f;
+          const T t = from_f32<T>(v[j] + b);
+          __builtin_memcpy(&hv[j], &t, 2);
+        }
+        *reinterpret_cast<uint2*>(out + o) =
+            make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+      }
+    }
+    __syncthreads();   // the next row pass reuses the LDS tiles
+  }
+}
+
+// K slices: out = sum of the fp32 slabs IN SLICE ORDER (+ bias); the slabs are re-zeroed (the registered GEMM scratch is
+// zero at rest: the int8 split-K path relies on it)
+template <typename T>
+__global__ __launch_bounds__(256) void wsb_reduce_kernel(float* __restrict__ slabs, T* __restrict__ out,
+                                                         const T* __restrict__ bias, int64_t M, int64_t N, int slices) {
+  const int64_t total = M * N;
+  for (int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; idx < total; idx += (int64_t)gridDim.x * 1024) {
+    wsb_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < slices; ++sl) {
+      wsb_f32x4* p = reinterpret_cast<wsb_f32x4*>(slabs + (int64_t)sl * total + idx);
+      const wsb_f32x4 v = *p;
+      *p = wsb_f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    const int64_t n = idx % N;
+    uint16_t hv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = bias ? to_f32<T>(bias[n + j]) : 0.0f;
+      const T t = from_f32<T>(acc[j] + b);
+      __builtin_memcpy(&hv[j], &t, 2);
+    }
+    *reinterpret_cast<uint2*>(out + idx) =
+        make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
+  }
+}
+
+static int g_wsb_mode = -2, g_wsb_slices = -2;
+static void wsb_env() {
+  if (g_wsb_mode == -2) {
+    const char* e = getenv("XLLM_MI355_WSB");          // 0: never (A/B against the tiled kernels), default 1
+    g_wsb_mode = e ? atoi(e) : 1;
+    e = getenv("XLLM_MI355_WSB_SLICES");               // force the K-slice count of the dense form
+    g_wsb_slices = e ? atoi(e) : -1;
+  }
+}
+
+template <typename T, int MB, bool GROUPED>
+static void wsb_launch(dim3 grid, hipStream_t s, const T* x, const T* w, T* out, float* slabs, const T* bias, int M, int N,
+                       int K, int per, WsbGroup g) {
+  const size_t lds = (size_t)4 * 16 * MB * kWsbPad * sizeof(float);   // 16 / 32 / 64 KiB
+  hipLaunchKernelGGL((gemm_wsb_kernel<T, MB, GROUPED>), grid, dim3(256), lds, s, x, w, out, slabs, bias, M, N, K, per, g);
+}
+
+// dense: returns XM_ERR_UNSUPPORTED when the shape is not this kernel's (the caller keeps its tiled kernels)
+template <typename T>
+int launch_gemm_wsb_dense(const void* x, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                          void* workspace, size_t ws_bytes, hipStream_t s) {
+  wsb_env();
+  if (!g_wsb_mode || M <= 0 || M > 64 || N % kWsbCols || K % kWsbK || K / kWsbK < 4 || N * K >= (1ll << 40) ||
+      ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8) || ((uintptr_t)bias % 8))
+    return XM_ERR_UNSUPPORTED;
+  const int n_tiles = (int)(N / kWsbCols), n_steps = (int)(K / kWsbK);
+  // K slices: enough workgroups for every CU (two per CU fit), every wave of a slice keeps >= 2 steps, slabs fit
+  int slices = 1;
+  while (n_tiles * slices < 256 && slices < 8 && n_steps / (slices + 1) >= 8 &&
+         (size_t)(slices + 1) * M * N * 4 <= ws_bytes)
+    ++slices;
+  if (g_wsb_slices > 0 && (size_t)g_wsb_slices * M * N * 4 <= ws_bytes && n_steps / g_wsb_slices >= 1) slices = g_wsb_slices;
+  if (!workspace) slices = 1;
+  const int per = (n_steps + slices - 1) / slices;
+  slices = (n_steps + per - 1) / per;
+  float* slabs = slices > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  const dim3 grid((unsigned)n_tiles, (unsigned)slices);
+  const WsbGroup g{nullptr, nullptr, 0, 1};
+  if (M <= 16) wsb_launch<T, 1, false>(grid, s, (const T*)x, (const T*)w, (T*)out, slabs, (const T*)bias, (int)M, (int)N, (int)K, per, g);
+  else if (M <= 32) wsb_launch<T, 2, false>(grid, s, (const T*)x, (const T*)w, (T*)out, slabs, (const T*)bias, (int)M, (int)N, (int)K, per, g);
+  else wsb_launch<T, 4, false>(grid, s, (const T*)x, (const T*)w, (T*)out, slabs, (const T*)bias, (int)M, (int)N, (int)K, per, g);
+  if (slices > 1) {
+    int64_t blocks = (M * N / 4 + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL((wsb_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, slabs, (T*)out, (const T*)bias, M, N,
+                       slices);
+  }
+  return hip_check_launch();
+}
+
+// grouped: experts with a handful of rows each (max_rows <= 16 * n_experts on average); any count is handled (16 rows per pass)
+template <typename T>
+int launch_gemm_wsb_grouped(const void* x, const void* w, const int32_t* counts, void* out, int64_t max_rows,
+                            int64_t n_experts, int64_t N, int64_t K, const int32_t* row_index, int64_t index_div,
+                            hipStream_t s) {
+  wsb_env();
+  if (!g_wsb_mode || n_experts > 65535 || N % kWsbCols || K % kWsbK || max_rows > 16 * n_experts ||
+      ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8))
+    return XM_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(N / kWsbCols), (unsigned)n_experts);
+  const WsbGroup g{counts, row_index, (int)n_experts, (int)(index_div > 0 ? index_div : 1)};
+  wsb_launch<T, 1, true>(grid, s, (const T*)x, (const T*)w, (T*)out, nullptr, nullptr, (int)max_rows, (int)N, (int)K,
+                         (int)(K / kWsbK), g);
+  return hip_check_launch();
+}
+
+template int launch_gemm_wsb_dense<bf16_t>(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, void*,
+                                           size_t, hipStream_t);
+template int launch_gemm_wsb_dense<f16_t>(const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, void*,
+                                          size_t, hipStream_t);
+template int launch_gemm_wsb_grouped<bf16_t>(const void*, const void*, const int32_t*, void*, int64_t, int64_t, int64_t,
+                                             int64_t, const int32_t*, int64_t, hipStream_t);
+template int launch_gemm_wsb_grouped<f16_t>(const void*, const void*, const int32_t*, void*, int64_t, int64_t, int64_t,
+                                            int64_t, const int32_t*, int64_t, hipStream_t);
+
+}  // namespace xm
