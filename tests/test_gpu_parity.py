@@ -373,7 +373,9 @@ def test_group_gemm_few_rows_per_expert():
     ref = orc.group_gemm(xs, w, sizes.cpu())
     assert_ulp_close(got, ref, torch.bfloat16, ulps=1.0, min_exact=0.97)
     fused = ops.group_gemm_gather(x.to(DEV), dst_src, topk, w.to(DEV), sizes)
-    assert fused is not None and torch.equal(fused, got)
+    if os.environ.get("XLLM_MI355_WSB", "1") != "0":          # (the tiled fallback declines the fused expand at this size)
+        assert fused is not None
+    assert fused is None or torch.equal(fused, got)
 
 
 # ------------------------------------------------------------------------------------------- attention
@@ -1074,8 +1076,16 @@ def test_model_prefill_chunked_prefill_and_decode_agree(mode):
         assert ((other - one_shot).norm() / one_shot.norm()).item() <= 2e-2
         assert torch.equal(other.argmax(-1), one_shot.argmax(-1)) or \
             ((other - one_shot).abs().max() / one_shot.abs().max()).item() <= 2e-2
-    # the KV caches written by the three schedules hold the same rows (layer 0 is bit-identical: same inputs, same kernel)
-    assert torch.equal(kv_b[0].k_cache, kv_c[0].k_cache)
+    # the KV caches written by the three schedules hold the same rows. Layer 0 sees the same inputs in every schedule: with
+    # int8 linears (exact integer sums whatever the kernel) its rows are bit-identical; with 16-bit linears a schedule that
+    # feeds <= 64 tokens runs the weight-stream GEMM and one that feeds more the tiled kernels (another fp32 summation
+    # order), so the rows agree to one 16-bit ulp
+    ka, kb = kv_b[0].k_cache.float(), kv_c[0].k_cache.float()
+    if mode == "int8":
+        assert torch.equal(kv_b[0].k_cache, kv_c[0].k_cache)
+    else:
+        assert ((ka - kb).abs() <= 2.0 ** -7 * torch.maximum(ka.abs(), kb.abs()) + 1e-6).all()
+        assert (ka == kb).float().mean().item() >= 0.9
 
 
 # ------------------------------------------------------------------------------------------- N3 sampler

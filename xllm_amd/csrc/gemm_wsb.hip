@@ -67,26 +67,27 @@ struct WsbGroup {
 // hipcc moves plain loads of a software pipeline next to their use (below a mid-loop exit, or behind the compute of a
 // counted loop: both seen in the ISA of the first two versions of this kernel), so the operand loads are inline asm, retired by
 // counted s_waitcnt that carry the stage's registers as operands (the MFMAs cannot be scheduled above them)
-#define WSB_LD(DST, PTR, OFF) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=v"(DST) : "v"(PTR))
+// (scalar base + 32-bit lane offset: the K walk lives in SGPRs, one VGPR per row pointer)
+#define WSB_LD(DST, VOFF, SBASE, OFF) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(VOFF), "s"(SBASE))
 
-template <typename T, int MB>
-__device__ __forceinline__ void wsb_issue(wsb_u32x4 (&wr)[4][2], wsb_u32x4 (&xr)[MB][2], const T* const (&wrow)[4],
-                                          const T* const (&xrow)[MB], int64_t koff) {
+__device__ __forceinline__ void wsb_issue_w(wsb_u32x4 (&wr)[4][2], const uint32_t (&woff)[4], const char* base) {
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    const T* p = wrow[nb] + koff;
-    WSB_LD(wr[nb][0], p, 0);
-    WSB_LD(wr[nb][1], p, 16);
+    WSB_LD(wr[nb][0], woff[nb], base, 0);
+    WSB_LD(wr[nb][1], woff[nb], base, 16);
   }
+}
+template <int MB>
+__device__ __forceinline__ void wsb_issue_x(wsb_u32x4 (&xr)[MB][2], const uint32_t (&xoff)[MB], const char* base) {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const T* p = xrow[mb] + koff;
-    WSB_LD(xr[mb][0], p, 0);
-    WSB_LD(xr[mb][1], p, 16);
+    WSB_LD(xr[mb][0], xoff[mb], base, 0);
+    WSB_LD(xr[mb][1], xoff[mb], base, 16);
   }
 }
 
-// wait until at most CNT vector loads are outstanding; the stage's registers are in/out operands
+// wait until at most CNT vector loads are outstanding; the registers about to be consumed are in/out operands
 template <int MB, int CNT>
 __device__ __forceinline__ void wsb_wait(wsb_u32x4 (&wr)[4][2], wsb_u32x4 (&xr)[MB][2]) {
   asm volatile("s_waitcnt vmcnt(%8)"
@@ -132,13 +133,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
   const int my_first = s_lo + wave;
   const int my_n = my_first < s_hi ? (s_hi - my_first + 3) / 4 : 0;
 
-  // per-lane row pointers of w: 4 column blocks
-  const T* wrow[4];
+  // per-lane byte offsets of the 4 column blocks' rows inside the workgroup's 64 rows of w (< 2^31: checked on the host)
+  const char* const wbase = reinterpret_cast<const char*>(wb + (int64_t)n0 * K);
+  uint32_t woff[4];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) wrow[nb] = wb + (int64_t)(n0 + nb * 16 + p16) * K + kq * 16;
+  for (int nb = 0; nb < 4; ++nb) woff[nb] = (uint32_t)(((nb * 16 + p16) * K + kq * 16) * 2);
 
   for (int rb0 = 0; rb0 < cnt; rb0 += 16 * MB) {
-    const T* xrow[MB];
+    uint32_t xoff[MB];                         // byte offsets of this lane's x rows (all of x < 2^31 bytes: host check)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       int r = rb0 + mb * 16 + p16;
@@ -147,45 +149,82 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
       if constexpr (GROUPED) {
         if (grp.row_index) src = grp.row_index[src] / grp.index_div;
       }
-      xrow[mb] = x + src * (int64_t)K + kq * 16;
+      xoff[mb] = (uint32_t)((src * (int64_t)K + kq * 16) * 2);
     }
+    const char* const xbase = reinterpret_cast<const char*>(x);
     wsb_f32x4 acc[4][MB];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = wsb_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // two named register stages; every load is unconditional: a step past the wave's range re-loads its last step
-    wsb_u32x4 w0[4][2], x0[MB][2], w1[4][2], x1[MB][2];
-    constexpr int kLoads = 8 + 2 * MB;   // vector loads per stage
-    auto koff_of = [&](int i) -> int64_t {
+    // register pipeline: the weights (HBM) run TWO steps ahead in a ring of three stages, the activations (L2) one step ahead
+    // in a ring of two. The vector-memory counter retires in order, so the issue order inside a step is x(i+1) THEN w(i+2):
+    // waiting for x(i) then leaves w(i+1), x(i+1), w(i+2) in flight (16 + 2 MB loads) -- two weight stages per wave, twice
+    // what a plain double buffer keeps outstanding (measured at M = 64: 3.0 TB/s with the double buffer). Loads are
+    // unconditional: a step past the wave's range re-loads its last step.
+    wsb_u32x4 wr0[4][2], wr1[4][2], wr2[4][2], xr0[MB][2], xr1[MB][2];
+    auto koff_of = [&](int i) -> int64_t {     // byte offset of the wave's step i along K (wave-uniform: SGPRs)
       i = i < my_n ? i : my_n - 1;
-      return (int64_t)(my_first + 4 * i) * kWsbK;
+      return (int64_t)(my_first + 4 * i) * (kWsbK * 2);
     };
-    if (my_n > 0) {
-      wsb_issue<T, MB>(w0, x0, wrow, xrow, koff_of(0));
-      for (int i = 0; i < my_n; i += 2) {
-        wsb_issue<T, MB>(w1, x1, wrow, xrow, koff_of(i + 1));
-        wsb_wait<MB, kLoads>(w0, x0);                     // stage 0 has landed, stage 1 stays in flight
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = TR::mfma(w0[nb][h], x0[mb][h], acc[nb][mb]);
-        wsb_issue<T, MB>(w0, x0, wrow, xrow, koff_of(i + 2));
-        wsb_wait<MB, kLoads>(w1, x1);
-        if (i + 1 < my_n) {
+#define WSB_STEP(I_, WC_, WN_, XC_, XN_)                                                        \
+  {                                                                                              \
+    wsb_issue_x<MB>(XN_, xoff, xbase + koff_of((I_) + 1));                                       \
+    wsb_issue_w(WN_, woff, wbase + koff_of((I_) + 2));                                           \
+    wsb_wait<MB, 16 + 2 * MB>(WC_, XC_);                                                         \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                \
+    _Pragma("unroll") for (int nb = 0; nb < 4; ++nb)                                             \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                            \
+        acc[nb][mb] = TR::mfma(WC_[nb][h], XC_[mb][h], acc[nb][mb]);                             \
+  }
+    if constexpr (MB == 1) {
+      // 16 rows: a step is 8 KiB of weights against 8 MFMAs and the wave needs few registers -- four workgroups per CU keep
+      // enough in flight with a plain double buffer (the three-stage form makes hipcc spill here)
+      if (my_n > 0) {
+        wsb_issue_w(wr0, woff, wbase + koff_of(0));
+        wsb_issue_x<MB>(xr0, xoff, xbase + koff_of(0));
+#pragma nounroll
+        for (int i = 0; i < my_n; i += 2) {
+          wsb_issue_w(wr1, woff, wbase + koff_of(i + 1));
+          wsb_issue_x<MB>(xr1, xoff, xbase + koff_of(i + 1));
+          wsb_wait<MB, 8 + 2 * MB>(wr0, xr0);
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < 4; ++nb) acc[nb][0] = TR::mfma(wr0[nb][h], xr0[0][h], acc[nb][0]);
+          if (i + 1 >= my_n) break;
+          wsb_issue_w(wr0, woff, wbase + koff_of(i + 2));
+          wsb_issue_x<MB>(xr0, xoff, xbase + koff_of(i + 2));
+          wsb_wait<MB, 8 + 2 * MB>(wr1, xr1);
 #pragma unroll
-              for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = TR::mfma(w1[nb][h], x1[mb][h], acc[nb][mb]);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[nb][0] = TR::mfma(wr1[nb][h], xr1[0][h], acc[nb][0]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (redundant) prefetch
+    } else if (my_n > 0) {
+      wsb_issue_w(wr0, woff, wbase + koff_of(0));
+      wsb_issue_x<MB>(xr0, xoff, xbase + koff_of(0));
+      wsb_issue_w(wr1, woff, wbase + koff_of(1));
+#pragma nounroll
+      for (int i = 0; i < my_n; i += 6) {
+        WSB_STEP(i, wr0, wr2, xr0, xr1)
+        if (i + 1 >= my_n) break;
+        WSB_STEP(i + 1, wr1, wr0, xr1, xr0)
+        if (i + 2 >= my_n) break;
+        WSB_STEP(i + 2, wr2, wr1, xr0, xr1)
+        if (i + 3 >= my_n) break;
+        WSB_STEP(i + 3, wr0, wr2, xr1, xr0)
+        if (i + 4 >= my_n) break;
+        WSB_STEP(i + 4, wr1, wr0, xr0, xr1)
+        if (i + 5 >= my_n) break;
+        WSB_STEP(i + 5, wr2, wr1, xr1, xr0)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (redundant) prefetches
     }
+#undef WSB_STEP
 
     // partial tiles -> LDS: lane holds D[n = nb*16 + 4 kq + r][m = mb*16 + p16]: 4 consecutive n of one row
     float* mine = red + wave * (16 * MB * kWsbPad);
@@ -280,12 +319,15 @@ int launch_gemm_wsb_dense(const void* x, const void* w, const void* bias, void* 
                           void* workspace, size_t ws_bytes, hipStream_t s) {
   wsb_env();
   if (!g_wsb_mode || M <= 0 || M > 64 || N % kWsbCols || K % kWsbK || K / kWsbK < 4 || N * K >= (1ll << 40) ||
+      64 * K * 2 >= (1ll << 31) ||
       ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8) || ((uintptr_t)bias % 8))
     return XM_ERR_UNSUPPORTED;
   const int n_tiles = (int)(N / kWsbCols), n_steps = (int)(K / kWsbK);
-  // K slices: enough workgroups for every CU (two per CU fit), every wave of a slice keeps >= 2 steps, slabs fit
+  // K slices: as many as keep the grid AT OR BELOW one workgroup per CU (measured at M = 64, profiles/r02_gemm_wsb.txt:
+  // down_proj 56 tiles x 4 slices = 224 workgroups 48.8 us, x 5 = 280 workgroups 68.4 us -- a second workgroup on some CUs
+  // costs more than the idle CUs do), every wave of a slice keeps >= 2 steps, slabs fit
   int slices = 1;
-  while (n_tiles * slices < 256 && slices < 8 && n_steps / (slices + 1) >= 8 &&
+  while (n_tiles * (slices + 1) <= 256 && slices < 8 && n_steps / (slices + 1) >= 8 &&
          (size_t)(slices + 1) * M * N * 4 <= ws_bytes)
     ++slices;
   if (g_wsb_slices > 0 && (size_t)g_wsb_slices * M * N * 4 <= ws_bytes && n_steps / g_wsb_slices >= 1) slices = g_wsb_slices;
@@ -314,6 +356,7 @@ int launch_gemm_wsb_grouped(const void* x, const void* w, const int32_t* counts,
                             hipStream_t s) {
   wsb_env();
   if (!g_wsb_mode || n_experts > 65535 || N % kWsbCols || K % kWsbK || max_rows > 16 * n_experts ||
+      64 * K * 2 >= (1ll << 31) || max_rows * K * 2 >= (1ll << 31) ||
       ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8))
     return XM_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(N / kWsbCols), (unsigned)n_experts);
