@@ -24,8 +24,9 @@ SELECT = ("scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matm
     {"XLLM_MI355_ASTAT": "1", "XLLM_MI355_ASTAT_SPLITS": "3"},
     {"XLLM_MI355_WSB": "0"},                                  # 16-bit decode linears / few-row experts on the tiled kernels
     {"XLLM_MI355_WSB_SLICES": "3"},                           # weight-stream 16-bit kernel with a forced K-slice count
+    {"XLLM_MI355_WSB": "2"},                                  # ... on every M <= 64 (default policy: M <= 32)
 ], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256", "astat", "astat_split3",
-        "wsb_off", "wsb_slices3"])
+        "wsb_off", "wsb_slices3", "wsb_to_64"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

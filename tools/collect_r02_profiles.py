@@ -101,10 +101,12 @@ def main():
          "# MFMAs, NOMFMA = LDS reads but no MFMAs; M = 32 rows first, then M = 256", "r02ws/gemm_ablate.txt"),
     ])
     write("r02_gemm_wsb.txt", [
-        ("tools/gemm_bench.py <M> bf16 on 1 x MI355X, Qwen2-7B layer shapes + lm_head: (1) weight-stream 16-bit kernel gemm_wsb.hip (default for M <= 64)",
-         "r02wsb/gemm_bf16_wsb.txt"),
+        ("tools/gemm_bench.py <M> bf16 on 1 x MI355X, Qwen2-7B layer shapes + lm_head: (1) weight-stream 16-bit kernel gemm_wsb.hip (final form: weights two steps ahead; forced up to M = 64 here, the default policy takes M <= 32)",
+         "r02wsb2/gemm_bf16_wsb.txt"),
         ("(2) the tiled kernels of round 1 (XLLM_MI355_WSB=0)", "r02wsb/gemm_bf16_tiled.txt"),
-        ("(3) M = 64, forced K-slice counts (XLLM_MI355_WSB_SLICES)", "r02wsb/gemm_bf16_slices.txt"),
+        ("(3) M = 64, forced K-slice counts (XLLM_MI355_WSB_SLICES)", "r02wsb2/gemm_bf16_slices.txt"),
+        ("(4) M = 32, forced K-slice counts", "r02wsb2/gemm_bf16_slices32.txt"),
+        ("(5) first version of the kernel (plain double buffer, two workgroups per CU allowed by the slice rule): M = 16 / 32 / 64", "r02wsb/gemm_bf16_wsb.txt"),
     ])
     write("r02_prefill_p.txt", [
         ("tools/prefill_p_accuracy.py + tools/prefill_attn_one.py (2 x 4096 tokens, 28 / 4 heads, d = 128): P mode 1 = one RNE-rounded\n"

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void wsb_reduce_kernel(float* __restrict__ sla
 static int g_wsb_mode = -2, g_wsb_slices = -2;
 static void wsb_env() {
   if (g_wsb_mode == -2) {
-    const char* e = getenv("XLLM_MI355_WSB");          // 0: never (A/B against the tiled kernels), default 1
+    const char* e = getenv("XLLM_MI355_WSB");          // 0: never (A/B against the tiled kernels), 1: default policy, 2: up to 64 rows
     g_wsb_mode = e ? atoi(e) : 1;
     e = getenv("XLLM_MI355_WSB_SLICES");               // force the K-slice count of the dense form
     g_wsb_slices = e ? atoi(e) : -1;
@@ -318,6 +318,10 @@ template <typename T>
 int launch_gemm_wsb_dense(const void* x, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                           void* workspace, size_t ws_bytes, hipStream_t s) {
   wsb_env();
+  // measured (profiles/r02_gemm_wsb.txt, Qwen2-7B bf16 layer, us): M = 16: 118.7 against 166.3 for the tiled kernels, M = 32:
+  // 139.8 against 174.4, M = 64: 180.9 against 177.3 (gate_up 95 against 90: both stop at ~3 TB/s there) -- so 33 .. 64 rows stay
+  // on the tiled kernels unless XLLM_MI355_WSB=2 asks for this one (A/B, tests)
+  if (g_wsb_mode != 2 && M > 32) return XM_ERR_UNSUPPORTED;
   if (!g_wsb_mode || M <= 0 || M > 64 || N % kWsbCols || K % kWsbK || K / kWsbK < 4 || N * K >= (1ll << 40) ||
       64 * K * 2 >= (1ll << 31) ||
       ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8) || ((uintptr_t)bias % 8))
