@@ -9,7 +9,8 @@ shapes of rank 0 of 8 and no exchange (the exchanges are counted and reported, n
               per-token activation scales; paged latent cache [n_blocks, 64, 1, 576] bf16, shuffled pages) + the routed experts
               (256 experts, top-8 of 4-of-8 groups, sigmoid scores + correction bias, intermediate 2048 / 8 per rank, 16-bit
               like the reference's DCU path, fused_moe.cpp:217-337).  roofline: mla_decode kernel against HBM.
-  cfg5-slice  the routed experts of one Qwen3-MoE layer (H 2048, 128 experts top-8, intermediate 768) on one expert-parallel
+  cfg5-slice  one Qwen3-MoE layer on one rank of 8: the attention block (4 of 32 q heads, W8A8 qkv / o, per-head q/k RMSNorm +
+              RoPE, chunked prefill through the block table) and the routed experts (H 2048, 128 experts top-8, intermediate 768) on one expert-parallel
               rank of 8 (16 local experts; every rank routes all T = 8192 tokens of the chunk, fused_moe.cpp:236-315), W8A8:
               per-token int8 quantisation, grouped GEMM w13 with the expand fused in, SiLU*mul + requantisation, grouped GEMM
               w2, weighted combine.  roofline: the w13 grouped GEMM against the dense int8 MFMA rate.
@@ -119,17 +120,59 @@ def cfg4_slice(a, dev):
     }
 
 
+class _Qwen3AttentionRank:
+    """the attention block of one Qwen3-MoE layer on one TP = 8 rank (qwen2_attention.cpp:132-193 with the Qwen3 branch :146-171:
+    per-head RMSNorm of q and k + RoPE inside the packed qkv; 32 / 8 = 4 q heads, 4 kv heads replicated -> 1 per rank), W8A8
+    linears, chunked prefill over the paged cache. The TP all-reduce after o_proj is counted, not timed."""
+
+    def __init__(self, H, nq, nkv, d, dev, gen, max_pos):
+        from xllm_amd import layers
+        self.nq, self.nkv, self.d = nq, nkv, d
+        self.qkv = layers.QuantLinear((nq + 2 * nkv) * d, H, False, "int8", torch.bfloat16, dev, gen)
+        self.o = layers.QuantLinear(H, nq * d, False, "int8", torch.bfloat16, dev, gen)
+        self.norm_w = (torch.rand(H, device=dev, generator=gen) + 0.5).bfloat16()
+        self.q_w = (torch.rand(d, device=dev, generator=gen) + 0.5).bfloat16()
+        self.k_w = (torch.rand(d, device=dev, generator=gen) + 0.5).bfloat16()
+        args = layers.ModelArgs(H, 1, nq, nkv, d, 1, 1, 1e-6, 1e6, max_pos)
+        self.cos_sin = layers.build_cos_sin_cache(args, torch.bfloat16, dev, max_pos)
+
+    def forward(self, x, positions, md, cache):
+        from xllm_amd import ops
+        q8, s8 = ops.rms_norm_dynamic_int8_quant(x, self.norm_w, 1e-6)
+        qkv = self.qkv.forward(None, pre_quant=(q8, s8))
+        ops.fused_qk_norm_rope(qkv, self.nq, self.nkv, self.nkv, self.d, 1e-6, self.q_w, self.k_w, self.cos_sin, False, positions)
+        qs, ks = self.nq * self.d, self.nkv * self.d
+        q = qkv[:, :qs].unflatten(-1, (self.nq, self.d))
+        k = qkv[:, qs:qs + ks].unflatten(-1, (self.nkv, self.d))
+        v = qkv[:, qs + ks:].unflatten(-1, (self.nkv, self.d))
+        ops.reshape_paged_cache(md.slot_mapping, k, v, cache.get_k_cache(), cache.get_v_cache())
+        attn = ops.paged_attention(q, cache.get_k_cache(), cache.get_v_cache(), md.q_cu_seq_lens, md.kv_seq_lens, md.block_table,
+                                   md.max_query_len, md.max_seq_len, self.d ** -0.5, True)
+        return self.o.forward(attn)
+
+
 def cfg5_slice(a, dev):
-    from xllm_amd import layers, ops
+    from xllm_amd import attention, layers, ops
+    from xllm_amd.attention import KVCache
     H, E, topk, moe_i, ep = 2048, 128, 8, 768, 8
-    T = 8192
+    T, n_seq, bs = 8192, 2, 128
     gen = torch.Generator(device=dev).manual_seed(5)
     moe = layers.FusedMoE(H, moe_i, E, topk, torch.bfloat16, dev, gen, renormalize=True, mode="int8", ep_rank=0, ep_size=ep)
     gate_w = (torch.randn(E, H, device=dev, generator=gen) / H ** 0.5).bfloat16()
     x = torch.randn(T, H, device=dev, generator=gen).bfloat16()
+    # attention of the chunk: 2 sequences x 4096 new tokens written to fresh pages and attended through the block table
+    attn = _Qwen3AttentionRank(H, 32 // 8, 1, 128, dev, gen, T // n_seq)
+    pages = T // n_seq // bs
+    table = torch.randperm(n_seq * pages, generator=torch.Generator().manual_seed(6)).to(torch.int32).view(n_seq, pages)
+    bi = attention.build_batch_input([0] * n_seq, [T // n_seq] * n_seq, table.tolist(), bs)
+    md = attention.build_attention_metadata(bi, is_prefill=False, is_chunked_prefill=True, device=dev)
+    cache = KVCache(torch.zeros(n_seq * pages, bs, 1, 128, dtype=torch.bfloat16, device=dev),
+                    torch.zeros(n_seq * pages, bs, 1, 128, dtype=torch.bfloat16, device=dev))
+    pos = bi.positions.to(dev).long()
 
     def step():
-        return moe.forward_experts(x, ops.matmul(x, gate_w))   # (EP all-reduce over the 8 ranks here)
+        h = x + attn.forward(x, pos, md, cache)                 # (TP all-reduce over the 8 ranks here)
+        return moe.forward_experts(h, ops.matmul(h, gate_w))   # (EP all-reduce over the 8 ranks here)
 
     sync = torch.cuda.synchronize
     step()
@@ -163,11 +206,12 @@ def cfg5_slice(a, dev):
     return {
         "metric": "prefill tokens/s through the routed experts of one Qwen3-MoE layer on one EP=8 rank (cfg5-slice)",
         "value": round(T / dt, 1), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "int8",
-        "config": {"workload": "qwen3_moe routed-expert slice: gate + top-8 of 128 + W8A8 grouped GEMMs (16 local experts, "
-                               "intermediate 768) + combine over a chunk of 8192 tokens, random-init weights",
+        "config": {"workload": "qwen3_moe layer slice: attention of one TP=8 rank (W8A8 qkv / o, per-head q/k RMSNorm + RoPE, KV write, "
+                               "chunked prefill of 2 x 4096 tokens through the block table, 4 q heads / 1 kv head) + gate + top-8 "
+                               "of 128 + W8A8 grouped GEMMs (16 local experts, intermediate 768) + combine, random-init weights",
                    "global_batch": T, "ctx": 4096, "per_gpu_batch": T, "rows_on_this_rank": rows,
                    "parallelism": "rank 0 of ep8 (all-reduce EP: every rank routes the whole chunk; no exchange timed)",
-                   "collectives_per_step": 1, "hip_graph": True},
+                   "collectives_per_step": 2, "hip_graph": True},
         "roofline": {"bound": "mfma", "kernel": "group_gemm_w8a8 (w13, expand fused)", "achieved": round(ach, 1),
                      "peak": I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(ach / I8_PEAK_TOPS, 4), "traffic": None,
                      "ops_per_launch": ops13, "avg_launch_ms": round(w13_ms, 4), "launches_timed": len(w13)},
