@@ -331,9 +331,10 @@ def main():
         return torch.argmax(logits, dim=-1)
 
     def sync_all():
+        torch.cuda.synchronize()        # this rank's work is done ...
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.barrier()              # ... and so is everybody's
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()

@@ -290,6 +290,18 @@ XM_API int xllm_mi355_paged_decode_attention_int8(const void* q, const void* k_c
                                                   int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
                                                   int64_t q_stride, int64_t max_kv_len, float scale,
                                                   int64_t window_left, int dtype, void* stream);
+/* The same fusion for every launch plan: with a workspace (xllm_mi355_paged_attention_workspace_bytes) the plans whose
+ * workgroups do not hold a whole token (grid-level split-KV at small batches, fewer than all kv heads per workgroup) leave
+ * their (o, m, l) partials there and ONE finishing launch merges and quantises them -- still bit-identical to paged_attention
+ * followed by scaled_quantize. workspace == NULL: the behaviour of the entry point above. */
+XM_API int xllm_mi355_paged_decode_attention_int8_ws(const void* q, const void* k_cache, const void* v_cache,
+                                                     void* out, int8_t* out_q, float* out_scale,
+                                                     const int32_t* kv_lens, const int32_t* block_table,
+                                                     int64_t max_blocks, int64_t batch, int64_t n_q_heads,
+                                                     int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                                                     int64_t q_stride, int64_t max_kv_len, float scale,
+                                                     int64_t window_left, int dtype, void* workspace,
+                                                     size_t workspace_bytes, void* stream);
 /* N1 fusion: RoPE (apply_rotary) + KV write (reshape_paged_cache) in one pass over the packed qkv row:
  * q and k are rotated in place, the rotated k and v are scattered to the caches at slot_ids. Bit-identical to the
  * two-operator sequence (cf. the MLA fused_mla_kv of param.h:1105-1178). */

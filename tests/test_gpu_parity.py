@@ -909,11 +909,25 @@ def test_decode_fusions_equal_unfused_ops(nq, nkv, bs):
     assert torch.equal(fused[2], out_a) and torch.equal(fused[0], qa_q) and torch.equal(fused[1], qa_s)
 
 
-def test_decode_int8_fusion_declines_split_kv_shapes():
-    md, kc, vc, q = _paged_case(2, 28, 4, 128, 128, [4096, 4096], [1, 1], torch.bfloat16, seed=1)
-    r = ops.paged_decode_attention_int8(q.to(DEV), kc.to(DEV), vc.to(DEV), md["kv_seq_lens"].to(DEV),
-                                        md["block_tables"].to(DEV), 4096, 128 ** -0.5)
-    assert r is None  # B=2 wants split-KV: the caller falls back to paged_attention + scaled_quantize
+@pytest.mark.parametrize("B,S,nq,nkv", [(2, 4096, 28, 4), (32, 700, 28, 4), (64, 300, 28, 4), (128, 257, 28, 4), (5, 2000, 14, 2),
+                                        (48, 900, 7, 1)])
+def test_decode_int8_fusion_on_split_plans_equals_the_two_operators(B, S, nq, nkv):
+    """small batches: the token range is split inside the workgroup (fewer kv heads per workgroup) and / or over the grid; the
+    partials go through ONE merge + quantise launch -- the bits of paged_attention followed by scaled_quantize"""
+    kv_lens = [max(1, S - 13 * i) for i in range(B)]
+    md, kc, vc, q = _paged_case(B, nq, nkv, 128, 128, kv_lens, [1] * B, torch.bfloat16, seed=B)
+    qd, kcd, vcd = q.to(DEV), kc.to(DEV), vc.to(DEV)
+    kv_d, bt = md["kv_seq_lens"].to(DEV), md["block_tables"].to(DEV)
+    ref = ops.paged_attention(qd, kcd, vcd, None, kv_d, bt, 1, max(kv_lens), 128 ** -0.5)
+    rq, rs = ops.scaled_quantize(ref)
+    r = ops.paged_decode_attention_int8(qd, kcd, vcd, kv_d, bt, max(kv_lens), 128 ** -0.5, want_16bit=True)
+    if os.environ.get("XLLM_MI355_ATTN_FINISH", "1") == "0":
+        assert r is None or torch.equal(r[0], rq)        # the round-1 behaviour: decline, the caller runs the two operators
+        return
+    assert r is not None
+    assert torch.equal(r[2], ref) and torch.equal(r[0], rq) and torch.equal(r[1], rs)
+    r2 = ops.paged_decode_attention_int8(qd, kcd, vcd, kv_d, bt, max(kv_lens), 128 ** -0.5)     # without the 16-bit copy
+    assert torch.equal(r2[0], rq) and torch.equal(r2[1], rs) and r2[2] is None
 
 
 def test_piecewise_graph_replay_equals_eager():

@@ -61,11 +61,11 @@ def main():
     copy_json(f"{final}/bench.json", "r02_bench.json")
     copy_json(f"{final}/bench_cfg2.json", "r02_bench_cfg2.json")
     copy_json(f"{final}/bench_cfg4_slice.json", "r02_bench_cfg4_slice.json")
-    copy_json(f"{final}/bench_cfg5_slice.json", "r02_bench_cfg5_slice.json")
+    copy_json("r02small/bench_cfg5_slice.json", "r02_bench_cfg5_slice.json")   # (the slice gained its attention block after the closing run)
     for src, dst in ((f"{final}/bench_kernel_stats.txt", "r02_bench_kernel_stats.txt"),
                      (f"{final}/cfg2_kernel_stats.txt", "r02_bench_cfg2_kernel_stats.txt"),
                      (f"{final}/cfg4-slice_kernel_stats.txt", "r02_bench_cfg4_slice_kernel_stats.txt"),
-                     (f"{final}/cfg5-slice_kernel_stats.txt", "r02_bench_cfg5_slice_kernel_stats.txt"),
+                     ("r02small/cfg5-slice_kernel_stats.txt", "r02_bench_cfg5_slice_kernel_stats.txt"),
                      (f"{final}/dp8_kernel_stats.txt", "r02_dp8_kernel_stats.txt"),
                      (f"{final}/pmc_fetch_size.txt", "r02_bench_pmc_fetch_size.txt"),
                      (f"{final}/pmc_write_size.txt", "r02_bench_pmc_write_size.txt"),

@@ -77,6 +77,8 @@ _SIGS = {
                                       ci, vp], ci),
     "xllm_mi355_paged_decode_attention_int8": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
                                                 f32, i64, ci, vp], ci),
+    "xllm_mi355_paged_decode_attention_int8_ws": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
+                                                f32, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_rotary_embedding_and_cache": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
                                                i64, i64, ci, ci, vp], ci),
     "xllm_mi355_paged_attention_workspace_bytes": ([i64, i64, i64, i64, i64], sz),

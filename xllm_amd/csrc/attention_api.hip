@@ -143,6 +143,17 @@ int xllm_mi355_paged_decode_attention_int8(const void* q, const void* k_cache, c
                                            int64_t n_q_heads, int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
                                            int64_t q_stride, int64_t max_kv_len, float scale, int64_t window_left,
                                            int dtype, void* stream) {
+  return xllm_mi355_paged_decode_attention_int8_ws(q, k_cache, v_cache, out, out_q, out_scale, kv_lens, block_table, max_blocks,
+                                                   batch, n_q_heads, n_kv_heads, head_dim, block_size, q_stride, max_kv_len,
+                                                   scale, window_left, dtype, nullptr, 0, stream);
+}
+
+int xllm_mi355_paged_decode_attention_int8_ws(const void* q, const void* k_cache, const void* v_cache, void* out,
+                                              int8_t* out_q, float* out_scale, const int32_t* kv_lens,
+                                              const int32_t* block_table, int64_t max_blocks, int64_t batch,
+                                              int64_t n_q_heads, int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
+                                              int64_t q_stride, int64_t max_kv_len, float scale, int64_t window_left,
+                                              int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   if (!q || !k_cache || !v_cache || !out_q || !out_scale || !kv_lens || !block_table) return XM_ERR_INVALID;
   if (batch < 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || block_size <= 0 || max_blocks <= 0)
     return XM_ERR_INVALID;
@@ -153,7 +164,7 @@ int xllm_mi355_paged_decode_attention_int8(const void* q, const void* k_cache, c
 #define XM_DECODEQ(T, DD)                                                                                            \
   return launch_paged_decode<T, DD>(q, k_cache, v_cache, out, nullptr, kv_lens, block_table, max_blocks, batch,      \
                                     n_q_heads, n_kv_heads, block_size, q_stride, max_kv_len, scale, window_left,     \
-                                    nullptr, 0, s, out_q, out_scale)
+                                    workspace, workspace ? workspace_bytes : 0, s, out_q, out_scale)
   if (dtype == XM_BF16 && head_dim == 128) XM_DECODEQ(bf16_t, 128);
   if (dtype == XM_BF16 && head_dim == 64) XM_DECODEQ(bf16_t, 64);
   if (dtype == XM_F16 && head_dim == 128) XM_DECODEQ(f16_t, 128);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     float* __restrict__ part_o, float* __restrict__ part_ml, const int32_t* __restrict__ cu_q,
     const int32_t* __restrict__ kv_lens, const int32_t* __restrict__ block_table, int max_blocks, int nq,
     int nkv, int block_size, int64_t q_stride, float scale_log2, int nsplit, int hpw, int window_left,
-    int8_t* __restrict__ out_q, float* __restrict__ out_scale) {
+    int8_t* __restrict__ out_q, float* __restrict__ out_scale, int part_mode) {
   using TR = AttnTraits<T>;
   using x8 = typename TR::x8;
   using x4 = typename TR::x4;
@@ -375,9 +375,9 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
       l += f * ml_sh[w][qq][1];
     }
     const int head = (hg * hpw + h_s) * G + qq;
-    if (nsplit == 1) {
+    if (!part_mode) {
       out[qtok * (int64_t)nq * D + (int64_t)head * D + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
-    } else {
+    } else {  // grid-level split-KV, or a finishing kernel that wants (o, m, l) of the whole range (nsplit == 1)
       const int64_t pi = ((int64_t)b * nq + head) * nsplit + split;
       part_o[pi * D + d] = o;
       if (d == 0) { part_ml[pi * 2] = m_star; part_ml[pi * 2 + 1] = l; }
@@ -404,6 +404,50 @@ __global__ void paged_decode_merge_kernel(const float* __restrict__ part_o, cons
   out[qtok * (int64_t)nq * D + (int64_t)head * D + d] = from_f32<T>(l > 0.0f ? o / l : 0.0f);
 }
 
+// merge + per-token int8 quantisation in one launch (N1 fusion for the plans whose workgroups do not hold a whole token:
+// fewer than all kv heads per workgroup, or grid-level split-KV): one workgroup per token merges the nsplit partials of all
+// nq heads exactly like paged_decode_merge_kernel, rounds to T, and quantises the row like scaled_quantize -- the bits of
+// paged_attention followed by scaled_quantize, one launch and one 16-bit round trip less
+template <typename T, int D, int VPT>
+__global__ __launch_bounds__(256) void paged_decode_finish_int8_kernel(const float* __restrict__ part_o,
+                                                                       const float* __restrict__ part_ml, T* __restrict__ out,
+                                                                       int8_t* __restrict__ out_q, float* __restrict__ out_scale,
+                                                                       int nq, int nsplit) {
+  __shared__ float red[32];
+  const int b = blockIdx.x;
+  const int n = nq * D;
+  float v[VPT];
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int e = threadIdx.x + i * 256;
+    v[i] = 0.0f;
+    if (e < n) {
+      const int head = e / D, d = e % D;
+      const int64_t base = ((int64_t)b * nq + head) * nsplit;
+      float m_star = kNegBig;
+      for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
+      float o = 0.0f, l = 0.0f;
+      for (int s = 0; s < nsplit; ++s) {
+        const float f = exp2f(part_ml[(base + s) * 2] - m_star);
+        o += f * part_o[(base + s) * D + d];
+        l += f * part_ml[(base + s) * 2 + 1];
+      }
+      v[i] = r16<T>(l > 0.0f ? o / l : 0.0f);
+      amax = fmaxf(amax, fabsf(v[i]));
+      if (out) out[(int64_t)b * n + e] = from_f32<T>(v[i]);
+    }
+  }
+  amax = block_max(amax, red);
+  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int e = threadIdx.x + i * 256;
+    if (e < n) out_q[(int64_t)b * n + e] = (int8_t)fmaxf(-127.0f, fminf(127.0f, rintf(v[i] * qinv)));
+  }
+  if (threadIdx.x == 0) out_scale[b] = amax / 127.0f;
+}
+
 int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len);
 bool decode_deep_prefetch();
 int decode_heads_per_wg(int64_t batch, int64_t nkv);
@@ -417,14 +461,19 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
                         int8_t* out_q, float* out_scale) {
   const int hpw = decode_heads_per_wg(batch, nkv);
   int nsplit = decode_num_splits(batch, nkv, hpw, max_kv_len);
-  // the fused int8 epilogue needs the whole token in one workgroup: decline shapes that want split-KV or have
-  // more than one head group (the caller then runs paged_attention + scaled_quantize)
-  if (out_q && (nsplit != 1 || nkv / hpw != 1)) return XM_ERR_UNSUPPORTED;
-  // degrade the split count to what the caller's workspace holds (1 split needs none)
+  // the fused int8 epilogue needs the whole token in one workgroup; the other plans (split-KV, fewer than all kv heads per
+  // workgroup) leave (o, m, l) partials in the workspace and a finishing launch merges + quantises them. Without a
+  // workspace those plans are declined (the caller then runs paged_attention + scaled_quantize)
   const size_t per_split = (size_t)batch * nq * (D + 2) * sizeof(float);
   if (!workspace) ws_bytes = 0;
+  const bool finish = out_q && (nsplit != 1 || nkv / hpw != 1);
+  if (finish && (ws_bytes < (size_t)nsplit * per_split || nq * D > 256 * 16 || cu_q)) return XM_ERR_UNSUPPORTED;
+  // degrade the split count to what the caller's workspace holds (1 split needs none)
   if ((size_t)nsplit * per_split > ws_bytes) nsplit = (int)(ws_bytes / per_split);
   if (nsplit < 1) nsplit = 1;
+  const int part_mode = (nsplit > 1 || finish) ? 1 : 0;
+  int8_t* const kq = finish ? nullptr : out_q;          // the attention kernel's own int8 epilogue
+  float* const kqs = finish ? nullptr : out_scale;
   float* part_o = reinterpret_cast<float*>(workspace);
   float* part_ml = part_o ? part_o + (size_t)batch * nq * nsplit * D : nullptr;
   const float scale_log2 = scale * 1.4426950408889634f;
@@ -436,18 +485,28 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   if (block_size % kTile == 0 && decode_deep_prefetch())
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
   else if (block_size % kTile == 0)
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
   else
     hipLaunchKernelGGL((paged_decode_kernel<T, D, false, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, out_q, out_scale);
-  if (nsplit > 1)
+                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
+  if (finish) {
+    const int vpt = (int)((nq * D + 255) / 256);
+#define XM_FINISH(V_)                                                                                                   \
+  hipLaunchKernelGGL((paged_decode_finish_int8_kernel<T, D, V_>), dim3((unsigned)batch), dim3(256), 0, s, part_o, part_ml, \
+                     (T*)out, out_q, out_scale, (int)nq, nsplit)
+    if (vpt <= 4) XM_FINISH(4);
+    else if (vpt <= 8) XM_FINISH(8);
+    else XM_FINISH(16);
+#undef XM_FINISH
+  } else if (nsplit > 1) {
     hipLaunchKernelGGL((paged_decode_merge_kernel<T, D>), dim3((unsigned)(batch * nq)), dim3(D), 0, s, part_o,
                        part_ml, (T*)out, cu_q, (int)nq, nsplit);
+  }
   return hip_check_launch();
 }
 

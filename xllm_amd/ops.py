@@ -660,6 +660,9 @@ def rotary_embedding_and_cache(positions, query, key, value, cos_sin_cache, slot
         key_cache.size(-3), key_cache.size(0), int(is_neox), _dt(query), _stream()), "rotary_embedding_and_cache")
 
 
+_ATTN_FINISH = os.environ.get("XLLM_MI355_ATTN_FINISH", "1") != "0"
+
+
 def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, max_kv_len, scale, window_left=-1,
                                 want_16bit: bool = False):
     """decode attention whose epilogue also emits scaled_quantize of its output: returns (int8 [B, nq*d], scale [B],
@@ -671,10 +674,15 @@ def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, m
     os_ = torch.empty(B, dtype=torch.float32, device=q.device)
     o16 = torch.empty(B, nq * d, dtype=q.dtype, device=q.device) if want_16bit else None
     bt = block_table if block_table.is_contiguous() else block_table.contiguous()
-    rc = _lib.lib().xllm_mi355_paged_decode_attention_int8(
+    # with the attention scratch the plans that split the token range (small batches) finish through ONE merge + quantise
+    # launch; XLLM_MI355_ATTN_FINISH=0 keeps the round-1 behaviour (decline, the caller runs paged_attention + scaled_quantize)
+    ws = None
+    if _ATTN_FINISH:
+        ws = _attn_workspace(q.device, _lib.lib().xllm_mi355_paged_attention_workspace_bytes(B, nq, d, 1, B))
+    rc = _lib.lib().xllm_mi355_paged_decode_attention_int8_ws(
         _p(q), _p(k_cache), _p(v_cache), _p(o16), _p(oq), _p(os_), _p(kv_seq_lens), _p(bt), bt.size(1), B, nq, nkv, d,
-        bs, q.stride(0), max_kv_len, scale, window_left, _dt(q), _stream())
-    if rc == -2:  # XM_ERR_UNSUPPORTED: split-KV shape
+        bs, q.stride(0), max_kv_len, scale, window_left, _dt(q), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    if rc == -2:  # XM_ERR_UNSUPPORTED: split-KV shape without a workspace
         return None
     check(rc, "paged_decode_attention_int8")
     return oq, os_, o16
