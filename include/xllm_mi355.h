@@ -215,6 +215,21 @@ XM_API int xllm_mi355_scaled_matmul_add_rms_norm_packed(const int8_t* a, const i
                                                         int8_t* out_q, float* out_q_scale, int64_t M, int64_t N,
                                                         int64_t K, int dtype, void* workspace, size_t ws_bytes,
                                                         void* stream);
+/* N1 fusion across the GEMM boundary ("quantized GEMM with fused dequant / RoPE"): the W8A8 qkv projection on packed weights,
+ * its dequant epilogue (acc * a_scale[m] * w_scale[n] + bias -> 16 bit), RoPE of q and k and the KV write in TWO launches
+ * (GEMM leaving exact int32 K-slice slabs in `workspace`, then one pass over each token's row): bit-identical to
+ * scaled_matmul -> apply_rotary -> reshape_paged_cache (linear.cpp:481-507, qwen2_attention.cpp:150-176,
+ * layers/dcu/attention.cpp:68-86). qkv [M, N] (N = (n_q_heads + 2 n_kv_heads) * head_size) receives the packed row with q and
+ * k rotated; k / v go to the caches at slot_ids (a slot < 0 or past n_blocks is skipped). cos_sin_cache in the out dtype.
+ * XM_ERR_UNSUPPORTED (no side effect) outside the envelope; XM_ERR_WORKSPACE below M * N * 4 bytes of scratch. */
+XM_API int xllm_mi355_scaled_matmul_rope_cache_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,
+                                                      const float* w_scale, const void* bias, void* qkv, int64_t M,
+                                                      int64_t N, int64_t K, int dtype, const int64_t* positions,
+                                                      const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache,
+                                                      void* v_cache, int64_t n_q_heads, int64_t n_kv_heads,
+                                                      int64_t head_size, int64_t rot_dim, int64_t block_size,
+                                                      int64_t n_blocks, int is_neox, void* workspace, size_t ws_bytes,
+                                                      void* stream);
 
 /* optional scratch for the int8 split-K path of scaled_matmul (>= M*N*4 bytes; the reference operator
  * has no workspace argument, so it is registered once per stream owner; NULL disables split-K). */

@@ -78,3 +78,16 @@ def test_group_gemm_parity_on_the_fallback_kernel():
                         "-k", "moe", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [
+    {"XLLM_MI355_ATTN_FINISH": "1"},                         # split-KV partials merged + quantised in one finishing launch
+    {"XLLM_MI355_QKV_ROPE": "0"},                            # qkv projection, RoPE and KV write as separate operators
+], ids=["attn_finish_int8", "qkv_rope_unfused"])
+def test_decode_fusion_switches(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-k", "fusion or model_step or engine or dual_micro", "-p", "no:cacheprovider"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -66,7 +66,6 @@ def main():
                      (f"{final}/cfg2_kernel_stats.txt", "r02_bench_cfg2_kernel_stats.txt"),
                      (f"{final}/cfg4-slice_kernel_stats.txt", "r02_bench_cfg4_slice_kernel_stats.txt"),
                      ("r02small/cfg5-slice_kernel_stats.txt", "r02_bench_cfg5_slice_kernel_stats.txt"),
-                     (f"{final}/dp8_kernel_stats.txt", "r02_dp8_kernel_stats.txt"),
                      (f"{final}/pmc_fetch_size.txt", "r02_bench_pmc_fetch_size.txt"),
                      (f"{final}/pmc_write_size.txt", "r02_bench_pmc_write_size.txt"),
                      (f"{final}/pytest.txt", "r02_pytest_gpu.txt")):
@@ -122,9 +121,41 @@ def main():
          "# time is meaningless)", "r02b3/bench_tp2_oneshot.json"),
         ("the same over gloo all-reduce", "r02b3/bench_tp2_gloo.json"),
     ])
+    # fusions across launch boundaries at small batch (one data-parallel replica of 8: 32 sequences)
+    def dp_lines(rel):
+        t = read(rel) or ""
+        out = []
+        for l in t.splitlines():
+            if l.startswith("{"):
+                d = json.loads(l)
+                out.append(f"    per-replica batch {d['config'].get('per_gpu_batch', '?'):>4}  ms_per_step {d['ms_per_step']:8.4f}")
+        return "\n".join(out)
+
+    def grep(rel, pats):
+        t = read(rel) or ""
+        return "\n".join("    " + l[:150] for l in t.splitlines() if any(p in l for p in pats))
+
+    pats = ("slab_rope", "rope_and_cache", "slab_epilogue", "merge_kernel", "finish_int8", "scaled_quantize_i8")
+    if read("r02finish3/bench_dp.txt"):
+        with open(os.path.join(P, "r02_fusions.txt"), "w") as f:
+            f.write("# bench.py --emulate-dp {2,4,8} + rocprofv3 --kernel-trace of the dp8 replica (32 sequences), 1 x MI355X\n"
+                    "# (1) first version: ONE workgroup per token for both fusions (GEMM slabs -> dequant + RoPE + KV write; split-KV\n"
+                    "#     partials -> merge + int8 quantise): both launches are as slow as or slower than the pairs they replace\n"
+                    + dp_lines("r02finish2/bench_dp.txt") + "\n  without the two fusions:\n" + dp_lines("r02finish2/bench_dp_nofusion.txt")
+                    + "\n" + grep("r02finish2/dp8_kernel_stats.txt", pats) + "\n"
+                    "# (2) qkv fusion re-gridded into independent work items (RoPE pairs / plain elements over blockIdx.y), the merge + quantise\n"
+                    "#     fusion switched off (its row maximum is a whole-row dependency: it stays opt-in, XLLM_MI355_ATTN_FINISH=1)\n"
+                    + dp_lines("r02finish3/bench_dp.txt") + "\n  without the qkv fusion (XLLM_MI355_QKV_ROPE=0):\n"
+                    + dp_lines("r02finish3/bench_dp_nofusion.txt") + "\n" + grep("r02finish3/dp8_kernel_stats.txt", pats) + "\n"
+                    "# before either fusion (closing run): slab epilogue 4.6 us + rope_and_cache 7.1 us, merge 4.9 us + scaled_quantize 4.75 us per layer\n")
+        print("wrote r02_fusions.txt")
+        t = read("r02finish3/dp8_kernel_stats.txt")
+        if t:
+            open(os.path.join(P, "r02_dp8_kernel_stats.txt"), "w").write(t)
+
     # layouts: per-replica steps measured on one GPU
     rows = []
-    for rel, what in ((f"{final}/bench_dp.txt", "final"), ("r02step/bench_dp.txt", "with the packed weight-stream GEMM"),
+    for rel, what in (("r02finish3/bench_dp.txt", "final (with the qkv -> RoPE -> KV-write fusion)"), (f"{final}/bench_dp.txt", "closing run"), ("r02step/bench_dp.txt", "with the packed weight-stream GEMM"),
                       ("r02b1/bench_dp.txt", "before the packed weight-stream GEMM")):
         t = read(rel)
         if not t:

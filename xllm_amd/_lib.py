@@ -41,6 +41,8 @@ _SIGS = {
     "xllm_mi355_host_cache_slots": ([vp, i64, i64, i64, i64, vp], ci),
     "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_scaled_matmul_rope_cache_packed": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, i64, i64,
+                                                    i64, i64, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_oneshot_allreduce_buffer_bytes": ([sz], sz),
     "xllm_mi355_ipc_alloc": ([sz, C.POINTER(vp), C.POINTER(ci)], ci),
     "xllm_mi355_ipc_free": ([vp], ci),

@@ -413,27 +413,48 @@ __global__ __launch_bounds__(256) void paged_decode_finish_int8_kernel(const flo
                                                                        const float* __restrict__ part_ml, T* __restrict__ out,
                                                                        int8_t* __restrict__ out_q, float* __restrict__ out_scale,
                                                                        int nq, int nsplit) {
+  constexpr int kMaxHeads = 32, kMaxSplit = 32;     // nq <= 32 (VPT * 256 / D), nsplit <= 32 (decode_num_splits)
   __shared__ float red[32];
+  __shared__ float fs[kMaxHeads][kMaxSplit];        // exp2(m_s - m*) per (head, split)
+  __shared__ float ls[kMaxHeads];                   // merged denominators
   const int b = blockIdx.x;
   const int n = nq * D;
+  // phase A: one thread per head turns the (m, l) pairs into the split weights -- ONE dependent load level for everybody after
+  if ((int)threadIdx.x < nq) {
+    const int head = threadIdx.x;
+    const int64_t base = ((int64_t)b * nq + head) * nsplit;
+    float m_star = kNegBig;
+    for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
+    float l = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float f = exp2f(part_ml[(base + s) * 2] - m_star);
+      fs[head][s] = f;
+      l += f * part_ml[(base + s) * 2 + 1];
+    }
+    ls[head] = l;
+  }
+  __syncthreads();
+  // phase B: o = sum_s f_s * o_s in split order (the merge kernel's order), all of a thread's elements per split at once
   float v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) v[i] = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < n) {
+        const int head = e / D, d = e % D;
+        v[i] += fs[head][s] * part_o[(((int64_t)b * nq + head) * nsplit + s) * D + d];
+      }
+    }
+  }
   float amax = 0.0f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int e = threadIdx.x + i * 256;
-    v[i] = 0.0f;
     if (e < n) {
-      const int head = e / D, d = e % D;
-      const int64_t base = ((int64_t)b * nq + head) * nsplit;
-      float m_star = kNegBig;
-      for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
-      float o = 0.0f, l = 0.0f;
-      for (int s = 0; s < nsplit; ++s) {
-        const float f = exp2f(part_ml[(base + s) * 2] - m_star);
-        o += f * part_o[(base + s) * D + d];
-        l += f * part_ml[(base + s) * 2 + 1];
-      }
-      v[i] = r16<T>(l > 0.0f ? o / l : 0.0f);
+      const float l = ls[e / D];
+      v[i] = r16<T>(l > 0.0f ? v[i] / l : 0.0f);
       amax = fmaxf(amax, fabsf(v[i]));
       if (out) out[(int64_t)b * n + e] = from_f32<T>(v[i]);
     }
@@ -466,8 +487,11 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   // workspace those plans are declined (the caller then runs paged_attention + scaled_quantize)
   const size_t per_split = (size_t)batch * nq * (D + 2) * sizeof(float);
   if (!workspace) ws_bytes = 0;
-  const bool finish = out_q && (nsplit != 1 || nkv / hpw != 1);
-  if (finish && (ws_bytes < (size_t)nsplit * per_split || nq * D > 256 * 16 || cu_q)) return XM_ERR_UNSUPPORTED;
+  // (plans with one split but fewer than all kv heads per workgroup write their 16-bit output directly: for them the
+  // finishing launch would only replace scaled_quantize by a launch of the same cost -- measured -- so they are declined)
+  if (out_q && nsplit == 1 && nkv / hpw != 1) return XM_ERR_UNSUPPORTED;
+  const bool finish = out_q && nsplit != 1;
+  if (finish && (ws_bytes < (size_t)nsplit * per_split || nq * D > 256 * 16 || nq > 32 || cu_q)) return XM_ERR_UNSUPPORTED;
   // degrade the split count to what the caller's workspace holds (1 split needs none)
   if ((size_t)nsplit * per_split > ws_bytes) nsplit = (int)(ws_bytes / per_split);
   if (nsplit < 1) nsplit = 1;

@@ -109,6 +109,12 @@ void xm_moe_scratch(void** ws, size_t* bytes);
 int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
                             const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
                             int dtype, int quant, hipStream_t s, int n_slabs = 0);
+// rowwise.hip: consumes int32 K-slice slabs of the packed qkv projection: dequant + RoPE + KV write in one pass
+int launch_slab_rope_and_cache(const int32_t* slabs, int n_slabs, const float* a_scale, const float* w_scale,
+                               const void* bias, void* qkv, int64_t M, int64_t N, const int64_t* positions,
+                               const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache, void* v_cache,
+                               int64_t n_q_heads, int64_t n_kv_heads, int64_t head_size, int64_t rot_dim, int64_t block_size,
+                               int64_t n_blocks, int is_neox, int dtype, hipStream_t s);
 
 }  // namespace xm
 

@@ -947,6 +947,31 @@ int xllm_mi355_scaled_matmul_add_rms_norm_packed(const int8_t* a, const int8_t* 
                                  (hipStream_t)stream, n_slabs);
 }
 
+int xllm_mi355_scaled_matmul_rope_cache_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,
+                                               const float* w_scale, const void* bias, void* qkv, int64_t M, int64_t N,
+                                               int64_t K, int dtype, const int64_t* positions, const void* cos_sin_cache,
+                                               const int32_t* slot_ids, void* k_cache, void* v_cache, int64_t n_q_heads,
+                                               int64_t n_kv_heads, int64_t head_size, int64_t rot_dim, int64_t block_size,
+                                               int64_t n_blocks, int is_neox, void* workspace, size_t ws_bytes,
+                                               void* stream) {
+  if (!a || !w_packed || !a_scale || !w_scale || !qkv || !positions || !cos_sin_cache || !slot_ids || !k_cache || !v_cache ||
+      M < 0 || N <= 0 || K <= 0 || block_size <= 0)
+    return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  if (!workspace || ws_bytes < (size_t)M * N * 4) return XM_ERR_WORKSPACE;
+  if (N != (n_q_heads + 2 * n_kv_heads) * head_size || N % 4 || N * 2 > 64 * 1024 || rot_dim <= 0 || (rot_dim & 1) ||
+      rot_dim > head_size || ((uintptr_t)w_scale % 16))
+    return XM_ERR_UNSUPPORTED;               // checked BEFORE the GEMM is launched: a declined call has no side effect
+  GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0, 1};
+  int n_slabs = 1;
+  const int rc = launch_gemm_ws_i8(a, w_packed, M, N, K, epi, workspace, ws_bytes, &n_slabs, (hipStream_t)stream);
+  if (rc != XM_OK) return rc;
+  return launch_slab_rope_and_cache(reinterpret_cast<const int32_t*>(workspace), n_slabs, a_scale, w_scale, bias, qkv, M, N,
+                                    positions, cos_sin_cache, slot_ids, k_cache, v_cache, n_q_heads, n_kv_heads, head_size,
+                                    rot_dim, block_size, n_blocks, is_neox, dtype, (hipStream_t)stream);
+}
+
 int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale, int64_t a_scale_numel,
                                  const float* w_scale, int64_t w_scale_numel, const void* bias, void* out, int64_t M,
                                  int64_t N, int64_t K, int out_dtype, void* stream) {

@@ -433,6 +433,94 @@ __global__ __launch_bounds__(256) void rope_and_cache_kernel(
   }
 }
 
+// N1 fusion across the GEMM boundary: the qkv projection's dequant epilogue + RoPE + KV write in ONE pass over the token's row.
+// The packed-weight GEMM (gemm_ws.hip) leaves exact int32 K-slice slabs; this kernel adds them, applies the scaled_matmul
+// epilogue (r16(acc * a_s[t] * w_s[n] + bias[n]): the 16-bit qkv row the reference's linear would have written,
+// linear.cpp:481-507), rotates q and k with the arithmetic of rope_and_cache_kernel, writes the packed qkv
+// row (q is the attention's input) and scatters the rotated k and v to the caches. Bit-identical to scaled_matmul ->
+// rotary_embedding -> reshape_paged_cache; one launch and one round trip of the qkv row instead of three.
+template <typename T, bool NEOX>
+__global__ __launch_bounds__(256) void slab_rope_and_cache_kernel(
+    const int32_t* __restrict__ slabs, int n_slabs, int64_t slab_stride, const float* __restrict__ a_scale,
+    const float* __restrict__ w_scale, const T* __restrict__ bias, T* __restrict__ qkv, int n_cols,
+    const int64_t* __restrict__ positions, const T* __restrict__ cache, const int32_t* __restrict__ slot_ids,
+    T* __restrict__ kc, T* __restrict__ vc, int rot_dim, int head_size, int nq, int nk, int64_t block_size, int64_t n_blocks) {
+  // no row-wide quantity is needed, so the row is cut into independent work items -- one RoPE pair of a q / k head, or one
+  // un-rotated element (tails of q / k, all of v) -- and spread over blockIdx.y: a decode batch of 32 tokens still fills the chip
+  // (one workgroup per token made this launch as slow as the two it replaces: measured, profiles/r02_fusions.txt)
+  const int64_t t = blockIdx.x;
+  const int half = rot_dim >> 1, tail = head_size - rot_dim;
+  const int n_pairs = (nq + nk) * half, n_tail = (nq + nk) * tail, n_v = nk * head_size;
+  const int item = blockIdx.y * blockDim.x + threadIdx.x;
+  if (item >= n_pairs + n_tail + n_v) return;
+  const float as = a_scale[t];
+  const int32_t* acc_row = slabs + t * (int64_t)n_cols;
+  auto value = [&](int c) -> float {   // the 16-bit qkv element the GEMM epilogue would have written
+    int a = acc_row[c];
+    for (int sl = 1; sl < n_slabs; ++sl) a += acc_row[sl * slab_stride + c];
+    return r16<T>((float)a * as * w_scale[c] + (bias ? to_f32(bias[c]) : 0.0f));
+  };
+  const int64_t slot = slot_ids[t];
+  const bool store = slot >= 0 && slot / block_size < n_blocks;
+  T* kc_row = kc + slot * (int64_t)nk * head_size;
+  T* vc_row = vc + slot * (int64_t)nk * head_size;
+  T* out_row = qkv + t * (int64_t)n_cols;
+  if (item < n_pairs) {
+    const int h = item / half, j = item - h * half;
+    const int base = h * head_size;                 // q heads then k heads are contiguous in the packed row
+    const int xi = NEOX ? j : 2 * j, yi = NEOX ? half + j : 2 * j + 1;
+    const T* cp = cache + positions[t] * rot_dim;
+    const float c = to_f32(cp[j]), sn = to_f32(cp[half + j]);
+    const float x = value(base + xi), y = value(base + yi);
+    const T nx = from_f32<T>(r16<T>(x * c) - r16<T>(y * sn));
+    const T ny = from_f32<T>(r16<T>(y * c) + r16<T>(x * sn));
+    out_row[base + xi] = nx;
+    out_row[base + yi] = ny;
+    if (h >= nq && store) {
+      kc_row[(h - nq) * head_size + xi] = nx;
+      kc_row[(h - nq) * head_size + yi] = ny;
+    }
+  } else if (item < n_pairs + n_tail) {             // un-rotated tail of a q / k head (rot_dim < head_size)
+    const int i2 = item - n_pairs;
+    const int h = i2 / tail, e = rot_dim + (i2 - h * tail);
+    const T v = from_f32<T>(value(h * head_size + e));
+    out_row[h * head_size + e] = v;
+    if (h >= nq && store) kc_row[(h - nq) * head_size + e] = v;
+  } else {                                          // v
+    const int i2 = item - n_pairs - n_tail;
+    const int c = (nq + nk) * head_size + i2;
+    const T v = from_f32<T>(value(c));
+    out_row[c] = v;
+    if (store) vc_row[i2] = v;
+  }
+}
+
+int launch_slab_rope_and_cache(const int32_t* slabs, int n_slabs, const float* a_scale, const float* w_scale,
+                               const void* bias, void* qkv, int64_t M, int64_t N, const int64_t* positions,
+                               const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache, void* v_cache,
+                               int64_t n_q_heads, int64_t n_kv_heads, int64_t head_size, int64_t rot_dim, int64_t block_size,
+                               int64_t n_blocks, int is_neox, int dtype, hipStream_t s) {
+  if (N != (n_q_heads + 2 * n_kv_heads) * head_size || N % 4 || N * 2 > 64 * 1024 || rot_dim <= 0 || (rot_dim & 1) ||
+      rot_dim > head_size || ((uintptr_t)slabs % 16) || ((uintptr_t)w_scale % 16))
+    return XM_ERR_UNSUPPORTED;
+  const int64_t items = (n_q_heads + n_kv_heads) * (rot_dim / 2) + (n_q_heads + n_kv_heads) * (head_size - rot_dim) +
+                        n_kv_heads * head_size;
+  const dim3 grid((unsigned)M, (unsigned)((items + 255) / 256));
+  XM_DISPATCH_HALF(dtype, T, {
+    if (is_neox)
+      hipLaunchKernelGGL((slab_rope_and_cache_kernel<T, true>), grid, dim3(256), 0, s, slabs, n_slabs, M * N,
+                         a_scale, w_scale, (const T*)bias, (T*)qkv, (int)N, positions, (const T*)cos_sin_cache, slot_ids,
+                         (T*)k_cache, (T*)v_cache, (int)rot_dim, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                         n_blocks);
+    else
+      hipLaunchKernelGGL((slab_rope_and_cache_kernel<T, false>), grid, dim3(256), 0, s, slabs, n_slabs, M * N,
+                         a_scale, w_scale, (const T*)bias, (T*)qkv, (int)N, positions, (const T*)cos_sin_cache, slot_ids,
+                         (T*)k_cache, (T*)v_cache, (int)rot_dim, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                         n_blocks);
+  });
+  return hip_check_launch();
+}
+
 // fused per-head RMSNorm + RoPE inside packed qkv (reference: kernels/cuda/fused_qknorm_rope.cu:88-300)
 // one wave per (token, head); fp32 math, one 16-bit store. head_dim <= 256, multiple of 2.
 template <typename T, typename CT>

@@ -184,12 +184,24 @@ class Qwen2DecoderLayer:
                                               self.args.rms_norm_eps, lin.bias, quantize=quantize, b_packed=lin.weight_packed)
 
     # ---- the decode step cut at the attention kernel (dual micro-batch executor, DualBatchDecoder below) ----------
+    def _qkv_rope_cache(self, h, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin):
+        """N1 across the GEMM boundary (small M, packed weights): W8A8 qkv projection -> dequant -> RoPE -> KV write in two
+        launches (ops.scaled_matmul_rope_cache), bit-identical to qkv_proj + rotary_embedding_and_cache; None = not applicable"""
+        if not self.fuse or self.qkv_proj.weight_packed is None or positions.dtype != torch.int64:
+            return None
+        return ops.scaled_matmul_rope_cache(h[0], self.qkv_proj.weight_packed, h[1], self.qkv_proj.w_scale, self.qkv_proj.bias,
+                                            positions, cos_sin, md.slot_mapping, kv_cache.k_cache, kv_cache.v_cache, self.nq,
+                                            self.nkv, self.d, self.dtype)
+
     def pre_attention(self, x, residual, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin, h_in=None):
         """input norm (unless the previous layer fused it) + qkv_proj + RoPE + KV write; returns (q, residual)"""
         if h_in is not None:
             h = h_in
         else:
             h, residual = self._norm(x, residual, self.input_norm_w)
+        qkv = self._qkv_rope_cache(h, positions, md, kv_cache, cos_sin)
+        if qkv is not None:
+            return qkv[:, :self.q_size], residual
         qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
         q = qkv[:, :self.q_size]
         k = qkv[:, self.q_size:self.q_size + self.kv_size]
@@ -231,7 +243,10 @@ class Qwen2DecoderLayer:
             h = h_in                      # the previous layer already ran this layer's input norm (fused)
         else:
             h, residual = self._norm(x, residual, self.input_norm_w)
-        qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
+        qkv = self._qkv_rope_cache(h, positions, md, kv_cache, cos_sin)   # small M: GEMM -> dequant + RoPE + KV write fused
+        rope_done = qkv is not None
+        if qkv is None:
+            qkv = self.qkv_proj.forward(None, pre_quant=h) if self.fuse else self.qkv_proj.forward(h)
         q = qkv[:, :self.q_size]
         k = qkv[:, self.q_size:self.q_size + self.kv_size]
         v = qkv[:, self.q_size + self.kv_size:]
@@ -240,8 +255,9 @@ class Qwen2DecoderLayer:
         if self.fuse and decode:
             # N1 fusions on the decode path: RoPE + KV write in one launch, and the attention epilogue emits the
             # int8 operand of o_proj directly (falls back when the batch is small enough to need split-KV)
-            ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
-                                           kv_cache.v_cache, self.d, True)
+            if not rope_done:
+                ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
+                                               kv_cache.v_cache, self.d, True)
             fused_attn = ops.paged_decode_attention_int8(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache,
                                                          kv_cache.v_cache, md.kv_seq_lens, md.block_table,
                                                          md.max_seq_len, self.attn.scale, self.attn.window_left)
@@ -250,8 +266,9 @@ class Qwen2DecoderLayer:
                                            md.kv_seq_lens, md.block_table, 1, md.max_seq_len, self.attn.scale, False,
                                            self.attn.window_left)
         elif self.fuse:  # prefill / chunked prefill: the same RoPE + KV-write fusion, then the attention kernel alone
-            ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
-                                           kv_cache.v_cache, self.d, True)
+            if not rope_done:
+                ops.rotary_embedding_and_cache(positions, q, k, v, cos_sin, md.slot_mapping, kv_cache.k_cache,
+                                               kv_cache.v_cache, self.d, True)
             attn, _ = self.attn.forward(md, q, k, v, kv_cache, kv_written=True)
         else:
             ops.rotary_embedding(positions, q, k, cos_sin, True, head_size=self.d)

@@ -660,7 +660,35 @@ def rotary_embedding_and_cache(positions, query, key, value, cos_sin_cache, slot
         key_cache.size(-3), key_cache.size(0), int(is_neox), _dt(query), _stream()), "rotary_embedding_and_cache")
 
 
-_ATTN_FINISH = os.environ.get("XLLM_MI355_ATTN_FINISH", "1") != "0"
+_QKV_ROPE_FUSION = os.environ.get("XLLM_MI355_QKV_ROPE", "1") != "0"
+
+
+def scaled_matmul_rope_cache(a, b_packed, a_scale, b_scale, bias, positions, cos_sin_cache, slot_ids, key_cache, value_cache,
+                             n_q_heads: int, n_kv_heads: int, head_size: int, output_dtype=torch.bfloat16, is_neox: bool = True):
+    """N1 fusion across the GEMM boundary: W8A8 qkv projection on packed weights -> dequant epilogue -> RoPE -> KV write
+    (scaled_matmul + rotary_embedding_and_cache, bit for bit). Returns the packed qkv rows [M, N] with q and k rotated, or None
+    when the shape is outside the fused path (the caller runs the separate operators)."""
+    _need_cuda(a, b_packed, a_scale, b_scale, positions, cos_sin_cache, slot_ids, key_cache, value_cache)
+    M, K = a.shape
+    N = (n_q_heads + 2 * n_kv_heads) * head_size
+    if not _QKV_ROPE_FUSION or b_packed.numel() != N * K or not _prefer_packed(M, N, K) or cos_sin_cache.dtype != output_dtype:
+        return None
+    ws = _slab_workspace(a.device)
+    out = torch.empty(M, N, dtype=output_dtype, device=a.device)
+    rc = _lib.lib().xllm_mi355_scaled_matmul_rope_cache_packed(
+        _p(a), _p(b_packed), _p(a_scale), _p(b_scale), _p(bias), _p(out), M, N, K, _DT[output_dtype], _p(positions),
+        _p(cos_sin_cache), _p(slot_ids), _p(key_cache), _p(value_cache), n_q_heads, n_kv_heads, head_size,
+        cos_sin_cache.size(-1), key_cache.size(-3), key_cache.size(0), int(is_neox), _p(ws), ws.numel(), _stream())
+    if rc == -2:
+        return None
+    check(rc, "scaled_matmul_rope_cache")
+    return out
+
+
+# merge + int8 quantisation of split-KV partials in one finishing launch: built, bit-identical, and NOT faster (one workgroup per
+# token, 12.7 us at 32 tokens, against 4.9 + 4.8 us for the merge and quantise launches it replaces, profiles/r02_fusions.txt:
+# the row maximum is a whole-row dependency, so the launch cannot be spread like the qkv fusion above) -- opt-in
+_ATTN_FINISH = os.environ.get("XLLM_MI355_ATTN_FINISH", "0") == "1"
 
 
 def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, max_kv_len, scale, window_left=-1,
@@ -674,8 +702,8 @@ def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, m
     os_ = torch.empty(B, dtype=torch.float32, device=q.device)
     o16 = torch.empty(B, nq * d, dtype=q.dtype, device=q.device) if want_16bit else None
     bt = block_table if block_table.is_contiguous() else block_table.contiguous()
-    # with the attention scratch the plans that split the token range (small batches) finish through ONE merge + quantise
-    # launch; XLLM_MI355_ATTN_FINISH=0 keeps the round-1 behaviour (decline, the caller runs paged_attention + scaled_quantize)
+    # XLLM_MI355_ATTN_FINISH=1: plans that split the token range over the grid finish through ONE merge + quantise launch
+    # (default: decline, the caller runs paged_attention + scaled_quantize)
     ws = None
     if _ATTN_FINISH:
         ws = _attn_workspace(q.device, _lib.lib().xllm_mi355_paged_attention_workspace_bytes(B, nq, d, 1, B))
