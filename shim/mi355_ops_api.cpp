@@ -7,6 +7,9 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/HIPGeneratorImpl.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../include/xllm_mi355.h"
 
 namespace xllm::kernel::mi355 {
@@ -202,6 +205,58 @@ std::tuple<torch::Tensor, torch::Tensor> scaled_quantize(
   return {q, s};
 }
 
+namespace {
+// Decode-shaped W8A8 GEMMs stream the weight in MFMA-fragment order (xllm_mi355_pack_weight_i8 + xllm_mi355_scaled_matmul_packed).
+// The reference's operator has no "packed weight" argument, so the shim keeps one packed copy per weight tensor, made on the
+// first decode-shaped call (weights are loaded once and live as long as the model; the key carries the tensor's version
+// counter so that an in-place update re-packs) and one K-slice scratch per device. The reference runs one worker thread per
+// device in one process (runtime/dist_manager.cpp:82-84): both maps are mutex-guarded, the scratch is per device.
+struct PackedEntry {
+  torch::Tensor packed;
+  int64_t n, k;
+  uint32_t version;
+};
+std::mutex g_pack_mu;
+std::unordered_map<const void*, PackedEntry> g_packed;
+std::unordered_map<int, torch::Tensor> g_slab_ws;
+constexpr int64_t kSlabBytes = 64ll << 20;
+
+bool prefer_packed(int64_t M, int64_t N, int64_t K) {   // the measured policy of xllm_amd/ops.py::_prefer_packed
+  return N % 16 == 0 && K % 128 == 0 && K / 128 >= 4 && (M <= 128 || (M <= 512 && N <= 8192 && K >= 8192));
+}
+
+const torch::Tensor* packed_weight_for(const torch::Tensor& b) {
+  const uint32_t ver = b.unsafeGetTensorImpl()->version_counter().current_version();
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  auto it = g_packed.find(b.data_ptr());
+  if (it != g_packed.end() && it->second.n == b.size(0) && it->second.k == b.size(1) && it->second.version == ver)
+    return &it->second.packed;
+  torch::Tensor packed = torch::empty_like(b);
+  if (xllm_mi355_pack_weight_i8(b.data_ptr<int8_t>(), packed.data_ptr<int8_t>(), b.size(0), b.size(1), cur_stream()) != 0)
+    return nullptr;
+  auto& e = g_packed[b.data_ptr()];
+  e = PackedEntry{packed, b.size(0), b.size(1), ver};
+  return &e.packed;
+}
+
+torch::Tensor slab_workspace(const torch::Tensor& like) {
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  auto& ws = g_slab_ws[like.device().index()];
+  if (!ws.defined()) ws = torch::empty({kSlabBytes}, like.options().dtype(torch::kUInt8));
+  return ws;
+}
+}  // namespace
+
+int64_t packed_weight_cache_size() {
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  return (int64_t)g_packed.size();
+}
+
+void clear_packed_weight_cache() {
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  g_packed.clear();
+}
+
 torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const std::optional<torch::Tensor>& a_scale,
                             const torch::Tensor& b_scale, torch::ScalarType output_dtype,
                             const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& /*c*/,
@@ -220,6 +275,16 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
   torch::Tensor out = output.has_value() ? *output : torch::empty({M, N}, a.options().dtype(output_dtype));
   auto as = a_scale->reshape({-1}).contiguous();
   auto bs = b_scale.reshape({-1}).contiguous();
+  if (prefer_packed(M, N, K)) {   // decode shapes: the weight-stream kernel on the packed copy; declines fall through
+    if (const torch::Tensor* wp = packed_weight_for(b)) {
+      torch::Tensor ws = slab_workspace(a);
+      const int rc = xllm_mi355_scaled_matmul_packed(a.data_ptr<int8_t>(), wp->data_ptr<int8_t>(), as.data_ptr<float>(),
+                                                     bs.data_ptr<float>(), p(bias), p(out), nullptr, M, N, K,
+                                                     dt(output_dtype), ws.data_ptr(), (size_t)ws.numel(), cur_stream());
+      if (rc == 0) return out;
+      TORCH_CHECK(rc == XM_ERR_UNSUPPORTED, "scaled_matmul (packed): ", xllm_mi355_strerror(rc));
+    }
+  }
   check(xllm_mi355_scaled_matmul(a.data_ptr<int8_t>(), b.data_ptr<int8_t>(), as.data_ptr<float>(),
                                  bs.data_ptr<float>(), p(bias), p(out), nullptr, M, N, K, dt(output_dtype),
                                  cur_stream()),

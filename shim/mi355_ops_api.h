@@ -63,6 +63,10 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
                             bool use_hp_active, int64_t a_quant_bit_size, const std::optional<torch::Tensor>& a_calib,
                             const std::optional<torch::Tensor>& b_calib, const std::optional<torch::Tensor>& output);
 // dcu_ops_api.h:48-51, 71-73
+// decode-shaped scaled_matmul calls run on a packed copy of the weight kept by the shim (one per weight tensor); these two
+// expose the cache to tests and to code that frees or replaces weights
+int64_t packed_weight_cache_size();
+void clear_packed_weight_cache();
 torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
                          std::optional<torch::Tensor> output = std::nullopt);
 // kernel::moe_active_topk / cuda::moe_fused_topk (ops_api.h:70; kernels/cuda/moe/moe_fused_topk.cu:31-61):

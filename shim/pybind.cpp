@@ -33,6 +33,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("scaled_matmul", [](const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& as, const torch::Tensor& bs, std::optional<torch::Tensor> bias) {
     return k::scaled_matmul(a, b, as, bs, torch::kBFloat16, bias, std::nullopt, "none", 8, 1.0, 0.0, false, 8, std::nullopt, std::nullopt, std::nullopt);
   });
+  m.def("packed_weight_cache_size", &k::packed_weight_cache_size);
+  m.def("clear_packed_weight_cache", &k::clear_packed_weight_cache);
   m.def("fp8_scaled_quantize", [](const torch::Tensor& x) { return k::fp8_scaled_quantize(x); });
   m.def("paged_attention", [](const torch::Tensor& q, const torch::Tensor& kc, const torch::Tensor& vc, const torch::Tensor& kv_lens, const torch::Tensor& bt, int64_t max_kv, double scale) {
     return k::paged_attention(q, kc, vc, std::nullopt, kv_lens, bt, 1, max_kv, scale, false, -1);

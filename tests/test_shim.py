@@ -59,9 +59,22 @@ def test_shim_matches_oracle_and_ctypes_path():
     assert torch.equal(q.cpu(), qr) and torch.equal(s.cpu(), sr)
     wq = torch.randint(-127, 128, (256, H), generator=g, dtype=torch.int8)
     ws = torch.rand(256, generator=g) * 0.02 + 0.01
-    y = m.scaled_matmul(q, wq.to(dev), s, ws.to(dev), None)
+    m.clear_packed_weight_cache()
+    wqd = wq.to(dev)
+    y = m.scaled_matmul(q, wqd, s, ws.to(dev), None)
     yr = orc.scaled_matmul(qr, wq, sr, ws)
     assert (y.float().cpu() - yr.float()).abs().max() <= 2.0 ** -7 * yr.float().abs().max()
+    # decode-shaped call (M = 9): the shim packed the weight once and ran the weight-stream kernel -- the bits of the
+    # row-major kernel and of the Python mirror's packed path; a second call reuses the copy, an in-place update re-packs
+    assert m.packed_weight_cache_size() == 1
+    assert torch.equal(y, ops.scaled_matmul(q, wqd, s, ws.to(dev), torch.bfloat16, None, b_packed=ops.pack_weight_i8(wqd)))
+    assert torch.equal(m.scaled_matmul(q, wqd, s, ws.to(dev), None), y) and m.packed_weight_cache_size() == 1
+    wqd.neg_()
+    y_neg = m.scaled_matmul(q, wqd, s, ws.to(dev), None)
+    assert m.packed_weight_cache_size() == 1 and torch.equal(y_neg.float(), -y.float())
+    big = torch.randint(-127, 128, (600, H), generator=g, dtype=torch.int8).to(dev)     # M = 600: the row-major kernels
+    sb = torch.rand(600, generator=g).to(dev) * 0.01
+    assert torch.equal(m.scaled_matmul(big, wqd, sb, ws.to(dev), None), ops.scaled_matmul(big, wqd, sb, ws.to(dev), torch.bfloat16))
     # AttentionImpl::forward (decode): KV write + paged attention
     B, nq, nkv, d, bs = 3, 28, 4, 128, 128
     kv_lens = [300, 129, 517]

@@ -68,7 +68,7 @@ def main():
                      ("r02small/cfg5-slice_kernel_stats.txt", "r02_bench_cfg5_slice_kernel_stats.txt"),
                      (f"{final}/pmc_fetch_size.txt", "r02_bench_pmc_fetch_size.txt"),
                      (f"{final}/pmc_write_size.txt", "r02_bench_pmc_write_size.txt"),
-                     (f"{final}/pytest.txt", "r02_pytest_gpu.txt")):
+                     ("r02last/pytest.txt", "r02_pytest_gpu.txt")):
         t = read(src)
         if t:
             open(os.path.join(P, dst), "w").write(t)
