@@ -105,7 +105,10 @@ def test_shim_stub_headers_mirror_the_reference_field_for_field():
     ref_root = "/root/reference/xllm/core"
     if not os.path.isdir(ref_root):
         pytest.skip("reference tree not present")
-    stub = _struct_members(os.path.join(ROOT, "shim", "stub", "layers", "common", "attention_metadata.h"), "AttentionMetadata")
+    # the stub keeps its members as one F(type, name, init) list that the struct is expanded from
+    stub_src = open(os.path.join(ROOT, "shim", "stub", "layers", "common", "attention_metadata.h")).read()
+    stub = [(t.strip(), n.strip()) for t, n in re.findall(r"^\s*F\(([^,]+),\s*(\w+),[^)]*\)", stub_src, flags=re.M)]
+    assert len(stub) >= 30
     ref = _struct_members(os.path.join(ref_root, "layers", "common", "attention_metadata.h"), "AttentionMetadata")
     assert stub == ref, [x for x in zip(stub, ref) if x[0] != x[1]][:3]
     kv = open(os.path.join(ref_root, "framework", "kv_cache", "kv_cache.h")).read()
