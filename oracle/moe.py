@@ -14,12 +14,19 @@ import torch
 from . import oracle as orc
 
 
-def fused_moe(x, gate_w, w13, w2, topk: int, renormalize: bool, scoring_func: str = "softmax", correction_bias=None):
-    """x [T, H]; gate_w [E, H]; w13 [E, 2 I, H] (gate rows first, then up); w2 [E, H, I]; returns [T, H] in x.dtype"""
+def fused_moe(x, gate_w, w13, w2, topk: int, renormalize: bool, scoring_func: str = "softmax", correction_bias=None,
+              num_expert_group: int = 1, topk_group: int = 1, route_scale: float = 1.0):
+    """x [T, H]; gate_w [E, H]; w13 [E, 2 I, H] (gate rows first, then up); w2 [E, H, I]; returns [T, H] in x.dtype.
+    num_expert_group > 1: the device-limited gate of DeepSeek-V2 / V3 (moe_active_topk -> dcu::moe_grouped_topk,
+    kernels/dcu/topk_gate.cpp:59-146; fused_moe.cpp:155-166)"""
     T, H = x.shape
     E = gate_w.size(0)
     logits = orc.matmul(x, gate_w.to(x.dtype))
-    weights, ids = orc.moe_fused_topk(logits, topk, renormalize, correction_bias, scoring_func)
+    if num_expert_group > 1 or route_scale != 1.0:
+        weights, ids = orc.moe_grouped_topk(logits, topk, num_expert_group, topk_group, renormalize, correction_bias,
+                                            scoring_func, route_scale)
+    else:
+        weights, ids = orc.moe_fused_topk(logits, topk, renormalize, correction_bias, scoring_func)
     src_dst, dst_src, sizes = orc.moe_compute_index(ids, E)
     xs = x.index_select(0, (dst_src // topk).long()).contiguous()          # expand, sorted by expert
     h13 = orc.group_gemm(xs, w13.to(x.dtype), sizes)
