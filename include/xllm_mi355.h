@@ -493,6 +493,22 @@ XM_API int xllm_mi355_host_build_batch(const int32_t* n_kv_cache_tokens, const i
                                        const int32_t* block_indptr, const int32_t* block_ids, int64_t num_sequences,
                                        int64_t block_size, xllm_mi355_host_batch_t* out);
 
+/* HOST side: the contiguous input buffer of one step (ForwardInputBufferPlan, runtime/forward_params.h:87-175): every host
+ * tensor of a ForwardInput in ONE byte buffer -- entries in insertion order, each at the next multiple of `alignment` bytes
+ * (the reference uses 16), tails zero-filled -- so that the step reaches the device in one H2D copy and the device tensors are
+ * views of one device buffer. plan: fills offset / aligned_bytes of every entry and *total_bytes. pack: copies the entries
+ * into `buffer` (XM_ERR_WORKSPACE when it is too small). No GPU is touched. */
+typedef struct {
+  const void* data;        /* in: the host tensor's bytes (may be NULL when bytes == 0) */
+  uint64_t bytes;          /* in */
+  uint64_t offset;         /* out (plan) / in (pack) */
+  uint64_t aligned_bytes;  /* out (plan) / in (pack) */
+} xllm_mi355_host_buffer_entry_t;
+XM_API int xllm_mi355_host_plan_input_buffer(xllm_mi355_host_buffer_entry_t* entries, int64_t n_entries,
+                                             uint64_t alignment, uint64_t* total_bytes);
+XM_API int xllm_mi355_host_pack_input_buffer(const xllm_mi355_host_buffer_entry_t* entries, int64_t n_entries,
+                                             void* buffer, uint64_t buffer_bytes);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * One-shot SUM all-reduce over peer-mapped buffers (xGMI), for the small tensor-parallel messages of a decode step.
  * Replaces, for messages <= max_message_bytes, parallel_state::reduce -> ProcessGroup::allreduce -> ProcessGroupNCCL

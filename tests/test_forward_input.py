@@ -86,3 +86,35 @@ def test_forward_input_reaches_the_device_in_one_copy_and_drives_a_model_step():
     ref_md = attention.build_attention_metadata(bi, False, True, dev)
     ref = model.forward(toks.to(dev).long(), bi.positions.to(dev).long(), ref_md, kv_b)
     assert torch.equal(out, ref) and torch.equal(kv_a[0].k_cache, kv_b[0].k_cache)
+
+
+def test_native_plan_and_pack_entry_points():
+    """xllm_mi355_host_plan_input_buffer / _pack_input_buffer (host code of the library, no GPU): the reference's arithmetic for
+    several alignments, an undersized buffer is refused, empty entries take no bytes"""
+    import ctypes as C
+    from xllm_amd import _lib
+    l = _lib.lib()
+    payloads = [bytes(range(1, 21)), b"", bytes([7] * 3), bytes([9] * 64)]
+    bufs = [C.create_string_buffer(p, max(len(p), 1)) for p in payloads]
+    for alignment in (16, 1, 0, 64):
+        arr = (_lib.HostBufferEntry * len(payloads))()
+        for i, p in enumerate(payloads):
+            arr[i].data, arr[i].bytes = C.cast(bufs[i], C.c_void_p).value if p else None, len(p)
+        total = C.c_uint64(0)
+        assert l.xllm_mi355_host_plan_input_buffer(arr, len(payloads), alignment, C.byref(total)) == 0
+        off, want = 0, []
+        for p in payloads:
+            off = align_up(off, alignment)
+            want.append((off, align_up(len(p), alignment)))
+            off += want[-1][1]
+        assert [(int(e.offset), int(e.aligned_bytes)) for e in arr] == want and total.value == off
+        out = C.create_string_buffer(b"\xff" * (off + 8), off + 8)
+        assert l.xllm_mi355_host_pack_input_buffer(arr, len(payloads), out, off) == 0
+        raw = out.raw
+        for p, (o, ab) in zip(payloads, want):
+            assert raw[o:o + len(p)] == p and raw[o + len(p):o + ab] == b"\x00" * (ab - len(p))
+        assert raw[off:] == b"\xff" * 8                                            # nothing written past the plan
+        if off:
+            assert l.xllm_mi355_host_pack_input_buffer(arr, len(payloads), out, off - 1) == -4   # XM_ERR_WORKSPACE
+    assert l.xllm_mi355_host_plan_input_buffer(None, 0, 16, C.byref(total)) == 0 and total.value == 0
+    assert l.xllm_mi355_host_plan_input_buffer(None, 3, 16, C.byref(total)) == -1   # XM_ERR_INVALID

@@ -27,6 +27,11 @@ class DecodeMetadata(C.Structure):
 
 
 
+class HostBufferEntry(C.Structure):
+    """xllm_mi355_host_buffer_entry_t (include/xllm_mi355.h)"""
+    _fields_ = [("data", vp), ("bytes", u64), ("offset", u64), ("aligned_bytes", u64)]
+
+
 class HostBatch(C.Structure):
     """xllm_mi355_host_batch_t (include/xllm_mi355.h)"""
     _fields_ = ([(n, i64) for n in ("cap_tokens", "cap_indices", "cap_sequences", "cap_block_table")] +
@@ -39,6 +44,8 @@ class HostBatch(C.Structure):
 
 _SIGS = {
     "xllm_mi355_host_cache_slots": ([vp, i64, i64, i64, i64, vp], ci),
+    "xllm_mi355_host_plan_input_buffer": ([C.POINTER(HostBufferEntry), i64, u64, C.POINTER(u64)], ci),
+    "xllm_mi355_host_pack_input_buffer": ([C.POINTER(HostBufferEntry), i64, vp, u64], ci),
     "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
     "xllm_mi355_scaled_matmul_rope_cache_packed": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, i64, i64,

@@ -80,3 +80,36 @@ extern "C" int xllm_mi355_host_build_batch(const int32_t* n_kv_cache_tokens, con
   out->total_kv_len = kv_cu;
   return XM_OK;
 }
+
+// ---- the contiguous input buffer of a step (runtime/forward_params.h:94-143: ForwardInputBufferPlan::prepare_layout /
+// build_host_buffer): every host tensor of a ForwardInput laid out in ONE byte buffer, entries in insertion order, each at
+// the next multiple of `alignment` bytes, tails zero-filled, so that the step reaches the device in one H2D copy.
+extern "C" int xllm_mi355_host_plan_input_buffer(xllm_mi355_host_buffer_entry_t* entries, int64_t n_entries,
+                                                 uint64_t alignment, uint64_t* total_bytes) {
+  if ((!entries && n_entries > 0) || n_entries < 0 || !total_bytes) return XM_ERR_INVALID;
+  auto align_up = [&](uint64_t v) { return alignment == 0 ? v : (v + alignment - 1) / alignment * alignment; };
+  uint64_t total = 0;
+  for (int64_t i = 0; i < n_entries; ++i) {
+    total = align_up(total);
+    entries[i].offset = total;
+    entries[i].aligned_bytes = align_up(entries[i].bytes);
+    total += entries[i].aligned_bytes;
+  }
+  *total_bytes = total;
+  return XM_OK;
+}
+
+extern "C" int xllm_mi355_host_pack_input_buffer(const xllm_mi355_host_buffer_entry_t* entries, int64_t n_entries,
+                                                 void* buffer, uint64_t buffer_bytes) {
+  if ((!entries && n_entries > 0) || n_entries < 0 || (!buffer && buffer_bytes > 0)) return XM_ERR_INVALID;
+  char* base = static_cast<char*>(buffer);
+  for (int64_t i = 0; i < n_entries; ++i) {
+    const xllm_mi355_host_buffer_entry_t& e = entries[i];
+    if (e.offset + e.aligned_bytes > buffer_bytes || e.aligned_bytes < e.bytes) return XM_ERR_WORKSPACE;
+    if (e.bytes == 0) continue;
+    if (!e.data) return XM_ERR_INVALID;
+    __builtin_memcpy(base + e.offset, e.data, e.bytes);
+    if (e.aligned_bytes > e.bytes) __builtin_memset(base + e.offset + e.bytes, 0, e.aligned_bytes - e.bytes);
+  }
+  return XM_OK;
+}

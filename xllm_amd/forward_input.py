@@ -46,24 +46,36 @@ class ForwardInputBufferPlan:
         self.entries.append({"host": tensor.contiguous(), "target": target, "offset": 0, "aligned_bytes": 0})
         return True
 
+    def _c_entries(self):
+        import ctypes as C
+        from . import _lib
+        arr = (_lib.HostBufferEntry * max(len(self.entries), 1))()
+        for i, e in enumerate(self.entries):
+            h = e["host"]
+            arr[i].data = h.data_ptr() if h.numel() else None
+            arr[i].bytes = h.numel() * h.element_size()
+            arr[i].offset, arr[i].aligned_bytes = e["offset"], e["aligned_bytes"]
+        return arr
+
     def prepare_layout(self) -> int:
-        total = 0
-        for e in self.entries:
-            total = align_up(total, kForwardInputBufferAlignment)
-            e["offset"] = total
-            nbytes = e["host"].numel() * e["host"].element_size()
-            e["aligned_bytes"] = align_up(nbytes, kForwardInputBufferAlignment)
-            total += e["aligned_bytes"]
-        return total
+        """offsets and padded sizes of every entry (the library's host code: xllm_mi355_host_plan_input_buffer)"""
+        import ctypes as C
+        from . import _lib
+        arr, total = self._c_entries(), C.c_uint64(0)
+        _lib.check(_lib.lib().xllm_mi355_host_plan_input_buffer(arr, len(self.entries), kForwardInputBufferAlignment,
+                                                               C.byref(total)), "host_plan_input_buffer")
+        for i, e in enumerate(self.entries):
+            e["offset"], e["aligned_bytes"] = int(arr[i].offset), int(arr[i].aligned_bytes)
+        return int(total.value)
 
     def build_host_buffer(self, total_bytes: int, pin: bool = True) -> torch.Tensor:
-        buf = torch.zeros(max(total_bytes, 1), dtype=torch.uint8)      # zero tails (:135-139)
+        """one (pinned) byte buffer holding every entry, tails zero-filled (xllm_mi355_host_pack_input_buffer)"""
+        from . import _lib
+        buf = torch.empty(max(total_bytes, 1), dtype=torch.uint8)
         if pin and torch.cuda.is_available():
             buf = buf.pin_memory()
-        for e in self.entries:
-            nbytes = e["host"].numel() * e["host"].element_size()
-            if nbytes:
-                buf[e["offset"]:e["offset"] + nbytes].copy_(e["host"].reshape(-1).view(torch.uint8))
+        _lib.check(_lib.lib().xllm_mi355_host_pack_input_buffer(self._c_entries(), len(self.entries), buf.data_ptr(), total_bytes),
+                   "host_pack_input_buffer")
         return buf
 
     def bind_device_views(self, device_buffer: torch.Tensor) -> None:
