@@ -157,3 +157,29 @@ def test_reference_patch_applies_and_every_call_it_enables_is_declared(tmp_path)
             called.update(re.findall(r"\b(?:cuda|dcu)::(\w+)\s*\(", s))
     assert len(called) >= 15 and {"scaled_matmul", "rms_norm", "moe_compute_index"} <= called, called
     assert called <= declared, sorted(called - declared)
+
+
+def test_python_sources_have_no_undefined_names():
+    """a cheap module-level scan (every name that is loaded is bound somewhere in the module or is a builtin): the kind of slip
+    that once moved a statement into the wrong function of ops.py (a NameError that only a GPU run would have met)"""
+    import ast
+    import builtins
+    import glob
+    files = glob.glob(os.path.join(ROOT, "xllm_amd", "*.py")) + [os.path.join(ROOT, f) for f in ("bench.py", "bench_slices.py",
+                                                                                              "__graft_entry__.py")]
+    for f in files:
+        tree = ast.parse(open(f).read(), filename=f)
+        bound = set(dir(builtins)) | {"__file__"}
+        for n in ast.walk(tree):
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                bound.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                bound.add(n.name)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                bound.add(n.id)
+            elif isinstance(n, ast.arg):
+                bound.add(n.arg)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                bound.add(n.name)
+        missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound})
+        assert not missing, (f, missing)
