@@ -160,26 +160,26 @@ def test_reference_patch_applies_and_every_call_it_enables_is_declared(tmp_path)
 
 
 def test_python_sources_have_no_undefined_names():
-    """a cheap module-level scan (every name that is loaded is bound somewhere in the module or is a builtin): the kind of slip
-    that once moved a statement into the wrong function of ops.py (a NameError that only a GPU run would have met)"""
-    import ast
+    """scope-aware scan (symtable): every name a function reads as a global must be bound at module level or be a builtin -- the
+    kind of slip that once moved a statement into the wrong function of ops.py (a NameError only a GPU run would have met)"""
     import builtins
     import glob
+    import symtable
     files = glob.glob(os.path.join(ROOT, "xllm_amd", "*.py")) + [os.path.join(ROOT, f) for f in ("bench.py", "bench_slices.py",
                                                                                               "__graft_entry__.py")]
+    ok = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+
+    def walk(table, module_names, path, bad):
+        for sym in table.get_symbols():
+            if table.get_type() != "module" and sym.is_global() and sym.is_referenced() and not sym.is_assigned() \
+                    and sym.get_name() not in module_names and sym.get_name() not in ok:
+                bad.append((path, table.get_name(), sym.get_name()))
+        for child in table.get_children():
+            walk(child, module_names, path, bad)
+
+    bad = []
     for f in files:
-        tree = ast.parse(open(f).read(), filename=f)
-        bound = set(dir(builtins)) | {"__file__"}
-        for n in ast.walk(tree):
-            if isinstance(n, (ast.Import, ast.ImportFrom)):
-                bound.update((a.asname or a.name).split(".")[0] for a in n.names)
-            elif isinstance(n, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
-                bound.add(n.name)
-            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
-                bound.add(n.id)
-            elif isinstance(n, ast.arg):
-                bound.add(n.arg)
-            elif isinstance(n, ast.ExceptHandler) and n.name:
-                bound.add(n.name)
-        missing = sorted({n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound})
-        assert not missing, (f, missing)
+        top = symtable.symtable(open(f).read(), f, "exec")
+        module_names = {sym.get_name() for sym in top.get_symbols() if sym.is_assigned() or sym.is_imported() or sym.is_namespace()}
+        walk(top, module_names, os.path.relpath(f, ROOT), bad)
+    assert not bad, bad
