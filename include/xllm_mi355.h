@@ -257,6 +257,21 @@ XM_API int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, cons
                                         int64_t w_scale_numel, const void* bias, void* out, int64_t M,
                                         int64_t N, int64_t K, int out_dtype, void* stream);
 
+/* kernel::fp8_scaled_matmul on PRE-PACKED e4m3 weights (decode-shaped problems, M <= 512): the weight-stream kernel of
+ * xllm_amd/csrc/gemm_ws.hip on v_mfma_f32_16x16x128_f8f6f4. The packed layout is byte-for-byte the int8 one
+ * (xllm_mi355_pack_weight_i8 above; xllm_mi355_pack_weight_fp8 is the same permutation under the fp8 name): the two 16-byte
+ * k-step fragments of a lane form the 32-byte MFMA operand. Same semantics as xllm_mi355_fp8_scaled_matmul
+ * (linear.cpp:137-182, scaled_mm_entry.cu:55-116: per-tensor or per-token a_scale, per-tensor or per-channel w_scale, fp32
+ * accumulation, out = r16(a_scale * (w_scale * acc) + bias)); the fp32 summation ORDER differs from the row-major kernel
+ * (K tiles in order, K slices summed in slice order: deterministic), so results agree to fp32 rounding, not bit for bit.
+ * `workspace` / `ws_bytes` explicit and caller-owned as for xllm_mi355_scaled_matmul_packed (fp32 slabs; NULL / 0 = K is
+ * never sliced). XM_ERR_UNSUPPORTED outside the envelope (M > 512, N % 16, K % 128, K < 512). */
+XM_API int xllm_mi355_pack_weight_fp8(const uint8_t* w, uint8_t* packed, int64_t N, int64_t K, void* stream);
+XM_API int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* w_packed, const float* a_scale,
+                                               int64_t a_scale_numel, const float* w_scale, int64_t w_scale_numel,
+                                               const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                                               int out_dtype, void* workspace, size_t ws_bytes, void* stream);
+
 /* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
  * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0.
  * Decode-shaped problems with a long K and few columns (M <= 512, N % 4 == 0) split K when a GEMM workspace is

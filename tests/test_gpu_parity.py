@@ -34,6 +34,11 @@ def assert_ulp_close(got, ref, dtype, ulps=1.0, min_exact=0.99):
     assert exact >= min_exact, f"only {exact:.4f} bit-identical"
 
 
+def rel_l2(got, ref):
+    got, ref = got.double(), ref.double().to(got.device)
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-300))
+
+
 def assert_attn_close(got, ref, rel=1e-3):
     got, ref = got.float().cpu(), ref.float().cpu()
     assert torch.isfinite(got).all()
@@ -1533,6 +1538,127 @@ def test_pack_weight_i8_layout():
     assert torch.equal(wp, exp)
     assert ops.pack_weight_i8(torch.zeros(40, 384, dtype=torch.int8, device=DEV)) is None       # N % 16
     assert ops.pack_weight_i8(torch.zeros(48, 320, dtype=torch.int8, device=DEV)) is None       # K % 128
+
+
+def _ws_waves(n):
+    from xllm_amd import _lib
+    _lib.lib().xllm_mi355_debug_ws_waves(int(n))
+
+
+@pytest.mark.parametrize("M", [129, 200, 256, 257, 512])
+@pytest.mark.parametrize("arm", [4, 80])
+def test_packed_gemm_four_wave_tile_still_exact(M, arm):
+    """round 3 moved 128 < M <= 512 to eight-wave workgroups with the two wave groups one barrier apart (gemm_ws8s_kernel); the
+    four-wave 256-row tile (xllm_mi355_debug_ws_waves(4) / XLLM_MI355_WS_WAVES=4) and the eight-wave tile with all waves in phase
+    (80 / XLLM_MI355_WS8_STAGGER=0) stay as A/B arms and must stay exact"""
+    g = torch.Generator().manual_seed(100 + M)
+    N, K = 1936, 1152
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.02 + 0.001).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.02 + 0.001).to(DEV)
+    wp = ops.pack_weight_i8(w)
+    ref_acc = (a.double() @ w.double().T).to(torch.int32)
+    ref_out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None)
+    ran = 0
+    try:
+        _ws_waves(arm)
+        for ng in ((2, 4, 6, 8, 10) if arm == 4 else (1, 2, 3, 4, 5)):
+            for slices in (1, 3):
+                _ws_plan(ng, slices)
+                rc, out, acc = _packed_gemm(a, wp, a_s, w_s, None, M, N, K, want_acc=True)
+                assert rc == 0
+                ran += 1
+                assert torch.equal(acc, ref_acc) and torch.equal(out, ref_out), (ng, slices)
+    finally:
+        _ws_plan(0, 0)
+        _ws_waves(0)
+    assert ran == 10
+
+
+def _packed_gemm_fp8(a, wp, a_s, w_s, bias, M, N, K, ws_bytes=64 << 20):
+    from xllm_amd import _lib
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=DEV)
+    ws.fill_(0x7f)   # poisoned slabs (0x7f7f7f7f = 3.4e38 as fp32): nothing may be read before it is written
+    rc = _lib.lib().xllm_mi355_fp8_scaled_matmul_packed(
+        a.data_ptr(), wp.data_ptr(), a_s.data_ptr(), a_s.numel(), w_s.data_ptr(), w_s.numel(),
+        0 if bias is None else bias.data_ptr(), out.data_ptr(), M, N, K, 1, ws.data_ptr() if ws_bytes else 0, ws_bytes,
+        torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return rc, out
+
+
+@pytest.mark.parametrize("M", [1, 16, 17, 32, 40, 64, 100, 128, 129, 256, 300, 512])
+@pytest.mark.parametrize("scales", ["tensor", "tc"])
+def test_packed_fp8_gemm_over_tile_shapes(M, scales):
+    """fp8 e4m3 weight-stream GEMM on packed weights (a14, round 3): every wave-tile family x width x K slices against the fp64
+    product of the dequantised operands. e4m3 x e4m3 products are exact in fp32, so the only freedom is the fp32 summation order:
+    |err| <= bf16 rounding + a few accumulation ulps of sum|a||w| -- the bar of test_fp8_gemm_full_size_against_fp64 -- and the
+    row-major kernel (another summation order) within the same distance. Ragged N, poisoned slabs, bias."""
+    g = torch.Generator().manual_seed(3 * M + len(scales))
+    N, K = 1936, 1152
+    a = (torch.randn(M, K, generator=g) * 2).to(DEV).to(torch.float8_e4m3fn)
+    w = (torch.randn(N, K, generator=g) * 0.5).to(DEV).to(torch.float8_e4m3fn)
+    per = scales == "tc"
+    a_s = (torch.rand(M if per else 1, generator=g) * 0.05 + 0.01).to(DEV)
+    w_s = (torch.rand(N if per else 1, generator=g) * 0.02 + 0.01).to(DEV)
+    bias = torch.randn(N, generator=g).bfloat16().to(DEV)
+    wp = ops.pack_weight_fp8(w)
+    assert wp is not None and wp.dtype == w.dtype
+    assert torch.equal(wp.view(torch.int8), ops.pack_weight_i8(w.view(torch.int8)))      # one byte permutation for both kinds
+    a64 = a.double() * (a_s.double()[:, None] if per else a_s.double())
+    w64 = w.double() * (w_s.double()[:, None] if per else w_s.double())
+    ref = a64 @ w64.T + bias.double()
+    mag = a64.abs() @ w64.abs().T
+    ref_rm = ops.fp8_scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias)
+    ran = 0
+    try:
+        for ng in (1, 2, 3, 4, 5, 6, 8, 10):
+            for slices in (1, 2, 3):
+                _ws_plan(ng, slices)
+                rc, out = _packed_gemm_fp8(a, wp, a_s, w_s, bias, M, N, K)
+                if rc == -2:
+                    continue
+                assert rc == 0
+                ran += 1
+                err = (out.double() - ref).abs()
+                assert (err <= 2.0 ** -8 * ref.abs() + 2.0 ** -17 * mag + 1e-6).all(), (ng, slices, float((err / mag).max()))
+                assert rel_l2(out, ref) <= 3e-3, (ng, slices)
+                assert ((out.double() - ref_rm.double()).abs() <= 2.0 ** -7 * ref.abs() + 2.0 ** -16 * mag + 1e-6).all()
+                if slices == 1:   # deterministic: the same launch twice gives the same bits
+                    rc2, out2 = _packed_gemm_fp8(a, wp, a_s, w_s, bias, M, N, K)
+                    assert rc2 == 0 and torch.equal(out, out2)
+    finally:
+        _ws_plan(0, 0)
+    assert ran >= 6
+    rc, out = _packed_gemm_fp8(a, wp, a_s, w_s, None, M, N, K, ws_bytes=0)     # no scratch: never sliced, still right
+    assert rc == 0 and rel_l2(out, ref - bias.double()) <= 3e-3
+
+
+def test_packed_fp8_dispatch_and_envelope():
+    """ops.fp8_scaled_matmul(b_packed=...) routes decode shapes to the packed kernel and everything else to the row-major one;
+    shapes outside the envelope decline with XM_ERR_UNSUPPORTED and have no side effect"""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 128, 3072, 1536                     # DeepSeek-V3 q_b_proj of one TP = 8 rank
+    a = (torch.randn(M, K, generator=g) * 2).to(DEV).to(torch.float8_e4m3fn)
+    w = (torch.randn(N, K, generator=g) * 0.5).to(DEV).to(torch.float8_e4m3fn)
+    a_s = torch.full((1,), 0.03, device=DEV)
+    w_s = torch.full((1,), 0.02, device=DEV)
+    wp = ops.pack_weight_fp8(w)
+    ref = (a.double() @ w.double().T) * 0.03 * 0.02
+    old = ops._PACKED_FP8_POLICY
+    try:
+        ops._PACKED_FP8_POLICY = "1"
+        y1 = ops.fp8_scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None, b_packed=wp)
+        ops._PACKED_FP8_POLICY = "0"
+        y0 = ops.fp8_scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None, b_packed=wp)
+    finally:
+        ops._PACKED_FP8_POLICY = old
+    assert rel_l2(y1, ref) <= 3e-3 and rel_l2(y0, ref) <= 3e-3
+    rc, _ = _packed_gemm_fp8(a[:, :384].contiguous(), wp, a_s, w_s, None, M, N, 384)        # K < 512
+    assert rc == -2
+    assert ops.pack_weight_fp8(torch.zeros(40, 384, device=DEV).to(torch.float8_e4m3fn)) is None
 
 
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 32, 33, 64, 65, 100, 128, 129, 250, 256, 257, 400, 512])

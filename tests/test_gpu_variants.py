@@ -15,18 +15,16 @@ SELECT = ("scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matm
 @pytest.mark.parametrize("env", [
     {"XLLM_MI355_P8": "1"},                                  # 8-phase kernels forced on every legal shape (+ split-K)
     {"XLLM_MI355_P8": "1", "XLLM_MI355_P8_MFMA32": "1"},     # int8 on the 32x32x32 8-phase kernel instead of 16x16x64
-    {"XLLM_MI355_P8": "1", "XLLM_MI355_P8_RING": "1"},       # role-split DMA + 3-deep weight ring variant
-    {"XLLM_MI355_P8N": "1"},                                 # narrow-tile decode kernel, 64 columns
-    {"XLLM_MI355_P8N": "1", "XLLM_MI355_P8N_NB": "4"},       # narrow-tile decode kernel, 128 columns
     {"XLLM_MI355_P8": "0", "XLLM_MI355_SKINNY_DISABLE": "1"},  # 128x128 kernel only
     {"XLLM_MI355_SKINNY_BM128": "0"},                         # decode kernel on 256-row tiles for M <= 128 too
-    {"XLLM_MI355_ASTAT": "1"},                                # activation-stationary decode kernel (gemm_astat.hip)
-    {"XLLM_MI355_ASTAT": "1", "XLLM_MI355_ASTAT_SPLITS": "3"},
     {"XLLM_MI355_WSB": "0"},                                  # 16-bit decode linears / few-row experts on the tiled kernels
     {"XLLM_MI355_WSB_SLICES": "3"},                           # weight-stream 16-bit kernel with a forced K-slice count
     {"XLLM_MI355_WSB": "2"},                                  # ... on every M <= 64 (default policy: M <= 32)
-], ids=["p8_forced", "p8_mfma32", "p8_ring", "p8n_64", "p8n_128", "general_only", "skinny_bm256", "astat", "astat_split3",
-        "wsb_off", "wsb_slices3", "wsb_to_64"])
+    {"XLLM_MI355_KSTAGGER": "0"},                             # every workgroup walks K from its first tile (round-2 behaviour)
+    {"XLLM_MI355_WS_WAVES": "4", "XLLM_MI355_PACKED": "1"},   # packed kernel on the four-wave 256-row tile, everywhere legal
+    {"XLLM_MI355_PACKED": "1"},                               # packed kernel (eight-wave tile above 128 rows) everywhere legal
+], ids=["p8_forced", "p8_mfma32", "general_only", "skinny_bm256", "wsb_off", "wsb_slices3", "wsb_to_64", "no_kstagger",
+        "ws_four_waves", "packed_everywhere"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)
@@ -57,10 +55,8 @@ def test_mla_parity_under_kernel_selector(env):
 
 @pytest.mark.parametrize("env", [
     {"XLLM_MI355_PREFILL_DMA": "0"},                         # register-staged flash prefill kernel for head dim 128 too
-    {"XLLM_MI355_PREFILL_DMA": "2"},                         # ping-pong wave groups (256 queries per workgroup)
-    {"XLLM_MI355_PREFILL_DMA": "3"},                         # the same two groups, offset by half a tile, one barrier per tile
     {"XLLM_MI355_PREFILL_P": "2"},                           # P = hi + lo on the default kernel (fp32-P accuracy, 1e-3 bar)
-], ids=["prefill_regstaged", "prefill_pingpong", "prefill_pingpong_free", "prefill_p_hi_lo"])
+], ids=["prefill_regstaged", "prefill_p_hi_lo"])
 def test_prefill_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

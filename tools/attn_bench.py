@@ -21,17 +21,21 @@ for name, B, nq, nkv, S in cases:
     nb = B * pages + 7
     mk = (lambda: torch.zeros(nb, bs, nkv, d, device=dev, dtype=torch.bfloat16)) if os.environ.get("ATTN_KV") == "zero" \
         else (lambda: torch.randn(nb, bs, nkv, d, device=dev).bfloat16())
-    caches = [(mk(), mk()) for _ in range(3)]
+    NC = int(os.environ.get("ATTN_COPIES", "3"))   # 28 = as many distinct KV regions as the model has layers (60 GB at cfg3)
+    caches = [(mk(), mk()) for _ in range(NC)]
     if os.environ.get("ATTN_PAGES") == "linear":   # pages in address order: is the random page placement a cost?
         table = torch.arange(B * pages, device=dev, dtype=torch.int32).view(B, pages)
     else:
         table = torch.randperm(nb, device=dev)[: B * pages].to(torch.int32).view(B, pages)
     kv_lens = torch.full((B,), S, dtype=torch.int32, device=dev)
     q = torch.randn(B, nq, d, device=dev).bfloat16()
-    fn = lambda i: ops.paged_attention(q, caches[i % 3][0], caches[i % 3][1], None, kv_lens, table, 1, S, d ** -0.5)
+    if os.environ.get("ATTN_INT8") == "1":          # the bench path: epilogue emits o_proj's int8 operand
+        fn = lambda i: ops.paged_decode_attention_int8(q, caches[i % NC][0], caches[i % NC][1], kv_lens, table, S, d ** -0.5)
+    else:
+        fn = lambda i: ops.paged_attention(q, caches[i % NC][0], caches[i % NC][1], None, kv_lens, table, 1, S, d ** -0.5)
     for i in range(3):
         fn(i)
-    n = 20
+    n = int(os.environ.get("ATTN_N", "20"))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(n):

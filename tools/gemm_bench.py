@@ -11,12 +11,14 @@ from xllm_amd import ops  # noqa: E402
 
 dev = "cuda"
 shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
+if os.environ.get("GEMM_SHAPES") == "dsv3":      # DeepSeek-V3 MLA projections of one TP = 8 rank (bench_slices.py cfg4-slice)
+    shapes = [("q_a", 1536, 7168), ("q_b", 16 * 192, 1536), ("kv_a", 576, 7168), ("o", 7168, 16 * 128)]
 Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
 kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED", "GEMM_COPIES"))
 for M in Ms:
     for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
-        copies = max(2, min(8, int(600e6 // (N * K)) + 1))
+        copies = int(os.environ.get('GEMM_COPIES', 0)) or max(2, min(8, int(600e6 // (N * K)) + 1))
         if kind == "int8":
             if os.environ.get("GEMM_DIST", "uniform") == "gauss":
                 # what W8A8 quantisation of Gaussian tensors yields (per-row amax -> 127): sigma ~ 127 / 4, most bits quiet
@@ -24,6 +26,9 @@ for M in Ms:
                     return torch.round(t / (t.abs().amax(-1, keepdim=True) / 127.0)).to(torch.int8)
                 ws = [q(torch.randn(N, K, device=dev)) for _ in range(copies)]
                 a = q(torch.randn(M, K, device=dev))
+            elif os.environ.get("GEMM_DIST") == "zero":     # no operand toggling: the clock the chip grants without the MAC power
+                ws = [torch.zeros(N, K, dtype=torch.int8, device=dev) for _ in range(copies)]
+                a = torch.zeros(M, K, dtype=torch.int8, device=dev)
             else:
                 ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev) for _ in range(copies)]
                 a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
@@ -35,6 +40,17 @@ for M in Ms:
             else:
                 fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)
             bytes_ = N * K + M * K + M * N * 2
+        elif kind == "fp8":
+            ws = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in range(copies)]
+            a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e4m3fn)
+            a_s = torch.full((1,), 0.03, device=dev)
+            w_s = torch.full((1,), 0.02, device=dev)
+            if os.environ.get("GEMM_PACKED", "0") == "1":
+                wps = [ops.pack_weight_fp8(x) for x in ws]
+                fn = lambda i: ops.fp8_scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])
+            else:
+                fn = lambda i: ops.fp8_scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16)
+            bytes_ = N * K + M * K + M * N * 2
         else:
             ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(copies)]
             a = torch.randn(M, K, device=dev).bfloat16()
@@ -42,7 +58,10 @@ for M in Ms:
             bytes_ = (N * K + M * K + M * N) * 2
         for i in range(3):
             fn(i)
-        n = 20
+        # GEMM_N launches per graph, GEMM_REPLAYS timed replays after as many untimed ones: long enough (>= 50 ms) for the clock
+        # governor to settle (round 3: 20-launch runs scattered by +-10 %)
+        n = int(os.environ.get("GEMM_N", "100"))
+        reps = int(os.environ.get("GEMM_REPLAYS", "10"))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if os.environ.get("GEMM_GRAPH", "1") == "1":   # n launches replayed from ONE HIP graph: no host launch cost in the figure
             torch.cuda.synchronize()
@@ -54,12 +73,15 @@ for M in Ms:
                 with torch.cuda.graph(g, stream=st):
                     for i in range(n):
                         fn(i)
-                g.replay()
+                for _ in range(reps):
+                    g.replay()
                 torch.cuda.synchronize()
                 e0.record()
-                g.replay()
+                for _ in range(reps):
+                    g.replay()
                 e1.record()
             torch.cuda.synchronize()
+            n *= reps
         else:
             e0.record()
             for i in range(n):

@@ -753,25 +753,15 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
   if constexpr (D == 128) {
     // LDS-DMA kernels: a 64-key tile must sit inside one page, and 64 row pitches must fit a 32-bit buffer offset
-    // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = one wave group per workgroup (default), 2 = ping-pong groups
-    // with a barrier at every phase switch, 3 = the two groups offset by half a tile with one barrier per tile
+    // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = LDS-DMA kernel (default). The ping-pong forms of the DMA kernel
+    // (NW = 8: two wave groups alternating MFMA / softmax, round-1 negative result, profiles/r01_prefill_attention.txt) are
+    // no longer instantiated in the library (round 3); the template parameter stays in the kernel for whoever revisits it.
     static int dma_mode = -1;
     if (dma_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_DMA"); dma_mode = e ? atoi(e) : 1; }  // (A/B, read once)
     const int64_t pitch = PAGED ? nkv * D : (k_stride > v_stride ? k_stride : v_stride);
     if (dma_mode && (!PAGED || block_size % kPf2Tile == 0) && pitch * 2 * kPf2Tile < (1ll << 31)) {
       const float sl2 = scale * 1.4426950408889634f;
-      if (dma_mode >= 2 && max_q_len > kPfQBlock) {  // two wave groups need more than 128 queries to alternate
-        const int qb2 = (int)((max_q_len + 2 * kPfQBlock - 1) / (2 * kPfQBlock));
-        const dim3 grid2((unsigned)(nq * batch * qb2));
-        if (dma_mode == 2)
-          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8, true>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
-                             (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
-                             (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
-        else
-          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 8, false>), grid2, dim3(512), 0, s, (const T*)q, (const T*)k,
-                             (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks, (int)nq, (int)nkv,
-                             (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qb2);
-      } else {
+      {
         // XLLM_MI355_PREFILL_P: 1 (default) = one 16-bit P per score, rounded to nearest even: the reference's semantics --
         // its eager spec casts P to the tensor dtype before PV (layers/cuda/flashinfer_attention.cpp:84-90) and its MLU decode
         // golden vector is reproduced to the last digit only with that rounding; the output is then

@@ -611,35 +611,6 @@ int launch_skinny(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb
   const bool half_kind = KIND == kBF16 || KIND == kF16 || KIND == kFP8;  // kinds that split K through fp32 slabs
   const bool can_split = (KIND == kI8 || (half_kind && N % 4 == 0 && ((uintptr_t)epi.out % 8) == 0)) && workspace &&
                          ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && (epi.out || epi.defer);
-  if constexpr (KIND == kI8) {
-    // few columns, M in (128, 256]: the activation-stationary kernel (gemm_astat.hip). XLLM_MI355_ASTAT = 0 off, 1 on for
-    // every legal shape; XLLM_MI355_ASTAT_SPLITS overrides the K split (tuning)
-    static int astat = -2, astat_splits = -2;
-    if (astat == -2) {
-      const char* e = getenv("XLLM_MI355_ASTAT");
-      astat = e ? atoi(e) : 0;
-      e = getenv("XLLM_MI355_ASTAT_SPLITS");
-      astat_splits = e ? atoi(e) : -1;
-    }
-    if (astat && can_split && M > 128 && M <= 256 && Kb % 256 == 0 && !epi.group_counts) {
-      const int64_t ranges = (N + 127) / 128;
-      const int slabs = (int)(Kb / 256);
-      int splits = (int)(256 / ranges);
-      const int by_k = slabs / 2 > 0 ? slabs / 2 : 1;
-      splits = splits > by_k ? by_k : splits;
-      splits = splits < 1 ? 1 : splits;
-      if (astat_splits > 0) splits = astat_splits;
-      const int rc = launch_gemm_astat_i8(A, W, M, N, Kb, reinterpret_cast<int32_t*>(workspace), splits, s);
-      if (rc != XM_ERR_UNSUPPORTED) {
-        if (rc != XM_OK || epi.defer) return rc;
-        int64_t blocks = (M * N + 255) / 256;
-        blocks = blocks > 1024 ? 1024 : blocks;
-        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
-        return hip_check_launch();
-      }
-    }
-  }
   SkinnyPlan p;
   if (half_kind) {  // one fp32 slab per K slice must fit the workspace
     const int64_t fit = can_split ? (int64_t)(ws_bytes / ((size_t)M * N * 4)) : 1;
@@ -714,45 +685,6 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
         return hip_check_launch();
       }
       return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
-    }
-  }
-  // narrow-tile pipelined kernel (gemm_p8n.hip) for decode-shaped int8 GEMMs whose 256-wide grid would be too small
-  if constexpr (KIND == kI8) {
-    static int pn = -2, pn_nb = -1, pn_splits = -1;
-    if (pn == -2) {
-      const char* e = getenv("XLLM_MI355_P8N");
-      pn = e ? atoi(e) : 0;
-      e = getenv("XLLM_MI355_P8N_NB");
-      pn_nb = e ? atoi(e) : -1;
-      e = getenv("XLLM_MI355_P8N_SPLITS");
-      pn_splits = e ? atoi(e) : -1;
-    }
-    if (pn && M <= 512 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 &&
-        M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && !epi.group_counts) {
-      const int nb = pn_nb > 0 ? pn_nb : 2;
-      const int64_t tiles = ((N + nb * 32 - 1) / (nb * 32)) * ((M + 255) / 256);
-      const int ktiles = (int)(Kb / BKB);
-      const bool can_split = workspace && ws_bytes >= (size_t)M * N * 4 && !epi.acc_out && epi.out;
-      int splits = 1;
-      if (can_split && tiles < 200) {
-        splits = (int)(256 / tiles);
-        const int by_k = ktiles / 6 > 0 ? ktiles / 6 : 1;
-        splits = splits > by_k ? by_k : splits;
-        splits = splits < 1 ? 1 : splits;
-      }
-      if (pn_splits > 0 && can_split) splits = pn_splits;
-      if (splits > 1) {
-        GemmEpi e2 = epi;
-        e2.acc_out = reinterpret_cast<int32_t*>(workspace);
-        const int rc = launch_gemm_p8n<KIND>(A, W, M, N, Kb, e2, nb, splits, s);
-        if (rc != XM_OK) return rc;
-        int64_t blocks = (M * N + 255) / 256;
-        blocks = blocks > 2048 ? 2048 : blocks;
-        hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                           reinterpret_cast<int32_t*>(workspace), M, N, epi);
-        return hip_check_launch();
-      }
-      return launch_gemm_p8n<KIND>(A, W, M, N, Kb, epi, nb, 1, s);
     }
   }
   const bool skinny_pays = KIND == kI8 || ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 256;
@@ -984,6 +916,23 @@ int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float
   size_t ws_bytes = 0;
   gemm_ws_for(stream, &ws, &ws_bytes);
   return launch_gemm<kFP8>(a, w, M, N, K, epi, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int xllm_mi355_pack_weight_fp8(const uint8_t* w, uint8_t* packed, int64_t N, int64_t K, void* stream) {
+  if (!w || !packed || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  return launch_pack_weight_i8(w, packed, N, K, (hipStream_t)stream);  // a byte permutation: the same for both 8-bit kinds
+}
+
+int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* w_packed, const float* a_scale,
+                                        int64_t a_scale_numel, const float* w_scale, int64_t w_scale_numel,
+                                        const void* bias, void* out, int64_t M, int64_t N, int64_t K, int out_dtype,
+                                        void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || !a_scale || !w_scale || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if ((a_scale_numel != 1 && a_scale_numel != M) || (w_scale_numel != 1 && w_scale_numel != N)) return XM_ERR_INVALID;
+  if (M == 0 || N == 0) return XM_OK;
+  GemmEpi epi{a_scale, a_scale_numel, w_scale, w_scale_numel, bias, out, nullptr, out_dtype == XM_BF16, nullptr, 0};
+  return launch_gemm_ws_fp8(a, w_packed, M, N, K, epi, workspace, ws_bytes, (hipStream_t)stream);
 }
 
 int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,

@@ -430,222 +430,6 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   p8_epilogue<KIND, SPLITK>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Variant "r" (role split, 3-deep weight ring). Same tile, phases and fragment schedule as gemm_p8_kernel, but
-//   * the activation stream is issued by waves 0-3 and the weight stream by waves 4-7 (4 DMA instructions of 1 KiB
-//     per half-tile and wave, 2 per phase as before). s_waitcnt vmcnt retires in order per wave, so with one wave
-//     issuing both streams a deeper weight prefetch would be waited for every time the next activation tile is
-//     needed; split by role each wave counts only its own stream: vmcnt(4) (activations, L2 latency) / vmcnt(14)
-//     (weights, HBM latency);
-//   * LDS = activations 2 K tiles (64 KiB) + weights 3 K tiles (96 KiB) = all 160 KiB: 14 weight DMA instructions
-//     per wave = 56 KiB of weights in flight per CU (24 KiB before) -- what a weight-streaming decode GEMM
-//     (M = 256, one m tile, 148 workgroups at gate_up) needs to cover the ~2 us HBM latency.
-// Stage schedule of K tile t (slot reuse rules as in the header comment):
-//   activations: P1,P2 <- A(mh=1) of tile t+1;  P3,P4 <- A(mh=0) of tile t+2        (buffer = tile & 1)
-//   weights:     P1 <- 2nd half of W(nh=1) of t+2;  P2,P3 <- W(nh=0) of t+3;  P4 <- 1st half of W(nh=1) of t+3
-//                (ring slot = tile % 3)
-// ------------------------------------------------------------------------------------------------
-template <int KIND, bool SPLITK>
-__global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8r_kernel(const uint8_t* __restrict__ A,
-                                                                const uint8_t* __restrict__ W, int M, int N,
-                                                                int64_t Kb, int m_tiles, int n_tiles,
-                                                                int ktiles_per_split, GemmEpi epi) {
-  using acc_t = typename MmaTraits<KIND>::acc_t;
-  constexpr int A_BYTES = 2 * 2 * P8_SLOT;  // [buffer 2][mh 2][16 KiB]
-  constexpr int W_BYTES = 3 * 2 * P8_SLOT;  // [ring 3][nh 2][16 KiB]
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[A_BYTES + W_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;  // wr: phase group AND DMA role (0 = activations, 1 = weights)
-  int mt, nt;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int sb = j >> 5, within = j & 31;
-    const int S = sb * 8 + xcd;
-    const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
-    const int n_sb_m = (m_tiles + (1 << lm) - 1) >> lm;
-    const int SM = S % n_sb_m, SN = S / n_sb_m;
-    mt = (SM << lm) + (within & ((1 << lm) - 1));
-    nt = (SN << (5 - lm)) + (within >> lm);
-    if (mt >= m_tiles || nt >= n_tiles) return;
-  }
-  const int m0 = mt * P8_BM, n0 = nt * P8_BN;
-  const int total_kt = (int)(Kb / P8_BK);
-  const int kt_begin = blockIdx.z * ktiles_per_split;
-  int kt_end = kt_begin + ktiles_per_split;
-  kt_end = kt_end > total_kt ? total_kt : kt_end;
-  const int nk = kt_end - kt_begin;
-  if (nk <= 0) return;
-
-  // K walk: every workgroup walks K in the same order (steps past the end re-load the last tile: every DMA is
-  // unconditional, so the vmcnt arithmetic is static). Starting each workgroup at a different K tile (to spread the
-  // readers of a shared operand panel over more L2 channels) was measured and is WORSE: 1033 -> 1272 us on
-  // gate_up at M = 8192 -- the workgroups of a super-block re-use each other's L2 lines only while they move in step.
-  auto kwalk = [&](int kt) { return kt < kt_end ? kt : kt_end - 1; };
-  // ---- DMA offsets of this wave's stream. A half-tile (128 LDS rows) = 16 instructions = 4 pieces per wave; piece j
-  // of wave wc covers LDS rows j*32 + wc*8 + lane/8.
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(wr == 0 ? A : W), 0, (int)((int64_t)(wr == 0 ? M : N) * Kb), 0x00020000);
-  int voff[4][2];  // [piece][half]
-  {
-    const int srow = wc * 8 + (lane >> 3);
-    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) << 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = j * 32 + srow;  // LDS row of the half-tile
-        int g;
-        if (wr == 0) {  // activation half mh = h: LDS rows 0-63 = reading group 0, 64-127 = group 1
-          g = m0 + (row >> 6) * 128 + h * 64 + (row & 63);
-          g = g < M ? g : M - 1;
-        } else {        // weight half nh = h: LDS row wc'*32 + c  <->  W row n0 + wc'*64 + h*32 + c
-          g = n0 + (row >> 5) * 64 + h * 32 + (row & 31);
-          g = g < N ? g : N - 1;
-        }
-        voff[j][h] = (int)((int64_t)g * Kb) + scol;
-      }
-  }
-  typedef __attribute__((address_space(3))) uint8_t* lds_ptr_t;
-  const lds_ptr_t lds3 = (lds_ptr_t)lds;
-  // two DMA instructions: pieces (2*pp, 2*pp+1) of half-tile `h` of K tile kt into LDS byte offset `slot_off`
-  auto stage2 = [&](int slot_off, int h, int pp, int kt, bool in_loop = true) {
-#ifdef P8_ABL_NOSTAGE
-    if (in_loop) return;
-#endif
-    const int soff = kwalk(kt) * P8_BK;
-    const lds_ptr_t dst = lds3 + slot_off + (pp * 2) * 4096 + wc * 1024;
-    if (h == 0) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, pp ? voff[2][0] : voff[0][0], soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + 4096, 16, pp ? voff[3][0] : voff[1][0], soff, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, pp ? voff[2][1] : voff[0][1], soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + 4096, 16, pp ? voff[3][1] : voff[1][1], soff, 0, 0);
-    }
-  };
-  // LDS byte offsets: activations [buf][mh], weights [ring][nh]
-  auto a_slot = [&](int buf, int mh) { return (buf * 2 + mh) * P8_SLOT; };
-  auto w_slot = [&](int ring, int nh) { return A_BYTES + (ring * 2 + nh) * P8_SLOT; };
-
-  unsigned rd_w[4], rd_a[4];
-  {
-    const unsigned base = (unsigned)(__UINTPTR_TYPE__)lds3;
-    const int f = ((lane & 31) >> 1) & 7;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const unsigned o = base + (lane & 31) * P8_BK + (((2 * kk + (lane >> 5)) ^ f) << 4);
-      rd_w[kk] = o + A_BYTES + wc * 32 * P8_BK;
-      rd_a[kk] = o + wr * 64 * P8_BK;
-    }
-  }
-
-  acc_t acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<KIND>::zero();
-
-  // ---- prologue = the state the loop maintains at the top of K tile t0 (see the stage schedule)
-  if (wr == 0) {
-    stage2(a_slot(0, 0), 0, 0, kt_begin, false); stage2(a_slot(0, 0), 0, 1, kt_begin, false);
-    stage2(a_slot(0, 1), 1, 0, kt_begin, false); stage2(a_slot(0, 1), 1, 1, kt_begin, false);
-    stage2(a_slot(1, 0), 0, 0, kt_begin + 1, false); stage2(a_slot(1, 0), 0, 1, kt_begin + 1, false);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      stage2(w_slot(d, 0), 0, 0, kt_begin + d, false); stage2(w_slot(d, 0), 0, 1, kt_begin + d, false);
-      stage2(w_slot(d, 1), 1, 0, kt_begin + d, false);
-      if (d < 2) stage2(w_slot(d, 1), 1, 1, kt_begin + d, false);
-    }
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-
-  u32x4 fw0[4], fw1[4], fa[8];
-#ifdef P8_ABL_NOMFMA
-#define P8_MMA(MB, NB, FW)                                                                    \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(FW[kk]), "v"(fa[kk]), "v"(fa[4 + kk])); \
-  __builtin_amdgcn_sched_barrier(0);
-#else
-#define P8_MMA(MB, NB, FW)                                                                    \
-  __builtin_amdgcn_s_setprio(1);                                                              \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                          \
-    acc[MB][NB] = mma4<KIND>(FW[kk], fa[kk], acc[MB][NB]);                                    \
-    acc[MB + 1][NB] = mma4<KIND>(FW[kk], fa[4 + kk], acc[MB + 1][NB]);                        \
-  }                                                                                           \
-  __builtin_amdgcn_s_setprio(0);                                                              \
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-
-  int abuf = 0, wring = 0;  // buffer / ring slot of the K tile being computed
-  for (int t = 0; t < nk; ++t) {
-    const int kt = kt_begin + t;
-    const int wnext = wring == 2 ? 0 : wring + 1;   // ring slot of tile t+1 == slot of tile t+... (t+2)%3 = wprev
-    const int wprev = wring == 0 ? 2 : wring - 1;   // (t+2) % 3
-    unsigned va[4], vw[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      va[kk] = rd_a[kk] + abuf * 2 * P8_SLOT;
-      vw[kk] = rd_w[kk] + wring * 2 * P8_SLOT;
-    }
-    (void)wnext;
-    // ---- P1: W(nh=0) + A(mh=0)
-    P8_DSR(fw0[0], vw[0], 0); P8_DSR(fw0[1], vw[1], 0); P8_DSR(fw0[2], vw[2], 0); P8_DSR(fw0[3], vw[3], 0);
-    P8_DSR(fa[0], va[0], 0); P8_DSR(fa[1], va[1], 0); P8_DSR(fa[2], va[2], 0); P8_DSR(fa[3], va[3], 0);
-    P8_DSR(fa[4], va[0], 32 * P8_BK); P8_DSR(fa[5], va[1], 32 * P8_BK);
-    P8_DSR(fa[6], va[2], 32 * P8_BK); P8_DSR(fa[7], va[3], 32 * P8_BK);
-    if (wr == 0) stage2(a_slot(abuf ^ 1, 1), 1, 0, kt + 1);
-    else stage2(w_slot(wprev, 1), 1, 1, kt + 2);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the W(nh=0) reads are done: P2 may restage that slot
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT4(fw0);
-    P8_WAIT8(fa);
-    P8_MMA(0, 0, fw0)
-    __builtin_amdgcn_s_barrier();
-    // ---- P2: W(nh=1)
-    P8_DSR(fw1[0], vw[0], P8_SLOT); P8_DSR(fw1[1], vw[1], P8_SLOT);
-    P8_DSR(fw1[2], vw[2], P8_SLOT); P8_DSR(fw1[3], vw[3], P8_SLOT);
-    if (wr == 0) stage2(a_slot(abuf ^ 1, 1), 1, 1, kt + 1);
-    else stage2(w_slot(wring, 0), 0, 0, kt + 3);
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT4(fw1);
-    P8_MMA(0, 1, fw1)
-    __builtin_amdgcn_s_barrier();
-    // ---- P3: A(mh=1)
-    P8_DSR(fa[0], va[0], P8_SLOT); P8_DSR(fa[1], va[1], P8_SLOT);
-    P8_DSR(fa[2], va[2], P8_SLOT); P8_DSR(fa[3], va[3], P8_SLOT);
-    P8_DSR(fa[4], va[0], P8_SLOT + 32 * P8_BK); P8_DSR(fa[5], va[1], P8_SLOT + 32 * P8_BK);
-    P8_DSR(fa[6], va[2], P8_SLOT + 32 * P8_BK); P8_DSR(fa[7], va[3], P8_SLOT + 32 * P8_BK);
-    if (wr == 0) stage2(a_slot(abuf, 0), 0, 0, kt + 2);
-    else stage2(w_slot(wring, 0), 0, 1, kt + 3);
-    __builtin_amdgcn_s_barrier();
-    P8_WAIT8(fa);
-    P8_MMA(2, 1, fw1)
-    __builtin_amdgcn_s_barrier();
-    // ---- P4
-    if (wr == 0) {
-      stage2(a_slot(abuf, 0), 0, 1, kt + 2);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A of tile t+1 has landed; A(mh=0) of t+2 in flight
-    } else {
-      stage2(w_slot(wring, 1), 1, 0, kt + 3);
-      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");  // W of tile t+1 has landed; 14 DMAs of t+2, t+3 in flight
-    }
-    __builtin_amdgcn_s_barrier();
-    P8_MMA(2, 0, fw0)
-    __builtin_amdgcn_s_barrier();
-    abuf ^= 1;
-    wring = wring == 2 ? 0 : wring + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef P8_MMA
-  p8_epilogue<KIND, SPLITK>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, tid, epi);
-}
-
 int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
                     int per, int splits, dim3 grid, hipStream_t s);  // gemm_p8i.hip
 
@@ -668,38 +452,27 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
   const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
-  // tuning selectors, read once: XLLM_MI355_P8_RING = 1 -> role-split kernel with the 3-deep weight ring (measured 2-4 %
-  // slower at M = 8192 and no faster at M = 256: off), XLLM_MI355_P8_MFMA32 = 1 -> int8 on the 32x32x32 kernel
-  static int ring = -2, mfma32 = -2;
-  if (ring == -2) {
-    const char* e = getenv("XLLM_MI355_P8_RING");
-    ring = e ? atoi(e) : 0;
-    e = getenv("XLLM_MI355_P8_MFMA32");
+  // tuning selector, read once: XLLM_MI355_P8_MFMA32 = 1 -> int8 on the 32x32x32 kernel (A/B arm of gemm_p8i.hip)
+  static int mfma32 = -2;
+  if (mfma32 == -2) {
+    const char* e = getenv("XLLM_MI355_P8_MFMA32");
     mfma32 = e ? atoi(e) : 0;
   }
   if constexpr (KIND == kI8) {
-    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless one of the selectors asks for a 32x32x32 kernel
-    if ((!mfma32 && !ring) || epi.group_tiles) {  // (the grouped mode lives in the 16x16x64 kernel)
+    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless the selector asks for the 32x32x32 kernel
+    if (!mfma32 || epi.group_tiles) {  // (the grouped mode lives in the 16x16x64 kernel)
       if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
       return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
     }
   }
-  const bool use_ring = ring && !epi.group_tiles;  // the grouped mode lives in the first-version kernel only
   if (splits > 1) {
     if constexpr (KIND == kI8) {
       if (!epi.acc_out) return XM_ERR_INVALID;  // the caller points acc_out at the zeroed split-K workspace
-      if (use_ring)
-        hipLaunchKernelGGL((gemm_p8r_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
-                           (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
-      else
-        hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
-                           (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+      hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
     } else {
       return XM_ERR_UNSUPPORTED;
     }
-  } else if (use_ring) {
-    hipLaunchKernelGGL((gemm_p8r_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
-                       (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   } else {
     hipLaunchKernelGGL((gemm_p8_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);

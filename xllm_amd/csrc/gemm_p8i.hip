@@ -119,7 +119,7 @@ template <bool SPLITK>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A_in,
                                                                 const uint8_t* __restrict__ W_in, int M_in, int N,
                                                                 int64_t Kb, int m_tiles, int n_tiles,
-                                                                int ktiles_per_split, GemmEpi epi_in) {
+                                                                int ktiles_per_split, GemmEpi epi_in, int stagger) {
   const uint8_t* A = A_in;
   const uint8_t* W = W_in;
   int M = M_in;
@@ -175,7 +175,15 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
   // unconditional, so the vmcnt arithmetic is static). Starting each workgroup at a different K tile (to spread the
   // readers of a shared operand panel over more L2 channels) was measured and is WORSE: 1033 -> 1272 us on
   // gate_up at M = 8192 -- the workgroups of a super-block re-use each other's L2 lines only while they move in step.
-  auto kwalk = [&](int kt) { return kt < kt_end ? kt : kt_end - 1; };
+  // Exception (round 3): ONE m tile (decode, M <= 256) -- the weight panels are private to their workgroups, nothing is
+  // re-used between them, and the only shared operand is the small activation slab of the K tile, which the address hash
+  // puts on a few L2 channels: there each workgroup starts at another tile and wraps around (exact int32 sums: any order).
+  const int phase = (stagger && m_tiles == 1 && !epi.group_tiles) ? (int)((unsigned)nt % (unsigned)nk) : 0;
+  auto kwalk = [&](int kt) {
+    int r = (kt < kt_end ? kt : kt_end - 1) - kt_begin + phase;
+    r = r >= nk ? r - nk : r;
+    return kt_begin + r;
+  };
   // ---- staging: each DMA instruction of a wave fills a lane-linear 1-KiB span = 8 rows x 128 B of a slot; the
   // XOR swizzle of the 16-B chunk index (conflict-free ds_read_b128) is applied to the per-lane SOURCE address.
   // A half-tile = 2 instructions per thread (i = 0, 1: LDS rows i*64 + wave*8 + lane/8).
@@ -345,14 +353,15 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
 }
 
 // same grid / envelope as launch_gemm_p8 (gemm_p8.hip decides which of the two int8 kernels runs)
+int ws_stagger();  // gemm_ws.hip: XLLM_MI355_KSTAGGER
 int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
                     int per, int splits, dim3 grid, hipStream_t s) {
   if (splits > 1)
     hipLaunchKernelGGL((gemm_p8i_kernel<true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
-                       (int)N, Kb, m_tiles, n_tiles, per, epi);
+                       (int)N, Kb, m_tiles, n_tiles, per, epi, ws_stagger());
   else
     hipLaunchKernelGGL((gemm_p8i_kernel<false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W,
-                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
+                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi, ws_stagger());
   return hip_check_launch();
 }
 

@@ -100,7 +100,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// ---- helpers of the hand-pipelined kernels (gemm_p8.hip, gemm_p8n.hip)
+// ---- helpers of the hand-pipelined kernels (gemm_p8.hip, gemm_p8i.hip)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KIND>
@@ -178,20 +178,11 @@ template <int KIND>
 int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                    size_t ws_bytes, int splits, hipStream_t s);
 
-// 256 x (32*NB) narrow-tile pipelined kernel for decode-shaped GEMMs (gemm_p8n.hip); splits > 1 needs epi.acc_out
-// = the zeroed int32 workspace (int8 only).
-template <int KIND>
-int launch_gemm_p8n(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int nb, int splits,
-                    hipStream_t s);
-
-// activation-stationary int8 kernel for decode GEMMs with few columns (gemm_astat.hip): adds the exact int32 sums into the
-// zeroed split-K workspace acc_ws [M, N]; the caller runs the dequant epilogue (or defers it to the fused consumer)
-int launch_gemm_astat_i8(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, int32_t* acc_ws, int splits,
-                         hipStream_t s);
-
 // weight-stream decode kernel on pre-packed int8 weights (gemm_ws.hip)
 int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
                       size_t ws_bytes, int* n_slabs, hipStream_t s);
+int launch_gemm_ws_fp8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                       size_t ws_bytes, hipStream_t s);
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s);
 
 // gemm_wsb.hip: weight-stream GEMM for 16-bit weights at decode shapes (dense M <= 64, grouped with few rows per expert)

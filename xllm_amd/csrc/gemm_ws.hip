@@ -20,6 +20,18 @@
 //    (all CUs busy) instead of 148 of 256; few-column problems take K slices, whose exact int32 partial sums go to
 //    separate slabs with plain stores (no atomics, nothing to zero) and are summed by the consumer;
 //  * one barrier per K tile; LDS-DMA and activation loads retire in order on vmcnt, so both run AD tiles ahead.
+//
+// Round 3:
+//  * EIGHT-wave workgroups (4 x 2 waves, two per SIMD) for 128 < M <= 512. The four-wave 256-row tile keeps ONE wave on each
+//    SIMD, so the 13 LDS-DMA pieces a wave issues per K tile (60-180 issue cycles each, MI355X_MICROARCH.md), its 28 fragment
+//    reads and its 80 MFMAs all serialise in one instruction stream: 2.86 us per K tile against 1280 matrix-pipe cycles
+//    (profiles/r02_gemm_ws.txt). With two waves per SIMD each wave carries half of every kind of work and one wave's DMA
+//    issue / lgkmcnt waits sit beside its partner's MFMAs. Fragments that do not divide over 8 waves are padded with
+//    out-of-range pieces (no memory request, zeros into a 1-KiB dump area behind the ring).
+//  * KIND = kFP8 (e4m3, fp8_scaled_matmul semantics, linear.cpp:137-182): the SAME packed byte layout -- the two 16-byte
+//    k-step fragments of a lane are the two halves of the 32-byte operand of v_mfma_f32_16x16x128_f8f6f4 (any K permutation
+//    shared by both operands is a valid contraction order) -- fp32 accumulators, K slices through fp32 slabs summed in
+//    slice order (deterministic).
 #include <stdlib.h>
 
 #include "gemm_types.h"
@@ -73,17 +85,30 @@ struct WsDma {
   __amdgpu_buffer_rsrc_t rsrc_a, rsrc_w;
   ws_lds_ptr_t dst_a, dst_w;  // this wave's first piece in the destination slot
   int so_a, so_w;             // scalar offsets of the K tile
+  ws_lds_ptr_t dump;          // 1-KiB area behind the ring: destination of a wave's padding pieces (eight-wave tiles whose
+  int nvalid_w;               // weight fragments do not divide over the waves); pieces >= nvalid_w are out of range
 };
 template <int NDA, int NDW>
 __device__ __forceinline__ void ws_dma_piece(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int j) {
   if (j < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_a, d.dst_a + j * WS_FRAG, 16, voff_a[j], d.so_a, 0, 0);
-  else __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, d.dst_w + (j - NDA) * WS_FRAG, 16, voff_w[j - NDA], d.so_w, 0, WS_W_AUX);
+  else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, (j - NDA) < d.nvalid_w ? d.dst_w + (j - NDA) * WS_FRAG : d.dump, 16,
+                                             voff_w[j - NDA], d.so_w, 0, WS_W_AUX);
 }
 // pieces due after MFMA group `slot` of 2 * NG (an even spread of ND pieces over the groups)
 template <int NDA, int NDW, int NG>
 __device__ __forceinline__ void ws_dma_slot(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int slot) {
   constexpr int ND = NDA + NDW;
   const int lo = slot * ND / (2 * NG), hi = (slot + 1) * ND / (2 * NG);
+#pragma unroll
+  for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW>(d, voff_a, voff_w, j);
+}
+
+// pieces [LO, HI) of the tile, the part due after MFMA group `slot` of `nslots` (staggered kernel: a tile's pieces are split
+// between a read phase and a matrix phase)
+template <int NDA, int NDW, int LO, int HI>
+__device__ __forceinline__ void ws_dma_range(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int slot, int nslots) {
+  const int lo = LO + slot * (HI - LO) / nslots, hi = LO + (slot + 1) * (HI - LO) / nslots;
 #pragma unroll
   for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW>(d, voff_a, voff_w, j);
 }
@@ -139,28 +164,191 @@ __device__ __forceinline__ void ws_compute(i32x4_t (&acc)[MB][NG], unsigned rw, 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves; DW K tiles in flight. BOTH operands go
-// HBM / L2 -> LDS by LDS-DMA in fragment order, so that every VMEM operation of a wave is an LDS-DMA with the same prefetch
-// distance: vmcnt retires in order, and with activation loads into registers next to the weight DMAs the weights could never
-// run further ahead than the (register-bound) activations -- measured: 2.1-3.0 TB/s. A wave issues its share of the
+
+// ---- fp8 (e4m3): one v_mfma_f32_16x16x128_f8f6f4 per (row block, column group) and K tile; its 32-byte operands are the
+// (k step 0, k step 1) fragment pairs. All fragment reads of the tile are issued up front (LDS operations retire in order):
+//   A0_0..A0_{MB-1}, A1_0..A1_{MB-1}, then (W0_ng, W1_ng) for ng = 0..NG-1; group ng needs its pair: 2 * (NG - 1 - ng) younger
+//   reads may still be outstanding. The DMA pieces of the next tile are spread over the NG groups.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ws_mma_fp8(const u32x4 w0, const u32x4 w1, const u32x4 a0, const u32x4 a1, f32x4_t c) {
+  const gi32x8_t wv = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+  const gi32x8_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, c, 0, 0, 0, 0, 0, 0);
+}
+template <int NDA, int NDW, int NSLOTS>
+__device__ __forceinline__ void ws_dma_slot_n(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int slot) {
+  constexpr int ND = NDA + NDW;
+  const int lo = slot * ND / NSLOTS, hi = (slot + 1) * ND / NSLOTS;
+#pragma unroll
+  for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW>(d, voff_a, voff_w, j);
+}
+template <int MB, int NG, int NDA, int NDW, int NG_LEFT>
+__device__ __forceinline__ void ws_fp8_groups(f32x4_t (&acc)[MB][NG], u32x4 (&fw0)[NG], u32x4 (&fw1)[NG], const u32x4 (&a0)[MB],
+                                              const u32x4 (&a1)[MB], const WsDma& d, const int (&voff_a)[8],
+                                              const int (&voff_w)[8]) {
+  if constexpr (NG_LEFT > 0) {
+    constexpr int ng = NG - NG_LEFT;
+    // (lgkmcnt is a 4-bit counter: a clamped count waits for a few more reads than needed, never fewer)
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fw0[ng]), "+v"(fw1[ng]) : "n"(2 * (NG_LEFT - 1) > 15 ? 15 : 2 * (NG_LEFT - 1)));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_fp8(fw0[ng], fw1[ng], a0[mb], a1[mb], acc[mb][ng]);
+    ws_dma_slot_n<NDA, NDW, NG>(d, voff_a, voff_w, ng);
+    ws_fp8_groups<MB, NG, NDA, NDW, NG_LEFT - 1>(acc, fw0, fw1, a0, a1, d, voff_a, voff_w);
+  }
+}
+template <int MB, int NG, int NDA, int NDW>
+__device__ __forceinline__ void ws_compute_fp8(f32x4_t (&acc)[MB][NG], unsigned rw, unsigned ra0, unsigned ra1, const WsDma& d,
+                                               const int (&voff_a)[8], const int (&voff_w)[8]) {
+  u32x4 a0[MB], a1[MB], fw0[NG], fw1[NG];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a0[mb], ra0, mb * 16 * WS_BK);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a1[mb], ra1, mb * 16 * WS_BK);
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    WS_DSR(fw0[ng], rw, ng * 2 * WS_FRAG);
+    WS_DSR(fw1[ng], rw, ng * 2 * WS_FRAG + WS_FRAG);
+  }
+  // the activation fragments are older than every weight read: the first group's wait covers them
+  if constexpr (MB == 4)
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+  else
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a1[0]), "+v"(a1[1]));
+  ws_fp8_groups<MB, NG, NDA, NDW, NG>(acc, fw0, fw1, a0, a1, d, voff_a, voff_w);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KIND>
+struct WsAcc { using type = i32x4_t; };
+template <>
+struct WsAcc<kFP8> { using type = f32x4_t; };
+
+// ---- epilogue shared by the weight-stream kernels. Accumulator layout: lane & 15 = m inside the row block, registers = four
+// consecutive n. Round 3 (in-kernel timing, profiles/r03_gemm_ws.txt): storing that layout directly -- 8-byte pieces, 16 rows x
+// 32 B per instruction -- cost gate_up's workgroups 20 k of their 81 k cycles at M = 256 (store-issue bound). The wave now
+// transposes its tile through a private LDS block (the ring is free: every DMA has landed and a barrier has passed) and stores
+// whole row segments, 16 B per lane, NG * 32 B (16-bit results) or NG * 64 B (slabs) contiguous per row.
+// K slices > 1: exact int32 (fp8: fp32) partial sums of this slice -> its slab; otherwise the dequant epilogue of
+// scaled_matmul / fp8_scaled_matmul (and the raw sums when epi.acc_out is set: tests).
+template <int KIND, int MB, int NG>
+__device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB][NG], const GemmEpi& epi,
+                                            int32_t* __restrict__ slabs, int slice, int n_slices, int M, int N, int m_base,
+                                            int g0, int g_live, int wn, int lane, uint8_t* lds, int wave) {
+  using acc_t = typename WsAcc<KIND>::type;
+  const int g4 = lane >> 4, ml = lane & 15;
+  const int gw = wn * NG;  // first column group of the wave inside the workgroup tile
+  if (n_slices > 1) {
+    // one 16-row block at a time: [16 rows][NG * 64 B + 16] in LDS, read back as NG 16-byte chunks per lane
+    constexpr int ROWB = NG * 64, PITCH = ROWB + 16, CH = ROWB / 16;
+    uint8_t* const tb = lds + wave * (16 * PITCH);
+    int32_t* const slab = slabs + (int64_t)slice * M * N;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) *reinterpret_cast<acc_t*>(tb + ml * PITCH + ng * 64 + g4 * 16) = acc[mb][ng];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
+        const uint4 v = *reinterpret_cast<const uint4*>(tb + row * PITCH + c * 16);
+        const int m = m_base + mb * 16 + row;
+        if (m < M && gw + (c >> 2) < g_live)
+          *reinterpret_cast<uint4*>(slab + (int64_t)m * N + (g0 + gw) * 16 + c * 4) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is rewritten by the next row block
+    }
+    return;
+  }
+  const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
+  const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+  const bool wide = epi.out && (((uintptr_t)epi.out & 15) == 0);  // (N % 16 == 0: every row segment is then 16-byte aligned)
+  constexpr int ROWB = NG * 32, PITCH = ROWB + 16, CH = ROWB / 16;  // 16-bit tile of the wave: [MB * 16 rows][NG * 32 B + 16]
+  uint8_t* const tb = lds + wave * (MB * 16 * PITCH);
+  float asv[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m_base + mb * 16 + ml, mc = m < M ? m : M - 1;
+    asv[mb] = epi.out ? (KIND == kI8 ? epi.a_scale[mc] : epi.a_scale[epi.a_scale_n > 1 ? mc : 0]) : 1.0f;
+  }
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int g = g0 + gw + ng;
+    const bool live = gw + ng < g_live;
+    const int n = (live ? g : g0) * 16 + 4 * g4;  // (dead groups compute on a valid column and are never stored)
+    float wsv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.out) {
+      if constexpr (KIND == kI8) {
+        const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+        wsv[0] = w4.x; wsv[1] = w4.y; wsv[2] = w4.z; wsv[3] = w4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsv[e] = epi.w_scale[epi.w_scale_n > 1 ? n + e : 0];
+      }
+    }
+    if (has_bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bsv[e] = load16(bias16, n + e, out_bf16);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = m_base + mb * 16 + ml;
+      if (epi.acc_out && live && m < M)
+        *reinterpret_cast<acc_t*>(epi.acc_out + (int64_t)m * N + n) = acc[mb][ng];  // raw sums (tests, one slab)
+      if (!epi.out) continue;
+      float v[4];
+      if constexpr (KIND == kI8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * asv[mb] * wsv[e] + bsv[e];
+      } else {  // the fp8 epilogue of gemm_p8.hip: as * (ws * acc) + bias
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = asv[mb] * (wsv[e] * acc[mb][ng][e]) + bsv[e];
+      }
+      uint2 pk;
+      if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
+      else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
+      if (wide) *reinterpret_cast<uint2*>(tb + (mb * 16 + ml) * PITCH + ng * 32 + g4 * 8) = pk;
+      else if (live && m < M) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)m * N + n) = pk;
+    }
+  }
+  if (!wide) return;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a wave's LDS operations execute in order; this retires the writes)
+#pragma unroll
+  for (int i = 0; i < MB * NG / 2; ++i) {  // MB * 16 rows x CH chunks over 64 lanes
+    const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
+    const uint4 v = *reinterpret_cast<const uint4*>(tb + row * PITCH + c * 16);
+    const int m = m_base + row;
+    if (m < M && gw + (c >> 1) < g_live)
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)m * N + (g0 + gw) * 16 + c * 8) = v;
+  }
+}
+
+// wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves (four or eight); DW K tiles in flight. BOTH
+// operands go HBM / L2 -> LDS by LDS-DMA in fragment order, so that every VMEM operation of a wave is an LDS-DMA with the same
+// prefetch distance: vmcnt retires in order, and with activation loads into registers next to the weight DMAs the weights could
+// never run further ahead than the (register-bound) activations -- measured: 2.1-3.0 TB/s. A wave issues its share of the
 // tile's NDW weight + NDA activation fragments per iteration and waits for all but the (DW - 1) newest tiles.
-template <int WM, int WN, int MB, int NG, int DW>
-__global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
-                                                            int M, int N, int64_t K, int m_tiles, int n_tiles,
-                                                            int kt_per_slice, int n_slices, GemmEpi epi,
-                                                            int32_t* __restrict__ slabs) {
-  static_assert(WM * WN == 4, "four waves per workgroup");
+
+template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
+__global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
+                                                             int M, int N, int64_t K, int m_tiles, int n_tiles,
+                                                             int kt_per_slice, int n_slices, GemmEpi epi,
+                                                             int32_t* __restrict__ slabs, int stagger) {
+  static_assert(NWV == 4 || NWV == 8, "one or two waves per SIMD");
+  static_assert(WM * WN == NWV, "waves per workgroup");
   static_assert(MB == 2 || MB == 4, "row blocks per wave");
+  static_assert(KIND == kI8 || KIND == kFP8, "8-bit operand kinds");
+  using acc_t = typename WsAcc<KIND>::type;
   constexpr int G = WN * NG;              // 16-column groups of a workgroup tile
   constexpr int NS = DW + 1;              // LDS slots
   constexpr int SLOT_W = G * 2 * WS_FRAG, SLOT_A = WM * MB * 2 * WS_FRAG, SLOT = SLOT_W + SLOT_A;
-  constexpr int NDW = (2 * G) / 4;        // weight LDS-DMA instructions per wave and K tile
-  constexpr int NDA = (2 * WM * MB) / 4;  // activation LDS-DMA instructions per wave and K tile
+  constexpr int NDW = (2 * G + NWV - 1) / NWV;  // weight LDS-DMA instructions per wave and K tile (the last ones may be padding)
+  constexpr int NDA = (2 * WM * MB) / NWV;      // activation LDS-DMA instructions per wave and K tile
+  constexpr bool PAD = (2 * G) % NWV != 0;      // some waves issue out-of-range padding pieces into the dump area
   constexpr int VMCNT = (DW - 1) * (NDW + NDA);
-  static_assert((2 * G) % 4 == 0 && (2 * WM * MB) % 4 == 0, "fragments per tile divide over the four waves");
-  static_assert(NS * SLOT <= 160 * 1024, "LDS ring");
+  static_assert((2 * WM * MB) % NWV == 0, "activation fragments per tile divide over the waves");
+  static_assert(NS * SLOT + (PAD ? WS_FRAG : 0) <= 160 * 1024, "LDS ring");
   static_assert(VMCNT < 64, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * SLOT];
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * SLOT + (PAD ? WS_FRAG : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +369,14 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
   int kt1 = kt0 + kt_per_slice;
   kt1 = kt1 > KT ? KT : kt1;
   const int nk = kt1 - kt0;  // >= 1 (the planner never makes an empty slice)
+  // K-walk stagger (round 3): every workgroup of a launch reads the SAME activation slab per K tile -- 256 rows x 128 B at a
+  // row pitch of K bytes, which the address hash puts on a few of the 16 L2 channels of an XCD -- so lock-step walkers queue
+  // on those channels (the three structurally different kernels all stopped at ~7 TB/s of LDS fill at M = 256). The weights
+  // of a decode GEMM are private to their workgroup (no L2 re-use to lose), so each workgroup starts its walk at another
+  // tile and wraps around: concurrent readers are spread over all slabs = all channels. Integer sums do not depend on the
+  // order; for fp8 the order is a fixed function of the block index (deterministic).
+  const int phase = stagger ? (int)(((unsigned)blockIdx.x >> 3) % (unsigned)nk) : 0;
+#define WS_ROT(X_) ((X_) + phase >= nk ? (X_) + phase - nk : (X_) + phase)
   const int n_groups = N >> 4;
   // balanced column split: tile nt owns groups [nt * n_groups / n_tiles, (nt + 1) * n_groups / n_tiles) -- at most G of them
   // (the launcher guarantees it), so that 2368 groups over 256 workgroups become 9 or 10 groups each instead of 197 x 12 + 4
@@ -204,36 +400,40 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
     const int row = (wave * NDA + i) * 8 + (lane >> 3);
     voff_a[i] = (m_tile0 + row) * (int)K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
   }
+  // this wave's weight fragments of a tile: f = wave * NDW + i (group f / 2, k step f % 2); f >= 2 G is padding
+  const int nvalid_w = PAD ? (2 * G - wave * NDW < 0 ? 0 : (2 * G - wave * NDW > NDW ? NDW : 2 * G - wave * NDW)) : NDW;
 #pragma unroll
   for (int i = 0; i < NDW; ++i) {
-    const int f = wave * NDW + i;  // weight fragment of the tile: group f / 2, k step f % 2
-    voff_w[i] = (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16;
+    const int f = wave * NDW + i;
+    voff_w[i] = i < nvalid_w ? (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
   }
   const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
+  const ws_lds_ptr_t lds_dump = lds3 + NS * SLOT;  // (only addressed when PAD)
   const unsigned rd_w = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
   // fragment (row block mb, k step ks): lane l reads row mb*16 + (l & 15), logical chunk ks*4 + (l >> 4)
   const unsigned rd_a_base = (unsigned)(__UINTPTR_TYPE__)lds3 + SLOT_W + (wm * MB * 16 + (lane & 15)) * WS_BK;
   const unsigned rd_a0 = rd_a_base + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
   const unsigned rd_a1 = rd_a_base + (((4 + (lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
 
-  i32x4_t acc[MB][NG];
+  acc_t acc[MB][NG];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int j = 0; j < NG; ++j) acc[i][j] = i32x4_t{0, 0, 0, 0};
+    for (int j = 0; j < NG; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   // tile T_ of the slice -> LDS slot T_ % NS (tiles past the end re-load the last tile: every load is unconditional, so
   // the vmcnt arithmetic is static; nobody reads them)
 #define WS_ISSUE(T_)                                                                                                 \
   {                                                                                                                  \
-    const int kt_ = kt0 + ((T_) < nk ? (T_) : nk - 1);                                                               \
+    const int kc_ = (T_) < nk ? (T_) : nk - 1;                                                                       \
+    const int kt_ = kt0 + WS_ROT(kc_);                                                                               \
     const ws_lds_ptr_t dw_ = lds3 + ((T_) % NS) * SLOT + wave * NDW * WS_FRAG;                                       \
     const ws_lds_ptr_t da_ = lds3 + ((T_) % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                              \
     _Pragma("unroll") for (int i_ = 0; i_ < NDA; ++i_)                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_A, da_ + i_ * WS_FRAG, 16, voff_a[i_], kt_ * WS_BK, 0, 0); \
     _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_)                                                               \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_W, dw_ + i_ * WS_FRAG, 16, voff_w[i_], kt_ * (2 * WS_FRAG), 0, \
-                                                 WS_W_AUX);                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_W, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,   \
+                                                 voff_w[i_], kt_ * (2 * WS_FRAG), 0, WS_W_AUX);                      \
   }
 
   // ablation builds (tools/build_ablations.sh; timing only, WRONG results): an empty buffer descriptor makes every DMA of
@@ -250,6 +450,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
 #else
 #define WS_ABL_RSRC_W rsrc_w
 #endif
+  // eight waves: the second-dispatched half loses every arbitration against the older half (MI355X_MICROARCH.md, "static
+  // priority for the younger half"); one static raise, no per-segment flips
+  if constexpr (NWV == 8) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
 #pragma unroll
   for (int i = 0; i < DW; ++i) WS_ISSUE(i)
   for (int t = 0; t < nk; ++t) {
@@ -258,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
     __builtin_amdgcn_s_barrier();  // everybody's have; and everybody has finished reading tile t - 1
     __builtin_amdgcn_sched_barrier(0);
     // tile t + DW goes into the slot of tile t - 1, piece by piece between the MFMA groups of tile t
-    const int tn = t + DW, ktn = kt0 + (tn < nk ? tn : nk - 1);
+    const int tn = t + DW, tc = tn < nk ? tn : nk - 1, ktn = kt0 + WS_ROT(tc);
     WsDma d;
     d.rsrc_a = WS_ABL_RSRC_A;
     d.rsrc_w = WS_ABL_RSRC_W;
@@ -266,88 +471,300 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_i8_kernel(const uint8_t* __res
     d.dst_a = lds3 + (tn % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;
     d.so_a = ktn * WS_BK;
     d.so_w = ktn * (2 * WS_FRAG);
+    d.dump = lds_dump;
+    d.nvalid_w = nvalid_w;
     const unsigned so = (t % NS) * SLOT;
 #ifndef WS_ABL_NOCOMPUTE
-    ws_compute<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
+    if constexpr (KIND == kI8) ws_compute<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
+    else ws_compute_fp8<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
 #else
     WS_ISSUE(tn)
 #endif
   }
 #undef WS_ISSUE
+#undef WS_ROT
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail prefetches have landed before the LDS is released
-  // MFMA -> VALU read hazard of the asm MFMAs: the accumulators of the LAST column group were written by the last MB MFMAs;
-  // the nops carry them as operands so that the epilogue's reads of exactly those registers are ordered behind the nops
-  // (every other accumulator was written >= MB * 16 cycles before the loop ended)
-  if constexpr (MB == 4)
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
-  else
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]));
+  if constexpr (KIND == kI8) {
+    // MFMA -> VALU read hazard of the asm MFMAs: the accumulators of the LAST column group were written by the last MB MFMAs;
+    // the nops carry them as operands so that the epilogue's reads of exactly those registers are ordered behind the nops
+    // (every other accumulator was written >= MB * 16 cycles before the loop ended)
+    if constexpr (MB == 4)
+      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
+    else
+      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]));
+  }
 
-  // ---- epilogue: lane & 15 = m inside the row block, registers = four consecutive n
-  const int g4 = lane >> 4, ml = lane & 15;
-  if (n_slices > 1) {  // exact int32 partial sums of this K slice -> its slab (plain 16-byte stores)
-    int32_t* const slab = slabs + (int64_t)slice * M * N;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = m_base + mb * 16 + ml;
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        const int g = g0 + wn * NG + ng;
-        if (m < M && wn * NG + ng < g_live) *reinterpret_cast<i32x4_t*>(slab + (int64_t)m * N + g * 16 + 4 * g4) = acc[mb][ng];
-      }
-    }
-    return;
-  }
-  const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
-  const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {
-    const int g = g0 + wn * NG + ng;
-    if (wn * NG + ng >= g_live) continue;
-    const int n = g * 16 + 4 * g4;
-    float wsv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (epi.out) {
-      const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
-      wsv[0] = w4.x; wsv[1] = w4.y; wsv[2] = w4.z; wsv[3] = w4.w;
-    }
-    if (has_bias) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bsv[e] = load16(bias16, n + e, out_bf16);
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = m_base + mb * 16 + ml;
-      if (m >= M) continue;
-      if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + (int64_t)m * N + n) = acc[mb][ng];  // raw sums (tests)
-      if (!epi.out) continue;
-      const float as = epi.a_scale[m];
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * as * wsv[e] + bsv[e];
-      uint2 pk;
-      if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
-      else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
-      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)m * N + n) = pk;
-    }
-  }
+  __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed and nobody reads the ring any more: the epilogue re-uses the LDS
+  ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
 }
 
-// sum of the K-slice slabs (exact int32) + the dequant epilogue of scaled_matmul; nothing is zeroed
+// ------------------------------------------------------------------------------------------------ staggered eight-wave tile
+// Round 3, after the ablation builds of the plain eight-wave tile (profiles/r03_gemm_ws.txt): its K-tile time is the SUM of
+// its fragment-read, MFMA and DMA-issue phases (gate_up, M = 256: 53.8 us full, 49.7 without any compute, 40.4 without the
+// weight DMA; 4500 shader cycles per K tile against 1280 matrix-pipe cycles) -- the two waves of a SIMD leave the per-tile
+// barrier together, both read fragments, both then want the matrix pipe, both then wait for DMAs: nothing overlaps.
+// This kernel runs the SAME tile with the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; wave w and
+// w + 4 share a SIMD) ONE BARRIER APART, the way the 8-phase kernel of gemm_p8.hip does:
+//     group 0:         READ(t) | MFMA(t)   | READ(t+1) | MFMA(t+1) | ...
+//     group 1:  (bar)          | READ(t)   | MFMA(t)   | READ(t+1) | ...          ("|" = workgroup barrier)
+// so every SIMD has one wave in its matrix phase while the other reads its fragments: the LDS and the matrix pipe work at the
+// same time. READ(t) = all 2 MB + 2 NG fragment reads of the K tile into registers, retired (lgkmcnt(0)) before the barrier;
+// MFMA(t) = 2 MB NG MFMAs back to back from registers, the wave's LDS-DMA pieces of a later tile in between, then the counted
+// vmcnt wait. Slot / landing rules (NS = DW + 1 ring slots, tile T lives in slot T % NS; global phase 2t = group 0 reads
+// tile t, phase 2t + 1 = group 1 reads it):
+//   * during MFMA(t) group 0 (phase 2t + 1) requests tile t + DW -> the slot of tile t - 1, last read in phase 2t - 1;
+//     group 1 (phase 2t + 2) requests tile t + DW + 1 -> the slot of tile t, last read (by itself, retired) in phase 2t + 1;
+//   * the wait at the end of MFMA(t) leaves DW - 1 tiles of the wave's own pieces in flight: group 0 then knows tile t + 1
+//     (read from phase 2t + 2 on) has landed, group 1 knows tile t + 2 has; a tile is only read after the barrier behind
+//     every wave's wait for it. The prologue requests tiles 0 .. DW - 1 (+ tile DW in group 1) and waits for tiles 0 (and 1).
+//   * second version (in-kernel timing: the matrix phase was 900 cycles for 680 of MFMA issue, the read phase 324 -- the DMA
+//     issue sat in the longer phase): a tile's ND pieces are split, NRD of them are issued in a READ phase where the wave
+//     only waits for the LDS. Group 0: pieces [0, NRD) of tile t + DW in READ(t), the rest in MFMA(t); group 1: pieces
+//     [0, NRD) of tile t + DW + 1 in MFMA(t), the rest in READ(t + 1) (its slot, that of tile t, is being read by group 1
+//     itself during READ(t), so nothing of that tile may be requested before MFMA(t)). Group 1 therefore waits (vmcnt) at the
+//     end of its READ phase, group 0 at the end of its matrix phase, both leaving DW - 1 whole tiles in flight.
+#ifdef WS8_TIMING
+__device__ long long ws8_dbg[64];
+#endif
+template <int KIND, int NG, int DW, int NRD>
+__global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
+                                                          int M, int N, int64_t K, int m_tiles, int n_tiles,
+                                                          int kt_per_slice, int n_slices, GemmEpi epi,
+                                                          int32_t* __restrict__ slabs) {
+  constexpr int NWV = 8, WM = 4, WN = 2, MB = 4;
+  using acc_t = typename WsAcc<KIND>::type;
+  constexpr int G = WN * NG, NS = DW + 1;
+  constexpr int SLOT_W = G * 2 * WS_FRAG, SLOT_A = WM * MB * 2 * WS_FRAG, SLOT = SLOT_W + SLOT_A;
+  constexpr int NDW = (2 * G + NWV - 1) / NWV, NDA = (2 * WM * MB) / NWV, ND = NDA + NDW;
+  constexpr bool PAD = (2 * G) % NWV != 0;
+  constexpr int VMCNT = (DW - 1) * ND;
+  static_assert(NS * SLOT + (PAD ? WS_FRAG : 0) <= 160 * 1024, "LDS ring");
+  static_assert(DW * ND + ND < 64, "vmcnt is a 6-bit counter");
+  static_assert(NRD >= 0 && NRD <= ND && DW >= 2, "pieces of a tile requested from a read phase");
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * SLOT + (PAD ? WS_FRAG : 0)];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN, grp = wave >> 2;
+#ifdef WS8_TIMING
+  const long long t_entry = __builtin_readcyclecounter(), r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+  int mt, nt, slice;
+  {
+    const int b = blockIdx.x, x = b & 7, y = b >> 3;
+    mt = y % m_tiles;
+    const int rest = (y / m_tiles) * 8 + x;
+    if (rest >= n_tiles * n_slices) return;
+    nt = rest % n_tiles;
+    slice = rest / n_tiles;
+  }
+  const int KT = (int)(K / WS_BK);
+  const int kt0 = slice * kt_per_slice;
+  int kt1 = kt0 + kt_per_slice;
+  kt1 = kt1 > KT ? KT : kt1;
+  const int nk = kt1 - kt0;
+  const int n_groups = N >> 4;
+  const int g0 = (int)((int64_t)nt * n_groups / n_tiles);
+  const int g_live = (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
+  const int m_tile0 = mt * (WM * MB * 16), m_base = m_tile0 + wm * (MB * 16);
+
+  const __amdgpu_buffer_rsrc_t rsrc_a =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(A), 0, (int)((int64_t)M * K), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(Wp) + (int64_t)g0 * KT * (2 * WS_FRAG), 0, (int)((int64_t)g_live * KT * (2 * WS_FRAG)), 0x00020000);
+  int voff_a[8], voff_w[8];
+  static_assert(NDW <= 8 && NDA <= 8, "voff arrays");
+#pragma unroll
+  for (int i = 0; i < NDA; ++i) {
+    const int row = (wave * NDA + i) * 8 + (lane >> 3);
+    voff_a[i] = (m_tile0 + row) * (int)K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  const int nvalid_w = PAD ? (2 * G - wave * NDW < 0 ? 0 : (2 * G - wave * NDW > NDW ? NDW : 2 * G - wave * NDW)) : NDW;
+#pragma unroll
+  for (int i = 0; i < NDW; ++i) {
+    const int f = wave * NDW + i;
+    voff_w[i] = i < nvalid_w ? (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
+  }
+  const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
+  const ws_lds_ptr_t lds_dump = lds3 + NS * SLOT;
+  const unsigned rd_w = (unsigned)(__UINTPTR_TYPE__)lds3 + wn * NG * (2 * WS_FRAG) + lane * 16;
+  const unsigned rd_a_base = (unsigned)(__UINTPTR_TYPE__)lds3 + SLOT_W + (wm * MB * 16 + (lane & 15)) * WS_BK;
+  const unsigned rd_a0 = rd_a_base + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
+  const unsigned rd_a1 = rd_a_base + (((4 + (lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
+
+  acc_t acc[MB][NG];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  // all pieces of tile T_ (clamped to the slice: requests past the end re-load the last tile into a slot nobody reads any more)
+#define WS8_ISSUE(T_)                                                                                                \
+  {                                                                                                                  \
+    const int kt_ = kt0 + ((T_) < nk ? (T_) : nk - 1);                                                               \
+    const ws_lds_ptr_t dw_ = lds3 + ((T_) % NS) * SLOT + wave * NDW * WS_FRAG;                                       \
+    const ws_lds_ptr_t da_ = lds3 + ((T_) % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDA; ++i_)                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, da_ + i_ * WS_FRAG, 16, voff_a[i_], kt_ * WS_BK, 0, 0);     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_)                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,          \
+                                                 voff_w[i_], kt_ * (2 * WS_FRAG), 0, WS_W_AUX);                      \
+  }
+#pragma unroll
+  for (int i = 0; i < DW; ++i) WS8_ISSUE(i)
+  // the descriptor of tile T_'s requests (clamped to the slice like WS8_ISSUE)
+#define WS8_DESC(D_, T_)                                                                                             \
+  WsDma D_;                                                                                                          \
+  {                                                                                                                  \
+    const int tt_ = (T_), kk_ = kt0 + (tt_ < nk ? tt_ : nk - 1);                                                     \
+    D_.rsrc_a = rsrc_a;                                                                                              \
+    D_.rsrc_w = rsrc_w;                                                                                              \
+    D_.dst_w = lds3 + (tt_ % NS) * SLOT + wave * NDW * WS_FRAG;                                                      \
+    D_.dst_a = lds3 + (tt_ % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                                             \
+    D_.so_a = kk_ * WS_BK;                                                                                           \
+    D_.so_w = kk_ * (2 * WS_FRAG);                                                                                   \
+    D_.dump = lds_dump;                                                                                              \
+    D_.nvalid_w = nvalid_w;                                                                                          \
+  }
+  if (grp) {
+    WS8_DESC(dp, DW)
+    ws_dma_range<NDA, NDW, 0, NRD>(dp, voff_a, voff_w, 0, 1);   // group 1 is one half-tile of requests ahead
+    // tiles 0 and 1 have landed: DW - 2 whole tiles + the NRD pieces stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * ND + NRD) : "memory");
+    __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise (MI355X_MICROARCH.md)
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");  // tile 0 has landed
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  u32x4 a0[MB], a1[MB], w0[NG], w1[NG];
+#ifdef WS8_TIMING  /* timing build (tools/r03): shader cycles per phase, summed over the K tiles, block 0, waves 0 and 4 */
+  const long long t_loop = __builtin_readcyclecounter();
+  long long tacc[5] = {0, 0, 0, 0, 0}, tq0, tq1;
+#define WS8_T(i_) { tq1 = __builtin_readcyclecounter(); tacc[i_] += tq1 - tq0; tq0 = tq1; }
+#else
+#define WS8_T(i_)
+#endif
+  for (int t = 0; t < nk; ++t) {
+    // ---- READ(t): every fragment of the tile into registers
+    const unsigned so = (t % NS) * SLOT;
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef WS8_TIMING
+    tq0 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) WS_DSR(a0[mb], rd_a0 + so, mb * 16 * WS_BK);
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) WS_DSR(w0[ng], rd_w + so, ng * 2 * WS_FRAG);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) WS_DSR(a1[mb], rd_a1 + so, mb * 16 * WS_BK);
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) WS_DSR(w1[ng], rd_w + so, ng * 2 * WS_FRAG + WS_FRAG);
+    {  // this phase's share of tile t + DW: group 0 opens the tile, group 1 completes it (and then waits for tile t + 1)
+      WS8_DESC(dr, t + DW)
+      if (grp) {
+        ws_dma_range<NDA, NDW, NRD, ND>(dr, voff_a, voff_w, 0, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");
+      } else {
+        ws_dma_range<NDA, NDW, 0, NRD>(dr, voff_a, voff_w, 0, 1);
+      }
+    }
+    // retired before the barrier: the other group (or this one) re-stages the slot in the next phase
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]),
+                 "+v"(a1[2]), "+v"(a1[3]));
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) asm volatile("" : "+v"(w0[ng]), "+v"(w1[ng]));
+    __builtin_amdgcn_sched_barrier(0);
+    WS8_T(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    WS8_T(1)
+    // ---- MFMA(t) from registers; between the column groups: group 0 the rest of tile t + DW, group 1 the head of t + DW + 1
+    WS8_DESC(d, t + DW + grp)
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+      if constexpr (KIND == kI8) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], w0[ng], a0[mb]);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, 2 * NG);
+        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, 2 * NG);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], w1[ng], a1[mb]);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, NG + ng, 2 * NG);
+        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, NG + ng, 2 * NG);
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_fp8(w0[ng], w1[ng], a0[mb], a1[mb], acc[mb][ng]);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, NG);
+        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, NG);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WS8_T(2)
+    if (!grp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");
+    WS8_T(3)
+    __builtin_amdgcn_s_barrier();
+    WS8_T(4)
+  }
+#ifdef WS8_TIMING
+  const long long t_loop_end = __builtin_readcyclecounter();
+#endif
+#undef WS8_DESC
+#undef WS8_T
+#undef WS8_ISSUE
+  if (!grp) __builtin_amdgcn_s_barrier();          // balance group 1's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail requests have landed before the LDS is released
+  if constexpr (KIND == kI8)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
+  __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed: the epilogue re-uses the LDS
+  ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
+#ifdef WS8_TIMING
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been accepted
+    const long long t_end = __builtin_readcyclecounter(), r_end = __builtin_amdgcn_s_memrealtime();
+    const int sel = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
+    if (sel >= 0 && (wave & 3) == 0 && lane == 0) {
+      long long* o = ws8_dbg + sel * 32 + grp * 16;
+      for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+      o[5] = nk;
+      o[6] = t_loop - t_entry;      // prologue: entry -> first K tile readable
+      o[7] = t_loop_end - t_loop;   // K loop
+      o[8] = t_end - t_loop_end;    // epilogue
+      o[9] = r_end - r_entry;       // the same span on the 100 MHz counter
+      o[10] = t_end - t_entry;
+    }
+  }
+#endif
+}
+
+// sum of the K-slice slabs (exact int32; fp8: fp32 in slice order) + the dequant epilogue; nothing is zeroed
+template <int KIND>
 __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __restrict__ slabs, int n_slices, int64_t M,
                                                                int64_t N, GemmEpi epi) {
+  using acc_t = typename WsAcc<KIND>::type;
   const int64_t total = M * N;
   for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x * 4) {
-    i32x4_t a = *reinterpret_cast<const i32x4_t*>(slabs + idx);
-    for (int s = 1; s < n_slices; ++s) a += *reinterpret_cast<const i32x4_t*>(slabs + (int64_t)s * total + idx);
+    acc_t a = *reinterpret_cast<const acc_t*>(slabs + idx);
+    for (int s = 1; s < n_slices; ++s) a += *reinterpret_cast<const acc_t*>(slabs + (int64_t)s * total + idx);
     const int64_t m = idx / N, n = idx - m * N;
-    if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = a;
+    if constexpr (KIND == kI8) {
+      if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = a;
+    }
     if (!epi.out) continue;
-    const float as = epi.a_scale[m];
     float v[4];
+    if constexpr (KIND == kI8) {
+      const float as = epi.a_scale[m];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      v[e] = (float)a[e] * as * epi.w_scale[n + e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+      for (int e = 0; e < 4; ++e)
+        v[e] = (float)a[e] * as * epi.w_scale[n + e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+    } else {
+      const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = as * (epi.w_scale[epi.w_scale_n > 1 ? n + e : 0] * a[e]) + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+    }
     uint2 pk;
     if (epi.out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
     else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
@@ -356,9 +773,24 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------ planner + launch
-struct WsPlan { int wm, wn, mb, ng, slices; };
+struct WsPlan { int waves, wm, wn, mb, ng, slices; };
 
-template <int WM, int WN, int MB, int NG, int DW>
+// XLLM_MI355_KSTAGGER=0: every workgroup walks K from its first tile (A/B arm), read once
+int ws_stagger() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("XLLM_MI355_KSTAGGER"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+// XLLM_MI355_WS8_STAGGER=0: the eight-wave tile with all waves in phase (A/B arm of gemm_ws8s_kernel), read once;
+// xllm_mi355_debug_ws_waves(80) / (81) switch it from the tests
+static int f_ws8s = -2;
+int ws_phase_stagger() {
+  if (f_ws8s == -2) { const char* e = getenv("XLLM_MI355_WS8_STAGGER"); f_ws8s = e ? atoi(e) : 1; }
+  return f_ws8s;
+}
+
+template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
   constexpr int G = WN * NG;
@@ -373,8 +805,20 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   if (fit > n_tiles) n_tiles = fit < n_groups ? fit : n_groups;
   const int rest = n_tiles * slices;
   const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
-  hipLaunchKernelGGL((gemm_ws_i8_kernel<WM, WN, MB, NG, DW>), dim3(grid), dim3(256), 0, s, (const uint8_t*)A,
-                     (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+  if constexpr (NWV == 8) {
+    if (ws_phase_stagger()) {
+      constexpr int ND8 = (2 * WN * NG + 7) / 8 + 4;  // pieces per wave and tile (weights + 4 activation pieces)
+      if (ws_phase_stagger() == 2)   // A/B arm: every request from the matrix phase (first version)
+        hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, 0>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                           (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+      else
+        hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                           (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+      return slices;
+    }
+  }
+  hipLaunchKernelGGL((gemm_ws_kernel<KIND, NWV, WM, WN, MB, NG, DW>), dim3(grid), dim3(NWV * 64), 0, s, (const uint8_t*)A,
+                     (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs, ws_stagger());
   return slices;
 }
 
@@ -382,6 +826,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
 // grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
 static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
+static int f_waves = -2;          // XLLM_MI355_WS_WAVES / xllm_mi355_debug_ws_waves: 4 = the round-2 four-wave 256-row tile (A/B)
 static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes) {
   if (f_ng == -2) {
     const char* e = getenv("XLLM_MI355_WS_NG");
@@ -389,11 +834,17 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     e = getenv("XLLM_MI355_WS_SLICES");
     f_sl = e ? atoi(e) : -1;
   }
+  if (f_waves == -2) {
+    const char* e = getenv("XLLM_MI355_WS_WAVES");
+    f_waves = e ? atoi(e) : -1;
+  }
   WsPlan p;
+  p.waves = 4;
   if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
-  else { p.wm = 4; p.wn = 1; p.mb = 4; }
+  else if (f_waves == 4) { p.wm = 4; p.wn = 1; p.mb = 4; }
+  else { p.waves = 8; p.wm = 4; p.wn = 2; p.mb = 4; }
   const int rows = p.wm * p.mb * 16;
   const int m_tiles = (int)((M + rows - 1) / rows);
   const int n_groups = (int)(N / 16), KT = (int)(K / WS_BK);
@@ -402,6 +853,7 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);
   const int n_ngs = p.wn == 4 ? 3 : 5;
   const int g_max = p.wn * ngs[n_ngs - 1];
+  const int per_simd = p.waves / 4;  // waves sharing one matrix pipe
   double best = 1e30;
   p.ng = ngs[n_ngs - 1];
   p.slices = 1;
@@ -417,9 +869,9 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
       if (p.wn * ngs[i] >= gl) { ng = ngs[i]; break; }
     const double rounds = (double)(((int64_t)m_tiles * nt * sl + 255) / 256);
     const int nk = (KT + sl - 1) / sl;
-    // per K tile and workgroup: matrix-pipe cycles of a wave against the cycles its CU needs to pull the tile's weights
+    // per K tile and workgroup: matrix-pipe cycles of a SIMD against the cycles its CU needs to pull the tile's weights
     // (~12 B / clk of HBM stream per CU) and activations (L2, ~40 B / clk)
-    const double mfma = p.mb * ng * 2 * 17.0, mem = gl * 2048.0 / 12.0 + p.wm * p.mb * 2048.0 / 40.0;
+    const double mfma = per_simd * p.mb * ng * 2 * 17.0, mem = gl * 2048.0 / 12.0 + p.wm * p.mb * 2048.0 / 40.0;
     double t = rounds * (nk * (mfma > mem ? mfma : mem) + 4000.0);
     if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 2000.0;  // slab write + read-back, spread over the chip
     if (t < best) { best = t; p.ng = ng; p.slices = sl; }
@@ -429,32 +881,36 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   return p;
 }
 
-#define WS_CASE(WM_, WN_, MB_, NG_, DW_)                                                                              \
-  if (p.wm == WM_ && p.wn == WN_ && p.mb == MB_ && p.ng == NG_)                                                       \
-    return ws_launch_cfg<WM_, WN_, MB_, NG_, DW_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
+#define WS_CASE(NWV_, WM_, WN_, MB_, NG_, DW_)                                                                        \
+  if (p.waves == NWV_ && p.wm == WM_ && p.wn == WN_ && p.mb == MB_ && p.ng == NG_)                                    \
+    return ws_launch_cfg<KIND, NWV_, WM_, WN_, MB_, NG_, DW_>(A, Wp, M, N, K, p.slices, epi, slabs, s);
 
+template <int KIND>
 int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi,
                        int32_t* slabs, hipStream_t s) {
-  // (WM, WN, MB, NG, DW): the ring of DW + 1 slots fills most of the 160 KiB of LDS (a CU needs of the order of 100 KiB of
-  // requests in flight to pull its share of the HBM stream, MI355X_MICROARCH.md "ldsdma-fill"); a slot holds the tile's
+  // (waves, WM, WN, MB, NG, DW): the ring of DW + 1 slots fills most of the 160 KiB of LDS (a CU needs of the order of 100 KiB
+  // of requests in flight to pull its share of the HBM stream, MI355X_MICROARCH.md "ldsdma-fill"); a slot holds the tile's
   // weight fragments (2 KiB per column group) and activation fragments (2 KiB per 16-row block)
-  WS_CASE(4, 1, 4, 10, 2) WS_CASE(4, 1, 4, 8, 2) WS_CASE(4, 1, 4, 6, 2) WS_CASE(4, 1, 4, 4, 3) WS_CASE(4, 1, 4, 2, 3)
-  WS_CASE(2, 2, 4, 5, 3) WS_CASE(2, 2, 4, 4, 4) WS_CASE(2, 2, 4, 3, 4) WS_CASE(2, 2, 4, 2, 5) WS_CASE(2, 2, 4, 1, 6)
-  WS_CASE(1, 4, 4, 3, 4) WS_CASE(1, 4, 4, 2, 5) WS_CASE(1, 4, 4, 1, 8)
-  WS_CASE(1, 4, 2, 3, 4) WS_CASE(1, 4, 2, 2, 6) WS_CASE(1, 4, 2, 1, 8)
+  WS_CASE(8, 4, 2, 4, 5, 2) WS_CASE(8, 4, 2, 4, 4, 2) WS_CASE(8, 4, 2, 4, 3, 2) WS_CASE(8, 4, 2, 4, 2, 3) WS_CASE(8, 4, 2, 4, 1, 3)
+  WS_CASE(4, 4, 1, 4, 10, 2) WS_CASE(4, 4, 1, 4, 8, 2) WS_CASE(4, 4, 1, 4, 6, 2) WS_CASE(4, 4, 1, 4, 4, 3) WS_CASE(4, 4, 1, 4, 2, 3)
+  WS_CASE(4, 2, 2, 4, 5, 3) WS_CASE(4, 2, 2, 4, 4, 4) WS_CASE(4, 2, 2, 4, 3, 4) WS_CASE(4, 2, 2, 4, 2, 5) WS_CASE(4, 2, 2, 4, 1, 6)
+  WS_CASE(4, 1, 4, 4, 3, 4) WS_CASE(4, 1, 4, 4, 2, 5) WS_CASE(4, 1, 4, 4, 1, 8)
+  WS_CASE(4, 1, 4, 2, 3, 4) WS_CASE(4, 1, 4, 2, 2, 6) WS_CASE(4, 1, 4, 2, 1, 8)
   return -1;
 }
 
-// Returns XM_ERR_UNSUPPORTED when the shape is outside the envelope. With epi.defer the exact int32 sums are left in
+// Returns XM_ERR_UNSUPPORTED when the shape is outside the envelope. With epi.defer (int8) the exact int32 sums are left in
 // `workspace` as *n_slabs slabs of M*N (the fused consumer adds them); otherwise the 16-bit result is written to epi.out.
-int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
-                      size_t ws_bytes, int* n_slabs, hipStream_t s) {
+template <int KIND>
+static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                          size_t ws_bytes, int* n_slabs, hipStream_t s) {
   if (M <= 0 || M > 512 || N % 16 != 0 || K % WS_BK != 0 || K / WS_BK < 4 || M * K >= (1ll << 31) || epi.group_counts ||
-      ((uintptr_t)A % 16) || ((uintptr_t)Wp % 16) || (epi.out && (uintptr_t)epi.out % 8) || (epi.w_scale && (uintptr_t)epi.w_scale % 16))
+      ((uintptr_t)A % 16) || ((uintptr_t)Wp % 16) || (epi.out && (uintptr_t)epi.out % 8) ||
+      (KIND == kI8 && epi.w_scale && (uintptr_t)epi.w_scale % 16))
     return XM_ERR_UNSUPPORTED;
   if (N * K >= (1ll << 31) * 16ll) return XM_ERR_UNSUPPORTED;
   const bool need_slab = epi.defer != 0;
-  if (need_slab && (!workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
+  if (need_slab && (KIND != kI8 || !workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
   const bool can_slice = workspace && ws_bytes >= (size_t)2 * M * N * 4;
   WsPlan p = ws_plan(M, N, K, can_slice, ws_bytes);
   int32_t* const slabs = reinterpret_cast<int32_t*>(workspace);
@@ -463,15 +919,24 @@ int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64
     e2.acc_out = slabs;
     e2.out = nullptr;
   }
-  const int slices = ws_dispatch(p, A, Wp, M, N, K, e2, slabs, s);
+  const int slices = ws_dispatch<KIND>(p, A, Wp, M, N, K, e2, slabs, s);
   if (slices < 0) return XM_ERR_UNSUPPORTED;
   if (n_slabs) *n_slabs = slices;
   if (slices > 1 && !need_slab) {
     int64_t blocks = (M * N / 4 + 255) / 256;
     blocks = blocks > 2048 ? 2048 : blocks;
-    hipLaunchKernelGGL(ws_slab_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, slices, M, N, epi);
+    hipLaunchKernelGGL(ws_slab_epilogue_kernel<KIND>, dim3((unsigned)blocks), dim3(256), 0, s, slabs, slices, M, N, epi);
   }
   return hip_check_launch();
+}
+
+int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                      size_t ws_bytes, int* n_slabs, hipStream_t s) {
+  return launch_gemm_ws<kI8>(A, Wp, M, N, K, epi, workspace, ws_bytes, n_slabs, s);
+}
+int launch_gemm_ws_fp8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
+                       size_t ws_bytes, hipStream_t s) {
+  return launch_gemm_ws<kFP8>(A, Wp, M, N, K, epi, workspace, ws_bytes, nullptr, s);
 }
 
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s) {
@@ -484,8 +949,20 @@ int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStre
 
 }  // namespace xm
 
+#ifdef WS8_TIMING
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_ws8(long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(xm::ws8_dbg), 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 // tests / tuning: force the tile width (16-column groups per wave) and the K-slice count of the next launches; <= 0 = planner
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan(int ng, int slices) {
   xm::f_ng = ng > 0 ? ng : -1;
   xm::f_sl = slices > 0 ? slices : -1;
+}
+// tests / tuning: 4 = the four-wave 256-row tile for M > 128 (round 2), anything else = the eight-wave tile (default)
+// 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default)
+extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_waves(int waves) {
+  if (waves == 80 || waves == 81) { xm::f_waves = -1; xm::f_ws8s = waves - 80; return; }
+  xm::f_waves = waves == 4 ? 4 : -1;
+  if (waves == 0) xm::f_ws8s = 1;
 }

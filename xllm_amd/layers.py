@@ -111,6 +111,8 @@ class QuantLinear:
             # decode-shaped GEMMs stream the weights in MFMA-fragment order (xllm_mi355_pack_weight_i8, once at load time);
             # the row-major copy stays for the prefill kernels
             self.weight_packed = ops.pack_weight_i8(self.weight)
+        elif mode == "fp8" and self.weight.is_cuda:
+            self.weight_packed = ops.pack_weight_fp8(self.weight)
 
     def forward(self, x, pre_quant=None):
         if self.mode == "int8":
@@ -118,7 +120,7 @@ class QuantLinear:
             y = ops.scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
         elif self.mode == "fp8":
             q, s = pre_quant if pre_quant is not None else ops.fp8_scaled_quantize(x)
-            y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias)
+            y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
         else:
             y = ops.matmul(x, self.weight, self.bias)
         return parallel.reduce(y, self.pg) if self.pg is not None else y

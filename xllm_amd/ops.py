@@ -273,7 +273,13 @@ def _prefer_packed(M: int, N: int, K: int) -> bool:
         return False
     if _PACKED_POLICY == "1":
         return M <= 512
-    return M <= 128 or (M <= 512 and N <= 8192 and K >= 8192)
+    if _PACKED_POLICY == "r2":      # the round-2 policy (A/B)
+        return M <= 128 or (M <= 512 and N <= 8192 and K >= 8192)
+    # round 3 (coalesced epilogue, eight-wave tile; profiles/r03_gemm_ws.txt, r03_policy.txt): the packed kernel serves every
+    # decode-shaped problem. Stand-alone the two small projections are 3 us slower on it at M = 256 (22.3 / 19.1 us with their
+    # slab pass against 19.4 / 17.9), but in the step their slabs feed the fused consumers (RoPE + KV write, add + norm + quant)
+    # that run anyway: whole step 14.93 ms (round-2 policy) -> 14.85 (wide problems only) -> 14.51 ms (everything packed)
+    return M <= 512
 
 
 def pack_weight_i8(w: torch.Tensor) -> Optional[torch.Tensor]:
@@ -331,7 +337,7 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
         rc = _lib.lib().xllm_mi355_scaled_matmul_packed(_p(a), _p(b_packed), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)),
                                                         _p(bias), _p(out), _p(acc_out), M, N, K, _DT[output_dtype],
                                                         ws.data_ptr(), ws.numel(), _stream())
-        if rc != -2:
+        if rc not in (-2, -4):   # XM_ERR_UNSUPPORTED / XM_ERR_WORKSPACE: a decline, the row-major kernel serves the shape
             check(rc, "scaled_matmul_packed")
             return out
     if acc_out is None:
@@ -402,9 +408,34 @@ def fp8_scaled_quantize(input, output=None, scale=None):
     return q, s
 
 
-def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None):
+def pack_weight_fp8(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """xllm_mi355_pack_weight_fp8: [N, K] e4m3 row-major -> MFMA-fragment order (the int8 byte permutation) for the weight-stream
+    decode GEMM; done once at weight-load time. None outside the packed kernel's envelope (N % 16, K % 128)."""
+    _need_cuda(w)
+    N, K = w.shape
+    if w.element_size() != 1 or not w.is_contiguous() or N % 16 or K % 128:
+        return None
+    out = torch.empty_like(w)
+    check(_lib.lib().xllm_mi355_pack_weight_fp8(_p(w), _p(out), N, K, _stream()), "pack_weight_fp8")
+    return out
+
+
+_PACKED_FP8_POLICY = os.environ.get("XLLM_MI355_PACKED_FP8", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
+
+
+def _prefer_packed_fp8(M: int, N: int, K: int) -> bool:
+    """decode-shaped fp8 GEMMs are one pass over the weights: the weight-stream kernel on packed weights (profiles/r03_gemm_ws.txt)"""
+    if _PACKED_FP8_POLICY == "0":
+        return False
+    if _PACKED_FP8_POLICY == "1":
+        return M <= 512
+    return M <= 128
+
+
+def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, b_packed=None):
     """cuda::fp8_scaled_matmul(a, b, a_scale, b_scale, out_dtype, bias?, out?) (fp8_scaled_matmul.cpp:20-47);
-    a [M,K] e4m3fn, b [N,K] e4m3fn (the reference takes the [N,K] weight and forms b.t() itself)."""
+    a [M,K] e4m3fn, b [N,K] e4m3fn (the reference takes the [N,K] weight and forms b.t() itself). `b_packed` = pack_weight_fp8(b):
+    decode-shaped calls then stream the weights in fragment order (same semantics, fp32 summation order differs)."""
     _need_cuda(a, b, a_scale, b_scale)
     if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1):
         raise Mi355Error("fp8_scaled_matmul: a [M,K], b [N,K]")
@@ -413,6 +444,14 @@ def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=
     if a_scale.numel() not in (1, M) or b_scale.numel() not in (1, N):
         raise Mi355Error("fp8_scaled_matmul: scales must be scalar or per-token / per-channel")
     out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+    if b_packed is not None and a.is_contiguous() and _prefer_packed_fp8(M, N, K):
+        ws = _slab_workspace(a.device)
+        rc = _lib.lib().xllm_mi355_fp8_scaled_matmul_packed(_p(a), _p(b_packed), _p(a_scale), a_scale.numel(), _p(b_scale),
+                                                            b_scale.numel(), _p(bias), _p(out), M, N, K, _DT[output_dtype],
+                                                            ws.data_ptr(), ws.numel(), _stream())
+        if rc not in (-2, -4):   # XM_ERR_UNSUPPORTED / XM_ERR_WORKSPACE: the row-major kernel serves the shape
+            check(rc, "fp8_scaled_matmul_packed")
+            return out
     if M <= 512:
         _ensure_gemm_workspace(a.device, 1)  # decode shapes may split K through it (fp32 slabs, deterministic reduce)
     check(_lib.lib().xllm_mi355_fp8_scaled_matmul(_p(a), _p(b), _p(a_scale), a_scale.numel(), _p(b_scale),
