@@ -9,13 +9,15 @@ gfx950 kernels only; the oracle is used for the cpu_baseline leg alone.
 
 Multi-GPU (one process per GPU; launched by torch.distributed.run, or by this script itself when WORLD_SIZE is not set):
 the global batch of 256 sequences is FIXED ("scaling": "strong") and the layout decides how N GPUs share it:
-  dp     (default) N replicas of the model (7.6 GB of int8 weights fit a 288 GB GPU many times over), 256 / N sequences each,
-         NO data-path exchange -- the decode path shards by sequences; only the timing barrier crosses ranks;
-  tp     the reference's tensor parallelism over RCCL / xGMI (heads / columns, all-reduce after o_proj and down_proj,
-         all-gather of logits); Qwen2-7B has 28 heads, so TP is 1, 2 or 4 (qwen2_attention.cpp:54-65);
-  tp4dp2 TP = 4 inside two replicas (what the reference would run on 8 GPUs).
-Measured per-replica steps on one GPU (--emulate-dp, profiles/r02_layouts.txt) put dp ahead of tp at every N: the weight
-stream of a replica does not shrink with N, but neither does a TP rank's 57 collectives per step, and DP has none.
+  tp     (headline for N = 2, 4) the reference's tensor parallelism over xGMI (heads / columns per rank, SUM all-reduce after
+         o_proj and down_proj, all-gather of logits; linear.cpp:1518-1520, 712-714); Qwen2-7B has 28 heads, so TP is 1, 2 or 4
+         (qwen2_attention.cpp:54-65). The 56 per-layer sums run on the one-shot all-reduce kernel of csrc/allreduce.hip (self-tested
+         at set-up, fused with the residual add + RMSNorm + int8 quant that follows; RCCL when the self-test fails --
+         config.allreduce says which), the logits all-gather on RCCL;
+  tp4dp2 (headline for N = 8) TP = 4 inside two replicas (what the reference would run on 8 GPUs);
+  dp     N replicas of the model (7.6 GB of int8 weights fit a 288 GB GPU many times over), 256 / N sequences each, NO data-path
+         exchange. A legitimate deployment answer for this path, measured in the same run and reported in `layouts` beside the
+         headline (never substituted for it); --layout dp makes it the headline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -62,10 +64,13 @@ def parse():
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
     p.add_argument("--no-engine", action="store_true", help="skip the step-level harness leg (xllm_amd.engine.DecodeEngine)")
     p.add_argument("--layout", default="auto", choices=["auto", "dp", "tp", "tp4dp2"],
-                   help="how N GPUs share the fixed global batch (auto = dp; see the module docstring)")
+                   help="how N GPUs share the fixed global batch (auto = tp for N = 2, 4, tp4dp2 for N = 8, with the dp line "
+                        "measured beside it; see the module docstring)")
     p.add_argument("--oneshot-allreduce", action="store_true",
-                   help="tensor parallel: the one-shot xGMI all-reduce of csrc/allreduce.hip for the per-layer sums (a kernel, "
-                        "captured into the step's graphs) instead of RCCL; opt-in until validated on a multi-GPU node")
+                   help="(default since round 3; kept for old command lines) tensor parallel: the one-shot xGMI all-reduce of "
+                        "csrc/allreduce.hip for the per-layer sums, self-tested at set-up, RCCL when the self-test fails")
+    p.add_argument("--no-oneshot-allreduce", action="store_true", help="tensor parallel: RCCL for every collective")
+    p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
     p.add_argument("--emulate-tp", type=int, default=0,
@@ -245,54 +250,31 @@ def main():
     model_name, mode, gbatch, ctx = CONFIGS[a.config]
     margs = getattr(layers.ModelArgs, model_name)()
     block_size = 128
-    layout = a.layout if a.layout != "auto" else "dp"
-    if world == 1:
-        tp_size = 1
-    elif layout == "dp":
-        tp_size = 1
-    elif layout == "tp":
-        tp_size = world
-        if margs.n_heads % tp_size:
-            raise SystemExit(f"--layout tp: {margs.n_heads} heads do not divide over {world} ranks "
-                             f"(qwen2_attention.cpp:54); use dp or tp4dp2")
-    else:
-        tp_size = 4
-        if world % 4:
-            raise SystemExit("--layout tp4dp2 needs a multiple of 4 GPUs")
-    dp_size = world // tp_size
-    if gbatch % dp_size:
-        raise SystemExit(f"global batch {gbatch} does not divide over {dp_size} replicas")
-    tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_size) if world > 1 else (None, 0))
-    if a.oneshot_allreduce and tp_pg is not None and tp_size > 1:
-        tp_pg.enable_oneshot(dev, 8 << 20)
-    B = gbatch // dp_size
-    if a.emulate_dp > 1 and world == 1:
-        B = gbatch // a.emulate_dp
     dtype = torch.bfloat16
+    from xllm_amd import ops
 
-    if a.emulate_tp > 1 and world == 1:
-        class _StubPG(parallel.ProcessGroup):  # shard shapes of TP=k, no exchange: per-rank compute only
-            def allreduce(self, x):
-                return None
+    def pick_layout():
+        """how N GPUs share the fixed global batch. auto = what `north_star` names: tensor parallel over RCCL / xGMI (heads / columns
+        per rank, SUM all-reduce after o_proj and down_proj, logits all-gather); 28 heads divide over 1, 2, 4, 7 ... ranks, so N = 8
+        is TP = 4 inside two replicas (qwen2_attention.cpp:54-65). The data-parallel line is measured beside it (`layouts`)."""
+        if world == 1:
+            return "single", 1
+        if a.layout == "dp":
+            return "dp", 1
+        if a.layout == "tp4dp2" or (a.layout == "auto" and world == 8):
+            if world % 4:
+                raise SystemExit("--layout tp4dp2 needs a multiple of 4 GPUs")
+            return "tp4dp2", 4
+        if a.layout == "tp" or margs.n_heads % world == 0:
+            if margs.n_heads % world:
+                raise SystemExit(f"--layout tp: {margs.n_heads} heads do not divide over {world} ranks "
+                                 f"(qwen2_attention.cpp:54); use dp or tp4dp2")
+            return "tp", world
+        return "dp", 1
 
-            def allgather(self, x):
-                return x.unsqueeze(0).expand(self._world, *x.shape)
-        tp_pg = _StubPG(None, 0, a.emulate_tp)
-        tp_size = a.emulate_tp
-    model = layers.Qwen2Model(margs, mode, dtype, dev, seed=1234, tp=tp_pg, fuse=not a.no_fuse)
-    md, n_blocks = build_metadata(B, ctx, block_size, dev, seed=dp_rank)
-    nkv_l = model.layers[0].nkv
-    gen = torch.Generator(device=dev).manual_seed(99 + rank)
-    kv_caches = []
-    for _ in model.layers:
-        kc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
-        vc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
-        kv_caches.append(KVCache(kc, vc))
-    tokens = torch.randint(0, margs.vocab_size, (B,), device=dev, generator=gen)
-    positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+    layout, tp_size = pick_layout()
 
     # per-launch HIP events around the dominant kernel (paged decode attention) on the launch stream
-    from xllm_amd import ops
     attn_events = []
     orig_paged = ops.paged_attention
     record = {"on": False}
@@ -323,87 +305,143 @@ def main():
 
     ops.paged_decode_attention_int8 = timed_fused
 
-    dual = layers.DualBatchDecoder(model, md, B) if (a.dual and world == 1 and not a.no_fuse and mode == "int8") else None
-
-    def step():
-        hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
-        logits = model.logits(hidden)
-        return torch.argmax(logits, dim=-1)
-
     def sync_all():
         torch.cuda.synchronize()        # this rank's work is done ...
         if world > 1:
             dist.barrier()              # ... and so is everybody's
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync_all()
-    # decode runs under HIP-graph replay in the reference (runtime/dcu_graph_executor_impl.h): capture one step
-    # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
-    graph = None
-    # no collective inside the step (one GPU, or data-parallel replicas): ONE graph; tensor parallel: piecewise graphs
-    use_graph = (not a.no_graph) and (tp_size == 1 or (a.graph and a.backend == "nccl"))
-    piecewise = (not a.no_graph) and tp_size > 1 and not use_graph
-    if piecewise:
-        # TP > 1: one graph per run of kernels between two collectives, collectives eager in between
-        # (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo never run inside a capture
-        try:
-            step()
-            pw = parallel.PiecewiseGraph()
-            static_out = pw.capture(step)
-            graph = pw
-            for _ in range(2):
-                graph.replay()
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] piecewise graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
-            graph = None
-    if use_graph:
-        try:
-            cap_stream = torch.cuda.Stream()
-            cap_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cap_stream):
-                step()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=cap_stream):
-                    static_out = step()
-            torch.cuda.current_stream().wait_stream(cap_stream)
-            graph = g
-            for _ in range(2):
-                graph.replay()
-        except Exception as e:  # noqa: BLE001
-            print(f"[bench] graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
-            graph = None
-    run_step = (lambda: graph.replay()) if graph is not None else step
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / a.steps * 1e3
-    tok_s = gbatch * a.steps / elapsed
-    # exchange accounting (reference: 2 all-reduces per layer + the logits all-gather, linear.cpp:1518-1520, 712-714)
-    collectives_per_step = (2 * len(model.layers) + 1) if tp_size > 1 else 0
-    exposed_comm_ms = 0.0 if tp_size == 1 else None
-    if piecewise and graph is not None:
-        # the same piecewise replay with the collectives left out (results are then wrong, timing only): the difference is
-        # the communication time that is NOT hidden under compute
+        return float(t.item())
+
+    def build(tp_sz):
+        """model shard + KV caches + metadata of this rank for TP = tp_sz inside world / tp_sz replicas"""
+        dp_sz = world // tp_sz
+        if gbatch % dp_sz:
+            raise SystemExit(f"global batch {gbatch} does not divide over {dp_sz} replicas")
+        tp_pg, dp_rank = (parallel.make_tp_dp_groups(world, rank, tp_sz) if world > 1 else (None, 0))
+        if tp_pg is not None and tp_sz > 1 and not a.no_oneshot_allreduce:
+            # the one-shot xGMI all-reduce for the per-layer sums (<= 8 MiB), self-tested at set-up; RCCL when the test fails
+            tp_pg.enable_oneshot(dev, 8 << 20)
+            if rank == 0 and tp_pg.oneshot is None:
+                print(f"[bench] one-shot all-reduce not used: {tp_pg.oneshot_note}", file=sys.stderr)
+        B = gbatch // dp_sz
+        if a.emulate_dp > 1 and world == 1:
+            B = gbatch // a.emulate_dp
+        if a.emulate_tp > 1 and world == 1:
+            class _StubPG(parallel.ProcessGroup):  # shard shapes of TP=k, no exchange: per-rank compute only
+                def allreduce(self, x):
+                    return None
+
+                def allgather(self, x):
+                    return x.unsqueeze(0).expand(self._world, *x.shape)
+            tp_pg = _StubPG(None, 0, a.emulate_tp)
+            tp_sz = a.emulate_tp
+        model = layers.Qwen2Model(margs, mode, dtype, dev, seed=1234, tp=tp_pg, fuse=not a.no_fuse)
+        md, n_blocks = build_metadata(B, ctx, block_size, dev, seed=dp_rank)
+        nkv_l = model.layers[0].nkv
+        gen = torch.Generator(device=dev).manual_seed(99 + rank)
+        kv_caches = []
+        for _ in model.layers:
+            kc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
+            vc = torch.empty(n_blocks, block_size, nkv_l, margs.head_dim, dtype=dtype, device=dev).normal_(generator=gen)
+            kv_caches.append(KVCache(kc, vc))
+        tokens = torch.randint(0, margs.vocab_size, (B,), device=dev, generator=gen)
+        positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+        return dict(model=model, md=md, n_blocks=n_blocks, kv_caches=kv_caches, tokens=tokens, positions=positions, B=B,
+                    tp_pg=tp_pg, tp_size=tp_sz, dp_size=dp_sz, nkv_l=nkv_l)
+
+    def time_decode(w, steps):
+        """warm up, capture (one graph without collectives, piecewise graphs around eager collectives, or -- one-shot kernel --
+        one graph WITH them), time `steps` replays; returns the timing record and the eager step function"""
+        model, md, kv_caches, tokens, positions, B = w["model"], w["md"], w["kv_caches"], w["tokens"], w["positions"], w["B"]
+        tp_sz, tp_pg = w["tp_size"], w["tp_pg"]
+        dual = layers.DualBatchDecoder(model, md, B) if (a.dual and world == 1 and not a.no_fuse and mode == "int8") else None
+
+        def step():
+            hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
+            return ops.greedy_argmax(model.logits(hidden))
+
+        for _ in range(a.warmup):
+            step()
+        sync_all()
+        # decode runs under HIP-graph replay in the reference (runtime/dcu_graph_executor_impl.h): capture one step
+        # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
+        graph = None
+        # no collective inside the step (one GPU, or data-parallel replicas): ONE graph; tensor parallel: piecewise graphs
+        use_graph = (not a.no_graph) and (tp_sz == 1 or (a.graph and a.backend == "nccl"))
+        piecewise = (not a.no_graph) and tp_sz > 1 and not use_graph
+        if piecewise:
+            # TP > 1: one graph per run of kernels between two EAGER collectives (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo
+            # never run inside a capture. With the one-shot kernel the per-layer sums are kernels INSIDE the pieces: the only eager
+            # collective left is the logits all-gather.
+            try:
+                step()
+                pw = parallel.PiecewiseGraph()
+                pw.capture(step)
+                graph = pw
+                for _ in range(2):
+                    graph.replay()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] piecewise graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
+                graph = None
+        if use_graph:
+            try:
+                cap_stream = torch.cuda.Stream()
+                cap_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap_stream):
+                    step()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=cap_stream):
+                        step()
+                torch.cuda.current_stream().wait_stream(cap_stream)
+                graph = g
+                for _ in range(2):
+                    graph.replay()
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] graph capture failed ({e!r}); falling back to eager launches", file=sys.stderr)
+                graph = None
+        run_step = (lambda: graph.replay()) if graph is not None else step
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            graph.replay(skip_collectives=True)
+        for _ in range(steps):
+            run_step()
         sync_all()
-        t_nc = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([t_nc], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_nc = float(t.item())
-        exposed_comm_ms = round(max(ms_per_step - t_nc / a.steps * 1e3, 0.0), 4)
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if tp_pg is not None:
+            tp_pg.check()     # the one-shot kernel's bounded waits: a timed-out launch voids the measurement (raises)
+        ms = elapsed / steps * 1e3
+        exposed = 0.0 if tp_sz == 1 else None
+        eager_collectives = 0
+        if piecewise and graph is not None:
+            eager_collectives = sum(1 for it in graph.items if not isinstance(it, torch.cuda.CUDAGraph))
+            # the same piecewise replay with the eager collectives left out (results are then wrong, timing only): the difference
+            # is the communication time that is NOT hidden under compute. (All-reduces that run as one-shot kernels inside the
+            # pieces stay in: their cost is part of both figures.)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                graph.replay(skip_collectives=True)
+            sync_all()
+            t_nc = max_over_ranks(time.perf_counter() - t0)
+            exposed = round(max(ms - t_nc / steps * 1e3, 0.0), 4)
+        return dict(ms_per_step=ms, tok_s=gbatch * steps / elapsed, graph=graph, piecewise=piecewise, exposed_comm_ms=exposed,
+                    eager_collectives=eager_collectives, dual=dual, step=step)
+
+    w = build(tp_size)
+    model, md, n_blocks, kv_caches, tokens, positions, B = (w["model"], w["md"], w["n_blocks"], w["kv_caches"], w["tokens"],
+                                                             w["positions"], w["B"])
+    tp_pg, tp_size, dp_size, nkv_l = w["tp_pg"], w["tp_size"], w["dp_size"], w["nkv_l"]
+    r = time_decode(w, a.steps)
+    ms_per_step, tok_s, graph, piecewise, exposed_comm_ms, dual, step = (r["ms_per_step"], r["tok_s"], r["graph"], r["piecewise"],
+                                                                        r["exposed_comm_ms"], r["dual"], r["step"])
+    # exchange accounting (reference: 2 all-reduces per layer + the logits all-gather, linear.cpp:1518-1520, 712-714)
+    collectives_per_step = (2 * len(model.layers) + 1) if tp_size > 1 else 0
+    allreduce_kind = tp_pg.allreduce_kind() if (tp_pg is not None and tp_size > 1 and world > 1) else None
 
     # roofline leg: per-launch HIP events around the dominant kernel (paged decode attention) on the launch
     # stream, over eager steps of the same workload (events cannot be read back from inside a replayed graph)
@@ -419,13 +457,32 @@ def main():
     # algorithmic bytes per launch: K+V of every cached token once + Q in + O out
     attn_bytes = B * (ctx * nkv_l * d * 2 * 2 + 2 * nq_l * d * 2)
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "decode_attn_pmc.json")
     if os.path.exists(pmc) and world == 1 and tp_size == 1 and a.config == "cfg3":
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/decode_attn_pmc.json (rocprofv3 --pmc passes of an earlier run, not this run)"
         except Exception:
             traffic = None
+
+    # the other way N GPUs can share the batch, measured in the same run (a legitimate deployment answer, reported, not
+    # substituted): N data-parallel replicas, no data-path exchange
+    layouts = None
+    if world > 1 and tp_size > 1 and a.layout == "auto" and not a.no_layouts:
+        layouts = {layout: {"ms_per_step": round(ms_per_step, 4), "tokens_per_s": round(tok_s, 2),
+                            "collectives_per_step": collectives_per_step, "allreduce": allreduce_kind,
+                            "exposed_comm_ms": exposed_comm_ms}}
+        try:
+            w2 = build(1)
+            r2 = time_decode(w2, a.steps)
+            layouts["dp"] = {"ms_per_step": round(r2["ms_per_step"], 4), "tokens_per_s": round(r2["tok_s"], 2),
+                             "collectives_per_step": 0, "allreduce": None, "exposed_comm_ms": 0.0,
+                             "per_gpu_batch": w2["B"]}
+            del w2, r2
+        except Exception as e:  # noqa: BLE001
+            layouts["dp"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     prefill = None
     if not a.no_prefill and a.config == "cfg3":
@@ -451,16 +508,20 @@ def main():
                        "parallelism": (f"dp{dp_size}" if tp_size == 1 and dp_size > 1 else
                                        f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else "")),
                        "layout": layout if world > 1 else "single", "collectives_per_step": collectives_per_step,
-                       "allreduce": (("oneshot-xgmi" if a.oneshot_allreduce else "rccl") if tp_size > 1 and world > 1 else None),
+                       "allreduce": allreduce_kind,
+                       "allreduce_note": (tp_pg.oneshot_note if (tp_pg is not None and tp_size > 1 and world > 1) else None),
+                       "eager_collectives_per_step": r["eager_collectives"] if tp_size > 1 else 0,
                        "exposed_comm_ms": exposed_comm_ms,
                        "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,
                        "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},
             "roofline": {"bound": "hbm", "kernel": "paged_decode_kernel (+ split-KV merge when the launch splits)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4),
                          "launches_timed": len(attn_events)},
         }
+        if layouts is not None:
+            out["layouts"] = layouts
         if prefill is not None:
             out["prefill"] = prefill
         if engine_info is not None:
@@ -505,7 +566,7 @@ def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, d
     """prefill TFLOPS (second half of the BASELINE metric): one chunk of 2 x ctx tokens through the
     full model -- causal varlen flash attention, W8A8 GEMMs at M = 8192, KV written to fresh pages; logits only
     for the last token of each sequence (llm_model_base.h:193-204). flops = 2*T*sum(N*K) + 2*nq*d*S^2*L per seq."""
-    from xllm_amd import attention
+    from xllm_amd import attention, ops
     nseq = 2
     T = nseq * ctx
     pages = ctx // block_size
@@ -518,7 +579,7 @@ def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, d
 
     def chunk():
         hidden = model.forward(tokens, positions, md, kv_caches)
-        return torch.argmax(model.logits(hidden.index_select(0, last)), dim=-1)
+        return ops.greedy_argmax(model.logits(hidden.index_select(0, last)))
 
     chunk()
     sync_all()

@@ -401,6 +401,11 @@ XM_API int xllm_mi355_random_sample(const float* probs, int32_t* out, int64_t ba
                                     const float* uniform, uint64_t philox_seed, uint64_t philox_offset,
                                     void* stream);
 XM_API int xllm_mi355_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* The greedy branch of the sampler: Sampler::greedy_sample = argmax over the last dim (framework/sampling/sampler.cpp:160-168).
+ * logits [batch, vocab] (XM_F32 / XM_BF16 / XM_F16) -> out[batch] int64 = the FIRST index of each row's maximum; a NaN counts
+ * as larger than every number (torch.argmax). One workgroup per row, one pass, 16-byte loads. */
+XM_API int xllm_mi355_greedy_argmax(const void* logits, int64_t* out, int64_t batch, int64_t vocab, int dtype, void* stream);
+
 /* dcu::rejection_sample (kernels/dcu/rejection_sample.hip:33-215): speculative-decoding verification.  For sequence
  * s with n = num_draft_tokens[s] drafts ending at cu_num_draft_tokens[s] (inclusive prefix sums): output slots
  * [start + s, start + s + n] are set to -1, draft i is accepted while uniform_rand[row] < target[row, tok] /
@@ -551,6 +556,20 @@ XM_API int xllm_mi355_ipc_close_handle(void* ptr);
 XM_API int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* const* peer_buffers, int rank,
                                         int world, size_t max_message_bytes, uint32_t* epoch_state, int* status,
                                         double timeout_s, void* stream);
+
+/* The one-shot all-reduce FUSED with what follows it in a tensor-parallel half-layer: row-parallel linear -> SUM all-reduce ->
+ * fused_add_rms_norm (-> scaled_quantize of the next W8A8 linear) (linear.cpp:1518-1520, qwen2_decoder_layer.cpp:66-110,
+ * kernels/cuda/norm.cu:229-425). partial [M, H] = this rank's 16-bit output of the row-parallel linear (read only);
+ * y = rT(sum over ranks, fp32, rank order); residual [M, H] <- rT(y + residual) in place; then EITHER out_norm [M, H] = the
+ * 16-bit RMSNorm OR out_q [M, H] int8 + out_q_scale [M] = its per-token quantisation. out_sum (optional, may be NULL) receives y.
+ * Bit-identical to xllm_mi355_oneshot_allreduce followed by xllm_mi355_fused_add_rms_norm / xllm_mi355_rms_norm_dynamic_int8_quant
+ * with a residual. Same buffers, epoch and status as xllm_mi355_oneshot_allreduce (the two may be mixed freely on one stream);
+ * every rank calls it with the same M, H. H % 8 == 0, H <= 16384, M * H * 2 <= max_message_bytes (XM_ERR_WORKSPACE otherwise). */
+XM_API int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residual, const void* norm_weight, float eps,
+                                                     void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum,
+                                                     int64_t M, int64_t H, int dtype, void* const* peer_buffers, int rank,
+                                                     int world, size_t max_message_bytes, uint32_t* epoch_state, int* status,
+                                                     double timeout_s, void* stream);
 
 #ifdef __cplusplus
 }

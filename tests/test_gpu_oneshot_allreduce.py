@@ -52,6 +52,47 @@ def _worker(rank, world, port, ret, distinct):
         # bigger than the shared slot: falls back to the group's own all-reduce (gloo here, RCCL on a node)
         big = torch.ones(3 << 20, dtype=torch.bfloat16)
         assert not ar.takes(big.cuda())
+        assert pg.allreduce_kind() == "oneshot-xgmi" and pg.oneshot_note == "ok"      # the set-up self-test passed on both ranks
+        # a message that is not contiguous on this rank is staged, not sent down another path (takes() is rank-invariant)
+        base = torch.zeros(64, 96, dtype=torch.bfloat16, device=f"cuda:{dev}")
+        view = base[:, 8:72] if rank == 0 else base[:, :64].contiguous()
+        view.copy_(_msg(rank, 7, 64 * 64, torch.bfloat16).view(64, 64))
+        assert ar.takes(view)
+        parallel.reduce(view, pg)
+        want = sum(_msg(r, 7, 64 * 64, torch.bfloat16).float() for r in range(world)).bfloat16().view(64, 64)
+        if not torch.equal(view.cpu(), want):
+            res["ok"] = False
+            res["log"].append("staged (non-contiguous) message mismatch")
+        # the fused tensor-parallel tail: all-reduce + residual add + RMSNorm (+ int8 quant) in one kernel == the three operators
+        from xllm_amd import ops
+        for (M, H, quant) in ((256, 3584, True), (256, 3584, False), (5, 512, True), (70, 7168, False), (1, 128, True)):
+            part = (_msg(rank, 300 + M, M * H, torch.bfloat16) * 0.5).view(M, H).cuda()
+            g0 = torch.Generator().manual_seed(M * 7 + H)
+            resid0 = torch.randn(M, H, generator=g0).bfloat16().cuda()
+            nw = (torch.rand(H, generator=g0) + 0.5).bfloat16().cuda()
+            y = part.clone()
+            parallel.reduce(y, pg)                                   # one-shot all-reduce alone
+            r_ref = resid0.clone()
+            if quant:
+                q_ref, s_ref = ops.rms_norm_dynamic_int8_quant(y.clone(), nw, 1e-6, residual=r_ref)
+            else:
+                n_ref = y.clone()
+                ops.fused_add_rms_norm(n_ref, r_ref, nw, 1e-6)
+            r_got = resid0.clone()
+            got = pg.allreduce_add_rms_norm(part, r_got, nw, 1e-6, quant)
+            good = got is not None and torch.equal(r_got, r_ref)
+            if good and quant:
+                good = torch.equal(got[0], q_ref) and torch.equal(got[1], s_ref)
+            elif good:
+                good = torch.equal(got, n_ref)
+            if not good:
+                res["ok"] = False
+                res["log"].append(f"fused all-reduce + add + norm mismatch at M={M} H={H} quant={quant}")
+        # one stream only: a launch from another stream declines (the group's own all-reduce serves it)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            res["declines_other_stream"] = not ar.takes(torch.ones(4096, dtype=torch.bfloat16, device=f"cuda:{dev}"))
+        torch.cuda.synchronize()
         # graph replay: the collective is a plain kernel
         static = _msg(rank, 99, 256 * 3584, torch.bfloat16).cuda()
         src = [_msg(rank, 100 + k, 256 * 3584, torch.bfloat16).cuda() for k in range(3)]
@@ -62,9 +103,7 @@ def _worker(rank, world, port, ret, distinct):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            parallel.reduce(static.clone(), pg)            # warm-up on the capture stream (both ranks: one epoch)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s):            # (a capture counts as the bound stream)
                 y = static * 1.0
                 parallel.reduce(y, pg)
         for k in range(3):
@@ -109,4 +148,5 @@ def test_oneshot_allreduce_protocol(distinct):
     mp.spawn(_worker, args=(2, _free_port(), ret, distinct), nprocs=2, join=True)
     for r in range(2):
         assert ret[r]["ok"], ret[r]["log"]
+        assert ret[r].get("declines_other_stream") is True
     assert ret[0].get("timeout_reported") is True

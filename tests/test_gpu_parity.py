@@ -1743,3 +1743,24 @@ def test_packed_gemm_add_norm_fusion_equals_separate_ops(M, N, K, bias, packed_e
             assert torch.equal(n16, y2) and torch.equal(res_b, res_ref2), slices
         finally:
             _ws_plan(0, 0)
+
+
+# ------------------------------------------------------------------------------------------- greedy sampler
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,V", [(1, 7), (5, 1000), (3, 152064), (256, 4099)])
+def test_greedy_argmax_equals_torch(B, V, dtype):
+    """Sampler::greedy_sample (sampler.cpp:160-168): first index of the row maximum, ties and NaN as torch.argmax"""
+    g = torch.Generator().manual_seed(B * 31 + V)
+    x = torch.randn(B, V, generator=g).to(dtype)
+    x[0, V // 2] = x[0].max()            # a tie: the lower index wins
+    x[0, V // 3] = x[0].max()
+    if B > 1:
+        x[1, V - 1] = float("nan")       # NaN beats everything
+        x[1, V // 4] = float("inf")
+    if B > 2:
+        x[2] = -float("inf")             # all equal: index 0
+    got = ops.greedy_argmax(x.to(DEV))
+    assert got.dtype == torch.int64
+    assert torch.equal(got.cpu(), torch.argmax(x.float(), dim=-1))
+    sl = x.to(DEV)[:, : V - 1] if V > 8 else x.to(DEV)      # a non-contiguous view (odd row pitch: the scalar path)
+    assert torch.equal(ops.greedy_argmax(sl).cpu(), torch.argmax(sl.float().cpu(), dim=-1))

@@ -202,3 +202,33 @@ def test_launch_reduce_finish_reduce_pair():
     for r, (y, again, single, ind, in_place) in enumerate(out):
         assert y == want and again == want and single == [1.0, 1.0] and in_place
         assert ind == [[float(r)] * 2] * 2
+
+
+def _fused_tail_fallback(rank, world):
+    """round 3: ProcessGroup.allreduce_add_rms_norm is the one-shot kernel's fused tail; without the kernel (CPU / gloo, or a
+    failed self-test) it declines and the caller runs all-reduce + the row-wise operator -- same numbers either way"""
+    from xllm_amd import parallel
+    pg, _ = parallel.make_tp_dp_groups(world, rank, world)
+    g = torch.Generator().manual_seed(3)
+    part = [torch.randn(6, 64, generator=g).bfloat16() for _ in range(world)][rank]
+    resid = torch.randn(6, 64, generator=torch.Generator().manual_seed(4)).bfloat16()
+    w = (torch.rand(64, generator=torch.Generator().manual_seed(5)) + 0.5).bfloat16()
+    declined = pg.allreduce_add_rms_norm(part, resid.clone(), w, 1e-6, True) is None
+    y = part.clone()
+    parallel.reduce(y, pg)
+    r = resid.clone()
+    orc.fused_add_rms_norm(y, r, w, 1e-6)
+    return declined, pg.allreduce_kind(), pg.oneshot_note, y.float().tolist(), r.float().tolist()
+
+
+def test_fused_allreduce_norm_declines_without_the_kernel():
+    out = _run(_fused_tail_fallback)
+    assert all(o[0] for o in out) and all(o[1] == "gloo" for o in out) and all(o[2] == "not requested" for o in out)
+    assert out[0][3] == out[1][3] and out[0][4] == out[1][4]          # every rank ends with the same bits
+    g = torch.Generator().manual_seed(3)
+    parts = [torch.randn(6, 64, generator=g).bfloat16() for _ in range(2)]
+    y = (parts[0].float() + parts[1].float()).bfloat16()               # gloo sums two bf16 tensors exactly like this
+    r = torch.randn(6, 64, generator=torch.Generator().manual_seed(4)).bfloat16()
+    w = (torch.rand(64, generator=torch.Generator().manual_seed(5)) + 0.5).bfloat16()
+    orc.fused_add_rms_norm(y, r, w, 1e-6)
+    assert out[0][3] == y.float().tolist() and out[0][4] == r.float().tolist()

@@ -57,6 +57,8 @@ _SIGS = {
     "xllm_mi355_ipc_open_handle": ([vp, C.POINTER(vp)], ci),
     "xllm_mi355_ipc_close_handle": ([vp], ci),
     "xllm_mi355_oneshot_allreduce": ([vp, i64, ci, C.POINTER(vp), ci, ci, sz, vp, vp, C.c_double, vp], ci),
+    "xllm_mi355_oneshot_allreduce_add_rms_norm": ([vp, vp, vp, f32, vp, vp, vp, vp, i64, i64, ci, C.POINTER(vp), ci, ci, sz, vp, vp,
+                                                   C.c_double, vp], ci),
     "xllm_mi355_decode_metadata_update": ([C.POINTER(DecodeMetadata), vp], ci),
     "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_build_block_table_from_paged_kv": ([vp, vp, i32, i32, vp, vp], ci),
@@ -104,6 +106,7 @@ _OPTIONAL = {
     "xllm_mi355_random_sample": ([vp, vp, i64, i64, vp, u64, u64, vp], ci),
     "xllm_mi355_philox_uniform": ([vp, i64, u64, u64, vp], ci),
     "xllm_mi355_rejection_sample": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp], ci),
+    "xllm_mi355_greedy_argmax": ([vp, vp, i64, i64, ci, vp], ci),
     "xllm_mi355_moe_fused_topk": ([vp, ci, i64, i64, i64, ci, vp, ci, vp, vp, vp], ci),
     "xllm_mi355_moe_grouped_topk": ([vp, ci, i64, i64, i64, i64, i64, ci, vp, ci, f32, vp, vp, vp], ci),
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),

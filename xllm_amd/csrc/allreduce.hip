@@ -105,6 +105,147 @@ __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_kernel(ArPeers p
   }
 }
 
+
+// ---- one-shot all-reduce FUSED with the residual add + RMSNorm (+ per-token int8 quant) that follows it (round 3) ----------
+// A tensor-parallel half-layer is: row-parallel linear -> SUM all-reduce -> fused_add_rms_norm -> (scaled_quantize of the next
+// W8A8 linear) (linear.cpp:1518-1520, qwen2_decoder_layer.cpp:66-110). In step 3 of the protocol above every block already
+// holds the summed values of its slice in registers, so when the slices are whole token rows the block finishes the row:
+//   y = rT(sum over ranks, fp32, rank order)                  -- the all-reduce result, as xllm_mi355_oneshot_allreduce
+//   residual <- rT(y + residual); n = rT(rT(residual * inv_rms) * w)       -- rms_norm_kernel<T, ADD, QUANT> of rowwise.hip
+//   QUANT: out_q = int8(n * 127 / amax), out_scale = amax / 127; else out_norm = n
+// bit-identical to xllm_mi355_oneshot_allreduce followed by xllm_mi355_fused_add_rms_norm (/ _rms_norm_dynamic_int8_quant),
+// which is how the tests check it. `residual` is rank-local (every rank holds the same residual and ends with the same bits).
+// Block b owns rows [b * rpb, (b + 1) * rpb); flags, slots and the epoch are shared with the plain kernel (same buffer).
+constexpr int kArNormMaxVec = 4;   // 16-byte chunks per thread: rows up to 512 * 4 * 8 = 16384 elements
+
+template <typename T, bool QUANT>
+__global__ __launch_bounds__(kArThreads) void oneshot_allreduce_norm_kernel(
+    ArPeers peers, const T* __restrict__ partial, T* __restrict__ residual, const T* __restrict__ weight, float eps,
+    T* __restrict__ out_norm, int8_t* __restrict__ out_q, float* __restrict__ out_scale, T* __restrict__ out_sum, int M, int H,
+    int rows_per_block, int rank, int world, int64_t slot_bytes, uint32_t* __restrict__ epoch_state, int* __restrict__ status,
+    long long timeout_ticks) {
+  static_assert(sizeof(T) == 2, "16-bit activations");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int N = 8;
+  __shared__ float smem[32];
+  __shared__ int timed_out;
+  const uint32_t epoch = epoch_state[0] + 1;
+  const int buf = epoch & 1;
+  const int b = blockIdx.x;
+  const int nvec = H / N;
+  const int r0 = b * rows_per_block, r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  const u32x4* in = reinterpret_cast<const u32x4*>(partial);
+  // 1. my rows -> my slot
+  u32x4* mine = reinterpret_cast<u32x4*>(peers.base[rank] + kArFlagBytes + (int64_t)buf * slot_bytes);
+  for (int64_t i = (int64_t)r0 * nvec + threadIdx.x; i < (int64_t)r1 * nvec; i += kArThreads) mine[i] = in[i];
+  __threadfence_system();
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
+    uint32_t* f = reinterpret_cast<uint32_t*>(peers.base[threadIdx.x]) + ((int64_t)buf * kArBlocks + b) * kArMaxWorld + rank;
+    __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 2. wait for rows r0 .. r1 of every rank
+  if (threadIdx.x == 0) timed_out = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
+    const uint32_t* f = reinterpret_cast<const uint32_t*>(peers.base[rank]) + ((int64_t)buf * kArBlocks + b) * kArMaxWorld + threadIdx.x;
+    const long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (timed_out) {
+    if (threadIdx.x == 0) atomicExch(status, 1);
+  } else {
+    // 3. row by row: sum in rank order, then the add + norm (+ quant) of rowwise.hip's rms_norm_kernel<T, true, QUANT>
+    for (int r = r0; r < r1; ++r) {
+      RowVec<T> xv[kArNormMaxVec];
+      float ss = 0.0f;
+      T* res_row = residual + (int64_t)r * H;
+#pragma unroll
+      for (int i = 0; i < kArNormMaxVec; ++i) {
+        const int c = threadIdx.x + i * kArThreads;
+        if (c < nvec) {
+          float acc[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[j] = 0.0f;
+          for (int p = 0; p < world; ++p) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(peers.base[p] + kArFlagBytes + (int64_t)buf * slot_bytes);
+            const u32x4 v = *reinterpret_cast<const volatile u32x4*>(&src[(int64_t)r * nvec + c]);
+            RowVec<T> pv;
+            pv.raw = make_uint4(v.x, v.y, v.z, v.w);
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] += pv.get(j);
+          }
+          RowVec<T> yv, rv;
+#pragma unroll
+          for (int j = 0; j < N; ++j) yv.set(j, acc[j]);                       // y = rT(sum): the all-reduce result
+          if (out_sum) reinterpret_cast<uint4*>(out_sum + (int64_t)r * H)[c] = yv.raw;
+          rv.raw = reinterpret_cast<const uint4*>(res_row)[c];
+#pragma unroll
+          for (int j = 0; j < N; ++j) xv[i].set(j, yv.get(j) + rv.get(j));     // rT(y + residual)
+          reinterpret_cast<uint4*>(res_row)[c] = xv[i].raw;
+#pragma unroll
+          for (int j = 0; j < N; ++j) { const float x = xv[i].get(j); ss += x * x; }
+        }
+      }
+      ss = block_sum(ss, smem);
+      const float inv = 1.0f / sqrtf(ss / (float)H + eps);
+      float amax = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kArNormMaxVec; ++i) {
+        const int c = threadIdx.x + i * kArThreads;
+        if (c < nvec) {
+          RowVec<T> wv;
+          wv.raw = reinterpret_cast<const uint4*>(weight)[c];
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float y = r16<T>(r16<T>(xv[i].get(j) * inv) * wv.get(j));
+            xv[i].set(j, y);
+            amax = fmaxf(amax, fabsf(y));
+          }
+          if constexpr (!QUANT) reinterpret_cast<uint4*>(out_norm + (int64_t)r * H)[c] = xv[i].raw;
+        }
+      }
+      if constexpr (QUANT) {
+        amax = block_max(amax, smem);
+        const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kArNormMaxVec; ++i) {
+          const int c = threadIdx.x + i * kArThreads;
+          if (c < nvec) {
+            uint32_t pk[2];
+#pragma unroll
+            for (int j = 0; j < N; j += 4) {
+              uint32_t w = 0;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(xv[i].get(j + e) * qinv)));
+                w |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+              }
+              pk[j / 4] = w;
+            }
+            *reinterpret_cast<uint2*>(out_q + (int64_t)r * H + (int64_t)c * N) = make_uint2(pk[0], pk[1]);
+          }
+        }
+        if (threadIdx.x == 0) out_scale[r] = amax / 127.0f;
+      }
+      __syncthreads();   // smem is reused by the next row's reductions
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&epoch_state[1], 1u) == gridDim.x - 1) {
+      epoch_state[1] = 0;
+      __threadfence();
+      epoch_state[0] = epoch;
+    }
+  }
+}
+
 }  // namespace xm
 
 using namespace xm;
@@ -193,6 +334,45 @@ int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* co
   else if (dtype == XM_BF16) XM_AR(bf16_t);
   else XM_AR(f16_t);
 #undef XM_AR
+  return hip_check_launch();
+}
+
+int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residual, const void* norm_weight, float eps,
+                                              void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M,
+                                              int64_t H, int dtype, void* const* peer_buffers, int rank, int world,
+                                              size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s,
+                                              void* stream) {
+  if (!partial || !residual || !norm_weight || !peer_buffers || !epoch_state || !status || M < 0 || H <= 0 || world < 1 ||
+      world > kArMaxWorld || rank < 0 || rank >= world)
+    return XM_ERR_INVALID;
+  if ((out_q != nullptr) == (out_norm != nullptr)) return XM_ERR_INVALID;  // exactly one output form
+  if (out_q && !out_q_scale) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (H % 8 || H > (int64_t)kArThreads * kArNormMaxVec * 8 ||
+      (((uintptr_t)partial | (uintptr_t)residual | (uintptr_t)norm_weight | (uintptr_t)out_norm | (uintptr_t)out_q |
+        (uintptr_t)out_sum) % 16))
+    return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  const size_t bytes = (size_t)M * H * 2;
+  if (bytes > max_message_bytes) return XM_ERR_WORKSPACE;
+  ArPeers peers;
+  for (int p = 0; p < kArMaxWorld; ++p) {
+    peers.base[p] = p < world ? (char*)peer_buffers[p] : nullptr;
+    if (p < world && !peers.base[p]) return XM_ERR_INVALID;
+  }
+  // whole rows per block; at most kArBlocks blocks (one flag row each)
+  const int rpb = (int)((M + kArBlocks - 1) / kArBlocks);
+  const int grid = (int)((M + rpb - 1) / rpb);
+  const int64_t slot_bytes = (int64_t)((max_message_bytes + 255) / 256 * 256);
+  const long long ticks = (long long)((timeout_s > 0 ? timeout_s : 2.0) * 1e8);
+  hipStream_t s = (hipStream_t)stream;
+#define XM_ARN(T, Q)                                                                                                  \
+  hipLaunchKernelGGL((oneshot_allreduce_norm_kernel<T, Q>), dim3((unsigned)grid), dim3(kArThreads), 0, s, peers,     \
+                     (const T*)partial, (T*)residual, (const T*)norm_weight, eps, (T*)out_norm, out_q, out_q_scale,  \
+                     (T*)out_sum, (int)M, (int)H, rpb, rank, world, slot_bytes, epoch_state, status, ticks)
+  if (dtype == XM_BF16) { if (out_q) XM_ARN(bf16_t, true); else XM_ARN(bf16_t, false); }
+  else { if (out_q) XM_ARN(f16_t, true); else XM_ARN(f16_t, false); }
+#undef XM_ARN
   return hip_check_launch();
 }
 

@@ -62,6 +62,34 @@ struct Vec16B<bf16_t> { static constexpr int N = 8; };
 template <>
 struct Vec16B<f16_t> { static constexpr int N = 8; };
 
+// 16-byte register vector of a row-wise kernel: element access with the tensor dtype's conversions
+template <typename T>
+struct RowVec {
+  static constexpr int N = Vec16B<T>::N;
+  uint4 raw;
+  __device__ __forceinline__ float get(int i) const {
+    if constexpr (sizeof(T) == 4) {
+      return __uint_as_float((&raw.x)[i]);
+    } else {
+      uint32_t w = (&raw.x)[i >> 1];
+      uint16_t h = (i & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
+      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) return bf16_bits_to_f32(h);
+      else { f16_t x; __builtin_memcpy(&x, &h, 2); return (float)x; }
+    }
+  }
+  __device__ __forceinline__ void set(int i, float f) {
+    if constexpr (sizeof(T) == 4) {
+      (&raw.x)[i] = __float_as_uint(f);
+    } else {
+      uint16_t h;
+      if constexpr (__is_same(T, bf16_t)) h = f32_to_bf16_bits(f);
+      else { f16_t x = (f16_t)f; __builtin_memcpy(&h, &x, 2); }
+      uint32_t& w = (&raw.x)[i >> 1];
+      w = (i & 1) ? ((w & 0x0000ffffu) | ((uint32_t)h << 16)) : ((w & 0xffff0000u) | h);
+    }
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m);

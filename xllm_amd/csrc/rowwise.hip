@@ -10,33 +10,6 @@ namespace xm {
 constexpr int kRowThreads = 256;
 constexpr int kMaxVec = 4;  // 16-B chunks cached per thread -> rows up to 16 KiB
 
-template <typename T>
-struct RowVec {
-  static constexpr int N = Vec16B<T>::N;
-  uint4 raw;
-  __device__ __forceinline__ float get(int i) const {
-    if constexpr (sizeof(T) == 4) {
-      return __uint_as_float((&raw.x)[i]);
-    } else {
-      uint32_t w = (&raw.x)[i >> 1];
-      uint16_t h = (i & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xffff);
-      if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) return bf16_bits_to_f32(h);
-      else { f16_t x; __builtin_memcpy(&x, &h, 2); return (float)x; }
-    }
-  }
-  __device__ __forceinline__ void set(int i, float f) {
-    if constexpr (sizeof(T) == 4) {
-      (&raw.x)[i] = __float_as_uint(f);
-    } else {
-      uint16_t h;
-      if constexpr (__is_same(T, bf16_t)) h = f32_to_bf16_bits(f);
-      else { f16_t x = (f16_t)f; __builtin_memcpy(&h, &x, 2); }
-      uint32_t& w = (&raw.x)[i >> 1];
-      w = (i & 1) ? ((w & 0x0000ffffu) | ((uint32_t)h << 16)) : ((w & 0xffff0000u) | h);
-    }
-  }
-};
-
 // ------------------------------------------------------------------------------------------------
 // KV write (reference: kernels/cuda/reshape_paged_cache.cu:24-63). grid = tokens; 16-B copies when
 // rows are 16-B aligned, else element copies.

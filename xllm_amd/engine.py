@@ -77,7 +77,7 @@ class DecodeEngine:
         hidden = self.model.forward(self._tokens64, self._pos64, self.md, self.kv_caches)
         logits = self.model.logits(hidden)
         if self.temperature <= 0.0:
-            return torch.argmax(logits, dim=-1).to(torch.int32)
+            return ops.greedy_argmax(logits).to(torch.int32)
         probs = torch.softmax(logits.float() / self.temperature, dim=-1)
         return ops.random_sample(probs, uniform=self._uniform)
 
@@ -118,6 +118,9 @@ class DecodeEngine:
         else:
             self._graph.replay()
         out = self._out.cpu()                          # the step's host sync: the scheduler needs the tokens
+        tp = getattr(self.model, "tp", None)
+        if tp is not None:
+            tp.check()                                 # one-shot all-reduce: a wait that timed out voids the step (raises)
         self._next_host = out
         self._lens_t += 1
         self.step_no += 1

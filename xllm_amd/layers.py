@@ -98,13 +98,19 @@ class QuantLinear:
                     rows.append(torch.arange(off + piece * step, off + (piece + 1) * step, device=device))
                     off += size
                 idx = torch.cat(rows)
-                self.weight = self.weight.index_select(0, idx).contiguous()
+                if self.weight.element_size() == 1 and self.weight.dtype != torch.int8:   # float8: index_select is not implemented
+                    self.weight = self.weight.view(torch.uint8).index_select(0, idx).contiguous().view(self.weight.dtype)
+                else:
+                    self.weight = self.weight.index_select(0, idx).contiguous()
                 if self.bias is not None:
                     self.bias = self.bias.index_select(0, idx).contiguous()
                 if mode == "int8":
                     self.w_scale = self.w_scale.index_select(0, idx).contiguous()
             else:
-                self.weight = _shard(self.weight, 1, rank, world)
+                if self.weight.element_size() == 1 and self.weight.dtype != torch.int8:
+                    self.weight = _shard(self.weight.view(torch.uint8), 1, rank, world).view(self.weight.dtype)
+                else:
+                    self.weight = _shard(self.weight, 1, rank, world)
                 if self.bias is not None and rank != 0:
                     self.bias = torch.zeros_like(self.bias)
         if mode == "int8" and self.weight.is_cuda:
@@ -114,7 +120,8 @@ class QuantLinear:
         elif mode == "fp8" and self.weight.is_cuda:
             self.weight_packed = ops.pack_weight_fp8(self.weight)
 
-    def forward(self, x, pre_quant=None):
+    def forward(self, x, pre_quant=None, reduce: bool = True):
+        """`reduce=False`: a row-parallel shard returns its PARTIAL sums (the caller fuses the all-reduce with what follows)"""
         if self.mode == "int8":
             q, s = pre_quant if pre_quant is not None else ops.scaled_quantize(x)
             y = ops.scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
@@ -123,7 +130,7 @@ class QuantLinear:
             y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
         else:
             y = ops.matmul(x, self.weight, self.bias)
-        return parallel.reduce(y, self.pg) if self.pg is not None else y
+        return parallel.reduce(y, self.pg) if (self.pg is not None and reduce) else y
 
     def weight_bytes(self) -> int:
         return self.weight.numel() * self.weight.element_size()
@@ -185,6 +192,17 @@ class Qwen2DecoderLayer:
         return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
                                               self.args.rms_norm_eps, lin.bias, quantize=quantize, b_packed=lin.weight_packed)
 
+    def _tp_linear_norm(self, lin: "QuantLinear", pre_quant, residual, norm_w, quantize=True):
+        """Tensor parallel (round 3): row-parallel W8A8 linear -> ONE kernel for the SUM all-reduce over xGMI + residual add +
+        RMSNorm (+ int8 quant) (ProcessGroup.allreduce_add_rms_norm = xllm_mi355_oneshot_allreduce_add_rms_norm), so a TP
+        half-layer is GEMM -> one kernel instead of GEMM -> collective -> row-wise kernel (linear.cpp:1518-1520 +
+        qwen2_decoder_layer.cpp:66-85). None = not applicable (no TP group, one-shot path off, message too large)."""
+        if not self.fuse or lin.pg is None or lin.pg.world_size() == 1 or lin.pg.oneshot is None or residual is None \
+                or norm_w is None:
+            return None
+        y = lin.forward(None, pre_quant=pre_quant, reduce=False)      # this rank's partial sums, 16 bit (bias on rank 0 only)
+        return lin.pg.allreduce_add_rms_norm(y, residual, norm_w, self.args.rms_norm_eps, quantize) if y.dim() == 2 else None
+
     # ---- the decode step cut at the attention kernel (dual micro-batch executor, DualBatchDecoder below) ----------
     def _qkv_rope_cache(self, h, positions, md: AttentionMetadata, kv_cache: KVCache, cos_sin):
         """N1 across the GEMM boundary (small M, packed weights): W8A8 qkv projection -> dequant -> RoPE -> KV write in two
@@ -228,11 +246,15 @@ class Qwen2DecoderLayer:
         """o_proj (+ post norm) + MLP (+ the next layer's input norm); returns (x, residual, h_next) like forward()"""
         h = self._fused_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)
         if h is None:
+            h = self._tp_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)
+        if h is None:
             x = self.o_proj.forward(None, pre_quant=o_in)
             h, residual = self._norm(x, residual, self.post_norm_w)
         gate_up = self.gate_up_proj.forward(None, pre_quant=h)
         act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
         h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
+        if h_next is None:
+            h_next = self._tp_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
         if h_next is not None:
             return None, residual, h_next
         return self.down_proj.forward(None, pre_quant=act_q), residual, None
@@ -279,6 +301,8 @@ class Qwen2DecoderLayer:
         if self.fuse and decode:
             o_in = (fused_attn[0], fused_attn[1]) if fused_attn is not None else ops.scaled_quantize(attn)
             h = self._fused_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)   # residual updated in place
+            if h is None:   # tensor parallel: GEMM -> all-reduce + add + norm + quant in one kernel
+                h = self._tp_linear_norm(self.o_proj, o_in, residual, self.post_norm_w)
             if h is None:
                 x = self.o_proj.forward(None, pre_quant=o_in)
         elif fused_attn is not None:
@@ -292,6 +316,8 @@ class Qwen2DecoderLayer:
             act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
             if decode:
                 h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
+                if h_next is None:
+                    h_next = self._tp_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
                 if h_next is not None:
                     return None, residual, h_next
             x = self.down_proj.forward(None, pre_quant=act_q)

@@ -805,6 +805,20 @@ def random_sample(probs, uniform=None, seed: int = 0, offset: int = 0):
     return out.view(probs.shape[:-1])
 
 
+def greedy_argmax(logits: torch.Tensor) -> torch.Tensor:
+    """Sampler::greedy_sample (framework/sampling/sampler.cpp:160-168): argmax over the last dim of [B, V] logits -> int64 [B];
+    first index of the maximum, NaN above everything (torch.argmax)"""
+    _need_cuda(logits)
+    if logits.dim() != 2:
+        raise Mi355Error("greedy_argmax: [batch, vocab] logits")
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    out = torch.empty(logits.size(0), dtype=torch.int64, device=logits.device)
+    check(_lib.lib().xllm_mi355_greedy_argmax(_p(logits), _p(out), logits.size(0), logits.size(1), _dt(logits), _stream()),
+          "greedy_argmax")
+    return out
+
+
 def rejection_sample(draft_token_ids, num_draft_tokens, cu_num_draft_tokens, draft_probs, target_probs,
                      bonus_token_ids, uniform_rand, uniform_probs):
     """dcu::rejection_sample (kernels/dcu/rejection_sample.hip:141-215) -> int32 [batch + total_drafts]"""

@@ -18,13 +18,56 @@ class ProcessGroup:
     def __init__(self, group: Optional[dist.ProcessGroup] = None, rank: int = 0, world_size: int = 1):
         self.group, self._rank, self._world = group, rank, world_size
         self.oneshot: Optional["OneShotAllReduce"] = None
+        self.oneshot_note = "not requested"
 
-    def enable_oneshot(self, device, max_bytes: int = 8 << 20) -> "OneShotAllReduce":
+    def enable_oneshot(self, device, max_bytes: int = 8 << 20, self_test: bool = True) -> Optional["OneShotAllReduce"]:
         """opt in to the one-shot xGMI all-reduce (csrc/allreduce.hip) for CUDA messages of at most max_bytes; larger
-        messages, other dtypes and CPU tensors keep going through RCCL / gloo. Collective: every rank of the group calls it."""
-        if self._world > 1 and self.oneshot is None:
-            self.oneshot = OneShotAllReduce(self, device, max_bytes)
+        messages, other dtypes and CPU tensors keep going through RCCL / gloo. Collective: every rank of the group calls it.
+        The set-up ends with a SELF-TEST (peer mapping + one checked message per size class, also through the fused
+        add + norm form); the verdict is agreed over the group, so either every rank uses the kernel or none does
+        (`oneshot_note` says why not) -- the group's own all-reduce stays the fallback."""
+        if self._world <= 1 or self.oneshot is not None:
+            return self.oneshot
+        ar, note = None, "ok"
+        try:
+            ar = OneShotAllReduce(self, device, max_bytes)
+            if ar.refused:
+                note = ar.refused
+            elif self_test and not ar.self_test():
+                note = "self-test failed (a checked message came back wrong or a wait timed out)"
+        except Exception as e:   # noqa: BLE001 -- any set-up failure means: keep RCCL
+            note = f"set-up failed: {e!r}"
+        verdicts = [None] * self._world
+        dist.all_gather_object(verdicts, note, group=self.group)
+        bad = [f"rank {r}: {v}" for r, v in enumerate(verdicts) if v != "ok"]
+        if bad:
+            if ar is not None:
+                try:
+                    ar.close()
+                except Exception:   # noqa: BLE001
+                    pass
+            self.oneshot, self.oneshot_note = None, "; ".join(bad)
+        else:
+            self.oneshot, self.oneshot_note = ar, "ok"
         return self.oneshot
+
+    def allreduce_kind(self) -> str:
+        """what a small CUDA all-reduce of this group runs on (bench.py's config.allreduce)"""
+        if self._world <= 1:
+            return "none"
+        if self.oneshot is not None:
+            return "oneshot-xgmi"
+        try:
+            be = dist.get_backend(self.group)
+        except Exception:   # noqa: BLE001
+            be = "unknown"
+        return "rccl" if be == "nccl" else str(be)
+
+    def check(self) -> None:
+        """host-side look at the one-shot kernel's status word; call it at a point where the step synchronises anyway (after the
+        sampled tokens' D2H copy, after a timed region). Raises if a launch gave up waiting for a peer: its result was undefined."""
+        if self.oneshot is not None:
+            self.oneshot.check()
 
     def rank(self) -> int:
         return self._rank
@@ -37,6 +80,15 @@ class ProcessGroup:
             self.oneshot.allreduce(x)     # a plain kernel: also inside a graph capture, no eager piece needed
             return
         _run_collective(lambda: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group))
+
+    def allreduce_add_rms_norm(self, partial: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                               quantize: bool):
+        """the tensor-parallel half-layer tail in ONE kernel when the one-shot path is on: SUM all-reduce of `partial` [M, H] ->
+        residual <- r16(sum + residual) -> RMSNorm (-> per-token int8 quant). Returns (q int8, scale) or the 16-bit norm; None when
+        the one-shot kernel does not take the message (the caller then runs allreduce + the row-wise operator)."""
+        if self.oneshot is None or not self.oneshot.takes(partial) or partial.dim() != 2:
+            return None
+        return self.oneshot.allreduce_add_rms_norm(partial, residual, weight, eps, quantize)
 
     def allreduce_async(self, x: torch.Tensor):
         """ProcessGroup::allreduce_async (process_group.cpp:103-108): returns the c10d Work. With RCCL the collective runs on
@@ -53,7 +105,6 @@ class ProcessGroup:
         _run_collective(lambda: dist.all_gather(parts, xc, group=self.group))
         return out
 
-
     def alltoall(self, send: torch.Tensor, send_counts, recv_counts) -> torch.Tensor:
         """variable-size all-to-all over dim 0 (RCCL all-to-all over xGMI; gloo on the CPU tests): rows
         [sum(send_counts[:r]), +send_counts[r]) of `send` go to rank r; returns the received rows, rank-major"""
@@ -69,7 +120,18 @@ class OneShotAllReduce:
     """One-shot SUM all-reduce over peer-mapped buffers (include/xllm_mi355.h, csrc/allreduce.hip): every rank copies its
     message into its own shared slot, raises a flag in every peer's buffer and sums all slots in rank order (fp32, one
     rounding), so the result is bit-identical on every rank and costs ONE xGMI hop instead of the ring's 2 (W - 1).
-    The handles travel over the group's object all-gather (host side, once). Opt-in: ProcessGroup.enable_oneshot."""
+    The handles travel over the group's object all-gather (host side, once). Opt-in: ProcessGroup.enable_oneshot.
+
+    Rules that keep the ranks in lock step (round-2 review):
+      * `takes()` looks only at properties every rank shares (dtype, element count, the size limit, being on the GPU) and at the
+        stream: a tensor that is not contiguous / 16-byte aligned on SOME rank is staged through an aligned copy instead of
+        sending that rank alone down the RCCL path;
+      * ONE stream: the epoch counter and the two data slots are per (rank, buffer), so two launches may never be in flight on
+        two streams at once. The first launch binds the object to its stream; launches from any other stream decline
+        (`takes()` is False there: RCCL) -- a graph capture counts as the stream it captures on;
+      * plain hipMalloc memory (kind 2) is only accepted when every rank sits on the SAME device (the two-processes-one-GPU
+        protocol test): across devices coarse-grained memory is not guaranteed visible to a peer while the kernel runs;
+      * the status word is checked where the step synchronises anyway (ProcessGroup.check / DecodeEngine.step / bench.py)."""
 
     _DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
@@ -80,6 +142,8 @@ class OneShotAllReduce:
         l = _lib.lib()
         self.pg, self.max_bytes, self.timeout_s = pg, int(max_bytes), float(timeout_s)
         self.device = torch.device(device)
+        self.refused = None
+        self._stream = None
         world, rank = pg.world_size(), pg.rank()
         total = l.xllm_mi355_oneshot_allreduce_buffer_bytes(self.max_bytes)
         handle = None
@@ -97,11 +161,15 @@ class OneShotAllReduce:
             if handle is None:
                 raise _lib.Mi355Error("one-shot all-reduce: hipIpcGetMemHandle failed for every memory kind")
             self.own, self.kind = ptr, kind.value
+            try:
+                dev_id = str(torch.cuda.get_device_properties(self.device).uuid)
+            except Exception:   # noqa: BLE001
+                dev_id = f"{os.uname().nodename}:{self.device.index}"
             everyone = [None] * world
-            dist.all_gather_object(everyone, (os.getpid(), handle), group=pg.group)
+            dist.all_gather_object(everyone, (os.getpid(), handle, self.kind, dev_id), group=pg.group)
             self.peers = (C.c_void_p * world)()
             self._opened = []
-            for r, (pid, h) in enumerate(everyone):
+            for r, (pid, h, _k, _d) in enumerate(everyone):
                 if r == rank:
                     self.peers[r] = self.own.value
                     continue
@@ -109,22 +177,109 @@ class OneShotAllReduce:
                 _lib.check(l.xllm_mi355_ipc_open_handle(h, C.byref(p)), f"ipc_open_handle(rank {r})")
                 self.peers[r] = p.value
                 self._opened.append(p)
+            same_device = len({d for (_p, _h, _k, d) in everyone}) == 1
+            if any(k >= 2 for (_p, _h, k, _d) in everyone) and not same_device:   # the same verdict on every rank
+                self.refused = ("only plain hipMalloc memory could be exported on some rank: not guaranteed visible to a peer "
+                                "GPU while the kernel runs")
         self.state = torch.zeros(2, dtype=torch.int32, device=self.device)     # epoch, blocks-done counter
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
         torch.cuda.synchronize(self.device)
         dist.barrier(group=pg.group)    # every rank has every buffer mapped before the first launch
 
-    def takes(self, x: torch.Tensor) -> bool:
-        n = x.numel() * x.element_size()
-        return (x.is_cuda and x.is_contiguous() and x.dtype in self._DT and 0 < n <= self.max_bytes and n % 16 == 0
-                and x.data_ptr() % 16 == 0)
+    # ---- which messages ------------------------------------------------------------------------------------------------
+    def _stream_ok(self) -> bool:
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if self._stream is None:
+            return True
+        return cur == self._stream or torch.cuda.is_current_stream_capturing()
 
+    def takes(self, x: torch.Tensor) -> bool:
+        """rank-invariant: dtype, element count, size limit, device kind (+ the one-stream rule)"""
+        n = x.numel() * x.element_size()
+        return bool(x.is_cuda and x.dtype in self._DT and 0 < n <= self.max_bytes and n % 16 == 0 and self._stream_ok())
+
+    def _bind(self) -> int:
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if self._stream is None and not torch.cuda.is_current_stream_capturing():
+            self._stream = s
+        return s
+
+    def rebind_stream(self) -> None:
+        """a caller that moves ALL further launches to another stream (e.g. a graph's capture stream) says so explicitly"""
+        torch.cuda.synchronize(self.device)
+        self._stream = torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---- the collectives -----------------------------------------------------------------------------------------------
     def allreduce(self, x: torch.Tensor) -> None:
         l = self._lib.lib()
+        s = self._bind()
+        staged = None
+        if not x.is_contiguous() or x.data_ptr() % 16:
+            staged = x.contiguous() if not x.is_contiguous() else x.clone()      # fresh allocations are 256-byte aligned
+        t = staged if staged is not None else x
         self._lib.check(l.xllm_mi355_oneshot_allreduce(
-            x.data_ptr(), x.numel(), self._DT[x.dtype], self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes,
-            self.state.data_ptr(), self.status.data_ptr(), self.timeout_s, torch.cuda.current_stream().cuda_stream),
-            "oneshot_allreduce")
+            t.data_ptr(), t.numel(), self._DT[t.dtype], self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes,
+            self.state.data_ptr(), self.status.data_ptr(), self.timeout_s, s), "oneshot_allreduce")
+        if staged is not None:
+            x.copy_(staged)
+
+    def allreduce_add_rms_norm(self, partial, residual, weight, eps: float, quantize: bool, want_sum: bool = False):
+        """xllm_mi355_oneshot_allreduce_add_rms_norm; returns (q, scale) | norm16 (and the reduced sum when want_sum)"""
+        l = self._lib.lib()
+        s = self._bind()
+        M, H = partial.shape
+        if residual.shape != partial.shape or not residual.is_contiguous() or residual.dtype != partial.dtype:
+            raise self._lib.Mi355Error("allreduce_add_rms_norm: residual [M, H] contiguous, same dtype as the partial sums")
+        pc = partial if (partial.is_contiguous() and partial.data_ptr() % 16 == 0) else partial.contiguous().clone()
+        dev = partial.device
+        q = qs = n16 = ysum = None
+        if quantize:
+            q = torch.empty(M, H, dtype=torch.int8, device=dev)
+            qs = torch.empty(M, dtype=torch.float32, device=dev)
+        else:
+            n16 = torch.empty(M, H, dtype=partial.dtype, device=dev)
+        if want_sum:
+            ysum = torch.empty(M, H, dtype=partial.dtype, device=dev)
+        P = lambda t: 0 if t is None else t.data_ptr()
+        rc = l.xllm_mi355_oneshot_allreduce_add_rms_norm(
+            pc.data_ptr(), residual.data_ptr(), weight.data_ptr(), float(eps), P(n16), P(q), P(qs), P(ysum), M, H,
+            self._DT[partial.dtype], self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes, self.state.data_ptr(),
+            self.status.data_ptr(), self.timeout_s, s)
+        self._lib.check(rc, "oneshot_allreduce_add_rms_norm")
+        out = (q, qs) if quantize else n16
+        return (out, ysum) if want_sum else out
+
+    # ---- health --------------------------------------------------------------------------------------------------------
+    def self_test(self) -> bool:
+        """one checked message per size class through both kernels (every rank calls it; the caller agrees on the verdict):
+        rank r sends (r + 1) * pattern, the sum must be pattern * W (W + 1) / 2 exactly (small integers: exact in bf16)"""
+        world, rank = self.pg.world_size(), self.pg.rank()
+        tri = world * (world + 1) // 2
+        ok = True
+        saved = self.timeout_s
+        self.timeout_s = min(saved, 5.0)
+        try:
+            for n in (8, 4096, 256 * 3584, self.max_bytes // 2):
+                if n * 2 > self.max_bytes:
+                    continue
+                pat = (torch.arange(n, device=self.device) % 7).to(torch.bfloat16)
+                x = pat * float(rank + 1)
+                self.allreduce(x)
+                ok = ok and bool(torch.equal(x, pat * float(tri)))
+            M, H = 8, 512
+            pat = (torch.arange(M * H, device=self.device).view(M, H) % 5).to(torch.bfloat16)
+            res = torch.ones(M, H, dtype=torch.bfloat16, device=self.device)
+            w = torch.ones(H, dtype=torch.bfloat16, device=self.device)
+            (n16, ysum) = self.allreduce_add_rms_norm(pat * float(rank + 1), res, w, 1e-6, quantize=False, want_sum=True)
+            ok = ok and bool(torch.equal(ysum, pat * float(tri))) and bool(torch.equal(res, pat * float(tri) + 1.0))
+            ok = ok and bool(torch.isfinite(n16.float()).all())
+            torch.cuda.synchronize(self.device)
+            ok = ok and int(self.status.item()) == 0
+        except Exception:   # noqa: BLE001
+            ok = False
+        finally:
+            self.timeout_s = saved
+        return ok
 
     def check(self) -> None:
         """host-side look at the status word (synchronises): raises if any launch gave up waiting for a peer"""
@@ -274,7 +429,11 @@ def launch_reduce(x: torch.Tensor, pg: Optional[ProcessGroup]) -> ReduceAsyncCtx
     if pg is None or pg.world_size() == 1:
         return ReduceAsyncCtx(x)
     xc = x.contiguous()
-    if _piecewise is not None:
+    # in place (no Work to wait for): inside a piecewise capture (the collective sits between two graph launches), inside a
+    # plain capture (RCCL's async form must not run there), and whenever the one-shot kernel takes the message (a kernel on the
+    # current stream: the caller's independent work simply queues behind it)
+    if _piecewise is not None or (xc.is_cuda and torch.cuda.is_current_stream_capturing()) or \
+            (pg.oneshot is not None and pg.oneshot.takes(xc)):
         pg.allreduce(xc)
         return ReduceAsyncCtx(xc)
     return ReduceAsyncCtx(xc, pg.allreduce_async(xc))
