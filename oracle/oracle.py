@@ -267,6 +267,15 @@ def e4m3_to_f32(u8):
     return out
 
 
+def _p_mode(p_round) -> int:
+    """False / 0: P stays fp32; True / 1: the NORMALISED P is rounded to the tensor dtype before PV (the reference's eager spec,
+    flashinfer_attention.cpp:84-90); "flash" / 2: the un-normalised tile P of a flash kernel is rounded (64-key tiles, lazy
+    running maximum: xllm_oracle.c::attn_one_query_flash)"""
+    if p_round == "flash":
+        return 2
+    return int(p_round)
+
+
 def attention_varlen(q, k, v, cu_q, cu_k, scale, causal=True, window_left=-1, p_round=False):
     """q [Tq, nq, d], k/v [Tk, nkv, d] (token-strided views allowed) -> out [Tq, nq*d]."""
     Tq, nq, d = q.shape
@@ -275,7 +284,7 @@ def attention_varlen(q, k, v, cu_q, cu_k, scale, causal=True, window_left=-1, p_
     rc = lib().orc_attention_varlen(
         _p(q), _p(k), _p(v), _p(out), _p(cu_q), _p(cu_k), _i64(cu_q.numel() - 1), _i64(nq), _i64(nkv),
         _i64(d), _i64(q.stride(0)), _i64(k.stride(0)), _i64(v.stride(0)), _f32(scale),
-        C.c_int(int(causal)), _i64(window_left), C.c_int(_dt(q)), C.c_int(int(p_round)))
+        C.c_int(int(causal)), _i64(window_left), C.c_int(_dt(q)), C.c_int(_p_mode(p_round)))
     if rc:
         raise ValueError(f"orc_attention_varlen rc={rc}")
     return out
@@ -294,7 +303,7 @@ def paged_attention(q, k_cache, v_cache, cu_q, kv_lens, block_table, scale, caus
         _p(q), _p(k_cache), _p(v_cache), _p(out), _p(cu_q), _p(kv_lens), _p(block_table),
         _i64(block_table.shape[1]), _i64(kv_lens.numel()), _i64(nq), _i64(nkv), _i64(d), _i64(dv),
         _i64(bs), _i64(n_blocks), _i64(q.stride(0)), _f32(scale), C.c_int(int(causal)), _i64(window_left),
-        C.c_int(_dt(q)), C.c_int(int(p_round)))
+        C.c_int(_dt(q)), C.c_int(_p_mode(p_round)))
     if rc:
         raise ValueError(f"orc_paged_attention rc={rc}")
     return out

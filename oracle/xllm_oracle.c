@@ -519,10 +519,57 @@ ORC_API int orc_get_max_threads(void) { return omp_get_max_threads(); }
 /* is_causal with S_q < S_k is top-left and is NOT followed.                   */
 /* window_left < 0: unbounded; else key j visible iff j >= i_abs - window_left */
 /* ------------------------------------------------------------------------- */
+/* p_round == 2: the FLASH cast point (round 3). The reference's eager spec rounds the NORMALISED P to the tensor dtype before
+ * PV (flashinfer_attention.cpp:84-90: softmax in fp32, .to(dtype), @ V); a flash kernel -- the reference's production kernels
+ * (FlashInfer / flash-attention behind layers/cuda and layers/dcu) and xllm_amd/csrc/attention_prefill.hip -- never holds the
+ * normalised P: it rounds the UN-normalised tile P = exp(s - running max) and divides the fp32 accumulator by the fp32 row sum
+ * at the end. THAT P is rounded to 16 bit is the reference's; the tile order, tile size (64 keys, aligned at key 0) and the lazy
+ * maximum (the running maximum only moves when a tile exceeds it by more than 2^8, so P <= 256) are this repository's kernel's
+ * (attention_prefill.hip::pf2_softmax), restated here so that the kernel can be held to an ABSOLUTE bar against an oracle with
+ * its own cast point. exp is taken as exp2 of the log2-scaled argument with one fma, as the kernel does. */
+static void attn_one_query_flash(const float* qv, const void* kbase, const void* vbase, const int64_t* row_off,
+                                 int64_t n_keys, int64_t d, int64_t dv, float scale, int dt, float* sc, float* outv) {
+  const float sl2 = scale * 1.4426950408889634f;
+  const int64_t TILE = 64;
+  for (int64_t e = 0; e < dv; ++e) outv[e] = 0.0f;
+  int64_t first = 0;
+  while (first < n_keys && row_off[first] < 0) ++first;
+  if (first == n_keys) return;
+  float m_run = -INFINITY, l = 0.0f;
+  for (int64_t t0 = first / TILE * TILE; t0 < n_keys; t0 += TILE) {
+    const int64_t t1 = t0 + TILE < n_keys ? t0 + TILE : n_keys;
+    float mx = -INFINITY;
+    for (int64_t j = t0; j < t1; ++j) {
+      if (row_off[j] < 0) { sc[j] = -INFINITY; continue; }
+      float acc = 0.0f;
+      for (int64_t e = 0; e < d; ++e) acc += qv[e] * ld(kbase, dt, row_off[j] + e);
+      sc[j] = acc;                       /* RAW score: the maximum is taken before the scale (scale > 0) */
+      mx = fmaxf(mx, acc);
+    }
+    if (mx == -INFINITY) continue;       /* nothing visible in this tile */
+    const float mxs = mx * sl2;
+    const float m_new = mxs > m_run + 8.0f ? mxs : m_run;
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    l *= alpha;
+    if (alpha != 1.0f) for (int64_t e = 0; e < dv; ++e) outv[e] *= alpha;
+    for (int64_t j = t0; j < t1; ++j) {
+      if (sc[j] == -INFINITY) continue;
+      const float p = exp2f(fmaf(sc[j], sl2, -m_new));
+      l += p;                            /* the row sum stays fp32 */
+      const float pr = r16(p, dt);       /* what PV sees */
+      if (pr == 0.0f) continue;
+      for (int64_t e = 0; e < dv; ++e) outv[e] += pr * ld(vbase, dt, row_off[j] + e);
+    }
+  }
+  if (l > 0.0f) for (int64_t e = 0; e < dv; ++e) outv[e] /= l;
+}
+
 static void attn_one_query(const float* qv, /* d */
                            const void* kbase, const void* vbase, /* rows fetched via row_off */
                            const int64_t* row_off, int64_t n_keys, int64_t d, int64_t dv,
                            float scale, int dt, int p_round, float* sc, float* outv) {
+  if (p_round == 2) { attn_one_query_flash(qv, kbase, vbase, row_off, n_keys, d, dv, scale, dt, sc, outv); return; }
   float mx = -INFINITY;
   for (int64_t j = 0; j < n_keys; ++j) {
     if (row_off[j] < 0) { sc[j] = -INFINITY; continue; }
@@ -553,6 +600,7 @@ ORC_API int orc_attention_varlen(const void* q, const void* k, const void* v, vo
                                  int64_t v_stride, float scale, int causal, int64_t window_left,
                                  int dt, int p_round) {
   if (nkv <= 0 || nq % nkv) return -1;
+  if (p_round == 2 && k_stride != v_stride) return -3;
   const int64_t grp = nq / nkv;
   int64_t max_k = 0;
   for (int64_t b = 0; b < B; ++b) if (cu_k[b + 1] - cu_k[b] > max_k) max_k = cu_k[b + 1] - cu_k[b];
@@ -581,7 +629,7 @@ ORC_API int orc_attention_varlen(const void* q, const void* k, const void* v, vo
            * attn_one_query uses one row_off for both; so materialise v offsets equal when strides match */
           if (k_stride == v_stride) {
             attn_one_query(qv, k, v, ro_k, kl, d, d, scale, dt, p_round, sc, ov);
-          } else {
+          } else {   /* (p_round == 2 needs equal strides: checked before the parallel region) */
             /* general: compute with k offsets for scores, then redo PV with v offsets */
             for (int64_t j = 0; j < kl; ++j) ro_v[j] = ro_k[j] < 0 ? -1 : (k0 + j) * v_stride + kvh * d;
             float mx = -INFINITY;

@@ -203,9 +203,41 @@ def test_prefill_full_size_causality_and_sample():
     e_ref = rel_l2(ref1, ref)
     strict = os.environ.get("XLLM_MI355_PREFILL_P") == "2"
     assert rel_l2(out[S - tail:S], ref) <= (1e-3 if strict else max(1e-3, 1.25 * e_ref))
+    if not strict and os.environ.get("XLLM_MI355_PREFILL_DMA", "1") != "0":
+        # round 3: at BASELINE's context length the default kernel holds the ABSOLUTE 1e-3 against the oracle with its own cast
+        # point (un-normalised 64-key-tile P rounded to bf16; oracle p_round="flash")
+        ref2 = orc.attention_varlen(q[S - tail:S].cpu().contiguous(), k[:S].cpu().contiguous(), v[:S].cpu().contiguous(),
+                                    torch.tensor([0, tail], dtype=torch.int32), torch.tensor([0, S], dtype=torch.int32),
+                                    scale, causal=True, p_round="flash")
+        assert rel_l2(out[S - tail:S], ref2) <= 1e-3, rel_l2(out[S - tail:S], ref2)
     cut = S - 1000
     qkv[cut:S, NQ * D:] = torch.empty(S - cut, 2 * NKV * D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
     out2 = ops.prefill_attention(q, k, v, cu, cu, S, scale, True)
     assert torch.equal(out2[:cut], out[:cut])          # the past is untouched
     assert torch.equal(out2[S:], out[S:])              # and so is the other sequence
     assert not torch.equal(out2[cut:S], out[cut:S])
+
+
+def test_mla_prefill_8192_tokens_against_the_flash_cast_point_oracle():
+    """cfg4's context (configs[3]: DeepSeek-V3 MLA, ctx = 8192), one TP = 8 rank's 16 heads: the tile-sharing MLA prefill kernel
+    (one 16-bit P per score, 64-token tiles, lazy running maximum) against the oracle with the same cast point (p_round="flash")
+    at an ABSOLUTE 1e-3 on the last 24 queries of an 8192-token sequence (every key visible to them), plus the two relative bars
+    that tie it to the reference's normalised-P spec (tests/_bars.py). Round-2 review, weak #1."""
+    from _bars import assert_p16_attention_close
+    g = torch.Generator().manual_seed(11)
+    S, Hh, bs = 8192, 16, 64
+    nb = S // bs + 2
+    kc = torch.randn(nb, bs, 1, 576, generator=g).bfloat16()
+    q = torch.randn(S, Hh, 576, generator=g).bfloat16()
+    table = torch.randperm(nb, generator=g)[: S // bs].to(torch.int32).view(1, -1)
+    cu_q = torch.tensor([0, S], dtype=torch.int32)
+    kv_lens = torch.tensor([S], dtype=torch.int32)
+    scale = 192 ** -0.5
+    out = ops.mla_prefill(q.to(DEV), kc.to(DEV), cu_q.to(DEV), kv_lens.to(DEV), table.to(DEV), 512, scale, S, is_causal=True)
+    tail = 24
+    qt = q[S - tail:].contiguous()
+    cu_t = torch.tensor([0, tail], dtype=torch.int32)
+    refs = [orc.paged_attention(qt, kc, kc, cu_t, kv_lens, table, scale, causal=True, dv=512, p_round=m)
+            for m in (False, True, "flash")]
+    got = out[S - tail:].reshape(tail, -1)
+    assert_p16_attention_close(got, refs[0].view(tail, -1), refs[1].view(tail, -1), refs[2].view(tail, -1))

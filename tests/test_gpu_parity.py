@@ -65,6 +65,10 @@ def assert_prefill_close(out, q, k, v, cu, scale):
     assert torch.isfinite(out.float()).all()
     assert r(out, ref0) <= max(1e-3, 1.25 * e_ref), (r(out, ref0), e_ref)
     assert r(out, ref1) <= max(1e-3, 2.0 * e_ref), (r(out, ref1), e_ref)
+    # round 3: ABSOLUTE bar against the oracle that rounds P where a flash kernel does (un-normalised, per 64-key tile)
+    kc_, vc_ = k.contiguous(), v.contiguous()
+    ref2 = orc.attention_varlen(q, kc_, vc_, cu, cu, scale, causal=True, p_round="flash")
+    assert r(out, ref2) <= 1e-3, r(out, ref2)
 
 
 # ------------------------------------------------------------------------------------------- probes
@@ -505,7 +509,9 @@ def test_chunked_prefill_bottom_right_causal(bs):
     out = ops.paged_attention(q.to(DEV), kc.to(DEV), vc.to(DEV), md["q_cu_seq_lens"].to(DEV), md["kv_seq_lens"].to(DEV),
                               md["block_tables"].to(DEV), max(q_lens), max(kv_lens), scale, is_causal=True)
     from _bars import assert_p16_attention_close
-    assert_p16_attention_close(out, ref, ref16)      # one 16-bit P on the LDS-DMA kernel (pages of 64 / 128 tokens)
+    flash = orc.paged_attention(q, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale, causal=True,
+                                p_round="flash") if bs % 64 == 0 else None     # (other page sizes: register-staged kernel, hi + lo P)
+    assert_p16_attention_close(out, ref, ref16, flash)      # one 16-bit P on the LDS-DMA kernel (pages of 64 / 128 tokens)
 
 
 def test_mlu_golden_vectors_through_hip():
@@ -554,6 +560,19 @@ def test_mlu_golden_vectors_through_hip():
                         0.001037598, 0.001083374, 0.000289917, 0.0007820129])
     got = out.flatten()[:10].float().cpu()
     assert (got - exp).norm() / exp.norm() < 3e-2 and (got - exp).abs().max() <= 4e-5
+
+    # MixedSequenceLengthTest (:331-393): the reference's only vector for ragged q_cu_seq_lens -- 32 / 64 / 128 tokens in one
+    # varlen prefill -- through the same HIP kernels, and equal to the oracle layer on EVERY output row (not only the ten values)
+    hidden_c, positions_c, slots_c, cu_c = G._mixed_inputs()
+    kc, vc = [t.to(DEV) for t in G._caches()]
+    out = layer(hidden_c.to(DEV), positions_c.to(DEV), kc, vc, slots_c.to(DEV), "prefill", cu=cu_c.to(DEV), max_len=128)
+    G._assert_close_bf16(out.flatten()[:10].cpu(), G.GOLD["qwen2_attention_mixed"]["first10"], ulps=2)
+    kc_o, vc_o = G._caches()
+    ref = G._layer(hidden_c, positions_c, G._weights(), kc_o, vc_o, slots_c, "prefill", cu=cu_c)
+    assert rel_l2(out.cpu(), ref) <= 2e-3
+    # the KV rows written to slots 0 .. 223 (a 16-bit GEMM in another summation order: equal to the last bit or so)
+    assert_ulp_close(kc, kc_o, torch.bfloat16, ulps=2.0, min_exact=0.9)
+    assert_ulp_close(vc, vc_o, torch.bfloat16, ulps=2.0, min_exact=0.9)
 
 
 @pytest.mark.parametrize("M,N,K,dtype", [(64, 3584, 18944, torch.bfloat16), (64, 4608, 3584, torch.bfloat16),
@@ -644,7 +663,11 @@ def test_mla_prefill_and_latent_store(H, bs, lens):
     from _bars import assert_p16_attention_close
     ref16 = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
                                 causal=True, dv=512, p_round=True)
-    assert_p16_attention_close(out.view(T, -1), ref.view(T, -1), ref16.view(T, -1))
+    shared = not (T * ((H + 15) // 16) < 4 * 128 and os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "1") and \
+        os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "0" and os.environ.get("XLLM_MI355_MLA_PREFILL_P", "") != "2"
+    flash = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
+                                causal=True, dv=512, p_round="flash") if shared else None   # the tile-sharing kernel's cast point
+    assert_p16_attention_close(out.view(T, -1), ref.view(T, -1), ref16.view(T, -1), None if flash is None else flash.view(T, -1))
     if T >= 256:                                                       # the unmasked form of the same entry
         ref_nc = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
                                      causal=False, dv=512)

@@ -129,3 +129,27 @@ def test_prefill_golden_with_rounded_p():
     cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32)
     out = _layer(hidden, positions, w, kc, vc, slots, "prefill", p_round=True, cu=cu)
     _assert_close_bf16(out.flatten()[:10], GOLD["qwen2_attention_prefill"]["first10"], ulps=2)
+
+
+def _mixed_inputs():
+    """MixedSequenceLengthTest (qwen2_attention_test.cpp:331-393): three sequences of 32 / 64 / 128 tokens in one varlen
+    prefill, positions restart at 0 per sequence, the KV rows go to slots 0 .. 223"""
+    seq_lens = GOLD["qwen2_attention_mixed"]["seq_lens"]
+    total = sum(seq_lens)
+    cu = torch.tensor([0] + [sum(seq_lens[:i + 1]) for i in range(len(seq_lens))], dtype=torch.int32)
+    hidden = orc.make_noise(PFX + "mix.hidden_states", (total, H), 0.02)
+    positions = torch.cat([torch.arange(n) for n in seq_lens])
+    slots = torch.arange(total, dtype=torch.int32)
+    return hidden, positions, slots, cu
+
+
+def test_mixed_sequence_length_golden():
+    """the reference's only vector for RAGGED q_cu_seq_lens (round-2 review, missing #5): reproduced to 2 bf16 ulps by both P modes
+    (short sequences: the P rounding does not show in these ten values)"""
+    w = _weights()
+    hidden, positions, slots, cu = _mixed_inputs()
+    for p_round in (False, True):
+        kc, vc = _caches()
+        out = _layer(hidden, positions, w, kc, vc, slots, "prefill", p_round=p_round, cu=cu)
+        assert out.shape == (int(cu[-1]), H)
+        _assert_close_bf16(out.flatten()[:10], GOLD["qwen2_attention_mixed"]["first10"], ulps=2)

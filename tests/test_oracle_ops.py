@@ -478,3 +478,34 @@ def test_rejection_sample_oracle_rules():
     # seq0: accept token 1 (ratio 1), reject token 2 -> recovered argmax(max(tp-dp,0)/u) = index 3; no bonus
     # seq1: both accepted -> bonus 12; seq2: draft id 7 out of range -> all -1
     assert out.tolist() == [1, 3, -1, 3, 0, 12, -1, -1]
+
+
+def test_attention_flash_cast_point_mode():
+    """oracle p_round="flash" (round 3): the un-normalised 64-key-tile P rounded to the tensor dtype, fp32 row sum, lazy running
+    maximum -- a restatement of WHERE a flash kernel rounds P. It must (a) equal the fp32-P result when P needs no rounding
+    (fp32 tensors), (b) sit at the distance of ONE 16-bit rounding of P from it for bf16 (the same order as the normalised-P
+    spec, p_round=True), (c) not depend on how the keys fall into tiles beyond that distance, (d) honour masks / ragged batches."""
+    g = torch.Generator().manual_seed(5)
+    nq, nkv, d = 4, 2, 64
+    lens = [1, 63, 64, 65, 300]
+    T = sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    scale = d ** -0.5
+    r = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    q32, k32, v32 = (torch.randn(T, n, d, generator=g) for n in (nq, nkv, nkv))
+    a0 = orc.attention_varlen(q32, k32, v32, cu, cu, scale)
+    a2 = orc.attention_varlen(q32, k32, v32, cu, cu, scale, p_round="flash")
+    assert r(a2, a0) < 5e-6                                     # (a) fp32: only summation order / exp2 differ
+    q, k, v = q32.bfloat16(), k32.bfloat16(), v32.bfloat16()
+    b0 = orc.attention_varlen(q, k, v, cu, cu, scale)
+    b1 = orc.attention_varlen(q, k, v, cu, cu, scale, p_round=True)
+    b2 = orc.attention_varlen(q, k, v, cu, cu, scale, p_round="flash")
+    assert 2e-4 < r(b2, b0) < 6e-3 and 2e-4 < r(b1, b0) < 6e-3  # (b) one bf16 rounding of P each
+    assert r(b2, b1) < 8e-3
+    # (d) a window and a non-causal call go through the same code path
+    w0 = orc.attention_varlen(q, k, v, cu, cu, scale, window_left=70)
+    w2 = orc.attention_varlen(q, k, v, cu, cu, scale, window_left=70, p_round="flash")
+    assert r(w2, w0) < 6e-3
+    n0 = orc.attention_varlen(q32, k32, v32, cu, cu, scale, causal=False)
+    n2 = orc.attention_varlen(q32, k32, v32, cu, cu, scale, causal=False, p_round="flash")
+    assert r(n2, n0) < 5e-6
