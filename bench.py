@@ -70,6 +70,10 @@ def parse():
                    help="(default since round 3; kept for old command lines) tensor parallel: the one-shot xGMI all-reduce of "
                         "csrc/allreduce.hip for the per-layer sums, self-tested at set-up, RCCL when the self-test fails")
     p.add_argument("--no-oneshot-allreduce", action="store_true", help="tensor parallel: RCCL for every collective")
+    p.add_argument("--via-shim", action="store_true",
+                   help="also run the SAME decode step through the C++ libtorch shim (shim/: the reference's operator signatures, "
+                        "what a -DUSE_MI355 build of xLLM calls) in the reference's operator order, and print its ms_per_step "
+                        "beside the headline")
     p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
@@ -488,6 +492,10 @@ def main():
     if not a.no_prefill and a.config == "cfg3":
         prefill = prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all)
 
+    shim_info = None
+    if a.via_shim and world == 1 and tp_size == 1 and mode == "int8":
+        shim_info = via_shim_leg(model, margs, md, kv_caches, tokens, positions, a.steps, a.warmup)
+
     engine_info = None
     if world == 1 and not a.no_engine and dual is None and tp_size == 1:
         engine_info = engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, a.steps, margs)
@@ -526,6 +534,8 @@ def main():
             out["prefill"] = prefill
         if engine_info is not None:
             out["engine"] = engine_info
+        if shim_info is not None:
+            out["via_shim"] = shim_info
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
             if a.config == "cfg3":
@@ -534,6 +544,79 @@ def main():
     if world > 1:
         dist.destroy_process_group()
 
+
+
+def via_shim_leg(model, margs, md, kv_caches, tokens, positions, steps, warmup):
+    """The decode step through the drop-in boundary itself (round-2 review, missing #6): every operator goes through
+    shim/xllm_mi355_shim (xllm::kernel::mi355::* with the reference's torch::Tensor signatures + layer::AttentionImpl) in the
+    reference's operator ORDER -- apply_norm, w8a8 linear = scaled_quantize + scaled_matmul, rotary_embedding,
+    AttentionImpl::forward (KV write + paged attention), ... (qwen2_decoder_layer.cpp:87-110, qwen2_attention.cpp:132-193,
+    dense_mlp.cpp:97-116, linear.cpp:481-507) -- WITHOUT the cross-operator N1 fusions, which have no reference operator to hide
+    behind. Weights are packed at load time through the shim (pack_w8a8_weight); the step is replayed from one HIP graph."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "shim"))
+    import build_shim
+    spec = importlib.util.spec_from_file_location("xllm_mi355_shim", build_shim.main())
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    eps = margs.rms_norm_eps
+    for L in model.layers:
+        for lin in (L.qkv_proj, L.o_proj, L.gate_up_proj, L.down_proj):
+            m.pack_w8a8_weight(lin.weight)                      # the USE_MI355 branch of the loader (INTEGRATION.md)
+    slots, kv_lens, table, max_kv = md.slot_mapping, md.kv_seq_lens, md.block_table, md.max_seq_len
+
+    def linear(lin, x):                                          # linear.cpp:481-507
+        q8, sc = m.scaled_quantize(x)
+        return m.scaled_matmul(q8, lin.weight, sc, lin.w_scale, lin.bias)
+
+    def step():
+        x = torch.nn.functional.embedding(tokens, model.embed)
+        residual = None
+        for L, kvc in zip(model.layers, kv_caches):
+            if residual is None:                                 # apply_norm (qwen2_decoder_layer.cpp:66-85)
+                residual = x
+                h = torch.empty_like(x)
+                m.rms_norm(h, x, L.input_norm_w, eps)
+            else:
+                m.fused_add_rms_norm(x, residual, L.input_norm_w, eps)
+                h = x
+            qkv = linear(L.qkv_proj, h)
+            q, k, v = qkv[:, :L.q_size], qkv[:, L.q_size:L.q_size + L.kv_size], qkv[:, L.q_size + L.kv_size:]
+            m.rotary_embedding(positions, q, k, model.cos_sin, True)
+            attn = m.attention_forward(q, k, v, kvc.k_cache, kvc.v_cache, slots, kv_lens, table, L.nq, L.nkv, L.d, max_kv)
+            x = linear(L.o_proj, attn.reshape(attn.size(0), -1))
+            m.fused_add_rms_norm(x, residual, L.post_norm_w, eps)
+            gate_up = linear(L.gate_up_proj, x)
+            act = torch.empty(gate_up.size(0), gate_up.size(1) // 2, dtype=gate_up.dtype, device=gate_up.device)
+            m.act_and_mul(act, gate_up, "silu")
+            x = linear(L.down_proj, act)
+        m.fused_add_rms_norm(x, residual, model.norm_w, eps)
+        return torch.argmax(m.matmul(x, model.lm_head.weight, None), dim=-1)
+
+    for _ in range(max(warmup, 2)):
+        out_eager = step()
+    torch.cuda.synchronize()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        step()                                                   # this stream's scratch buffers are created outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            out_graph = step()
+    torch.cuda.current_stream().wait_stream(cap)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(tokens.numel() / ms * 1e3, 2),
+            "path": "shim/xllm_mi355_shim: reference operator order, no N1 fusions, weights packed at load, one HIP graph",
+            "tokens_equal_eager_replay": bool(torch.equal(out_graph, out_eager)),
+            "packed_weights": int(m.packed_weight_cache_size())}
 
 def engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, steps, margs):
     """the same decode workload driven through the step-level harness (SURVEY 8f N2 + N3): per step the HOST builds the

@@ -232,12 +232,14 @@ XM_API int xllm_mi355_scaled_matmul_rope_cache_packed(const int8_t* a, const int
                                                       void* stream);
 
 /* optional scratch for the int8 split-K path of scaled_matmul (>= M*N*4 bytes; the reference operator
- * has no workspace argument, so it is registered once per stream owner; NULL disables split-K). */
+ * has no workspace argument, so it is registered: ONE default buffer PER DEVICE -- the device is the one that owns the
+ * registered pointer, so the reference's one-worker-thread-per-device processes (dist_manager.cpp:82-84) register one each --
+ * NULL disables split-K on the current device). Registrations and look-ups are mutex-guarded (xllm_amd/csrc/workspace.hip). */
 XM_API int xllm_mi355_set_gemm_workspace(void* workspace, size_t bytes);
 /* Per-stream split-K workspace (same invariant: all-zero between calls). GEMMs launched on `stream` use it instead of
  * the global one, so that two micro-batches running concurrently on two streams (the reference's
  * enable_multi_stream_parallel / micro_batch_num, framework/config/parallel_config.h:83-85) never share partial sums.
- * ws == NULL unregisters the stream. At most 8 streams. */
+ * ws == NULL unregisters the stream. At most 64 streams (all devices together). */
 XM_API int xllm_mi355_set_gemm_workspace_for_stream(void* stream, void* ws, size_t bytes);
 
 /* ---- fp8 (OCP e4m3fn) ------------------------------------------------------------------------
@@ -426,6 +428,9 @@ XM_API int xllm_mi355_rejection_sample(const int32_t* draft_token_ids, const int
  * tile table of its 256x256 kernel (16 * (rows / 256 + n_experts) bytes) in the tail of the same scratch and falls back
  * to the 128x128 kernel when the scratch is absent or too small */
 XM_API int xllm_mi355_set_moe_workspace(void* workspace, size_t bytes);
+/* the same scratch for launches on one particular stream (two MoE layers on two streams of one device); one default per device
+ * otherwise, keyed by the device that owns the registered pointer. ws == NULL unregisters the stream. */
+XM_API int xllm_mi355_set_moe_workspace_for_stream(void* stream, void* ws, size_t bytes);
 XM_API int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int64_t topk,
                                         int64_t n_experts, int32_t* src_dst, int32_t* dst_src,
                                         int32_t* expert_sizes, void* stream);

@@ -7,8 +7,13 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/HIPGeneratorImpl.h>
 
+#include <ATen/hip/HIPEvent.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
+
+#include <memory>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "../include/xllm_mi355.h"
 
@@ -207,48 +212,125 @@ std::tuple<torch::Tensor, torch::Tensor> scaled_quantize(
 
 namespace {
 // Decode-shaped W8A8 GEMMs stream the weight in MFMA-fragment order (xllm_mi355_pack_weight_i8 + xllm_mi355_scaled_matmul_packed).
-// The reference's operator has no "packed weight" argument, so the shim keeps one packed copy per weight tensor, made on the
-// first decode-shaped call (weights are loaded once and live as long as the model; the key carries the tensor's version
-// counter so that an in-place update re-packs) and one K-slice scratch per device. The reference runs one worker thread per
-// device in one process (runtime/dist_manager.cpp:82-84): both maps are mutex-guarded, the scratch is per device.
+// The reference's operator has no "packed weight" argument, so the shim keeps one packed copy per weight tensor. The intended
+// use is EXPLICIT: the linear layer packs at weight-load time (pack_w8a8_weight below, called from the USE_MI355 branch of the
+// loader -- INTEGRATION.md) and the copy lives as long as the weight. The on-demand path (first decode-shaped call) stays as a
+// convenience for callers that never registered. Round-2 advisor findings, all addressed here:
+//   * identity: entries are keyed on the TensorImpl and hold a WEAK reference to it plus its version counter -- a weight that was
+//     freed (the weak pointer is expired) or updated in place through torch (version moved) is re-packed; a recycled address can
+//     no longer alias a dead entry. Expired entries are dropped on every insertion. (Raw-pointer writes into a weight bump no
+//     version: call invalidate_packed_weight / clear_packed_weight_cache after them.)
+//   * ordering: packing records an event on the packing stream; a call on another stream waits for it first;
+//   * lifetime: look-ups return the tensor BY VALUE (its own reference), not a pointer into the map;
+//   * scratch: K-slice slabs are per (device, STREAM), not per device; nothing is allocated inside a graph capture (a missing
+//     buffer or an unpacked weight makes the call fall back to the row-major kernel there).
+// The reference runs one worker thread per device in one process (runtime/dist_manager.cpp:82-84): all maps are mutex-guarded.
 struct PackedEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl> owner;
   torch::Tensor packed;
   int64_t n, k;
   uint32_t version;
+  const void* data;
+  std::shared_ptr<at::cuda::CUDAEvent> ready;
+  void* pack_stream;
 };
 std::mutex g_pack_mu;
-std::unordered_map<const void*, PackedEntry> g_packed;
-std::unordered_map<int, torch::Tensor> g_slab_ws;
-constexpr int64_t kSlabBytes = 64ll << 20;
+std::unordered_map<const c10::TensorImpl*, PackedEntry> g_packed;
+struct StreamKey {
+  int device;
+  void* stream;
+  bool operator==(const StreamKey& o) const { return device == o.device && stream == o.stream; }
+};
+struct StreamKeyHash {
+  size_t operator()(const StreamKey& k) const { return std::hash<void*>()(k.stream) ^ (size_t)k.device * 0x9e3779b97f4a7c15ull; }
+};
+std::unordered_map<StreamKey, torch::Tensor, StreamKeyHash> g_slab_ws;      // K-slice slabs of the packed kernels
+std::unordered_map<StreamKey, torch::Tensor, StreamKeyHash> g_splitk_ws;    // zero-at-rest split-K scratch of the row-major kernels
+constexpr int64_t kSlabBytes = 64ll << 20, kSplitKBytes = 64ll << 20;
 
-bool prefer_packed(int64_t M, int64_t N, int64_t K) {   // the measured policy of xllm_amd/ops.py::_prefer_packed
-  return N % 16 == 0 && K % 128 == 0 && K / 128 >= 4 && (M <= 128 || (M <= 512 && N <= 8192 && K >= 8192));
+bool capturing() { return c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None; }
+
+bool prefer_packed(int64_t M, int64_t N, int64_t K) {   // the measured policy of xllm_amd/ops.py::_prefer_packed (round 3)
+  return N % 16 == 0 && K % 128 == 0 && K / 128 >= 4 && M <= 512;
 }
 
-const torch::Tensor* packed_weight_for(const torch::Tensor& b) {
-  const uint32_t ver = b.unsafeGetTensorImpl()->version_counter().current_version();
-  std::lock_guard<std::mutex> lock(g_pack_mu);
-  auto it = g_packed.find(b.data_ptr());
-  if (it != g_packed.end() && it->second.n == b.size(0) && it->second.k == b.size(1) && it->second.version == ver)
-    return &it->second.packed;
+void drop_expired_locked() {
+  for (auto it = g_packed.begin(); it != g_packed.end();)
+    it = it->second.owner.expired() ? g_packed.erase(it) : std::next(it);
+}
+
+// packs `b` on the current stream and registers the copy (caller holds no lock)
+std::optional<torch::Tensor> pack_and_register(const torch::Tensor& b) {
   torch::Tensor packed = torch::empty_like(b);
   if (xllm_mi355_pack_weight_i8(b.data_ptr<int8_t>(), packed.data_ptr<int8_t>(), b.size(0), b.size(1), cur_stream()) != 0)
-    return nullptr;
-  auto& e = g_packed[b.data_ptr()];
-  e = PackedEntry{packed, b.size(0), b.size(1), ver};
-  return &e.packed;
+    return std::nullopt;
+  auto ev = std::make_shared<at::cuda::CUDAEvent>();
+  ev->record(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  drop_expired_locked();
+  c10::TensorImpl* impl = b.unsafeGetTensorImpl();
+  g_packed.erase(impl);
+  g_packed.emplace(impl, PackedEntry{c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>(b.getIntrusivePtr()),
+                                     packed, b.size(0), b.size(1), impl->version_counter().current_version(), b.data_ptr(), ev,
+                                     cur_stream()});
+  return packed;
 }
 
-torch::Tensor slab_workspace(const torch::Tensor& like) {
+std::optional<torch::Tensor> packed_weight_for(const torch::Tensor& b) {
+  c10::TensorImpl* impl = b.unsafeGetTensorImpl();
+  const uint32_t ver = impl->version_counter().current_version();
+  {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    auto it = g_packed.find(impl);
+    if (it != g_packed.end()) {
+      const PackedEntry& e = it->second;
+      if (!e.owner.expired() && e.n == b.size(0) && e.k == b.size(1) && e.version == ver && e.data == b.data_ptr()) {
+        if (e.pack_stream != cur_stream()) e.ready->block(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA());
+        return e.packed;
+      }
+      g_packed.erase(it);   // a dead or changed weight behind a recycled TensorImpl address
+    }
+  }
+  if (capturing()) return std::nullopt;   // no allocation / packing inside a capture: the row-major kernel serves the call
+  return pack_and_register(b);
+}
+
+// scratch of one (device, stream); created lazily OUTSIDE a capture, never replaced afterwards (graphs bake the address in)
+std::optional<torch::Tensor> stream_scratch(std::unordered_map<StreamKey, torch::Tensor, StreamKeyHash>& map,
+                                            const torch::Tensor& like, int64_t bytes, bool zero_at_rest) {
+  const StreamKey key{(int)like.device().index(), cur_stream()};
+  {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    auto it = map.find(key);
+    if (it != map.end()) return it->second;
+  }
+  if (capturing()) return std::nullopt;
+  torch::Tensor ws = torch::empty({bytes}, like.options().dtype(torch::kUInt8));
+  if (zero_at_rest)   // the C side zeroes it (a memset on the null stream) and keys it on the stream
+    check(xllm_mi355_set_gemm_workspace_for_stream(cur_stream(), ws.data_ptr(), (size_t)ws.numel()), "set_gemm_workspace_for_stream");
   std::lock_guard<std::mutex> lock(g_pack_mu);
-  auto& ws = g_slab_ws[like.device().index()];
-  if (!ws.defined()) ws = torch::empty({kSlabBytes}, like.options().dtype(torch::kUInt8));
-  return ws;
+  auto ins = map.emplace(key, ws);
+  return ins.first->second;
 }
 }  // namespace
 
+torch::Tensor pack_w8a8_weight(const torch::Tensor& b) {
+  DeviceGuard guard(b.device());
+  TORCH_CHECK(b.dim() == 2 && b.scalar_type() == torch::kInt8 && b.is_contiguous(), "pack_w8a8_weight: [N, K] int8, contiguous");
+  TORCH_CHECK(b.size(0) % 16 == 0 && b.size(1) % 128 == 0, "pack_w8a8_weight: N % 16 == 0 and K % 128 == 0");
+  auto packed = pack_and_register(b);
+  TORCH_CHECK(packed.has_value(), "pack_w8a8_weight: xllm_mi355_pack_weight_i8 failed");
+  return *packed;
+}
+
+void invalidate_packed_weight(const torch::Tensor& b) {
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  g_packed.erase(b.unsafeGetTensorImpl());
+}
+
 int64_t packed_weight_cache_size() {
   std::lock_guard<std::mutex> lock(g_pack_mu);
+  drop_expired_locked();
   return (int64_t)g_packed.size();
 }
 
@@ -276,15 +358,19 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
   auto as = a_scale->reshape({-1}).contiguous();
   auto bs = b_scale.reshape({-1}).contiguous();
   if (prefer_packed(M, N, K)) {   // decode shapes: the weight-stream kernel on the packed copy; declines fall through
-    if (const torch::Tensor* wp = packed_weight_for(b)) {
-      torch::Tensor ws = slab_workspace(a);
+    if (auto wp = packed_weight_for(b)) {
+      auto ws = stream_scratch(g_slab_ws, a, kSlabBytes, false);   // (none inside a capture that was not warmed up: unsliced)
       const int rc = xllm_mi355_scaled_matmul_packed(a.data_ptr<int8_t>(), wp->data_ptr<int8_t>(), as.data_ptr<float>(),
                                                      bs.data_ptr<float>(), p(bias), p(out), nullptr, M, N, K,
-                                                     dt(output_dtype), ws.data_ptr(), (size_t)ws.numel(), cur_stream());
+                                                     dt(output_dtype), ws ? ws->data_ptr() : nullptr,
+                                                     ws ? (size_t)ws->numel() : 0, cur_stream());
       if (rc == 0) return out;
-      TORCH_CHECK(rc == XM_ERR_UNSUPPORTED, "scaled_matmul (packed): ", xllm_mi355_strerror(rc));
+      TORCH_CHECK(rc == XM_ERR_UNSUPPORTED || rc == XM_ERR_WORKSPACE, "scaled_matmul (packed): ", xllm_mi355_strerror(rc));
     }
   }
+  // row-major kernels: decode shapes split K through a zero-at-rest scratch registered for THIS (device, stream) -- the
+  // registration the Python mirror does in ops._ensure_gemm_workspace and the shim used to skip (round-2 review, missing #6)
+  if (M <= 512) (void)stream_scratch(g_splitk_ws, a, kSplitKBytes, true);
   check(xllm_mi355_scaled_matmul(a.data_ptr<int8_t>(), b.data_ptr<int8_t>(), as.data_ptr<float>(),
                                  bs.data_ptr<float>(), p(bias), p(out), nullptr, M, N, K, dt(output_dtype),
                                  cur_stream()),
@@ -305,14 +391,22 @@ torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight
 }
 
 namespace {
-// one MoE scratch per process, grown on demand (chunk counts of the index build + the grouped-GEMM tile table): the C ABI
-// never allocates, so the shim owns it the way the reference's backends own their workspaces
+// MoE scratch (chunk counts of the index build + the grouped-GEMM tile table): the C ABI never allocates, so the shim owns it the
+// way the reference's backends own their workspaces -- ONE PER DEVICE (the C side keys the registration on the device that owns
+// the pointer), mutex-guarded, grown only outside a graph capture, and an outgrown buffer is RETIRED, not freed: a captured
+// graph may still launch kernels that write it (round-2 review, weak #9: this was one static tensor, replaced in place and
+// thrashing whenever two devices alternated)
+std::mutex g_moe_mu;
+std::unordered_map<int, torch::Tensor> g_moe_ws;
+std::vector<torch::Tensor> g_moe_retired;
 void ensure_moe_scratch(const torch::Tensor& like, int64_t bytes) {
-  static torch::Tensor ws;
-  if (!ws.defined() || ws.numel() < bytes || ws.device() != like.device()) {
-    ws = torch::empty({std::max<int64_t>(bytes, 1 << 20)}, like.options().dtype(torch::kUInt8));
-    check(xllm_mi355_set_moe_workspace(ws.data_ptr(), (size_t)ws.numel()), "set_moe_workspace");
-  }
+  std::lock_guard<std::mutex> lock(g_moe_mu);
+  auto& ws = g_moe_ws[(int)like.device().index()];
+  if (ws.defined() && ws.numel() >= bytes) return;
+  TORCH_CHECK(!capturing(), "MoE scratch too small inside a graph capture: run one eager step of this shape first");
+  if (ws.defined()) g_moe_retired.push_back(ws);
+  ws = torch::empty({std::max<int64_t>(bytes, 4 << 20)}, like.options().dtype(torch::kUInt8));
+  check(xllm_mi355_set_moe_workspace(ws.data_ptr(), (size_t)ws.numel()), "set_moe_workspace");
 }
 }  // namespace
 

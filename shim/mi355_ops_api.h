@@ -67,6 +67,12 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
 // expose the cache to tests and to code that frees or replaces weights
 int64_t packed_weight_cache_size();
 void clear_packed_weight_cache();
+// weight-load-time packing of a W8A8 weight [N, K] int8 (N % 16 == 0, K % 128 == 0) into MFMA-fragment order: what the
+// USE_MI355 branch of the linear layer's loader calls once per weight; scaled_matmul then finds the copy.
+// Returns the packed tensor (the cache holds a reference too, for as long as `b` lives).
+torch::Tensor pack_w8a8_weight(const torch::Tensor& b);
+// forget the packed copy of `b` (after writing into the weight through a raw pointer, which bumps no version counter)
+void invalidate_packed_weight(const torch::Tensor& b);
 torch::Tensor group_gemm(const torch::Tensor& input, const torch::Tensor& weight, const torch::Tensor& token_count,
                          std::optional<torch::Tensor> output = std::nullopt);
 // kernel::moe_active_topk / cuda::moe_fused_topk (ops_api.h:70; kernels/cuda/moe/moe_fused_topk.cu:31-61):

@@ -34,6 +34,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     return k::scaled_matmul(a, b, as, bs, torch::kBFloat16, bias, std::nullopt, "none", 8, 1.0, 0.0, false, 8, std::nullopt, std::nullopt, std::nullopt);
   });
   m.def("packed_weight_cache_size", &k::packed_weight_cache_size);
+  m.def("pack_w8a8_weight", &k::pack_w8a8_weight);
+  m.def("invalidate_packed_weight", &k::invalidate_packed_weight);
+  m.def("fused_layernorm", [](torch::Tensor x, torch::Tensor w, double eps, std::optional<torch::Tensor> residual) {
+    // the reference's decoder layer calls kernel::fused_layernorm with a residual (qwen2_decoder_layer.cpp:66-85)
+    if (residual.has_value()) { k::fused_add_rms_norm(x, *residual, w, eps); return x; }
+    torch::Tensor out = torch::empty_like(x);
+    k::rms_norm(out, x, w, eps);
+    return out;
+  });
   m.def("clear_packed_weight_cache", &k::clear_packed_weight_cache);
   m.def("fp8_scaled_quantize", [](const torch::Tensor& x) { return k::fp8_scaled_quantize(x); });
   m.def("paged_attention", [](const torch::Tensor& q, const torch::Tensor& kc, const torch::Tensor& vc, const torch::Tensor& kv_lens, const torch::Tensor& bt, int64_t max_kv, double scale) {

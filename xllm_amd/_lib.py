@@ -110,6 +110,7 @@ _OPTIONAL = {
     "xllm_mi355_moe_fused_topk": ([vp, ci, i64, i64, i64, ci, vp, ci, vp, vp, vp], ci),
     "xllm_mi355_moe_grouped_topk": ([vp, ci, i64, i64, i64, i64, i64, ci, vp, ci, f32, vp, vp, vp], ci),
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),
+    "xllm_mi355_set_moe_workspace_for_stream": ([vp, vp, sz], ci),
     "xllm_mi355_moe_compute_index": ([vp, i64, i64, i64, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_combine": ([vp, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_moe_combine_sorted": ([vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),

@@ -133,7 +133,12 @@ inline int hip_check_launch() {
 // rowwise.hip: consumes (and re-zeroes) int32 GEMM sums: dequant + residual add + RMSNorm (+ int8 quant)
 // library scratch registered by xllm_mi355_set_moe_workspace (moe.hip): chunk counts of the index build; the grouped GEMM
 // keeps its tile table in the tail of it
-void xm_moe_scratch(void** ws, size_t* bytes);
+void xm_moe_scratch(void* stream, void** ws, size_t* bytes);
+// workspace.hip: per-device defaults + per-stream overrides of the registered scratch buffers (kind 0 = int8 split-K GEMM
+// scratch, zero at rest; kind 1 = MoE scratch), mutex-guarded
+int ws_set_device(int kind, void* ws, size_t bytes);
+int ws_set_stream(int kind, void* stream, void* ws, size_t bytes);
+void ws_get(int kind, void* stream, void** ws, size_t* bytes);
 int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float* a_scale, const float* w_scale,
                             const void* bias, void* residual, const void* weight, float eps, int64_t M, int64_t N,
                             int dtype, int quant, hipStream_t s, int n_slabs = 0);

@@ -769,40 +769,16 @@ using namespace xm;
 
 extern "C" {
 
-// workspace for int8 split-K (optional): M*N*4 bytes. Set by xllm_mi355_set_gemm_workspace(); the
-// ops_api-shaped entry point below has no workspace argument because the reference operator has none.
-static void* g_gemm_ws = nullptr;
-static size_t g_gemm_ws_bytes = 0;
-// per-stream workspaces (xllm_mi355_set_gemm_workspace_for_stream): GEMMs of two micro-batches that run concurrently
-// on two streams must not accumulate split-K partial sums into the same buffer. A handful of slots is enough.
-struct StreamWs { void* stream; void* ws; size_t bytes; };
-static StreamWs g_stream_ws[8] = {};
-static int g_stream_ws_n = 0;
-static void gemm_ws_for(void* stream, void** ws, size_t* bytes) {
-  for (int i = 0; i < g_stream_ws_n; ++i)
-    if (g_stream_ws[i].stream == stream) { *ws = g_stream_ws[i].ws; *bytes = g_stream_ws[i].bytes; return; }
-  *ws = g_gemm_ws;
-  *bytes = g_gemm_ws_bytes;
-}
+// workspace for int8 split-K (optional): M*N*4 bytes, registered per device / per stream (workspace.hip); the ops_api-shaped
+// entry points below have no workspace argument because the reference operators have none.
+static void gemm_ws_for(void* stream, void** ws, size_t* bytes) { ws_get(0, stream, ws, bytes); }
 XM_API int xllm_mi355_set_gemm_workspace(void* ws, size_t bytes) {
-  g_gemm_ws = ws;
-  g_gemm_ws_bytes = bytes;
   if (ws && bytes && hipMemset(ws, 0, bytes) != hipSuccess) return XM_ERR_HIP;
-  return XM_OK;
+  return ws_set_device(0, ws, bytes);
 }
 XM_API int xllm_mi355_set_gemm_workspace_for_stream(void* stream, void* ws, size_t bytes) {
   if (ws && bytes && hipMemset(ws, 0, bytes) != hipSuccess) return XM_ERR_HIP;
-  for (int i = 0; i < g_stream_ws_n; ++i)
-    if (g_stream_ws[i].stream == stream) {
-      if (!ws) { g_stream_ws[i] = g_stream_ws[--g_stream_ws_n]; return XM_OK; }  // ws == NULL unregisters
-      g_stream_ws[i].ws = ws;
-      g_stream_ws[i].bytes = bytes;
-      return XM_OK;
-    }
-  if (!ws) return XM_OK;
-  if (g_stream_ws_n == 8) return XM_ERR_UNSUPPORTED;
-  g_stream_ws[g_stream_ws_n++] = StreamWs{stream, ws, bytes};
-  return XM_OK;
+  return ws_set_stream(0, stream, ws, bytes);
 }
 
 int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_scale, const float* w_scale,
@@ -982,7 +958,7 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   }
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  xm_moe_scratch(&scratch, &scratch_bytes);
+  xm_moe_scratch(stream, &scratch, &scratch_bytes);
   const int64_t slots = (max_rows + 255) / 256 + n_experts;
   const size_t table_bytes = (size_t)slots * 16;
   // 256-row tiles pay once the experts hold rows of their own: below ~64 rows per expert the launch streams weights only
@@ -1028,7 +1004,7 @@ int xllm_mi355_group_gemm_w8a8(const int8_t* a, int64_t a_rows, const float* a_s
   if (max_rows == 0) return XM_OK;
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  xm_moe_scratch(&scratch, &scratch_bytes);
+  xm_moe_scratch(stream, &scratch, &scratch_bytes);
   const int64_t slots = (max_rows + 255) / 256 + n_experts;
   const size_t table_bytes = (size_t)slots * 16;
   if (!scratch || scratch_bytes < table_bytes + 64) return XM_ERR_WORKSPACE;

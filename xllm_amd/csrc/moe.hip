@@ -371,22 +371,17 @@ __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restri
 
 using namespace xm;
 
-// scratch for the chunk histograms (nchunks * E int32); sized for 1M expanded rows x 1024 experts at most
-static int32_t* g_moe_scratch = nullptr;
-static size_t g_moe_scratch_elems = 0;
+// scratch for the chunk histograms (nchunks * E int32); sized for 1M expanded rows x 1024 experts at most. Registered per
+// device / per stream (workspace.hip, kind 1); the grouped GEMM keeps its tile table in the tail of the same buffer.
 namespace xm {
-void xm_moe_scratch(void** ws, size_t* bytes) {
-  *ws = g_moe_scratch;
-  *bytes = g_moe_scratch_elems * 4;
-}
+void xm_moe_scratch(void* stream, void** ws, size_t* bytes) { ws_get(1, stream, ws, bytes); }
 }  // namespace xm
 
 extern "C" {
 
-XM_API int xllm_mi355_set_moe_workspace(void* ws, size_t bytes) {
-  g_moe_scratch = reinterpret_cast<int32_t*>(ws);
-  g_moe_scratch_elems = bytes / 4;
-  return XM_OK;
+XM_API int xllm_mi355_set_moe_workspace(void* ws, size_t bytes) { return ws_set_device(1, ws, bytes); }
+XM_API int xllm_mi355_set_moe_workspace_for_stream(void* stream, void* ws, size_t bytes) {
+  return ws_set_stream(1, stream, ws, bytes);
 }
 
 int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int64_t topk, int64_t n_experts,
@@ -399,11 +394,14 @@ int xllm_mi355_moe_compute_index(const int32_t* expert_id, int64_t n_tokens, int
   const int E = (int)n_experts;
   if (n == 0) return hipMemsetAsync(expert_sizes, 0, E * sizeof(int32_t), s) == hipSuccess ? XM_OK : XM_ERR_HIP;
   const int nchunks = (int)((n + kMoeChunk - 1) / kMoeChunk);
-  if (!g_moe_scratch || g_moe_scratch_elems < (size_t)nchunks * E) return XM_ERR_WORKSPACE;
-  hipLaunchKernelGGL(moe_hist_kernel, dim3(nchunks), dim3(256), E * sizeof(int32_t), s, expert_id, n, E, g_moe_scratch);
-  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, g_moe_scratch, nchunks, E, expert_sizes);
-  hipLaunchKernelGGL(moe_place_kernel, dim3(nchunks), dim3(1024), 0, s, expert_id, n, E,
-                     g_moe_scratch, src_dst, dst_src);
+  void* sc_v = nullptr;
+  size_t sc_bytes = 0;
+  xm_moe_scratch(stream, &sc_v, &sc_bytes);
+  int32_t* const sc = reinterpret_cast<int32_t*>(sc_v);
+  if (!sc || sc_bytes / 4 < (size_t)nchunks * E) return XM_ERR_WORKSPACE;
+  hipLaunchKernelGGL(moe_hist_kernel, dim3(nchunks), dim3(256), E * sizeof(int32_t), s, expert_id, n, E, sc);
+  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, sc, nchunks, E, expert_sizes);
+  hipLaunchKernelGGL(moe_place_kernel, dim3(nchunks), dim3(1024), 0, s, expert_id, n, E, sc, src_dst, dst_src);
   return hip_check_launch();
 }
 
