@@ -15,7 +15,7 @@ if os.environ.get("GEMM_SHAPES") == "dsv3":      # DeepSeek-V3 MLA projections o
     shapes = [("q_a", 1536, 7168), ("q_b", 16 * 192, 1536), ("kv_a", 576, 7168), ("o", 7168, 16 * 128)]
 Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
 kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED", "GEMM_COPIES"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED", "GEMM_COPIES", "GEMM_FUSED"))
 for M in Ms:
     for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
         copies = int(os.environ.get('GEMM_COPIES', 0)) or max(2, min(8, int(600e6 // (N * K)) + 1))
@@ -34,7 +34,14 @@ for M in Ms:
                 a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
             a_s = torch.rand(M, device=dev)
             w_s = torch.rand(N, device=dev)
-            if os.environ.get("GEMM_PACKED", "0") == "1":
+            if os.environ.get("GEMM_FUSED", "0") == "1" and N == 3584:
+                # the row-parallel projections as the decode step runs them: GEMM -> (slabs) -> residual add + RMSNorm + int8 quant
+                wps = [ops.pack_weight_i8(x) for x in ws]
+                res = torch.randn(M, N, device=dev).bfloat16()
+                nw = torch.ones(N, device=dev).bfloat16()
+                fn = lambda i: ops.scaled_matmul_add_rms_norm(a, ws[i % copies], a_s, w_s, res, nw, 1e-6, None, quantize=True,
+                                                              b_packed=wps[i % copies])
+            elif os.environ.get("GEMM_PACKED", "0") == "1":
                 wps = [ops.pack_weight_i8(x) for x in ws]
                 fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])
             else:
