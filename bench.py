@@ -62,6 +62,7 @@ def parse():
                         "layers of the other; xllm_amd.layers.DualBatchDecoder), TP=1 only")
     p.add_argument("--micro", action="store_true", help="also print per-operator timings (stderr)")
     p.add_argument("--no-prefill", action="store_true", help="skip the prefill-TFLOPS leg")
+    p.add_argument("--no-gemm", action="store_true", help="skip the quantised-GEMM leg (int8 / fp8 gate_up at M = 8192 and M = 128)")
     p.add_argument("--no-engine", action="store_true", help="skip the step-level harness leg (xllm_amd.engine.DecodeEngine)")
     p.add_argument("--layout", default="auto", choices=["auto", "dp", "tp", "tp4dp2"],
                    help="how N GPUs share the fixed global batch (auto = tp for N = 2, 4, tp4dp2 for N = 8, with the dp line "
@@ -492,6 +493,10 @@ def main():
     if not a.no_prefill and a.config == "cfg3":
         prefill = prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all)
 
+    gemm_info = None
+    if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_gemm:
+        gemm_info = gemm_leg(dev)
+
     shim_info = None
     if a.via_shim and world == 1 and tp_size == 1 and mode == "int8":
         shim_info = via_shim_leg(model, margs, md, kv_caches, tokens, positions, a.steps, a.warmup)
@@ -536,6 +541,8 @@ def main():
             out["engine"] = engine_info
         if shim_info is not None:
             out["via_shim"] = shim_info
+        if gemm_info is not None:
+            out["gemm"] = gemm_info
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
             if a.config == "cfg3":
@@ -545,6 +552,66 @@ def main():
         dist.destroy_process_group()
 
 
+
+
+def gemm_leg(dev):
+    """the quantised GEMM by itself (north_star: ">= 60 % fp8 MFMA util on quant GEMM at TP = 1"): Qwen2-7B gate_up
+    (N = 37888, K = 3584) at the prefill M = 8192 and at a decode M = 128, int8 and fp8, timed with HIP events over a
+    100-launch graph (weights rotate over 4 copies = 543 MB > Infinity Cache). `frac_of_peak` is achieved / 5 PFLOP/s (the
+    dense 8-bit MFMA peak, MI355X_MICROARCH.md); at M = 128 the bound is the weight stream, so `frac_of_hbm` is given too.
+    `mfma_busy` is a PMC figure (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE x SIMDs) and cannot be read inside a run: it is
+    quoted from the committed profile with its source."""
+    from xllm_amd import ops
+    N, K = 37888, 3584
+    out = {"shape": f"gate_up N={N} K={K}", "peak_tops": 5000.0, "hbm_peak_gbs": HBM_PEAK_GBS,
+           "mfma_busy": {"int8_M8192": 0.657, "fp8_M8192": 0.700,
+                         "source": "profiles/r01_gemm_p8_pmc.txt (rocprofv3 --pmc, an earlier run; not measured in this run)"}}
+    g = torch.Generator(device=dev).manual_seed(3)
+    copies = 4
+    for kind in ("int8", "fp8"):
+        if kind == "int8":
+            ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g) for _ in range(copies)]
+            wps = [ops.pack_weight_i8(w) for w in ws]
+        else:
+            ws = [(torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.float8_e4m3fn) for _ in range(copies)]
+            wps = [ops.pack_weight_fp8(w) for w in ws]
+        w_s = torch.rand(N, device=dev, generator=g) * 0.02 + 0.01
+        for M in (8192, 128):
+            if kind == "int8":
+                a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g)
+                a_s = torch.rand(M, device=dev, generator=g) * 0.01
+                fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])
+            else:
+                a = (torch.randn(M, K, device=dev, generator=g) * 2).to(torch.float8_e4m3fn)
+                a_s = torch.rand(M, device=dev, generator=g) * 0.05 + 0.01
+                fn = lambda i: ops.fp8_scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])
+            n = 20 if M > 512 else 100
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                fn(0)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    for i in range(n):
+                        fn(i)
+                gr.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                gr.replay()
+                gr.replay()
+                e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (2 * n)
+            tops = 2.0 * M * N * K / us / 1e6
+            out[f"{kind}_M{M}"] = {"us": round(us, 1), "tops": round(tops, 1), "frac_of_peak": round(tops / 5000.0, 4),
+                                    "gbs": round((N * K + M * K + 2 * M * N) / us / 1e3, 1),
+                                    "frac_of_hbm": round((N * K + M * K + 2 * M * N) / us / 1e3 / HBM_PEAK_GBS, 4)}
+        del ws, wps
+    torch.cuda.empty_cache()
+    return out
 
 def via_shim_leg(model, margs, md, kv_caches, tokens, positions, steps, warmup):
     """The decode step through the drop-in boundary itself (round-2 review, missing #6): every operator goes through

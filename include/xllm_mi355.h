@@ -274,6 +274,17 @@ XM_API int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* 
                                                const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                                                int out_dtype, void* workspace, size_t ws_bytes, void* stream);
 
+/* kernel::matmul (F::linear, kernels/dcu/matmul.cpp:20-25) on PRE-PACKED 16-bit weights for decode-shaped problems (M <= 512):
+ * the weight-stream kernel of gemm_ws.hip on v_mfma_f32_16x16x32_{bf16,f16}. The packed layout is the 8-bit kinds' byte
+ * permutation applied to rows of 2 K bytes: packed[((g * KT + kt) * 2 + ks) * 1024 + lane * 16 + j] = byte
+ * kt*128 + ks*64 + (lane >> 4)*16 + j of row g*16 + (lane & 15) (KT = 2 K / 128), i.e. a lane's 16 bytes are 8 consecutive
+ * elements -- one MFMA operand. out = r16(sum_fp32 + bias); the fp32 summation order differs from xllm_mi355_matmul (K tiles in
+ * order, K slices in slice order: deterministic), so results agree to fp32 rounding. N % 16 == 0, K % 64 == 0, K >= 256;
+ * explicit caller-owned `workspace, ws_bytes` (fp32 slabs; NULL / 0: K is never sliced). XM_ERR_UNSUPPORTED outside the envelope. */
+XM_API int xllm_mi355_pack_weight_16(const void* w, void* packed, int64_t N, int64_t K, void* stream);
+XM_API int xllm_mi355_matmul_packed(const void* a, const void* w_packed, const void* bias, void* out, int64_t M, int64_t N,
+                                    int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream);
+
 /* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
  * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0.
  * Decode-shaped problems with a long K and few columns (M <= 512, N % 4 == 0) split K when a GEMM workspace is

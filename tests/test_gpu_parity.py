@@ -663,7 +663,8 @@ def test_mla_prefill_and_latent_store(H, bs, lens):
     from _bars import assert_p16_attention_close
     ref16 = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
                                 causal=True, dv=512, p_round=True)
-    shared = not (T * ((H + 15) // 16) < 4 * 128 and os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "1") and \
+    # (the tile-sharing kernel needs pages that are a multiple of its 64-token tiles; other page sizes run per token, P = hi + lo)
+    shared = bs % 64 == 0 and not (T * ((H + 15) // 16) < 4 * 128 and os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "1") and \
         os.environ.get("XLLM_MI355_MLA_PREFILL", "") != "0" and os.environ.get("XLLM_MI355_MLA_PREFILL_P", "") != "2"
     flash = orc.paged_attention(q, kc_ref, kc_ref, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale,
                                 causal=True, dv=512, p_round="flash") if shared else None   # the tile-sharing kernel's cast point
@@ -1787,3 +1788,52 @@ def test_greedy_argmax_equals_torch(B, V, dtype):
     assert torch.equal(got.cpu(), torch.argmax(x.float(), dim=-1))
     sl = x.to(DEV)[:, : V - 1] if V > 8 else x.to(DEV)      # a non-contiguous view (odd row pitch: the scalar path)
     assert torch.equal(ops.greedy_argmax(sl).cpu(), torch.argmax(sl.float().cpu(), dim=-1))
+
+
+# ------------------------------------------------------------------------------------------- 16-bit weight-stream GEMM, packed
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 100, 128, 200, 256, 512])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_packed_16bit_gemm_over_tile_shapes(M, dtype):
+    """kernel::matmul on packed 16-bit weights (a15, round 3; cfg2's linears): every wave-tile family x width x K slices against
+    the oracle's F::linear (fp32 accumulation in another order: <= 1 ulp of the 16-bit result on almost every element), ragged N,
+    poisoned slabs, bias; identical bits run to run"""
+    from xllm_amd import _lib
+    g = torch.Generator().manual_seed(M * 3 + (dtype == torch.float16))
+    N, K = 1936, 576                         # 121 column groups, 9 K tiles of 64 elements
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, generator=g).to(dtype)
+    ref = orc.matmul(a, w, bias)
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    wp = ops.pack_weight_16(wd)
+    assert wp is not None
+    assert torch.equal(wp.view(torch.int8).view(N, 2 * K), ops.pack_weight_i8(wd.view(torch.int8).view(N, 2 * K)))   # bytes
+    ran = 0
+    try:
+        for ng in (1, 2, 3, 4, 5, 6, 8, 10):
+            for slices in (1, 2, 3):
+                _ws_plan(ng, slices)
+                out = torch.empty(M, N, dtype=dtype, device=DEV)
+                ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+                ws.fill_(0x7f)
+                rc = _lib.lib().xllm_mi355_matmul_packed(ad.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), M, N, K,
+                                                         1 if dtype == torch.bfloat16 else 2, ws.data_ptr(), ws.numel(),
+                                                         torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                if rc == -2:
+                    continue
+                assert rc == 0
+                ran += 1
+                assert_ulp_close(out, ref, dtype, ulps=1.0, min_exact=0.95)
+    finally:
+        _ws_plan(0, 0)
+    assert ran >= 6
+    old = ops._PACKED_16_POLICY
+    try:
+        ops._PACKED_16_POLICY = "1"
+        y1 = ops.matmul(ad, wd, bd, b_packed=wp)
+        y2 = ops.matmul(ad, wd, bd, b_packed=wp)
+    finally:
+        ops._PACKED_16_POLICY = old
+    assert torch.equal(y1, y2)
+    assert_ulp_close(y1, ref, dtype, ulps=1.0, min_exact=0.95)

@@ -61,7 +61,11 @@ for M in Ms:
         else:
             ws = [torch.randn(N, K, device=dev).bfloat16() for _ in range(copies)]
             a = torch.randn(M, K, device=dev).bfloat16()
-            fn = lambda i: ops.matmul(a, ws[i % copies])
+            if os.environ.get("GEMM_PACKED", "0") == "1":
+                wps = [ops.pack_weight_16(x) for x in ws]
+                fn = lambda i: ops.matmul(a, ws[i % copies], b_packed=wps[i % copies])
+            else:
+                fn = lambda i: ops.matmul(a, ws[i % copies])
             bytes_ = (N * K + M * K + M * N) * 2
         for i in range(3):
             fn(i)

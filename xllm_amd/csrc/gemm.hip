@@ -911,6 +911,20 @@ int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* w_packe
   return launch_gemm_ws_fp8(a, w_packed, M, N, K, epi, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+int xllm_mi355_pack_weight_16(const void* w, void* packed, int64_t N, int64_t K, void* stream) {
+  if (!w || !packed || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  return launch_pack_weight_i8(w, packed, N, K * 2, (hipStream_t)stream);   // the byte permutation of the 8-bit kinds, rows of 2 K bytes
+}
+
+int xllm_mi355_matmul_packed(const void* a, const void* w_packed, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                             int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0 || N == 0) return XM_OK;
+  GemmEpi epi{nullptr, 0, nullptr, 0, bias, out, nullptr, dtype == XM_BF16, nullptr, 0};
+  return launch_gemm_ws_h16(a, w_packed, M, N, K * 2, epi, workspace, ws_bytes, (hipStream_t)stream);
+}
+
 int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                       int dtype, void* stream) {
   if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;

@@ -183,6 +183,8 @@ int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64
                       size_t ws_bytes, int* n_slabs, hipStream_t s);
 int launch_gemm_ws_fp8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
                        size_t ws_bytes, hipStream_t s);
+int launch_gemm_ws_h16(const void* A, const void* Wp, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                       size_t ws_bytes, hipStream_t s);
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s);
 
 // gemm_wsb.hip: weight-stream GEMM for 16-bit weights at decode shapes (dense M <= 64, grouped with few rows per expert)

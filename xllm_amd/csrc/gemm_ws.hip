@@ -218,10 +218,61 @@ __device__ __forceinline__ void ws_compute_fp8(f32x4_t (&acc)[MB][NG], unsigned 
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- 16-bit weights (bf16 / f16, kernel::matmul = F::linear, kernels/dcu/matmul.cpp:20-25) on the same packed BYTE layout: a
+// K tile of 128 bytes is 64 elements, a k-step fragment (16 B per lane = 8 consecutive elements of one row) is the operand of
+// v_mfma_f32_16x16x32_{bf16,f16}; two MFMAs per (row block, column group) and K tile, like the int8 form. fp32 accumulation,
+// K tiles in order, K slices summed in slice order (deterministic); out = r16(acc + bias).
+template <int KIND>
+__device__ __forceinline__ f32x4_t ws_mma_h16(const u32x4 w, const u32x4 a, f32x4_t c) {
+  if constexpr (KIND == kBF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8_t, w), __builtin_bit_cast(gbf16x8_t, a), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gf16x8_t, w), __builtin_bit_cast(gf16x8_t, a), c, 0, 0, 0);
+}
+template <int KIND, int MB, int NG, int NDA, int NDW, int NG_LEFT>
+__device__ __forceinline__ void ws_h16_groups(f32x4_t (&acc)[MB][NG], u32x4 (&fw0)[NG], u32x4 (&fw1)[NG], const u32x4 (&a0)[MB],
+                                              const u32x4 (&a1)[MB], const WsDma& d, const int (&voff_a)[8],
+                                              const int (&voff_w)[8]) {
+  if constexpr (NG_LEFT > 0) {
+    constexpr int ng = NG - NG_LEFT;
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fw0[ng]), "+v"(fw1[ng]) : "n"(2 * (NG_LEFT - 1) > 15 ? 15 : 2 * (NG_LEFT - 1)));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(fw0[ng], a0[mb], acc[mb][ng]);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(fw1[ng], a1[mb], acc[mb][ng]);
+    ws_dma_slot_n<NDA, NDW, NG>(d, voff_a, voff_w, ng);
+    ws_h16_groups<KIND, MB, NG, NDA, NDW, NG_LEFT - 1>(acc, fw0, fw1, a0, a1, d, voff_a, voff_w);
+  }
+}
+template <int KIND, int MB, int NG, int NDA, int NDW>
+__device__ __forceinline__ void ws_compute_h16(f32x4_t (&acc)[MB][NG], unsigned rw, unsigned ra0, unsigned ra1, const WsDma& d,
+                                               const int (&voff_a)[8], const int (&voff_w)[8]) {
+  u32x4 a0[MB], a1[MB], fw0[NG], fw1[NG];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a0[mb], ra0, mb * 16 * WS_BK);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) WS_DSR(a1[mb], ra1, mb * 16 * WS_BK);
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    WS_DSR(fw0[ng], rw, ng * 2 * WS_FRAG);
+    WS_DSR(fw1[ng], rw, ng * 2 * WS_FRAG + WS_FRAG);
+  }
+  if constexpr (MB == 4)
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+  else
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a1[0]), "+v"(a1[1]));
+  ws_h16_groups<KIND, MB, NG, NDA, NDW, NG>(acc, fw0, fw1, a0, a1, d, voff_a, voff_w);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int KIND>
 struct WsAcc { using type = i32x4_t; };
 template <>
 struct WsAcc<kFP8> { using type = f32x4_t; };
+template <>
+struct WsAcc<kBF16> { using type = f32x4_t; };
+template <>
+struct WsAcc<kF16> { using type = f32x4_t; };
 
 // ---- epilogue shared by the weight-stream kernels. Accumulator layout: lane & 15 = m inside the row block, registers = four
 // consecutive n. Round 3 (in-kernel timing, profiles/r03_gemm_ws.txt): storing that layout directly -- 8-byte pieces, 16 rows x
@@ -268,7 +319,9 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = m_base + mb * 16 + ml, mc = m < M ? m : M - 1;
-    asv[mb] = epi.out ? (KIND == kI8 ? epi.a_scale[mc] : epi.a_scale[epi.a_scale_n > 1 ? mc : 0]) : 1.0f;
+    if constexpr (KIND == kI8) asv[mb] = epi.out ? epi.a_scale[mc] : 1.0f;
+    else if constexpr (KIND == kFP8) asv[mb] = epi.out ? epi.a_scale[epi.a_scale_n > 1 ? mc : 0] : 1.0f;
+    else asv[mb] = 1.0f;
   }
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
@@ -280,7 +333,7 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
       if constexpr (KIND == kI8) {
         const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
         wsv[0] = w4.x; wsv[1] = w4.y; wsv[2] = w4.z; wsv[3] = w4.w;
-      } else {
+      } else if constexpr (KIND == kFP8) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) wsv[e] = epi.w_scale[epi.w_scale_n > 1 ? n + e : 0];
       }
@@ -299,9 +352,12 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
       if constexpr (KIND == kI8) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * asv[mb] * wsv[e] + bsv[e];
-      } else {  // the fp8 epilogue of gemm_p8.hip: as * (ws * acc) + bias
+      } else if constexpr (KIND == kFP8) {  // the fp8 epilogue of gemm_p8.hip: as * (ws * acc) + bias
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = asv[mb] * (wsv[e] * acc[mb][ng][e]) + bsv[e];
+      } else {                              // 16-bit linear: acc + bias (gemm_p8.hip)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mb][ng][e] + bsv[e];
       }
       uint2 pk;
       if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
@@ -336,7 +392,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
   static_assert(NWV == 4 || NWV == 8, "one or two waves per SIMD");
   static_assert(WM * WN == NWV, "waves per workgroup");
   static_assert(MB == 2 || MB == 4, "row blocks per wave");
-  static_assert(KIND == kI8 || KIND == kFP8, "8-bit operand kinds");
+  static_assert(KIND == kI8 || KIND == kFP8 || KIND == kBF16 || KIND == kF16, "operand kinds");
   using acc_t = typename WsAcc<KIND>::type;
   constexpr int G = WN * NG;              // 16-column groups of a workgroup tile
   constexpr int NS = DW + 1;              // LDS slots
@@ -476,7 +532,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
     const unsigned so = (t % NS) * SLOT;
 #ifndef WS_ABL_NOCOMPUTE
     if constexpr (KIND == kI8) ws_compute<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
-    else ws_compute_fp8<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
+    else if constexpr (KIND == kFP8) ws_compute_fp8<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
+    else ws_compute_h16<KIND, MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
 #else
     WS_ISSUE(tn)
 #endif
@@ -693,9 +750,16 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
         for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], w1[ng], a1[mb]);
         if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, NG + ng, 2 * NG);
         else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, NG + ng, 2 * NG);
-      } else {
+      } else if constexpr (KIND == kFP8) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_fp8(w0[ng], w1[ng], a0[mb], a1[mb], acc[mb][ng]);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, NG);
+        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, NG);
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(w0[ng], a0[mb], acc[mb][ng]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(w1[ng], a1[mb], acc[mb][ng]);
         if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, NG);
         else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, NG);
       }
@@ -759,11 +823,14 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         v[e] = (float)a[e] * as * epi.w_scale[n + e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
-    } else {
+    } else if constexpr (KIND == kFP8) {
       const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         v[e] = as * (epi.w_scale[epi.w_scale_n > 1 ? n + e : 0] * a[e]) + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a[e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
     }
     uint2 pk;
     if (epi.out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
@@ -937,6 +1004,12 @@ int launch_gemm_ws_i8(const void* A, const void* Wp, int64_t M, int64_t N, int64
 int launch_gemm_ws_fp8(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
                        size_t ws_bytes, hipStream_t s) {
   return launch_gemm_ws<kFP8>(A, Wp, M, N, K, epi, workspace, ws_bytes, nullptr, s);
+}
+// 16-bit weights: Kb = K * 2 BYTES per row (the kernel and the packing work on bytes)
+int launch_gemm_ws_h16(const void* A, const void* Wp, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
+                       size_t ws_bytes, hipStream_t s) {
+  if (epi.out_bf16) return launch_gemm_ws<kBF16>(A, Wp, M, N, Kb, epi, workspace, ws_bytes, nullptr, s);
+  return launch_gemm_ws<kF16>(A, Wp, M, N, Kb, epi, workspace, ws_bytes, nullptr, s);
 }
 
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s) {

@@ -14,6 +14,7 @@ not a checkpoint loader.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -71,7 +72,7 @@ class QuantLinear:
     int8 scales are per output channel over the FULL K (a checkpoint is quantised before it is sharded)."""
 
     def __init__(self, n: int, k: int, bias: bool, mode: str, dtype, device, gen, row_parallel_pg=None, shard=None,
-                 col_blocks=None):
+                 col_blocks=None, pack16: bool = True):
         self.mode, self.dtype, self.pg = mode, dtype, row_parallel_pg
         self.weight_packed = None
         if mode == "int8":
@@ -119,6 +120,8 @@ class QuantLinear:
             self.weight_packed = ops.pack_weight_i8(self.weight)
         elif mode == "fp8" and self.weight.is_cuda:
             self.weight_packed = ops.pack_weight_fp8(self.weight)
+        elif self.weight.is_cuda and self.weight.dtype in (torch.bfloat16, torch.float16) and pack16:
+            self.weight_packed = ops.pack_weight_16(self.weight)     # (cfg2: BASELINE config 2 runs 16-bit linears at M = 64)
 
     def forward(self, x, pre_quant=None, reduce: bool = True):
         """`reduce=False`: a row-parallel shard returns its PARTIAL sums (the caller fuses the all-reduce with what follows)"""
@@ -129,7 +132,7 @@ class QuantLinear:
             q, s = pre_quant if pre_quant is not None else ops.fp8_scaled_quantize(x)
             y = ops.fp8_scaled_matmul(q, self.weight, s, self.w_scale, self.dtype, self.bias, b_packed=self.weight_packed)
         else:
-            y = ops.matmul(x, self.weight, self.bias)
+            y = ops.matmul(x, self.weight, self.bias, b_packed=self.weight_packed)
         return parallel.reduce(y, self.pg) if (self.pg is not None and reduce) else y
 
     def weight_bytes(self) -> int:
@@ -341,7 +344,8 @@ class Qwen2Model:
                        for _ in range(n_layers if n_layers is not None else args.n_layers)]
         self.norm_w = (torch.rand(args.hidden_size, device=device, generator=gen) + 0.5).to(dtype)
         self.lm_head = QuantLinear(args.vocab_size, args.hidden_size, False, "16bit", dtype, device, gen,
-                                   shard=("col", tp.rank() if tp else 0, tp_size))
+                                   shard=("col", tp.rank() if tp else 0, tp_size),
+                                   pack16=os.environ.get("XLLM_MI355_PACK_LM_HEAD", "1") == "1")
         self.embed = (torch.randn(args.vocab_size, args.hidden_size, device=device, generator=gen)).to(dtype)
         self.cos_sin = build_cos_sin_cache(args, dtype, device, 8192)
 

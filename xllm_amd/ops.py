@@ -460,8 +460,36 @@ def fp8_scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=
     return out
 
 
-def matmul(a, b, bias=None):
-    """dcu::matmul(a, w, bias) == F::linear (kernels/dcu/matmul.cpp:20-25); a [..., K], w [N, K]."""
+def pack_weight_16(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """xllm_mi355_pack_weight_16: [N, K] bf16 / f16 row-major -> MFMA-fragment order (the 8-bit kinds' byte permutation on rows of
+    2 K bytes) for the weight-stream decode GEMM; once, at weight-load time. None outside the envelope (N % 16, K % 64)."""
+    _need_cuda(w)
+    N, K = w.shape
+    if w.dtype not in (torch.bfloat16, torch.float16) or not w.is_contiguous() or N % 16 or K % 64:
+        return None
+    out = torch.empty_like(w)
+    check(_lib.lib().xllm_mi355_pack_weight_16(_p(w), _p(out), N, K, _stream()), "pack_weight_16")
+    return out
+
+
+_PACKED_16_POLICY = os.environ.get("XLLM_MI355_PACKED_16", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
+
+
+def _prefer_packed_16(M: int, N: int, K: int) -> bool:
+    """16-bit decode linears on packed weights: a single pass over the weights in fragment order"""
+    if _PACKED_16_POLICY == "0":
+        return False
+    if _PACKED_16_POLICY == "1":
+        return M <= 512
+    # measured (profiles/r03_gemm_ws16.txt, Qwen2-7B shapes, us): M = 64 gate_up 79.6 -> 46.1 (6.0 TB/s), down 45.2 -> 32.9,
+    # lm_head 257 -> 218; M = 256 gate_up 94.7 -> 79.8, down 79.4 -> 51.7; at M <= 32 the small projections (qkv, o) are 1-2 us
+    # faster on the no-LDS row-major weight-stream kernel (gemm_wsb.hip), the large ones 15-23 us faster here
+    return M <= 512 and (M > 32 or N * K >= 48 * 1024 * 1024)
+
+
+def matmul(a, b, bias=None, b_packed=None):
+    """dcu::matmul(a, w, bias) == F::linear (kernels/dcu/matmul.cpp:20-25); a [..., K], w [N, K]. `b_packed` = pack_weight_16(w):
+    decode-shaped calls then stream the weights in fragment order (same semantics, another fp32 summation order)."""
     _need_cuda(a, b)
     K = a.size(-1)
     a2 = a.reshape(-1, K)
@@ -469,6 +497,13 @@ def matmul(a, b, bias=None):
         a2 = a2.contiguous()
     N = b.size(0)
     out = torch.empty(a2.size(0), N, dtype=a.dtype, device=a.device)
+    if b_packed is not None and _prefer_packed_16(a2.size(0), N, K):
+        ws = _slab_workspace(a.device)
+        rc = _lib.lib().xllm_mi355_matmul_packed(_p(a2), _p(b_packed), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
+                                                 ws.data_ptr(), ws.numel(), _stream())
+        if rc not in (-2, -4):
+            check(rc, "matmul_packed")
+            return out.view(*a.shape[:-1], N)
     if a2.size(0) <= 512:
         _ensure_gemm_workspace(a.device, 1)  # decode shapes may split K through it (fp32 slabs, deterministic reduce)
     b_c = b.contiguous()  # keep the (possibly new) tensor alive across the call
