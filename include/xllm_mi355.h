@@ -242,6 +242,23 @@ XM_API int xllm_mi355_set_gemm_workspace(void* workspace, size_t bytes);
  * ws == NULL unregisters the stream. At most 64 streams (all devices together). */
 XM_API int xllm_mi355_set_gemm_workspace_for_stream(void* stream, void* ws, size_t bytes);
 
+/* N1 fusion across the GEMM boundary (round 3): DenseMLP's gate_up_proj with its SiLU.mul fused into the GEMM epilogue, for the
+ * W8A8 path (dense_mlp.cpp:97-116: gate_up_proj -> act_fn(gate) * up; linear.cpp:481-507: scaled_quantize -> scaled_matmul).
+ * w [N = 2 I, K] int8 row-major, rows [0, I) = gate, [I, 2 I) = up (the reference's merged weight); w_packed = its
+ * xllm_mi355_pack_weight_i8 copy (either may be NULL: packed serves M <= 512, row-major any M). The kernel computes the gate and
+ * the up columns of the same act columns in one workgroup and writes act[m, i] = rT(rT(silu(g)) * u), g / u = the 16-bit
+ * scaled_matmul outputs rT(acc * a_scale[m] * w_scale[n] + bias[n]), to act_out [M, I] -- bit-identical to scaled_matmul ->
+ * act_and_mul -- and folds every row's |max| into row_amax [M] (f32; atomic max, MUST be zero on entry). Then
+ * xllm_mi355_quantize_with_row_amax(act_out, row_amax, q, scale): q = rint(act * 127 / amax), scale = amax / 127
+ * (scaled_quantize's expression) in one pass, and row_amax is zero again. The gate_up output (2 I columns of 16-bit values) is
+ * never written. N % 256 == 0, K % 128 == 0; `workspace` is unused by this mode (K is never sliced) and may be NULL. */
+XM_API int xllm_mi355_scaled_matmul_gate_up_act(const int8_t* a, const int8_t* w, const int8_t* w_packed, const float* a_scale,
+                                                const float* w_scale, const void* bias, void* act_out, float* row_amax,
+                                                int64_t M, int64_t N, int64_t K, int dtype, void* workspace, size_t ws_bytes,
+                                                void* stream);
+XM_API int xllm_mi355_quantize_with_row_amax(const void* act, float* row_amax, int8_t* out_q, float* out_scale,
+                                             int64_t n_tokens, int64_t d, int dtype, void* stream);
+
 /* ---- fp8 (OCP e4m3fn) ------------------------------------------------------------------------
  * kernel::static_scaled_fp8_quant (ops_api.h:160) -> kernels/cuda/fp8_quant.cu:115-155 */
 XM_API int xllm_mi355_static_scaled_fp8_quant(uint8_t* out, const void* input, const float* scale,

@@ -1837,3 +1837,48 @@ def test_packed_16bit_gemm_over_tile_shapes(M, dtype):
         ops._PACKED_16_POLICY = old
     assert torch.equal(y1, y2)
     assert_ulp_close(y1, ref, dtype, ulps=1.0, min_exact=0.95)
+
+
+# ------------------------------------------------------------------------------------------- gate_up GEMM with SiLU.mul fused
+@pytest.mark.parametrize("M,I,K", [(1, 128, 512), (17, 384, 1024), (64, 1280, 512), (128, 18944, 3584), (256, 18944, 3584),
+                                   (300, 640, 512), (512, 2432, 1152), (600, 1024, 512), (1500, 2432, 1152), (8192, 4736, 3584)])
+def test_gate_up_silu_mul_fusion_equals_separate_ops(M, I, K):
+    """scaled_matmul_silu_mul_quant (gate_up GEMM whose epilogue applies SiLU(gate) * up and folds the row maxima, then one
+    quantising pass) == scaled_matmul -> act_and_mul_dynamic_int8_quant, bit for bit (q and scale), on the packed kernels
+    (M <= 512: every tile family) and on the 256 x 256 8-phase kernel (larger M); the row-amax scratch is zero again afterwards;
+    twice in a row on the same scratch"""
+    g = torch.Generator().manual_seed(M + I + K)
+    N = 2 * I
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.004 + 0.0005).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.004 + 0.0005).to(DEV)
+    wp = ops.pack_weight_i8(w)
+    gate_up = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None)
+    q_ref, s_ref = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+    for _ in range(2):
+        out = ops.scaled_matmul_silu_mul_quant(a, w, a_s, w_s, torch.bfloat16, None, b_packed=wp)
+        assert out is not None
+        assert torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref)
+    assert all(float(v.abs().max()) == 0.0 for v in ops._row_amax.values())
+    if M <= 512:      # every width of the tile family, the four-wave and the in-phase eight-wave arms
+        try:
+            for waves in (0, 4, 80):
+                _ws_waves(waves)
+                for ng in (1, 2, 3, 4, 5, 6, 8, 10):
+                    _ws_plan(ng, 0)
+                    out = ops.scaled_matmul_silu_mul_quant(a, w, a_s, w_s, torch.bfloat16, None, b_packed=wp)
+                    assert out is not None and torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref), (waves, ng)
+        finally:
+            _ws_plan(0, 0)
+            _ws_waves(0)
+    # row-major weights only (no packed copy): the 8-phase kernel serves any M
+    out = ops.scaled_matmul_silu_mul_quant(a, w, a_s, w_s, torch.bfloat16, None, b_packed=None)
+    assert out is not None and torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref)
+
+
+def test_gate_up_fusion_declines_outside_its_envelope():
+    a = torch.zeros(8, 512, dtype=torch.int8, device=DEV)
+    w = torch.zeros(2 * 96, 512, dtype=torch.int8, device=DEV)          # I = 96: not a multiple of the 128-column act tile
+    s1, s2 = torch.ones(8, device=DEV), torch.ones(192, device=DEV)
+    assert ops.scaled_matmul_silu_mul_quant(a, w, s1, s2) is None

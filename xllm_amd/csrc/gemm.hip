@@ -880,6 +880,27 @@ int xllm_mi355_scaled_matmul_rope_cache_packed(const int8_t* a, const int8_t* w_
                                     rot_dim, block_size, n_blocks, is_neox, dtype, (hipStream_t)stream);
 }
 
+int xllm_mi355_scaled_matmul_gate_up_act(const int8_t* a, const int8_t* w, const int8_t* w_packed, const float* a_scale,
+                                         const float* w_scale, const void* bias, void* act_out, float* row_amax, int64_t M,
+                                         int64_t N, int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || (!w && !w_packed) || !a_scale || !w_scale || !act_out || !row_amax || M < 0 || N <= 0 || K <= 0)
+    return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (N % 256 != 0 || K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)act_out % 16) || ((uintptr_t)w_scale % 16))
+    return XM_ERR_UNSUPPORTED;                                   // I = N / 2 a multiple of the 128-column act tile
+  if (M == 0) return XM_OK;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0};
+  epi.gate_up = 1;
+  epi.act_out = act_out;
+  epi.row_amax = row_amax;
+  if (w_packed && M <= 512) {
+    const int rc = launch_gemm_ws_i8(a, w_packed, M, N, K, epi, workspace, ws_bytes, nullptr, (hipStream_t)stream);
+    if (rc != XM_ERR_UNSUPPORTED) return rc;
+  }
+  if (!w || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;
+  return launch_gemm_p8<kI8>(a, w, M, N, K, epi, nullptr, 0, 1, (hipStream_t)stream);   // 256 x 256 tiles, any M
+}
+
 int xllm_mi355_fp8_scaled_matmul(const uint8_t* a, const uint8_t* w, const float* a_scale, int64_t a_scale_numel,
                                  const float* w_scale, int64_t w_scale_numel, const void* bias, void* out, int64_t M,
                                  int64_t N, int64_t K, int out_dtype, void* stream) {

@@ -115,6 +115,76 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
   }
 }
 
+// gate_up projection with the SiLU.mul of DenseMLP fused (GemmEpi::gate_up, round 3; prefill shapes). Tile nt covers ACT columns
+// [nt * 128, + 128): its W slots nh = 0 hold the gate rows of those columns, nh = 1 the up rows (rows I + ...), so a wave's
+// accumulator blocks nb = 0, 1 are the gate values and nb = 2, 3 the up values of the SAME (row, column) positions: the
+// activation is lane-local. rT(acc * a_scale * w_scale + bias) for both, act = rT(rT(silu(g)) * u) (act_and_mul_i8_reg_kernel's
+// expression), transposed through wave-private LDS for 16-byte row-segment stores; the row |max| of the per-token int8
+// quantisation that follows goes through a per-row LDS maximum into GemmEpi::row_amax (atomic max on float bits).
+template <bool OUT_BF16>
+__device__ __forceinline__ void p8i_epilogue_gate_up(i32x4_t (&acc)[8][4], uint8_t* lds, int M, int N, int m0, int nt, int wr,
+                                                     int wc, int wave, int lane, int tid, const GemmEpi& epi) {
+  using T = typename std::conditional<OUT_BF16, bf16_t, f16_t>::type;
+  constexpr int PITCH = 80;                      // 32 act columns x 2 B + 16
+  const int g4 = lane >> 4, ml = lane & 15;
+  const int64_t I = N / 2;
+  __builtin_amdgcn_s_barrier();                  // every wave has drained its DMAs and finished its fragment reads
+  unsigned* const rowmax = reinterpret_cast<unsigned*>(lds + 8 * 128 * PITCH);
+  if (tid < 256) rowmax[tid] = 0u;
+  __builtin_amdgcn_s_barrier();
+  uint8_t* const tb = lds + wave * (128 * PITCH);
+  const int ncol0 = nt * 128 + wc * 32;          // first act column of the wave
+  float wg[2][4], wu[2][4], bg[2][4], bu[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = ncol0 + nb * 16 + 4 * g4;
+    const float4 a4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+    const float4 b4 = *reinterpret_cast<const float4*>(epi.w_scale + I + n);
+    wg[nb][0] = a4.x; wg[nb][1] = a4.y; wg[nb][2] = a4.z; wg[nb][3] = a4.w;
+    wu[nb][0] = b4.x; wu[nb][1] = b4.y; wu[nb][2] = b4.z; wu[nb][3] = b4.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bg[nb][e] = epi.bias ? load16(epi.bias, n + e, OUT_BF16) : 0.0f;
+      bu[nb][e] = epi.bias ? load16(epi.bias, I + n + e, OUT_BF16) : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int m = m0 + wr * 128 + mb * 16 + ml;
+    const float as = epi.a_scale[m < M ? m : M - 1];
+    float amax = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float r[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g = r16<T>((float)acc[mb][nb][e] * as * wg[nb][e] + bg[nb][e]);
+        const float u = r16<T>((float)acc[mb][nb + 2][e] * as * wu[nb][e] + bu[nb][e]);
+        r[e] = r16<T>(r16<T>(act_f<XM_ACT_SILU>(g)) * u);
+        amax = fmaxf(amax, fabsf(r[e]));
+      }
+      uint2 pk;
+      pk.x = pack2x16<OUT_BF16>(r[0], r[1]);
+      pk.y = pack2x16<OUT_BF16>(r[2], r[3]);
+      *reinterpret_cast<uint2*>(tb + (mb * 16 + ml) * PITCH + nb * 32 + g4 * 8) = pk;
+    }
+    if (m < M) atomicMax(&rowmax[wr * 128 + mb * 16 + ml], __float_as_uint(amax));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own writes (in-order LDS queue): visible to its reads below
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                  // 128 rows x 4 chunks of 8 columns over 64 lanes
+    const int idx = i * 64 + lane, row = idx >> 2, c = idx & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(tb + row * PITCH + c * 16);
+    const int m = m0 + wr * 128 + row;
+    if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + ncol0 + c * 8) = v;
+  }
+  __builtin_amdgcn_s_barrier();
+  if (tid < 256) {
+    const int m = m0 + tid;
+    if (m < M && rowmax[tid]) atomicMax(reinterpret_cast<unsigned*>(epi.row_amax) + m, rowmax[tid]);
+  }
+}
+
 template <bool SPLITK>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A_in,
                                                                 const uint8_t* __restrict__ W_in, int M_in, int N,
@@ -217,6 +287,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
         voff_a[i][h] = (int)((int64_t)ar * Kb) + scol;
         // W slot (nh = h): LDS row wc*32 + c  <->  weight row n0 + wc*64 + h*32 + c, wc = (i*64 + srow) / 32
         int wrow = n0 + (i * 2 + (srow >> 5)) * 64 + h * 32 + (srow & 31);
+        if (epi.gate_up)   // slot nh = 0: gate rows of act columns nt*128 + wc*32 + c; nh = 1: their up rows (I = N / 2 further)
+          wrow = h * (N / 2) + nt * 128 + (i * 2 + (srow >> 5)) * 32 + (srow & 31);
         wrow = wrow < N ? wrow : N - 1;
         voff_w[i][h] = (int)((int64_t)wrow * Kb) + scol;
       }
@@ -348,6 +420,13 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
 #undef P8I_MMA
 #undef P8I_RD_W
 #undef P8I_RD_A
+  if constexpr (!SPLITK) {
+    if (epi.gate_up) {
+      if (epi.out_bf16) p8i_epilogue_gate_up<true>(acc, lds, M, N, m0, nt, wr, wc, wave, lane, tid, epi);
+      else p8i_epilogue_gate_up<false>(acc, lds, M, N, m0, nt, wr, wc, wave, lane, tid, epi);
+      return;
+    }
+  }
   if (epi.out_bf16) p8i_epilogue<SPLITK, true>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
   else p8i_epilogue<SPLITK, false>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
 }

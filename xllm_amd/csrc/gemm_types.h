@@ -81,6 +81,14 @@ struct GemmEpi {
   const int32_t* gather_rows;
   int gather_div;
   int gather_src_rows;  // rows of the un-expanded A
+  // round 3: gate_up projection with the SiLU.mul of DenseMLP fused into the epilogue (dense_mlp.cpp:97-116: gate_up_proj ->
+  // act_fn(gate) * up; linear.cpp:481-507). N = 2 I, weight rows [0, I) = gate, [I, 2 I) = up. The kernel computes the gate and
+  // the up columns of the SAME act columns in one workgroup, writes act = rT(rT(silu(g)) * u) [M, I] (16 bit) to act_out and
+  // folds each row's |max| into row_amax (atomic max on the bits of a non-negative float; zero at rest) for the per-token int8
+  // quantisation that follows (xllm_mi355_quantize_with_row_amax). epi.out is unused in this mode.
+  int gate_up;
+  void* act_out;
+  float* row_amax;
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {

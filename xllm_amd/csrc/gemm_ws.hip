@@ -378,6 +378,93 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
   }
 }
 
+// ---- gate_up epilogue with SiLU.mul fused (GemmEpi::gate_up; int8 only). Slot groups [0, G / 2) of the workgroup tile hold the
+// GATE columns of act groups ga0 .. ga0 + ga_live, slots [G / 2, G) the UP columns of the same act groups. Phase 1: every wave
+// dequantises its accumulators exactly like the plain epilogue (rT(acc * a_scale * w_scale + bias)) into ONE workgroup-shared
+// 16-bit tile in the LDS; phase 2: every thread takes (row, 8 act columns) items, reads the gate and the up chunk, computes
+// rT(rT(silu(g)) * u) -- act_and_mul_i8_reg_kernel's expression, bit for bit -- stores 16 bytes of act and folds the |max|
+// into a per-row LDS maximum, which leaves the workgroup as one atomic max per row.
+template <int MB, int NG, int WM, int WN, int NWV>
+__device__ __forceinline__ void ws_epilogue_gate_up(i32x4_t (&acc)[MB][NG], const GemmEpi& epi, int M, int N, int m_tile0, int wm,
+                                                    int wn, int lane, int tid, int ga0, int ga_live, int n_groups_act,
+                                                    uint8_t* lds) {
+  constexpr int G = WN * NG, GH = G / 2, ROWS = WM * MB * 16, PITCH = G * 32 + 16;
+  static_assert(G % 2 == 0 && ROWS * PITCH + ROWS * 4 <= 160 * 1024, "gate_up tile");
+  const int g4 = lane >> 4, ml = lane & 15;
+  const bool out_bf16 = epi.out_bf16 != 0, has_bias = epi.bias != nullptr;
+  unsigned* const rowmax = reinterpret_cast<unsigned*>(lds + ROWS * PITCH);
+  for (int r = tid; r < ROWS; r += NWV * 64) rowmax[r] = 0u;
+  float asv[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m_tile0 + wm * MB * 16 + mb * 16 + ml;
+    asv[mb] = epi.a_scale[m < M ? m : M - 1];
+  }
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int q = wn * NG + ng, half = q / GH, j = q % GH;
+    const int jl = j < ga_live ? j : 0;                                     // (dead slots compute on a valid column, never read)
+    const int n = (half * n_groups_act + ga0 + jl) * 16 + 4 * g4;
+    const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+    const float wsv[4] = {w4.x, w4.y, w4.z, w4.w};
+    float bsv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bsv[e] = load16(epi.bias, n + e, out_bf16);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * asv[mb] * wsv[e] + bsv[e];
+      uint2 pk;
+      if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
+      else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
+      *reinterpret_cast<uint2*>(lds + (wm * MB * 16 + mb * 16 + ml) * PITCH + q * 32 + g4 * 8) = pk;
+    }
+  }
+  __syncthreads();
+  const int64_t I = (int64_t)n_groups_act * 16;
+  for (int item = tid; item < ROWS * G; item += NWV * 64) {
+    const int row = item / G, c = item % G, j = c >> 1, hc = c & 1;
+    const int m = m_tile0 + row;
+    if (j >= ga_live || m >= M) continue;
+    const uint4 gv = *reinterpret_cast<const uint4*>(lds + row * PITCH + j * 32 + hc * 16);
+    const uint4 uv = *reinterpret_cast<const uint4*>(lds + row * PITCH + (GH + j) * 32 + hc * 16);
+    const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w};
+    uint32_t ow[4];
+    float amax = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float r0, r1;
+      if (out_bf16) {
+        r0 = r16<bf16_t>(r16<bf16_t>(act_f<XM_ACT_SILU>(bf16_bits_to_f32(gw[w] & 0xffffu))) * bf16_bits_to_f32(uw[w] & 0xffffu));
+        r1 = r16<bf16_t>(r16<bf16_t>(act_f<XM_ACT_SILU>(bf16_bits_to_f32(gw[w] >> 16))) * bf16_bits_to_f32(uw[w] >> 16));
+        ow[w] = f32_to_bf16_bits(r0) | ((uint32_t)f32_to_bf16_bits(r1) << 16);
+      } else {
+        uint16_t g0h = (uint16_t)(gw[w] & 0xffffu), g1h = (uint16_t)(gw[w] >> 16), u0h = (uint16_t)(uw[w] & 0xffffu), u1h = (uint16_t)(uw[w] >> 16);
+        f16_t g0f, g1f, u0f, u1f;
+        __builtin_memcpy(&g0f, &g0h, 2); __builtin_memcpy(&g1f, &g1h, 2); __builtin_memcpy(&u0f, &u0h, 2); __builtin_memcpy(&u1f, &u1h, 2);
+        r0 = r16<f16_t>(r16<f16_t>(act_f<XM_ACT_SILU>((float)g0f)) * (float)u0f);
+        r1 = r16<f16_t>(r16<f16_t>(act_f<XM_ACT_SILU>((float)g1f)) * (float)u1f);
+        const f16_t o0 = (f16_t)r0, o1 = (f16_t)r1;
+        uint16_t o0h, o1h;
+        __builtin_memcpy(&o0h, &o0, 2); __builtin_memcpy(&o1h, &o1, 2);
+        ow[w] = (uint32_t)o0h | ((uint32_t)o1h << 16);
+      }
+      amax = fmaxf(amax, fmaxf(fabsf(r0), fabsf(r1)));
+    }
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + (int64_t)(ga0 + j) * 16 + hc * 8) =
+        make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    atomicMax(&rowmax[row], __float_as_uint(amax));       // non-negative floats order like their bits (NaN: above everything)
+  }
+  __syncthreads();
+  for (int r = tid; r < ROWS; r += NWV * 64) {
+    const int m = m_tile0 + r;
+    if (m < M && rowmax[r]) atomicMax(reinterpret_cast<unsigned*>(epi.row_amax) + m, rowmax[r]);
+  }
+}
+
 // wave tile: MB 16-row blocks x NG 16-column groups; workgroup: WM x WN waves (four or eight); DW K tiles in flight. BOTH
 // operands go HBM / L2 -> LDS by LDS-DMA in fragment order, so that every VMEM operation of a wave is an LDS-DMA with the same
 // prefetch distance: vmcnt retires in order, and with activation loads into registers next to the weight DMAs the weights could
@@ -436,8 +523,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
   const int n_groups = N >> 4;
   // balanced column split: tile nt owns groups [nt * n_groups / n_tiles, (nt + 1) * n_groups / n_tiles) -- at most G of them
   // (the launcher guarantees it), so that 2368 groups over 256 workgroups become 9 or 10 groups each instead of 197 x 12 + 4
-  const int g0 = (int)((int64_t)nt * n_groups / n_tiles);
-  const int g_live = (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
+  // gate_up mode (GemmEpi::gate_up): the tile owns ACT groups [ga0, ga0 + ga_live) -- its first G / 2 slot groups are their gate
+  // columns, the other G / 2 their up columns (groups n_groups / 2 + ...); the descriptor then spans the whole matrix
+  const bool gu = KIND == kI8 && epi.gate_up != 0;
+  const int n_groups_act = n_groups >> 1;
+  const int ga0 = gu ? (int)((int64_t)nt * n_groups_act / n_tiles) : 0;
+  const int ga_live = gu ? (int)((int64_t)(nt + 1) * n_groups_act / n_tiles) - ga0 : 0;
+  const int g0 = gu ? 0 : (int)((int64_t)nt * n_groups / n_tiles);
+  const int g_live = gu ? n_groups : (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
   const int m_tile0 = mt * (WM * MB * 16), m_base = m_tile0 + wm * (MB * 16);
 
   // ---- sources (rows past M and column groups past N read as zeros: buffer range check)
@@ -461,7 +554,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
 #pragma unroll
   for (int i = 0; i < NDW; ++i) {
     const int f = wave * NDW + i;
-    voff_w[i] = i < nvalid_w ? (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
+    int grp_i = f >> 1;
+    bool ok = i < nvalid_w;
+    if (gu) {   // slot group -> (gate | up) group of the act group it belongs to
+      const int half = grp_i / (G / 2), j = grp_i % (G / 2);
+      ok = ok && j < ga_live;
+      grp_i = half * n_groups_act + ga0 + j;
+    }
+    voff_w[i] = ok ? grp_i * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
   }
   const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
   const ws_lds_ptr_t lds_dump = lds3 + NS * SLOT;  // (only addressed when PAD)
@@ -552,6 +652,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
   }
 
   __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed and nobody reads the ring any more: the epilogue re-uses the LDS
+  if constexpr (KIND == kI8 && (WN * NG) % 2 == 0) {
+    if (gu) {
+      ws_epilogue_gate_up<MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
+      return;
+    }
+  }
   ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
 }
 
@@ -621,8 +727,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   kt1 = kt1 > KT ? KT : kt1;
   const int nk = kt1 - kt0;
   const int n_groups = N >> 4;
-  const int g0 = (int)((int64_t)nt * n_groups / n_tiles);
-  const int g_live = (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
+  // gate_up mode (GemmEpi::gate_up): the tile owns ACT groups [ga0, ga0 + ga_live) -- its first G / 2 slot groups are their gate
+  // columns, the other G / 2 their up columns (groups n_groups / 2 + ...); the descriptor then spans the whole matrix
+  const bool gu = KIND == kI8 && epi.gate_up != 0;
+  const int n_groups_act = n_groups >> 1;
+  const int ga0 = gu ? (int)((int64_t)nt * n_groups_act / n_tiles) : 0;
+  const int ga_live = gu ? (int)((int64_t)(nt + 1) * n_groups_act / n_tiles) - ga0 : 0;
+  const int g0 = gu ? 0 : (int)((int64_t)nt * n_groups / n_tiles);
+  const int g_live = gu ? n_groups : (int)((int64_t)(nt + 1) * n_groups / n_tiles) - g0;
   const int m_tile0 = mt * (WM * MB * 16), m_base = m_tile0 + wm * (MB * 16);
 
   const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -640,7 +752,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
 #pragma unroll
   for (int i = 0; i < NDW; ++i) {
     const int f = wave * NDW + i;
-    voff_w[i] = i < nvalid_w ? (f >> 1) * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
+    int grp_i = f >> 1;
+    bool ok = i < nvalid_w;
+    if (gu) {   // slot group -> (gate | up) group of the act group it belongs to
+      const int half = grp_i / (G / 2), j = grp_i % (G / 2);
+      ok = ok && j < ga_live;
+      grp_i = half * n_groups_act + ga0 + j;
+    }
+    voff_w[i] = ok ? grp_i * KT * (2 * WS_FRAG) + (f & 1) * WS_FRAG + lane * 16 : 0x7ffff000;
   }
   const ws_lds_ptr_t lds3 = (ws_lds_ptr_t)lds;
   const ws_lds_ptr_t lds_dump = lds3 + NS * SLOT;
@@ -782,7 +901,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   if constexpr (KIND == kI8)
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
   __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed: the epilogue re-uses the LDS
-  ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
+  if constexpr (KIND == kI8) {
+    if (gu) ws_epilogue_gate_up<MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
+  }
+  if (!gu) ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
 #ifdef WS8_TIMING
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been accepted
@@ -862,12 +984,17 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
                          int32_t* slabs, hipStream_t s) {
   constexpr int G = WN * NG;
   const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
-  const int n_groups = (int)(N / 16);
+  // gate_up mode: a tile holds G / 2 ACT groups (their gate and their up columns); the split is over the N / 32 act groups
+  const bool gu = epi.gate_up != 0;
+  if (gu && (G % 2 != 0 || KIND != kI8)) return -1;
+  const int n_groups = gu ? (int)(N / 32) : (int)(N / 16);
   const int KT = (int)(K / WS_BK);
+  if (gu) slices = 1;
   int per = (KT + slices - 1) / slices;
   slices = (KT + per - 1) / per;  // no empty slice
   // at least ceil(n_groups / G) column tiles; more (narrower, balanced) ones while the grid still fits one round of 256 CUs
-  int n_tiles = (n_groups + G - 1) / G;
+  constexpr int GCAP = G;   // (gate_up: capacity G / 2 act groups, applied below)
+  int n_tiles = gu ? (n_groups + G / 2 - 1) / (G / 2) : (n_groups + GCAP - 1) / GCAP;
   const int fit = 256 / (m_tiles * slices);
   if (fit > n_tiles) n_tiles = fit < n_groups ? fit : n_groups;
   const int rest = n_tiles * slices;
@@ -894,7 +1021,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
 static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
 static int f_waves = -2;          // XLLM_MI355_WS_WAVES / xllm_mi355_debug_ws_waves: 4 = the round-2 four-wave 256-row tile (A/B)
-static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes) {
+static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes, bool gu = false) {
   if (f_ng == -2) {
     const char* e = getenv("XLLM_MI355_WS_NG");
     f_ng = e ? atoi(e) : -1;
@@ -914,12 +1041,15 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   else { p.waves = 8; p.wm = 4; p.wn = 2; p.mb = 4; }
   const int rows = p.wm * p.mb * 16;
   const int m_tiles = (int)((M + rows - 1) / rows);
-  const int n_groups = (int)(N / 16), KT = (int)(K / WS_BK);
+  // gate_up mode: the columns are split over the N / 32 act groups and a tile of G slot groups holds G / 2 of them
+  const int n_groups = gu ? (int)(N / 32) : (int)(N / 16), KT = (int)(K / WS_BK);
+  const int cap_div = gu ? 2 : 1;
+  if (gu) can_slice = false;
   // candidates of the family, narrowest first (a narrower ring slot = more tiles in flight in the same LDS)
   static const int ngs_w1[] = {2, 4, 6, 8, 10}, ngs_w2[] = {1, 2, 3, 4, 5}, ngs_w4[] = {1, 2, 3};
   const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);
   const int n_ngs = p.wn == 4 ? 3 : 5;
-  const int g_max = p.wn * ngs[n_ngs - 1];
+  const int g_max = p.wn * ngs[n_ngs - 1] / cap_div;
   const int per_simd = p.waves / 4;  // waves sharing one matrix pipe
   double best = 1e30;
   p.ng = ngs[n_ngs - 1];
@@ -933,7 +1063,7 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     if (gl > g_max) { gl = g_max; nt = (n_groups + g_max - 1) / g_max; }
     int ng = ngs[n_ngs - 1];
     for (int i = 0; i < n_ngs; ++i)
-      if (p.wn * ngs[i] >= gl) { ng = ngs[i]; break; }
+      if (p.wn * ngs[i] / cap_div >= gl && (p.wn * ngs[i]) % cap_div == 0) { ng = ngs[i]; break; }
     const double rounds = (double)(((int64_t)m_tiles * nt * sl + 255) / 256);
     const int nk = (KT + sl - 1) / sl;
     // per K tile and workgroup: matrix-pipe cycles of a SIMD against the cycles its CU needs to pull the tile's weights
@@ -979,7 +1109,10 @@ static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, i
   const bool need_slab = epi.defer != 0;
   if (need_slab && (KIND != kI8 || !workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
   const bool can_slice = workspace && ws_bytes >= (size_t)2 * M * N * 4;
-  WsPlan p = ws_plan(M, N, K, can_slice, ws_bytes);
+  if (epi.gate_up && (KIND != kI8 || N % 32 != 0 || !epi.act_out || !epi.row_amax || !epi.a_scale || !epi.w_scale ||
+                      ((uintptr_t)epi.act_out % 16) || N * K >= (1ll << 31)))
+    return XM_ERR_UNSUPPORTED;
+  WsPlan p = ws_plan(M, N, K, can_slice, ws_bytes, epi.gate_up != 0);
   int32_t* const slabs = reinterpret_cast<int32_t*>(workspace);
   GemmEpi e2 = epi;
   if (need_slab && p.slices == 1) {  // one slab = the kernel's raw-accumulator output

@@ -544,33 +544,6 @@ __global__ __launch_bounds__(256) void fused_qk_norm_rope_kernel(T* __restrict__
 // act_and_mul (reference: kernels/cuda/activation.cu:49-120): out = r16(r16(act(float(x))) * y)
 // QUANT: also per-token int8 quantise the 16-bit result
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ float act_f(float f) {
-  // SiLU on the hardware transcendental units (v_exp_f32, v_rcp_f32) with the two cheap corrections that bring it
-  // back to ~2 ulp in f32: the argument of exp2 carries its rounding residual (x*log2e in two pieces), and the
-  // reciprocal takes one Newton step. 12 VALU instead of the 23 of libm expf + IEEE division, which made the fused
-  // silu+quant kernel VALU-bound (2.6 TB/s at 8192 x 18944; 4.8 TB/s with this form).
-  if constexpr (MODE == XM_ACT_SILU) {
-    const float kL2E = 1.44269504088896340736f, kL2E_lo = 1.92596299112661746e-8f, kLn2 = 0.69314718055994530942f;
-    const float a = -f;
-    const float hi = a * kL2E;
-    const float lo = fmaf(a, kL2E, -hi) + a * kL2E_lo;
-    float e = __builtin_amdgcn_exp2f(hi);
-    e = fmaf(e, lo * kLn2, e);
-    const float dn = 1.0f + e;
-    float r = __builtin_amdgcn_rcpf(dn);
-    const float rn = fmaf(r, fmaf(-dn, r, 1.0f), r);
-    r = (dn < 3.0e38f) ? rn : r;  // dn = inf: keep r = 0 (the Newton step would be inf * 0); NaN keeps NaN
-    return f * r;
-  }
-  else if constexpr (MODE == XM_ACT_GELU) return f * 0.5f * (1.0f + erff(f * 0.70710678118654752440f));
-  else {
-    const float kBeta = 1.41421356237309504880f * 1.12837916709551257390f * 0.5f;
-    const float inner = kBeta * (f + 0.044715f * f * f * f);
-    return 0.5f * f * (1.0f + tanhf(inner));
-  }
-}
-
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void act_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d,
                                                           bool vec) {
@@ -1223,7 +1196,52 @@ static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64
   return hip_check_launch();
 }
 
+// second half of the gate_up -> SiLU.mul -> per-token int8 fusion (round 3): the GEMM's epilogue wrote act = silu(gate) * up in
+// 16 bit and folded each row's |max| into row_amax (atomic max on the bits of a non-negative float, zero at rest); this kernel
+// quantises the row with that maximum in ONE pass (scaled_quantize's expression: q = rint(v * 127 / amax), scale = amax / 127)
+// and puts the row's entry of row_amax back to zero. Bit-identical to act_and_mul -> scaled_quantize.
+template <typename T>
+__global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __restrict__ act, float* __restrict__ row_amax,
+                                                                    int8_t* __restrict__ out_q, float* __restrict__ out_s, int d) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t t = blockIdx.x;
+  const float amax = row_amax[t];
+  const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
+  const int nvec = d / 8;
+  const u32x4* x = reinterpret_cast<const u32x4*>(act + t * (int64_t)d);
+  for (int c = threadIdx.x; c < nvec; c += 512) {
+    const u32x4 v = x[c];
+    uint32_t pk[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t wq = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t word = v[h * 2 + (e >> 1)];
+        const float r = half_bits_to_f32<T>((e & 1) ? (word >> 16) : (word & 0xffffu));
+        const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(r * qinv)));
+        wq |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+      }
+      pk[h] = wq;
+    }
+    *reinterpret_cast<uint2*>(out_q + t * (int64_t)d + (int64_t)c * 8) = make_uint2(pk[0], pk[1]);
+  }
+  __syncthreads();                       // every thread has read row_amax[t]
+  if (threadIdx.x == 0) { out_s[t] = amax / 127.0f; row_amax[t] = 0.0f; }
+}
+
 extern "C" {
+
+int xllm_mi355_quantize_with_row_amax(const void* act, float* row_amax, int8_t* out_q, float* out_scale, int64_t n_tokens,
+                                      int64_t d, int dtype, void* stream) {
+  if (!act || !row_amax || !out_q || !out_scale || n_tokens < 0 || d <= 0) return XM_ERR_INVALID;
+  if (d % 8 || ((uintptr_t)act % 16) || ((uintptr_t)out_q % 8)) return XM_ERR_UNSUPPORTED;
+  if (n_tokens == 0) return XM_OK;
+  XM_DISPATCH_HALF(dtype, T,
+                   hipLaunchKernelGGL((quantize_with_row_amax_kernel<T>), dim3((unsigned)n_tokens), dim3(512), 0,
+                                      (hipStream_t)stream, (const T*)act, row_amax, out_q, out_scale, (int)d));
+  return hip_check_launch();
+}
 
 int xllm_mi355_act_and_mul(void* out, const void* input, int64_t n_tokens, int64_t d, int act_mode, int dtype,
                            void* stream) {

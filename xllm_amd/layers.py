@@ -195,6 +195,16 @@ class Qwen2DecoderLayer:
         return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
                                               self.args.rms_norm_eps, lin.bias, quantize=quantize, b_packed=lin.weight_packed)
 
+    def _gate_up_act_quant(self, h):
+        """gate_up_proj + SiLU * mul + the int8 quant of down_proj's operand (dense_mlp.cpp:97-116): the GEMM epilogue computes the
+        activation (ops.scaled_matmul_silu_mul_quant, round 3); the unfused pair of operators when the shape is outside its envelope"""
+        lin = self.gate_up_proj
+        if lin.mode == "int8" and lin.bias is None:
+            out = ops.scaled_matmul_silu_mul_quant(h[0], lin.weight, h[1], lin.w_scale, self.dtype, None, b_packed=lin.weight_packed)
+            if out is not None:
+                return out
+        return ops.act_and_mul_dynamic_int8_quant(lin.forward(None, pre_quant=h), "silu")
+
     def _tp_linear_norm(self, lin: "QuantLinear", pre_quant, residual, norm_w, quantize=True):
         """Tensor parallel (round 3): row-parallel W8A8 linear -> ONE kernel for the SUM all-reduce over xGMI + residual add +
         RMSNorm (+ int8 quant) (ProcessGroup.allreduce_add_rms_norm = xllm_mi355_oneshot_allreduce_add_rms_norm), so a TP
@@ -253,8 +263,7 @@ class Qwen2DecoderLayer:
         if h is None:
             x = self.o_proj.forward(None, pre_quant=o_in)
             h, residual = self._norm(x, residual, self.post_norm_w)
-        gate_up = self.gate_up_proj.forward(None, pre_quant=h)
-        act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+        act_q = self._gate_up_act_quant(h)
         h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
         if h_next is None:
             h_next = self._tp_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
@@ -314,9 +323,9 @@ class Qwen2DecoderLayer:
             x = self.o_proj.forward(attn)
         if h is None:
             h, residual = self._norm(x, residual, self.post_norm_w)
-        gate_up = self.gate_up_proj.forward(None, pre_quant=h) if self.fuse else self.gate_up_proj.forward(h)
-        if self.fuse:  # N1: silu*mul + int8 quant feeding down_proj
-            act_q = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+        gate_up = None if self.fuse else self.gate_up_proj.forward(h)
+        if self.fuse:  # N1: gate_up GEMM with silu*mul in its epilogue + int8 quant feeding down_proj
+            act_q = self._gate_up_act_quant(h)
             if decode:
                 h_next = self._fused_linear_norm(self.down_proj, act_q, residual, next_norm_w, quantize=next_quant)
                 if h_next is None:

@@ -348,6 +348,43 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
     return out
 
 
+_row_amax = {}
+_GATE_UP_FUSION = os.environ.get("XLLM_MI355_GATE_UP_FUSION", "1") == "1"   # A/B switch of the fusion below
+
+
+def scaled_matmul_silu_mul_quant(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, b_packed=None):
+    """N1 fusion across the GEMM boundary (round 3): the W8A8 gate_up projection -> SiLU(gate) * up -> per-token int8 quant of
+    DenseMLP (dense_mlp.cpp:97-116 + the scaled_quantize of down_proj, linear.cpp:481-507) in TWO launches: the GEMM whose
+    epilogue writes act [M, I] and the rows' |max| (xllm_mi355_scaled_matmul_gate_up_act), then one quantising pass
+    (xllm_mi355_quantize_with_row_amax). a [M, K] int8, b [2 I, K] int8 (gate rows, then up rows). Returns (q [M, I] int8,
+    scale [M]) -- bit-identical to scaled_matmul -> act_and_mul_dynamic_int8_quant -- or None outside the envelope."""
+    _need_cuda(a, b, a_scale, b_scale)
+    M, K = a.shape
+    N = b.size(0)
+    if not _GATE_UP_FUSION or N % 256 or K % 128 or not a.is_contiguous() or not b.is_contiguous() or M == 0:
+        return None
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream if torch.cuda.current_stream(a.device).cuda_stream in _private_streams else 0)
+    amax = _row_amax.get(key)
+    if amax is None or amax.numel() < M:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("row-amax scratch must exist before a graph capture: run one eager step of this shape first")
+        amax = torch.zeros(max(M, 8192), dtype=torch.float32, device=a.device)     # zero at rest (the quantising pass re-zeroes)
+        _row_amax[key] = amax
+    I = N // 2
+    act = torch.empty(M, I, dtype=output_dtype, device=a.device)
+    rc = _lib.lib().xllm_mi355_scaled_matmul_gate_up_act(_p(a), _p(b), _p(b_packed), _p(a_scale.reshape(-1)),
+                                                        _p(b_scale.reshape(-1)), _p(bias), _p(act), _p(amax), M, N, K,
+                                                        _DT[output_dtype], 0, 0, _stream())
+    if rc == -2:
+        return None
+    check(rc, "scaled_matmul_gate_up_act")
+    q = torch.empty(M, I, dtype=torch.int8, device=a.device)
+    qs = torch.empty(M, dtype=torch.float32, device=a.device)
+    check(_lib.lib().xllm_mi355_quantize_with_row_amax(_p(act), _p(amax), _p(q), _p(qs), M, I, _DT[output_dtype], _stream()),
+          "quantize_with_row_amax")
+    return q, qs
+
+
 # ------------------------------------------------------------------------------------------------ fp8
 def scaled_matmul_add_rms_norm(a, b, a_scale, b_scale, residual, norm_weight, eps: float, bias=None,
                                quantize: bool = True, b_packed=None):
