@@ -301,6 +301,14 @@ XM_API int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* 
 XM_API int xllm_mi355_pack_weight_16(const void* w, void* packed, int64_t N, int64_t K, void* stream);
 XM_API int xllm_mi355_matmul_packed(const void* a, const void* w_packed, const void* bias, void* out, int64_t M, int64_t N,
                                     int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream);
+/* The gate_up linear of the dense MLP on packed 16-bit weights with SiLU * mul in its epilogue (dense_mlp.cpp:97-116 with an
+ * unquantised layer: gate_up_proj -> kernel::act_and_mul, kernels/cuda/activation.cu:49-120): w_packed = pack_weight_16 of the
+ * [N = 2 I, K] weight (gate rows first), act_out [M, I] = r16(r16(silu(gate)) * up) with gate / up = r16(sum_fp32 + bias) --
+ * the expression of xllm_mi355_matmul_packed followed by xllm_mi355_act_and_mul on fp32 sums in this launch's own (fixed,
+ * deterministic) K order, so the two agree to fp32 rounding like any two tile plans of the packed kernel (the fused form never
+ * slices K). N % 32 == 0; otherwise the envelope of xllm_mi355_matmul_packed; XM_ERR_UNSUPPORTED outside it. */
+XM_API int xllm_mi355_matmul_gate_up_act(const void* a, const void* w_packed, const void* bias, void* act_out, int64_t M,
+                                         int64_t N, int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream);
 
 /* kernel::matmul (ops_api.h:48) -> dcu::matmul == F::linear (kernels/dcu/matmul.cpp:20-25):
  * out = r16(a @ w^T + bias); a [M,K], w [N,K], dtype bf16/f16. K % 64 == 0.

@@ -946,6 +946,18 @@ int xllm_mi355_matmul_packed(const void* a, const void* w_packed, const void* bi
   return launch_gemm_ws_h16(a, w_packed, M, N, K * 2, epi, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+int xllm_mi355_matmul_gate_up_act(const void* a, const void* w_packed, const void* bias, void* act_out, int64_t M, int64_t N,
+                                  int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || !act_out || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (N % 32 != 0 || ((uintptr_t)act_out % 16)) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  GemmEpi epi{nullptr, 0, nullptr, 0, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0};
+  epi.gate_up = 1;
+  epi.act_out = act_out;
+  return launch_gemm_ws_h16(a, w_packed, M, N, K * 2, epi, workspace, ws_bytes, (hipStream_t)stream);
+}
+
 int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                       int dtype, void* stream) {
   if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;

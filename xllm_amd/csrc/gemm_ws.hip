@@ -378,16 +378,16 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
   }
 }
 
-// ---- gate_up epilogue with SiLU.mul fused (GemmEpi::gate_up; int8 only). Slot groups [0, G / 2) of the workgroup tile hold the
+// ---- gate_up epilogue with SiLU.mul fused (GemmEpi::gate_up; int8 and the 16-bit kinds). Slot groups [0, G / 2) of the workgroup tile hold the
 // GATE columns of act groups ga0 .. ga0 + ga_live, slots [G / 2, G) the UP columns of the same act groups. Phase 1: every wave
 // dequantises its accumulators exactly like the plain epilogue (rT(acc * a_scale * w_scale + bias)) into ONE workgroup-shared
 // 16-bit tile in the LDS; phase 2: every thread takes (row, 8 act columns) items, reads the gate and the up chunk, computes
 // rT(rT(silu(g)) * u) -- act_and_mul_i8_reg_kernel's expression, bit for bit -- stores 16 bytes of act and folds the |max|
 // into a per-row LDS maximum, which leaves the workgroup as one atomic max per row.
-template <int MB, int NG, int WM, int WN, int NWV>
-__device__ __forceinline__ void ws_epilogue_gate_up(i32x4_t (&acc)[MB][NG], const GemmEpi& epi, int M, int N, int m_tile0, int wm,
-                                                    int wn, int lane, int tid, int ga0, int ga_live, int n_groups_act,
-                                                    uint8_t* lds) {
+template <int KIND, int MB, int NG, int WM, int WN, int NWV>
+__device__ __forceinline__ void ws_epilogue_gate_up(typename WsAcc<KIND>::type (&acc)[MB][NG], const GemmEpi& epi, int M, int N,
+                                                    int m_tile0, int wm, int wn, int lane, int tid, int ga0, int ga_live,
+                                                    int n_groups_act, uint8_t* lds) {
   constexpr int G = WN * NG, GH = G / 2, ROWS = WM * MB * 16, PITCH = G * 32 + 16;
   static_assert(G % 2 == 0 && ROWS * PITCH + ROWS * 4 <= 160 * 1024, "gate_up tile");
   const int g4 = lane >> 4, ml = lane & 15;
@@ -398,15 +398,18 @@ __device__ __forceinline__ void ws_epilogue_gate_up(i32x4_t (&acc)[MB][NG], cons
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int m = m_tile0 + wm * MB * 16 + mb * 16 + ml;
-    asv[mb] = epi.a_scale[m < M ? m : M - 1];
+    asv[mb] = KIND == kI8 ? epi.a_scale[m < M ? m : M - 1] : 1.0f;
   }
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int q = wn * NG + ng, half = q / GH, j = q % GH;
     const int jl = j < ga_live ? j : 0;                                     // (dead slots compute on a valid column, never read)
     const int n = (half * n_groups_act + ga0 + jl) * 16 + 4 * g4;
-    const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
-    const float wsv[4] = {w4.x, w4.y, w4.z, w4.w};
+    float wsv[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (KIND == kI8) {
+      const float4 w4 = *reinterpret_cast<const float4*>(epi.w_scale + n);
+      wsv[0] = w4.x; wsv[1] = w4.y; wsv[2] = w4.z; wsv[3] = w4.w;
+    }
     float bsv[4] = {0.f, 0.f, 0.f, 0.f};
     if (has_bias) {
 #pragma unroll
@@ -415,8 +418,13 @@ __device__ __forceinline__ void ws_epilogue_gate_up(i32x4_t (&acc)[MB][NG], cons
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       float v[4];
+      if constexpr (KIND == kI8) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * asv[mb] * wsv[e] + bsv[e];
+        for (int e = 0; e < 4; ++e) v[e] = (float)acc[mb][ng][e] * asv[mb] * wsv[e] + bsv[e];
+      } else {                                // 16-bit linear: acc + bias (ws_epilogue)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mb][ng][e] + bsv[e];
+      }
       uint2 pk;
       if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
       else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
@@ -456,8 +464,9 @@ __device__ __forceinline__ void ws_epilogue_gate_up(i32x4_t (&acc)[MB][NG], cons
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + (int64_t)(ga0 + j) * 16 + hc * 8) =
         make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    atomicMax(&rowmax[row], __float_as_uint(amax));       // non-negative floats order like their bits (NaN: above everything)
+    if (epi.row_amax) atomicMax(&rowmax[row], __float_as_uint(amax));   // non-negative floats order like their bits (NaN: above everything)
   }
+  if (!epi.row_amax) return;                   // (16-bit linears: the activation is the result, nothing to quantise)
   __syncthreads();
   for (int r = tid; r < ROWS; r += NWV * 64) {
     const int m = m_tile0 + r;
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
   // (the launcher guarantees it), so that 2368 groups over 256 workgroups become 9 or 10 groups each instead of 197 x 12 + 4
   // gate_up mode (GemmEpi::gate_up): the tile owns ACT groups [ga0, ga0 + ga_live) -- its first G / 2 slot groups are their gate
   // columns, the other G / 2 their up columns (groups n_groups / 2 + ...); the descriptor then spans the whole matrix
-  const bool gu = KIND == kI8 && epi.gate_up != 0;
+  const bool gu = KIND != kFP8 && epi.gate_up != 0;
   const int n_groups_act = n_groups >> 1;
   const int ga0 = gu ? (int)((int64_t)nt * n_groups_act / n_tiles) : 0;
   const int ga_live = gu ? (int)((int64_t)(nt + 1) * n_groups_act / n_tiles) - ga0 : 0;
@@ -652,9 +661,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
   }
 
   __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed and nobody reads the ring any more: the epilogue re-uses the LDS
-  if constexpr (KIND == kI8 && (WN * NG) % 2 == 0) {
+  if constexpr (KIND != kFP8 && (WN * NG) % 2 == 0) {
     if (gu) {
-      ws_epilogue_gate_up<MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
+      ws_epilogue_gate_up<KIND, MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
       return;
     }
   }
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   const int n_groups = N >> 4;
   // gate_up mode (GemmEpi::gate_up): the tile owns ACT groups [ga0, ga0 + ga_live) -- its first G / 2 slot groups are their gate
   // columns, the other G / 2 their up columns (groups n_groups / 2 + ...); the descriptor then spans the whole matrix
-  const bool gu = KIND == kI8 && epi.gate_up != 0;
+  const bool gu = KIND != kFP8 && epi.gate_up != 0;
   const int n_groups_act = n_groups >> 1;
   const int ga0 = gu ? (int)((int64_t)nt * n_groups_act / n_tiles) : 0;
   const int ga_live = gu ? (int)((int64_t)(nt + 1) * n_groups_act / n_tiles) - ga0 : 0;
@@ -901,8 +910,8 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   if constexpr (KIND == kI8)
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][NG - 1]), "+a"(acc[1][NG - 1]), "+a"(acc[2][NG - 1]), "+a"(acc[3][NG - 1]));
   __builtin_amdgcn_s_barrier();  // every wave's DMAs have landed: the epilogue re-uses the LDS
-  if constexpr (KIND == kI8) {
-    if (gu) ws_epilogue_gate_up<MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
+  if constexpr (KIND != kFP8) {
+    if (gu) ws_epilogue_gate_up<KIND, MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
   }
   if (!gu) ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
 #ifdef WS8_TIMING
@@ -986,7 +995,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
   // gate_up mode: a tile holds G / 2 ACT groups (their gate and their up columns); the split is over the N / 32 act groups
   const bool gu = epi.gate_up != 0;
-  if (gu && (G % 2 != 0 || KIND != kI8)) return -1;
+  if (gu && (G % 2 != 0 || KIND == kFP8)) return -1;
   const int n_groups = gu ? (int)(N / 32) : (int)(N / 16);
   const int KT = (int)(K / WS_BK);
   if (gu) slices = 1;
@@ -1109,8 +1118,8 @@ static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, i
   const bool need_slab = epi.defer != 0;
   if (need_slab && (KIND != kI8 || !workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
   const bool can_slice = workspace && ws_bytes >= (size_t)2 * M * N * 4;
-  if (epi.gate_up && (KIND != kI8 || N % 32 != 0 || !epi.act_out || !epi.row_amax || !epi.a_scale || !epi.w_scale ||
-                      ((uintptr_t)epi.act_out % 16) || N * K >= (1ll << 31)))
+  if (epi.gate_up && (KIND == kFP8 || N % 32 != 0 || !epi.act_out || ((uintptr_t)epi.act_out % 16) || N * K >= (1ll << 31) ||
+                      (KIND == kI8 && (!epi.row_amax || !epi.a_scale || !epi.w_scale))))
     return XM_ERR_UNSUPPORTED;
   WsPlan p = ws_plan(M, N, K, can_slice, ws_bytes, epi.gate_up != 0);
   int32_t* const slabs = reinterpret_cast<int32_t*>(workspace);

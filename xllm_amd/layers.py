@@ -323,6 +323,9 @@ class Qwen2DecoderLayer:
             x = self.o_proj.forward(attn)
         if h is None:
             h, residual = self._norm(x, residual, self.post_norm_w)
+        act16 = None if self.fuse else self._gate_up_act_16(h)   # unquantised layer, decode shapes: SiLU * mul in the GEMM epilogue
+        if act16 is not None:
+            return self.down_proj.forward(act16), residual, None
         gate_up = None if self.fuse else self.gate_up_proj.forward(h)
         if self.fuse:  # N1: gate_up GEMM with silu*mul in its epilogue + int8 quant feeding down_proj
             act_q = self._gate_up_act_quant(h)
@@ -338,6 +341,14 @@ class Qwen2DecoderLayer:
             ops.act_and_mul(act, gate_up, "silu")
             x = self.down_proj.forward(act)
         return x, residual, None
+
+    def _gate_up_act_16(self, h):
+        """unquantised layer: gate_up_proj with SiLU * mul in the GEMM epilogue (ops.matmul_silu_mul, packed 16-bit weights,
+        decode shapes); None = not applicable"""
+        lin = self.gate_up_proj       # (column-parallel: a rank's shard holds its gate rows, then its up rows -- no reduce)
+        if lin.mode in ("int8", "fp8") or lin.weight_packed is None or h.dim() != 2:
+            return None
+        return ops.matmul_silu_mul(h, lin.weight, lin.bias, b_packed=lin.weight_packed)
 
 
 class Qwen2Model:

@@ -549,6 +549,25 @@ def matmul(a, b, bias=None, b_packed=None):
     return out.view(*a.shape[:-1], N)
 
 
+def matmul_silu_mul(a, b, bias=None, b_packed=None):
+    """N1 fusion across the GEMM boundary for an UNQUANTISED dense MLP (dense_mlp.cpp:97-116: gate_up_proj -> act_and_mul): the
+    16-bit gate_up projection on packed weights with SiLU(gate) * up in its epilogue (xllm_mi355_matmul_gate_up_act). a [M, K],
+    b [2 I, K] (gate rows, then up rows), b_packed = pack_weight_16(b). Returns act [M, I] -- the expression of matmul ->
+    act_and_mul on the packed kernel's fp32 sums (their order is the tile plan's, so the two agree to fp32 rounding) -- or None
+    outside the envelope (caller runs the two operators)."""
+    _need_cuda(a, b)
+    M, K = a.shape
+    N = b.size(0)
+    if not _GATE_UP_FUSION or b_packed is None or N % 32 or M == 0 or not a.is_contiguous() or not _prefer_packed_16(M, N, K):
+        return None
+    act = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
+    rc = _lib.lib().xllm_mi355_matmul_gate_up_act(_p(a), _p(b_packed), _p(bias), _p(act), M, N, K, _dt(a), 0, 0, _stream())
+    if rc in (-2, -4):
+        return None
+    check(rc, "matmul_gate_up_act")
+    return act
+
+
 # ------------------------------------------------------------------------------------------------ attention
 _attn_ws = {}
 _retired_ws = []   # outgrown scratch buffers stay allocated: a captured HIP graph may still launch kernels that write them
