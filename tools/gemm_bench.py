@@ -13,9 +13,11 @@ dev = "cuda"
 shapes = [("qkv", 4608, 3584), ("o", 3584, 3584), ("gate_up", 37888, 3584), ("down", 3584, 18944)]
 if os.environ.get("GEMM_SHAPES") == "dsv3":      # DeepSeek-V3 MLA projections of one TP = 8 rank (bench_slices.py cfg4-slice)
     shapes = [("q_a", 1536, 7168), ("q_b", 16 * 192, 1536), ("kv_a", 576, 7168), ("o", 7168, 16 * 128)]
+if os.environ.get("GEMM_SHAPES_ONLY"):
+    shapes = [s for s in shapes if s[0] in os.environ["GEMM_SHAPES_ONLY"].split(",")]
 Ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256"])]
 kind = sys.argv[2] if len(sys.argv) > 2 else "int8"
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED", "GEMM_COPIES", "GEMM_FUSED"))
+tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("XLLM_MI355") or k in ("GEMM_DIST", "GEMM_PACKED", "GEMM_COPIES", "GEMM_FUSED", "GEMM_GU"))
 for M in Ms:
     for name, N, K in shapes + ([("lm_head", 152064, 3584)] if kind == "bf16" else []):
         copies = int(os.environ.get('GEMM_COPIES', 0)) or max(2, min(8, int(600e6 // (N * K)) + 1))
@@ -41,6 +43,16 @@ for M in Ms:
                 nw = torch.ones(N, device=dev).bfloat16()
                 fn = lambda i: ops.scaled_matmul_add_rms_norm(a, ws[i % copies], a_s, w_s, res, nw, 1e-6, None, quantize=True,
                                                               b_packed=wps[i % copies])
+            elif os.environ.get("GEMM_GU", "0") in ("1", "2") and name == "gate_up":
+                # gate_up as the MLP runs it: GEMM -> SiLU * mul -> per-token int8 quant; 1 = fused into the GEMM epilogue + one
+                # quantising pass, 2 = the GEMM and the fused row-wise operator
+                wps = [ops.pack_weight_i8(x) for x in ws]
+                a_s.mul_(0.01); w_s.mul_(0.01)
+                if os.environ["GEMM_GU"] == "1":
+                    fn = lambda i: ops.scaled_matmul_silu_mul_quant(a, ws[i % copies], a_s, w_s, torch.bfloat16, None, b_packed=wps[i % copies])
+                else:
+                    fn = lambda i: ops.act_and_mul_dynamic_int8_quant(
+                        ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies]), "silu")
             elif os.environ.get("GEMM_PACKED", "0") == "1":
                 wps = [ops.pack_weight_i8(x) for x in ws]
                 fn = lambda i: ops.scaled_matmul(a, ws[i % copies], a_s, w_s, torch.bfloat16, b_packed=wps[i % copies])

@@ -464,13 +464,17 @@ __device__ __forceinline__ void ws_epilogue_gate_up(typename WsAcc<KIND>::type (
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + (int64_t)(ga0 + j) * 16 + hc * 8) =
         make_uint4(ow[0], ow[1], ow[2], ow[3]);
+#ifndef WS_ABL_GU_NOLDSATOMIC
     if (epi.row_amax) atomicMax(&rowmax[row], __float_as_uint(amax));   // non-negative floats order like their bits (NaN: above everything)
+#endif
   }
   if (!epi.row_amax) return;                   // (16-bit linears: the activation is the result, nothing to quantise)
   __syncthreads();
   for (int r = tid; r < ROWS; r += NWV * 64) {
     const int m = m_tile0 + r;
+#ifndef WS_ABL_GU_NOATOMIC
     if (m < M && rowmax[r]) atomicMax(reinterpret_cast<unsigned*>(epi.row_amax) + m, rowmax[r]);
+#endif
   }
 }
 
