@@ -21,5 +21,10 @@ def assert_p16_attention_close(out, ref_fp32_p, ref_p16, ref_flash=None):
     assert torch.isfinite(out.float()).all()
     assert rel_l2(out, ref_fp32_p) <= max(1e-3, 1.25 * e_ref), (rel_l2(out, ref_fp32_p), e_ref)
     assert rel_l2(out, ref_p16) <= max(1e-3, 2.0 * e_ref), (rel_l2(out, ref_p16), e_ref)
-    if ref_flash is not None:
+    import os
+    # the oracle's flash mode restates the DEFAULT kernel (64-key tiles, one 16-bit P): the A/B arms -- register-staged tiles, P = hi + lo
+    # (which lands on the fp32-P result instead) -- stay under the bars above
+    default_arm = (os.environ.get("XLLM_MI355_PREFILL_DMA") != "0" and os.environ.get("XLLM_MI355_PREFILL_P") != "2"
+                   and os.environ.get("XLLM_MI355_MLA_PREFILL_P") != "2")
+    if ref_flash is not None and default_arm:
         assert rel_l2(out, ref_flash) <= FLASH_BAR, rel_l2(out, ref_flash)

@@ -65,7 +65,11 @@ def assert_prefill_close(out, q, k, v, cu, scale):
     assert torch.isfinite(out.float()).all()
     assert r(out, ref0) <= max(1e-3, 1.25 * e_ref), (r(out, ref0), e_ref)
     assert r(out, ref1) <= max(1e-3, 2.0 * e_ref), (r(out, ref1), e_ref)
-    # round 3: ABSOLUTE bar against the oracle that rounds P where a flash kernel does (un-normalised, per 64-key tile)
+    # round 3: ABSOLUTE bar against the oracle that rounds P where a flash kernel does (un-normalised, per 64-key tile).
+    # The oracle mode restates the DEFAULT kernel's tiling; the register-staged A/B arm (XLLM_MI355_PREFILL_DMA=0) walks the keys
+    # in other tiles, so its cast points differ and it stays under the two relative bars above.
+    if os.environ.get("XLLM_MI355_PREFILL_DMA") == "0":
+        return
     kc_, vc_ = k.contiguous(), v.contiguous()
     ref2 = orc.attention_varlen(q, kc_, vc_, cu, cu, scale, causal=True, p_round="flash")
     assert r(out, ref2) <= 1e-3, r(out, ref2)
@@ -1570,11 +1574,12 @@ def _ws_waves(n):
 
 
 @pytest.mark.parametrize("M", [129, 200, 256, 257, 512])
-@pytest.mark.parametrize("arm", [4, 80])
+@pytest.mark.parametrize("arm", [4, 80, 81])
 def test_packed_gemm_four_wave_tile_still_exact(M, arm):
-    """round 3 moved 128 < M <= 512 to eight-wave workgroups with the two wave groups one barrier apart (gemm_ws8s_kernel); the
-    four-wave 256-row tile (xllm_mi355_debug_ws_waves(4) / XLLM_MI355_WS_WAVES=4) and the eight-wave tile with all waves in phase
-    (80 / XLLM_MI355_WS8_STAGGER=0) stay as A/B arms and must stay exact"""
+    """round 3 moved 128 < M <= 512 to eight-wave workgroups with the two wave groups one barrier apart (gemm_ws8s_kernel) for
+    the wide problems and to 128-row tiles for the few-column ones (N <= 8192: this shape). The 256-row tiles forced onto this
+    shape (arm 131 = XLLM_MI355_WS_ROWS128=0) -- four waves (xllm_mi355_debug_ws_waves(4) / XLLM_MI355_WS_WAVES=4), eight waves in
+    phase (80 / XLLM_MI355_WS8_STAGGER=0) and eight waves staggered (81) -- must stay exact"""
     g = torch.Generator().manual_seed(100 + M)
     N, K = 1936, 1152
     a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
@@ -1586,6 +1591,7 @@ def test_packed_gemm_four_wave_tile_still_exact(M, arm):
     ref_out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None)
     ran = 0
     try:
+        _ws_waves(131)
         _ws_waves(arm)
         for ng in ((2, 4, 6, 8, 10) if arm == 4 else (1, 2, 3, 4, 5)):
             for slices in (1, 3):
@@ -1638,6 +1644,9 @@ def test_packed_fp8_gemm_over_tile_shapes(M, scales):
     ref_rm = ops.fp8_scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias)
     ran = 0
     try:
+      # (M > 128, N <= 8192 runs on 128-row tiles by default: the second pass forces the 256-row eight-wave tile, arm 131)
+      for rows_arm in ((0,) if M <= 128 else (0, 131)):
+        _ws_waves(rows_arm)
         for ng in (1, 2, 3, 4, 5, 6, 8, 10):
             for slices in (1, 2, 3):
                 _ws_plan(ng, slices)
@@ -1655,6 +1664,7 @@ def test_packed_fp8_gemm_over_tile_shapes(M, scales):
                     assert rc2 == 0 and torch.equal(out, out2)
     finally:
         _ws_plan(0, 0)
+        _ws_waves(0)
     assert ran >= 6
     rc, out = _packed_gemm_fp8(a, wp, a_s, w_s, None, M, N, K, ws_bytes=0)     # no scratch: never sliced, still right
     assert rc == 0 and rel_l2(out, ref - bias.double()) <= 3e-3
@@ -1701,6 +1711,9 @@ def test_packed_gemm_exact_over_tile_shapes(M):
     ref_out = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias)
     ran = 0
     try:
+      # (M > 128 with N <= 8192 runs on 128-row tiles by default, m tiles > 1; arm 131 forces the 256-row eight-wave tile here)
+      for rows_arm in ((0,) if M <= 128 else (0, 131)):
+        _ws_waves(rows_arm)
         for ng in (1, 2, 3, 4, 5, 6, 8, 10):
             for slices in (1, 2, 3):
                 _ws_plan(ng, slices)
@@ -1709,10 +1722,11 @@ def test_packed_gemm_exact_over_tile_shapes(M):
                     continue          # this width does not exist for this tile family
                 assert rc == 0
                 ran += 1
-                assert torch.equal(acc, ref_acc), (ng, slices)
-                assert torch.equal(out, ref_out), (ng, slices)
+                assert torch.equal(acc, ref_acc), (rows_arm, ng, slices)
+                assert torch.equal(out, ref_out), (rows_arm, ng, slices)
     finally:
         _ws_plan(0, 0)
+        _ws_waves(0)
     assert ran >= 6
     rc, out, _ = _packed_gemm(a, wp, a_s, w_s, None, M, N, K, ws_bytes=0)          # no scratch: never sliced, still right
     assert rc == 0 and torch.equal(out, ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None))
@@ -1810,6 +1824,8 @@ def test_packed_16bit_gemm_over_tile_shapes(M, dtype):
     assert torch.equal(wp.view(torch.int8).view(N, 2 * K), ops.pack_weight_i8(wd.view(torch.int8).view(N, 2 * K)))   # bytes
     ran = 0
     try:
+      for rows_arm in ((0,) if M <= 128 else (0, 131)):   # (131: the 256-row eight-wave tile also for this small N)
+        _ws_waves(rows_arm)
         for ng in (1, 2, 3, 4, 5, 6, 8, 10):
             for slices in (1, 2, 3):
                 _ws_plan(ng, slices)
@@ -1827,6 +1843,7 @@ def test_packed_16bit_gemm_over_tile_shapes(M, dtype):
                 assert_ulp_close(out, ref, dtype, ulps=1.0, min_exact=0.95)
     finally:
         _ws_plan(0, 0)
+        _ws_waves(0)
     assert ran >= 6
     old = ops._PACKED_16_POLICY
     try:

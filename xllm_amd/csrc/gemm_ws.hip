@@ -1033,6 +1033,9 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
 // grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
 static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
+static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 8192 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
+                                  // 3 = N and K <= 8192, 4 = N <= 8192, 0 = never
+                                  // (xllm_mi355_debug_ws_waves(128 | 129 | 130 | 131) = 1 | 2 | 3 | 0; XLLM_MI355_WS_ROWS128)
 static int f_waves = -2;          // XLLM_MI355_WS_WAVES / xllm_mi355_debug_ws_waves: 4 = the round-2 four-wave 256-row tile (A/B)
 static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes, bool gu = false) {
   if (f_ng == -2) {
@@ -1044,6 +1047,8 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   if (f_waves == -2) {
     const char* e = getenv("XLLM_MI355_WS_WAVES");
     f_waves = e ? atoi(e) : -1;
+    e = getenv("XLLM_MI355_WS_ROWS128");
+    if (e) f_rows128 = atoi(e);
   }
   WsPlan p;
   p.waves = 4;
@@ -1051,6 +1056,17 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
   else if (f_waves == 4) { p.wm = 4; p.wn = 1; p.mb = 4; }
+  else if (f_rows128 == 1 || (f_rows128 == 2 && N <= 8192 && (K <= 8192 || M % 256 == 0)) ||
+           (f_rows128 == 3 && N <= 8192 && K <= 8192) || (f_rows128 == 4 && N <= 8192)) {
+    // 128-row tiles also above 128 rows for the few-column problems (qkv, o, down: N <= 8192). They need K slices to fill the
+    // chip; with 2+ m tiles per column range half as many slices do, i.e. half the slab bytes written here and read back by the
+    // fused consumer -- at the price of streaming the weights once per m tile (the m tiles of a column range are neighbours in
+    // dispatch order on one XCD, but its L2 does not hold the stream between them). Measured (profiles/r03_step_ab.txt):
+    // in-process A/B of the step at B = 256 -0.14 ms (qkv / o -0.05, down -0.09), gate_up (never sliced) +0.35 ms; stand-alone
+    // qkv / o win or tie at every M (M = 512: 27.5 -> 18.6, 24.0 -> 15.7 us), the long-K down projection only ties at
+    // M = 256 / 512 and loses at 160 / 384 (30.7 -> 36.4, 46.9 -> 72.8 us): hence K <= 8192 or whole 256-row multiples.
+    p.wm = 2; p.wn = 2; p.mb = 4;
+  }
   else { p.waves = 8; p.wm = 4; p.wn = 2; p.mb = 4; }
   const int rows = p.wm * p.mb * 16;
   const int m_tiles = (int)((M + rows - 1) / rows);
@@ -1182,6 +1198,8 @@ extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan(
 // 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default)
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_waves(int waves) {
   if (waves == 80 || waves == 81) { xm::f_waves = -1; xm::f_ws8s = waves - 80; return; }
+  if (waves >= 128 && waves <= 131) { xm::f_rows128 = waves == 131 ? 0 : waves - 127; return; }
+  if (waves == 0) xm::f_rows128 = 2;
   xm::f_waves = waves == 4 ? 4 : -1;
   if (waves == 0) xm::f_ws8s = 1;
 }

@@ -185,9 +185,20 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
         reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
         reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
       }
-      for (int sl = 1; sl < n_slabs; ++sl) {
-        a0 += reinterpret_cast<const i32x4*>(acc_row + sl * slab_stride)[2 * c];
-        a1 += reinterpret_cast<const i32x4*>(acc_row + sl * slab_stride)[2 * c + 1];
+      // the slabs in groups of four with every load of a group in flight at once (round 3: the one-slab-at-a-time loop of
+      // round 2 paid one memory latency per slab, up to eight per row); integer sums: any order is exact
+      for (int sl = 1; sl < n_slabs; sl += 4) {
+        i32x4 b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = sl + u < n_slabs;
+          const int32_t* p = acc_row + (ok ? sl + u : 0) * slab_stride;
+          b0[u] = reinterpret_cast<const i32x4*>(p)[2 * c];
+          b1[u] = reinterpret_cast<const i32x4*>(p)[2 * c + 1];
+          if (!ok) { b0[u] = i32x4{0, 0, 0, 0}; b1[u] = i32x4{0, 0, 0, 0}; }
+        }
+        a0 += (b0[0] + b0[1]) + (b0[2] + b0[3]);
+        a1 += (b1[0] + b1[1]) + (b1[2] + b1[3]);
       }
       const float4 w0 = reinterpret_cast<const float4*>(w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
       const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -468,6 +479,120 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_kernel(
   }
 }
 
+// The same operator four elements per thread (round 3): 16-byte slab loads with all slabs of a group in flight, 8-byte stores.
+// Items: four consecutive RoPE pairs of a q / k head, four tail elements, or four elements of v. Needs rot_dim / 2, the tail and
+// head_size to be multiples of 4 (the launcher falls back to the scalar kernel otherwise). Same arithmetic, bit for bit.
+template <typename T, bool NEOX>
+__global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
+    const int32_t* __restrict__ slabs, int n_slabs, int64_t slab_stride, const float* __restrict__ a_scale,
+    const float* __restrict__ w_scale, const T* __restrict__ bias, T* __restrict__ qkv, int n_cols,
+    const int64_t* __restrict__ positions, const T* __restrict__ cache, const int32_t* __restrict__ slot_ids,
+    T* __restrict__ kc, T* __restrict__ vc, int rot_dim, int head_size, int nq, int nk, int64_t block_size, int64_t n_blocks) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int64_t t = blockIdx.x;
+  const int half = rot_dim >> 1, tail = head_size - rot_dim;
+  const int n_pq = (nq + nk) * half / 4, n_tq = (nq + nk) * tail / 4, n_vq = nk * head_size / 4;
+  const int item = blockIdx.y * blockDim.x + threadIdx.x;
+  if (item >= n_pq + n_tq + n_vq) return;
+  const float as = a_scale[t];
+  const int32_t* acc_row = slabs + t * (int64_t)n_cols;
+  auto value4 = [&](int c, float (&v)[4]) {   // the four 16-bit qkv elements c .. c + 3 the GEMM epilogue would have written
+    i32x4 a = *reinterpret_cast<const i32x4*>(acc_row + c);
+    for (int sl = 1; sl < n_slabs; sl += 4) {
+      i32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = sl + u < n_slabs;
+        b[u] = *reinterpret_cast<const i32x4*>(acc_row + (ok ? sl + u : 0) * slab_stride + c);
+        if (!ok) b[u] = i32x4{0, 0, 0, 0};
+      }
+      a += (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    const float4 w = *reinterpret_cast<const float4*>(w_scale + c);
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const uint2 braw = *reinterpret_cast<const uint2*>(bias + c);
+      T b4[4];
+      __builtin_memcpy(b4, &braw, 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = to_f32(b4[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r16<T>((float)a[e] * as * wv[e] + bv[e]);
+  };
+  auto store4 = [](T* dst, const T (&v)[4]) {
+    uint2 raw;
+    __builtin_memcpy(&raw, v, 8);
+    *reinterpret_cast<uint2*>(dst) = raw;
+  };
+  const int64_t slot = slot_ids[t];
+  const bool store = slot >= 0 && slot / block_size < n_blocks;
+  T* kc_row = kc + slot * (int64_t)nk * head_size;
+  T* vc_row = vc + slot * (int64_t)nk * head_size;
+  T* out_row = qkv + t * (int64_t)n_cols;
+  if (item < n_pq) {
+    const int hq = half / 4;
+    const int h = item / hq, j = (item - h * hq) * 4;   // pairs j .. j + 3 of head h
+    const int base = h * head_size;
+    const T* cp = cache + positions[t] * rot_dim;
+    uint2 craw = *reinterpret_cast<const uint2*>(cp + j), sraw = *reinterpret_cast<const uint2*>(cp + half + j);
+    T c4[4], s4[4];
+    __builtin_memcpy(c4, &craw, 8);
+    __builtin_memcpy(s4, &sraw, 8);
+    float x[4], y[4];
+    T nx[4], ny[4];
+    if constexpr (NEOX) {
+      value4(base + j, x);
+      value4(base + half + j, y);
+    } else {                       // interleaved: elements 2 j .. 2 j + 7 = (x0 y0 x1 y1 | x2 y2 x3 y3)
+      float lo[4], hi[4];
+      value4(base + 2 * j, lo);
+      value4(base + 2 * j + 4, hi);
+      x[0] = lo[0]; y[0] = lo[1]; x[1] = lo[2]; y[1] = lo[3];
+      x[2] = hi[0]; y[2] = hi[1]; x[3] = hi[2]; y[3] = hi[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float c = to_f32(c4[e]), sn = to_f32(s4[e]);
+      nx[e] = from_f32<T>(r16<T>(x[e] * c) - r16<T>(y[e] * sn));
+      ny[e] = from_f32<T>(r16<T>(y[e] * c) + r16<T>(x[e] * sn));
+    }
+    if constexpr (NEOX) {
+      store4(out_row + base + j, nx);
+      store4(out_row + base + half + j, ny);
+      if (h >= nq && store) {
+        store4(kc_row + (h - nq) * head_size + j, nx);
+        store4(kc_row + (h - nq) * head_size + half + j, ny);
+      }
+    } else {
+      const T lo[4] = {nx[0], ny[0], nx[1], ny[1]}, hi[4] = {nx[2], ny[2], nx[3], ny[3]};
+      store4(out_row + base + 2 * j, lo);
+      store4(out_row + base + 2 * j + 4, hi);
+      if (h >= nq && store) {
+        store4(kc_row + (h - nq) * head_size + 2 * j, lo);
+        store4(kc_row + (h - nq) * head_size + 2 * j + 4, hi);
+      }
+    }
+  } else if (item < n_pq + n_tq) {                  // un-rotated tail of a q / k head (rot_dim < head_size)
+    const int i2 = item - n_pq, tq = tail / 4;
+    const int h = i2 / tq, e = rot_dim + (i2 - h * tq) * 4;
+    float v[4];
+    value4(h * head_size + e, v);
+    const T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+    store4(out_row + h * head_size + e, o);
+    if (h >= nq && store) store4(kc_row + (h - nq) * head_size + e, o);
+  } else {                                          // v
+    const int i2 = (item - n_pq - n_tq) * 4;
+    const int c = (nq + nk) * head_size + i2;
+    float v[4];
+    value4(c, v);
+    const T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+    store4(out_row + c, o);
+    if (store) store4(vc_row + i2, o);
+  }
+}
+
 int launch_slab_rope_and_cache(const int32_t* slabs, int n_slabs, const float* a_scale, const float* w_scale,
                                const void* bias, void* qkv, int64_t M, int64_t N, const int64_t* positions,
                                const void* cos_sin_cache, const int32_t* slot_ids, void* k_cache, void* v_cache,
@@ -478,6 +603,26 @@ int launch_slab_rope_and_cache(const int32_t* slabs, int n_slabs, const float* a
     return XM_ERR_UNSUPPORTED;
   const int64_t items = (n_q_heads + n_kv_heads) * (rot_dim / 2) + (n_q_heads + n_kv_heads) * (head_size - rot_dim) +
                         n_kv_heads * head_size;
+  const int64_t half = rot_dim / 2, tail = head_size - rot_dim;
+  static int use_vec = -1;
+  if (use_vec < 0) { const char* e = getenv("XLLM_MI355_SLAB_ROPE_VEC"); use_vec = e ? atoi(e) : 1; }   // 0: the scalar kernel (A/B)
+  if (use_vec && half % 4 == 0 && tail % 4 == 0 && head_size % 4 == 0 && (!bias || (uintptr_t)bias % 8 == 0) &&
+      (uintptr_t)qkv % 8 == 0 && (uintptr_t)k_cache % 8 == 0 && (uintptr_t)v_cache % 8 == 0 && (uintptr_t)cos_sin_cache % 8 == 0) {
+    const dim3 gridv((unsigned)M, (unsigned)((items / 4 + 255) / 256));
+    XM_DISPATCH_HALF(dtype, T, {
+      if (is_neox)
+        hipLaunchKernelGGL((slab_rope_and_cache_vec_kernel<T, true>), gridv, dim3(256), 0, s, slabs, n_slabs, M * N,
+                           a_scale, w_scale, (const T*)bias, (T*)qkv, (int)N, positions, (const T*)cos_sin_cache, slot_ids,
+                           (T*)k_cache, (T*)v_cache, (int)rot_dim, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                           n_blocks);
+      else
+        hipLaunchKernelGGL((slab_rope_and_cache_vec_kernel<T, false>), gridv, dim3(256), 0, s, slabs, n_slabs, M * N,
+                           a_scale, w_scale, (const T*)bias, (T*)qkv, (int)N, positions, (const T*)cos_sin_cache, slot_ids,
+                           (T*)k_cache, (T*)v_cache, (int)rot_dim, (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size,
+                           n_blocks);
+    });
+    return hip_check_launch();
+  }
   const dim3 grid((unsigned)M, (unsigned)((items + 255) / 256));
   XM_DISPATCH_HALF(dtype, T, {
     if (is_neox)
