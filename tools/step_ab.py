@@ -7,7 +7,8 @@ changes of round 3 are worth; here every variant is captured from the same weigh
     python tools/step_ab.py [B] [ctx] [variants...]      variants: name=setting;setting  with settings
         fuse_gu=0|1        ops._GATE_UP_FUSION
         ws_ng=N  ws_sl=N   xllm_mi355_debug_ws_plan
-        ws_waves=N         xllm_mi355_debug_ws_waves (4, 80, 81, 0)
+        ws_waves=N         xllm_mi355_debug_ws_waves (4, 80, 81, 128..131, 0)
+        shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
         env:NAME=VALUE     os.environ (only for switches that are read at call time)
     default: python tools/step_ab.py 256 4096 fused=fuse_gu=1 unfused=fuse_gu=0
 """
@@ -37,6 +38,10 @@ def apply(settings):
             sl = int(v)
         elif k == "ws_waves":
             _lib.lib().xllm_mi355_debug_ws_waves(int(v))
+        elif k == "shape":                       # shape=N,K,ng,slices : plan override for that GEMM only
+            n_, k_, g_, s_ = (int(x) for x in v.split(","))
+            import ctypes
+            _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(n_), ctypes.c_longlong(k_), g_, s_)
         elif k.startswith("env:"):
             os.environ[k[4:]] = v
         else:
@@ -46,6 +51,8 @@ def apply(settings):
 
 def reset():
     ops._GATE_UP_FUSION = True
+    import ctypes
+    _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)
     _lib.lib().xllm_mi355_debug_ws_plan(0, 0)
     _lib.lib().xllm_mi355_debug_ws_waves(0)
 

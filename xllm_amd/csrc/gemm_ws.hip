@@ -1033,6 +1033,9 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
 // grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
 static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
+struct WsShapePlan { int64_t N, K; int ng, slices; };
+static WsShapePlan shape_plans[8];
+static int n_shape_plans = 0;
 static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 8192 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
                                   // 3 = N and K <= 8192, 4 = N <= 8192, 0 = never
                                   // (xllm_mi355_debug_ws_waves(128 | 129 | 130 | 131) = 1 | 2 | 3 | 0; XLLM_MI355_WS_ROWS128)
@@ -1099,11 +1102,16 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     // (~12 B / clk of HBM stream per CU) and activations (L2, ~40 B / clk)
     const double mfma = per_simd * p.mb * ng * 2 * 17.0, mem = gl * 2048.0 / 12.0 + p.wm * p.mb * 2048.0 / 40.0;
     double t = rounds * (nk * (mfma > mem ? mfma : mem) + 4000.0);
-    if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 2000.0;  // slab write + read-back, spread over the chip
+    if (sl > 1) t += (double)sl * M * N * 4 / 256.0 / 8.0 + 800.0;   // slab write + read-back, spread over the chip (800: in-step sweep at M = 32, round 3)
     if (t < best) { best = t; p.ng = ng; p.slices = sl; }
   }
   if (f_ng > 0) p.ng = f_ng;
   if (f_sl > 0 && can_slice) p.slices = f_sl;
+  for (int i = 0; i < n_shape_plans; ++i)   // per-shape overrides (tuning: tools/step_ab.py sweeps one GEMM of the step at a time)
+    if (shape_plans[i].N == N && shape_plans[i].K == K) {
+      if (shape_plans[i].ng > 0) p.ng = shape_plans[i].ng;
+      if (shape_plans[i].slices > 0 && (can_slice || shape_plans[i].slices == 1)) p.slices = shape_plans[i].slices;
+    }
   return p;
 }
 
@@ -1193,6 +1201,13 @@ extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_ws8(long 
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan(int ng, int slices) {
   xm::f_ng = ng > 0 ? ng : -1;
   xm::f_sl = slices > 0 ? slices : -1;
+}
+// tuning: plan override for ONE problem shape (N, K) of the following launches; N <= 0 clears all of them
+extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan_shape(long long N, long long K, int ng, int slices) {
+  if (N <= 0) { xm::n_shape_plans = 0; return; }
+  for (int i = 0; i < xm::n_shape_plans; ++i)
+    if (xm::shape_plans[i].N == N && xm::shape_plans[i].K == K) { xm::shape_plans[i].ng = ng; xm::shape_plans[i].slices = slices; return; }
+  if (xm::n_shape_plans < 8) xm::shape_plans[xm::n_shape_plans++] = {N, K, ng, slices};
 }
 // tests / tuning: 4 = the four-wave 256-row tile for M > 128 (round 2), anything else = the eight-wave tile (default)
 // 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default)

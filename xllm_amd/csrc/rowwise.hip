@@ -185,20 +185,20 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
         reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
         reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
       }
-      // the slabs in groups of four with every load of a group in flight at once (round 3: the one-slab-at-a-time loop of
+      // the slabs in groups of seven with every load of a group in flight at once (round 3: the one-slab-at-a-time loop of
       // round 2 paid one memory latency per slab, up to eight per row); integer sums: any order is exact
-      for (int sl = 1; sl < n_slabs; sl += 4) {
-        i32x4 b0[4], b1[4];
+      for (int sl = 1; sl < n_slabs; sl += 7) {   // (the planner makes at most 8 slices: one pass)
+        i32x4 b0[7], b1[7];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 7; ++u) {
           const bool ok = sl + u < n_slabs;
           const int32_t* p = acc_row + (ok ? sl + u : 0) * slab_stride;
           b0[u] = reinterpret_cast<const i32x4*>(p)[2 * c];
           b1[u] = reinterpret_cast<const i32x4*>(p)[2 * c + 1];
           if (!ok) { b0[u] = i32x4{0, 0, 0, 0}; b1[u] = i32x4{0, 0, 0, 0}; }
         }
-        a0 += (b0[0] + b0[1]) + (b0[2] + b0[3]);
-        a1 += (b1[0] + b1[1]) + (b1[2] + b1[3]);
+        a0 += ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b0[4] + b0[5]) + b0[6]);
+        a1 += ((b1[0] + b1[1]) + (b1[2] + b1[3])) + ((b1[4] + b1[5]) + b1[6]);
       }
       const float4 w0 = reinterpret_cast<const float4*>(w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
       const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -498,15 +498,15 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
   const int32_t* acc_row = slabs + t * (int64_t)n_cols;
   auto value4 = [&](int c, float (&v)[4]) {   // the four 16-bit qkv elements c .. c + 3 the GEMM epilogue would have written
     i32x4 a = *reinterpret_cast<const i32x4*>(acc_row + c);
-    for (int sl = 1; sl < n_slabs; sl += 4) {
-      i32x4 b[4];
+    for (int sl = 1; sl < n_slabs; sl += 7) {   // (at most 8 slices: one pass with every load in flight)
+      i32x4 b[7];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 7; ++u) {
         const bool ok = sl + u < n_slabs;
         b[u] = *reinterpret_cast<const i32x4*>(acc_row + (ok ? sl + u : 0) * slab_stride + c);
         if (!ok) b[u] = i32x4{0, 0, 0, 0};
       }
-      a += (b[0] + b[1]) + (b[2] + b[3]);
+      a += ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + b[6]);
     }
     const float4 w = *reinterpret_cast<const float4*>(w_scale + c);
     const float wv[4] = {w.x, w.y, w.z, w.w};
