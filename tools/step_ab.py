@@ -9,6 +9,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
         ws_ng=N  ws_sl=N   xllm_mi355_debug_ws_plan
         ws_waves=N         xllm_mi355_debug_ws_waves (4, 80, 81, 128..131, 0)
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
+        attn=s,h,d,e       xllm_mi355_debug_decode_plan: split-KV count, kv heads per workgroup, deep prefetch, exclusive CU
         env:NAME=VALUE     os.environ (only for switches that are read at call time)
     default: python tools/step_ab.py 256 4096 fused=fuse_gu=1 unfused=fuse_gu=0
 """
@@ -42,6 +43,8 @@ def apply(settings):
             n_, k_, g_, s_ = (int(x) for x in v.split(","))
             import ctypes
             _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(n_), ctypes.c_longlong(k_), g_, s_)
+        elif k == "attn":                        # attn=splits,hpw,deep,excl (0 = planner / default)
+            _lib.lib().xllm_mi355_debug_decode_plan(*(int(x) for x in v.split(",")))
         elif k.startswith("env:"):
             os.environ[k[4:]] = v
         else:
@@ -55,6 +58,7 @@ def reset():
     _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)
     _lib.lib().xllm_mi355_debug_ws_plan(0, 0)
     _lib.lib().xllm_mi355_debug_ws_waves(0)
+    _lib.lib().xllm_mi355_debug_decode_plan(0, 0, 0, 0)
 
 
 def main():

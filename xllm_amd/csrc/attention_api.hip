@@ -86,6 +86,15 @@ int decode_exclusive_cu() {
 
 using namespace xm;
 
+// tuning (tools/step_ab.py): the decode kernel's launch plan for the following calls; < 0 = leave as it is, 0 = planner / default
+extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_decode_plan(int splits, int hpw, int deep, int excl) {
+  (void)decode_num_splits(1, 4, 4, 4096); (void)decode_heads_per_wg(1, 4); (void)decode_deep_prefetch(); (void)decode_exclusive_cu();  // env first
+  if (splits >= 0) g_split_override = splits > 0 ? splits : -1;
+  if (hpw >= 0) g_hpw_override = hpw > 0 ? hpw : -1;
+  if (deep >= 0) g_deep = deep;
+  if (excl >= 0) g_excl = excl;
+}
+
 extern "C" {
 
 size_t xllm_mi355_paged_attention_workspace_bytes(int64_t batch, int64_t n_q_heads, int64_t head_dim_v,
