@@ -170,7 +170,8 @@ XM_API int xllm_mi355_act_and_mul_dynamic_int8_quant(int8_t* out_q, float* out_s
                                                      int dtype, void* stream);
 /* the same operator on the sorted rows of one expert-parallel rank (FusedMoEImpl::forward_experts with EP, layers/dcu/
  * fused_moe.cpp:236-315): only the first sum(live_sizes[0 .. n_sizes)) rows exist (the rank's own experts sort to the front);
- * the count is read on the device, rows past it are neither read nor written. live_sizes == NULL: every row. */
+ * the count is read on the device; a row past it is not read, its scale is written as 0 and its quantised bytes are left as
+ * they are (the same on every kernel path). live_sizes == NULL: every row. */
 XM_API int xllm_mi355_act_and_mul_dynamic_int8_quant_live(int8_t* out_q, float* out_scale, const void* input,
                                                           int64_t n_tokens, int64_t d, int act_mode, int dtype,
                                                           const int32_t* live_sizes, int64_t n_sizes, void* stream);

@@ -1940,6 +1940,30 @@ def test_gate_up_silu_mul_fusion_16bit_equals_separate_ops(M, I, K, dtype):
         _ws_waves(0)
 
 
+@pytest.mark.parametrize("T,d", [(1024, 768), (600, 512), (40, 768), (64, 3584), (24, 24576)])
+def test_act_quant_live_sizes_is_the_same_contract_on_every_kernel_path(T, d):
+    """act_and_mul_dynamic_int8_quant(live_sizes=...) on the one-wave-per-row kernel (short rows, many tokens), the
+    register-resident kernel and the LDS-staged kernel: rows below sum(live_sizes) equal the unmasked operator bit for bit, rows
+    past it get scale 0 (never a NaN out of uninitialised memory: the input rows there are poisoned) and are not read"""
+    from xllm_amd import _lib
+    g = torch.Generator().manual_seed(T + d)
+    x = torch.randn(T, 2 * d, generator=g).bfloat16().to(DEV)
+    sizes = torch.tensor([T // 4, 0, T // 8, 3], dtype=torch.int32, device=DEV)
+    live = int(sizes.sum())
+    ref_q, ref_s = ops.act_and_mul_dynamic_int8_quant(x, "silu")
+    xp = x.clone()
+    xp[live:] = float("nan")                                   # dead input rows must not be read
+    q = torch.full((T, d), 77, dtype=torch.int8, device=DEV)
+    s = torch.full((T,), float("nan"), dtype=torch.float32, device=DEV)
+    rc = _lib.lib().xllm_mi355_act_and_mul_dynamic_int8_quant_live(q.data_ptr(), s.data_ptr(), xp.data_ptr(), T, d, 0, 1,
+                                                                  sizes.data_ptr(), sizes.numel(),
+                                                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(q[:live], ref_q[:live]) and torch.equal(s[:live], ref_s[:live])
+    assert bool((s[live:] == 0).all()) and bool((q[live:] == 77).all())
+
+
 def test_gate_up_fusion_declines_outside_its_envelope():
     a = torch.zeros(8, 512, dtype=torch.int8, device=DEV)
     w = torch.zeros(2 * 96, 512, dtype=torch.int8, device=DEV)          # I = 96: not a multiple of the 128-column act tile

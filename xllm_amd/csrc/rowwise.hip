@@ -728,12 +728,29 @@ __device__ __forceinline__ uint32_t f32_to_half_bits(float f) {
   if constexpr (__is_same(T, bf16_t)) return f32_to_bf16_bits(f);
   else { const f16_t x = (f16_t)f; uint16_t h; __builtin_memcpy(&h, &x, 2); return h; }
 }
+// expert-parallel rank: only the first sum(live_sizes) sorted rows exist (device-side count, no host read). Every wave sums the
+// sizes itself (n_sizes is a few hundred at most). A row past the count is not read; its scale is written as 0 so that nothing
+// downstream can pick up a NaN from uninitialised memory, its quantised bytes are left as they are -- the same for every kernel.
+__device__ __forceinline__ bool row_is_dead(const int32_t* __restrict__ live_sizes, int n_sizes, int64_t t, int lane) {
+  if (!live_sizes) return false;
+  int part = 0;
+  for (int e = lane; e < n_sizes; e += 64) part += live_sizes[e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  return t >= part;
+}
+
 template <typename T, int MODE, int VPT>
 __global__ __launch_bounds__(512) void act_and_mul_i8_reg_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
-                                                                 const T* __restrict__ in, int d) {
+                                                                 const T* __restrict__ in, int d,
+                                                                 const int32_t* __restrict__ live_sizes = nullptr, int n_sizes = 0) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   __shared__ float red[32];
   const int64_t t = blockIdx.x;
+  if (row_is_dead(live_sizes, n_sizes, t, threadIdx.x & 63)) {   // (uniform over the workgroup: one row per workgroup)
+    if (threadIdx.x == 0) out_s[t] = 0.0f;
+    return;
+  }
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(in + t * 2 * (int64_t)d);
   const u32x4* y = x + nvec;
@@ -791,12 +808,9 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_wave_kernel(int8_t* __rest
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 6);
   if (t >= n_rows) return;
-  if (live_sizes) {  // expert-parallel rank: only the first sum(live_sizes) sorted rows exist (device-side count, no host read)
-    int part = 0;
-    for (int e = lane; e < n_sizes; e += 64) part += live_sizes[e];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if (t >= part) return;
+  if (row_is_dead(live_sizes, n_sizes, t, lane)) {
+    if (lane == 0) out_s[t] = 0.0f;
+    return;
   }
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(in + t * 2 * (int64_t)d);
@@ -848,12 +862,17 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_wave_kernel(int8_t* __rest
 // LDS-staged variant for rows too long for the register kernel (d up to 32768 elements of 2 bytes = 64 KiB)
 template <typename T, int MODE>
 __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict__ out_q, float* __restrict__ out_s,
-                                                             const T* __restrict__ in, int d) {
+                                                             const T* __restrict__ in, int d,
+                                                             const int32_t* __restrict__ live_sizes = nullptr, int n_sizes = 0) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   __shared__ float red[32];
   constexpr int N = RowVec<T>::N;
   T* stage = reinterpret_cast<T*>(dyn_smem);
   const int64_t t = blockIdx.x;
+  if (row_is_dead(live_sizes, n_sizes, t, threadIdx.x & 63)) {
+    if (threadIdx.x == 0) out_s[t] = 0.0f;
+    return;
+  }
   const T* x = in + t * 2 * (int64_t)d;
   const T* y = x + d;
   const int nvec = d / N;
@@ -1315,7 +1334,7 @@ static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64
     const int nvec = (int)(d / 8);
 #define XM_ACTQ_REG(VPT)                                                                                         \
   hipLaunchKernelGGL((act_and_mul_i8_reg_kernel<T, XM_ACT_SILU, VPT>), dim3(n_tokens), dim3(512), 0, s, out_q,   \
-                     out_scale, (const T*)input, (int)d)
+                     out_scale, (const T*)input, (int)d, live_sizes, n_sizes)
     if (nvec <= 512 * 2) XM_ACTQ_REG(2);
     else if (nvec <= 512 * 3) XM_ACTQ_REG(3);
     else XM_ACTQ_REG(5);
@@ -1326,15 +1345,15 @@ static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64
   switch (act_mode) {
     case XM_ACT_SILU:
       hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(512), lds, s, out_q,
-                         out_scale, (const T*)input, (int)d);
+                         out_scale, (const T*)input, (int)d, live_sizes, n_sizes);
       break;
     case XM_ACT_GELU:
       hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_GELU>), dim3(n_tokens), dim3(512), lds, s, out_q,
-                         out_scale, (const T*)input, (int)d);
+                         out_scale, (const T*)input, (int)d, live_sizes, n_sizes);
       break;
     case XM_ACT_GELU_TANH:
       hipLaunchKernelGGL((act_and_mul_i8_kernel<T, XM_ACT_GELU_TANH>), dim3(n_tokens), dim3(512), lds, s, out_q,
-                         out_scale, (const T*)input, (int)d);
+                         out_scale, (const T*)input, (int)d, live_sizes, n_sizes);
       break;
     default: return XM_ERR_UNSUPPORTED;
   }

@@ -192,7 +192,8 @@ def act_and_mul(out, input, act_mode: str = "silu") -> None:
 
 def act_and_mul_dynamic_int8_quant(input, act_mode: str = "silu", live_sizes=None):
     """N1 fusion (ScaledQuantizeParams.act_mode/is_gated, param.h:805-815). live_sizes (int32, device): the expert sizes of an
-    expert-parallel rank -- only the first sum(live_sizes) sorted rows exist; rows past them are left untouched."""
+    expert-parallel rank -- only the first sum(live_sizes) sorted rows exist; a row past them is not read, gets scale 0 and keeps
+    whatever bytes its quantised row held (the same on every kernel path)."""
     _need_cuda(input)
     d = input.size(-1) // 2
     T = input.numel() // (2 * d)
@@ -247,10 +248,18 @@ _SLAB_WS_BYTES = 64 << 20
 
 def _slab_workspace(device):
     """explicit scratch of the packed-weight GEMMs (K-slice slabs; no invariant: nothing to zero, calls ordered on a stream may
-    share it). One fixed buffer per device, never replaced; a stream that runs GEMMs CONCURRENTLY with another one (the dual
-    micro-batch executor) registers its own with set_gemm_workspace_for_stream."""
-    own = _slab_ws.get((device, torch.cuda.current_stream(device).cuda_stream))
+    share it). One fixed buffer per device for the default stream and for captures, never replaced; every other stream that
+    launches eagerly gets its own (lazily), and the dual micro-batch executor registers one per stream with
+    set_gemm_workspace_for_stream."""
+    cur = torch.cuda.current_stream(device)
+    own = _slab_ws.get((device, cur.cuda_stream))
     if own is not None:
+        return own
+    if cur != torch.cuda.default_stream(device) and not torch.cuda.is_current_stream_capturing():
+        # eager launches on a side stream (FusedMoE's shared experts next to the routed path) may run CONCURRENTLY with the main
+        # stream's GEMMs: they get slabs of their own (a capture orders its launches explicitly and keeps the device buffer)
+        own = torch.empty(_SLAB_WS_BYTES, dtype=torch.uint8, device=device)
+        _slab_ws[(device, cur.cuda_stream)] = own
         return own
     ws = _slab_ws.get(device)
     if ws is None:
