@@ -89,6 +89,7 @@ struct GemmEpi {
   int gate_up;
   void* act_out;
   float* row_amax;
+  int w_policy;   // packed kernels, cache policy of the weight stream: 0 = by the launch shape, 1 = nt, 2 = default (tuning arm)
 };
 
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {

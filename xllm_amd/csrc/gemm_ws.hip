@@ -87,13 +87,19 @@ struct WsDma {
   int so_a, so_w;             // scalar offsets of the K tile
   ws_lds_ptr_t dump;          // 1-KiB area behind the ring: destination of a wave's padding pieces (eight-wave tiles whose
   int nvalid_w;               // weight fragments do not divide over the waves); pieces >= nvalid_w are out of range
+  int w_nt;                   // cache policy of the weight stream: nt when ONE workgroup reads a column range's weights (one m
+                              // tile), the default policy when the m tiles of a column range share them through their XCD's L2
+                              // (wave-uniform: a scalar branch; round 3, M = 256 on 128-row tiles: qkv 19.4 -> 17.2, o 19.7 -> 17.9 us)
 };
 template <int NDA, int NDW>
 __device__ __forceinline__ void ws_dma_piece(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int j) {
   if (j < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_a, d.dst_a + j * WS_FRAG, 16, voff_a[j], d.so_a, 0, 0);
-  else
+  else if (d.w_nt)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, (j - NDA) < d.nvalid_w ? d.dst_w + (j - NDA) * WS_FRAG : d.dump, 16,
                                              voff_w[j - NDA], d.so_w, 0, WS_W_AUX);
+  else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, (j - NDA) < d.nvalid_w ? d.dst_w + (j - NDA) * WS_FRAG : d.dump, 16,
+                                             voff_w[j - NDA], d.so_w, 0, 0);
 }
 // pieces due after MFMA group `slot` of 2 * NG (an even spread of ND pieces over the groups)
 template <int NDA, int NDW, int NG>
@@ -521,6 +527,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
     slice = rest / n_tiles;
   }
   const int KT = (int)(K / WS_BK);
+  const int w_nt = epi.w_policy ? epi.w_policy == 1 : m_tiles == 1;   // (WsDma::w_nt)
   const int kt0 = slice * kt_per_slice;
   int kt1 = kt0 + kt_per_slice;
   kt1 = kt1 > KT ? KT : kt1;
@@ -600,9 +607,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
     const ws_lds_ptr_t da_ = lds3 + ((T_) % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                              \
     _Pragma("unroll") for (int i_ = 0; i_ < NDA; ++i_)                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_A, da_ + i_ * WS_FRAG, 16, voff_a[i_], kt_ * WS_BK, 0, 0); \
-    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_)                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_) {                                                             \
+      if (w_nt)                                                                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_W, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,   \
                                                  voff_w[i_], kt_ * (2 * WS_FRAG), 0, WS_W_AUX);                      \
+      else                                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(WS_ABL_RSRC_W, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,   \
+                                                 voff_w[i_], kt_ * (2 * WS_FRAG), 0, 0);                             \
+    }                                                                                                                \
   }
 
   // ablation builds (tools/build_ablations.sh; timing only, WRONG results): an empty buffer descriptor makes every DMA of
@@ -642,6 +654,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
     d.so_w = ktn * (2 * WS_FRAG);
     d.dump = lds_dump;
     d.nvalid_w = nvalid_w;
+    d.w_nt = w_nt;
     const unsigned so = (t % NS) * SLOT;
 #ifndef WS_ABL_NOCOMPUTE
     if constexpr (KIND == kI8) ws_compute<MB, NG, NDA, NDW>(acc, rd_w + so, rd_a0 + so, rd_a1 + so, d, voff_a, voff_w);
@@ -735,6 +748,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
     slice = rest / n_tiles;
   }
   const int KT = (int)(K / WS_BK);
+  const int w_nt = epi.w_policy ? epi.w_policy == 1 : m_tiles == 1;   // (WsDma::w_nt)
   const int kt0 = slice * kt_per_slice;
   int kt1 = kt0 + kt_per_slice;
   kt1 = kt1 > KT ? KT : kt1;
@@ -795,9 +809,14 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
     const ws_lds_ptr_t da_ = lds3 + ((T_) % NS) * SLOT + SLOT_W + wave * NDA * WS_FRAG;                              \
     _Pragma("unroll") for (int i_ = 0; i_ < NDA; ++i_)                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, da_ + i_ * WS_FRAG, 16, voff_a[i_], kt_ * WS_BK, 0, 0);     \
-    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_)                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDW; ++i_) {                                                             \
+      if (w_nt)                                                                                                      \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,          \
                                                  voff_w[i_], kt_ * (2 * WS_FRAG), 0, WS_W_AUX);                      \
+      else                                                                                                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, i_ < nvalid_w ? dw_ + i_ * WS_FRAG : lds_dump, 16,          \
+                                                 voff_w[i_], kt_ * (2 * WS_FRAG), 0, 0);                             \
+    }                                                                                                                \
   }
 #pragma unroll
   for (int i = 0; i < DW; ++i) WS8_ISSUE(i)
@@ -814,6 +833,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
     D_.so_w = kk_ * (2 * WS_FRAG);                                                                                   \
     D_.dump = lds_dump;                                                                                              \
     D_.nvalid_w = nvalid_w;                                                                                          \
+    D_.w_nt = w_nt;                                                                                                  \
   }
   if (grp) {
     WS8_DESC(dp, DW)
@@ -992,6 +1012,7 @@ int ws_phase_stagger() {
   return f_ws8s;
 }
 
+static int f_wpolicy = 0;   // xllm_mi355_debug_ws_waves(140 | 141 | 142): weight-stream cache policy by shape | nt | default
 template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
@@ -999,6 +1020,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   const int m_tiles = (int)((M + WM * MB * 16 - 1) / (WM * MB * 16));
   // gate_up mode: a tile holds G / 2 ACT groups (their gate and their up columns); the split is over the N / 32 act groups
   const bool gu = epi.gate_up != 0;
+  epi.w_policy = f_wpolicy;
   if (gu && (G % 2 != 0 || KIND == kFP8)) return -1;
   const int n_groups = gu ? (int)(N / 32) : (int)(N / 16);
   const int KT = (int)(K / WS_BK);
@@ -1214,6 +1236,8 @@ extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan_
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_waves(int waves) {
   if (waves == 80 || waves == 81) { xm::f_waves = -1; xm::f_ws8s = waves - 80; return; }
   if (waves >= 128 && waves <= 131) { xm::f_rows128 = waves == 131 ? 0 : waves - 127; return; }
+  if (waves >= 140 && waves <= 142) { xm::f_wpolicy = waves - 140; return; }
+  if (waves == 0) xm::f_wpolicy = 0;
   if (waves == 0) xm::f_rows128 = 2;
   xm::f_waves = waves == 4 ? 4 : -1;
   if (waves == 0) xm::f_ws8s = 1;
