@@ -1058,7 +1058,7 @@ static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLIC
 struct WsShapePlan { int64_t N, K; int ng, slices; };
 static WsShapePlan shape_plans[8];
 static int n_shape_plans = 0;
-static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 8192 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
+static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 20480 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
                                   // 3 = N and K <= 8192, 4 = N <= 8192, 0 = never
                                   // (xllm_mi355_debug_ws_waves(128 | 129 | 130 | 131) = 1 | 2 | 3 | 0; XLLM_MI355_WS_ROWS128)
 static int f_waves = -2;          // XLLM_MI355_WS_WAVES / xllm_mi355_debug_ws_waves: 4 = the round-2 four-wave 256-row tile (A/B)
@@ -1081,7 +1081,7 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
   else if (f_waves == 4) { p.wm = 4; p.wn = 1; p.mb = 4; }
-  else if (f_rows128 == 1 || (f_rows128 == 2 && N <= 8192 && (K <= 8192 || M % 256 == 0)) ||
+  else if (f_rows128 == 1 || (f_rows128 == 2 && N <= 20480 && (K <= 8192 || M % 256 == 0)) ||
            (f_rows128 == 3 && N <= 8192 && K <= 8192) || (f_rows128 == 4 && N <= 8192)) {
     // 128-row tiles also above 128 rows for the few-column problems (qkv, o, down: N <= 8192). They need K slices to fill the
     // chip; with 2+ m tiles per column range half as many slices do, i.e. half the slab bytes written here and read back by the
@@ -1090,6 +1090,7 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     // in-process A/B of the step at B = 256 -0.14 ms (qkv / o -0.05, down -0.09), gate_up (never sliced) +0.35 ms; stand-alone
     // qkv / o win or tie at every M (M = 512: 27.5 -> 18.6, 24.0 -> 15.7 us), the long-K down projection only ties at
     // M = 256 / 512 and loses at 160 / 384 (30.7 -> 36.4, 46.9 -> 72.8 us): hence K <= 8192 or whole 256-row multiples.
+    // N up to 20480: the gate_up shards of TP = 2 / 4 (N = 18944 / 9472) gain 0.06 / 0.07 ms per step (profiles/r03_tp_shapes.txt).
     p.wm = 2; p.wn = 2; p.mb = 4;
   }
   else { p.waves = 8; p.wm = 4; p.wn = 2; p.mb = 4; }
