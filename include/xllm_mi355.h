@@ -613,6 +613,19 @@ XM_API int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* 
                                                      int world, size_t max_message_bytes, uint32_t* epoch_state, int* status,
                                                      double timeout_s, void* stream);
 
+/* The same with the row-parallel W8A8 linear in front of it (linear.cpp:481-507 + 1518-1520): the packed-weight GEMM of
+ * xllm_mi355_scaled_matmul_packed leaves this rank's exact int32 K-slice sums in `workspace` and step 1 of the one-shot kernel
+ * dequantises them -- rT(sum * a_scale[m] * w_scale[n] + bias[n]), the GEMM's own epilogue expression -- on their way into the
+ * exchange slot, so a TP half-layer is GEMM -> ONE kernel with no dequant pass in between. a [M, K] int8, w_packed =
+ * pack_weight_i8 of this rank's [N, K] shard, bias (rank 0 only, or NULL) in the output dtype; the rest as above with H = N.
+ * Bit-identical to xllm_mi355_scaled_matmul_packed -> xllm_mi355_oneshot_allreduce_add_rms_norm. M <= 512 and the envelope of
+ * the packed GEMM (XM_ERR_UNSUPPORTED otherwise, nothing written); workspace >= 4 M N bytes (XM_ERR_WORKSPACE). */
+XM_API int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
+    const int8_t* a, const int8_t* w_packed, const float* a_scale, const float* w_scale, const void* bias, void* residual,
+    const void* norm_weight, float eps, void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t N,
+    int64_t K, int dtype, void* workspace, size_t ws_bytes, void* const* peer_buffers, int rank, int world,
+    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

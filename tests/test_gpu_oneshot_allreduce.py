@@ -88,6 +88,32 @@ def _worker(rank, world, port, ret, distinct):
             if not good:
                 res["ok"] = False
                 res["log"].append(f"fused all-reduce + add + norm mismatch at M={M} H={H} quant={quant}")
+        # the same tail fed by the row-parallel W8A8 GEMM's int32 K-slice sums (no dequant pass, no 16-bit partial in memory)
+        # == packed scaled_matmul -> all-reduce + add + norm (+ quant), bit for bit; rank 0 carries the bias
+        for (M, N, K, quant) in ((256, 3584, 1792, True), (256, 3584, 4736, False), (32, 3584, 896, True), (130, 512, 1024, True)):
+            g1 = torch.Generator().manual_seed(1000 * rank + M + K)
+            a = torch.randint(-127, 128, (M, K), generator=g1, dtype=torch.int8).cuda()
+            w = torch.randint(-127, 128, (N, K), generator=g1, dtype=torch.int8).cuda()
+            a_s = (torch.rand(M, generator=g1) * 0.002 + 0.0005).cuda()
+            w_s = (torch.rand(N, generator=g1) * 0.002 + 0.0005).cuda()
+            g0 = torch.Generator().manual_seed(M + N + K)
+            bias = (torch.randn(N, generator=g0).bfloat16() if rank == 0 else torch.zeros(N, dtype=torch.bfloat16)).cuda()
+            resid0 = torch.randn(M, N, generator=g0).bfloat16().cuda()
+            nw = (torch.rand(N, generator=g0) + 0.5).bfloat16().cuda()
+            wp = ops.pack_weight_i8(w)
+            part = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias, b_packed=wp)
+            r_ref = resid0.clone()
+            ref = pg.allreduce_add_rms_norm(part, r_ref, nw, 1e-6, quant)
+            r_got = resid0.clone()
+            got = pg.matmul_allreduce_add_rms_norm(a, a_s, wp, w_s, bias, r_got, nw, 1e-6, quant)
+            good = got is not None and ref is not None and torch.equal(r_got, r_ref)
+            if good and quant:
+                good = torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            elif good:
+                good = torch.equal(got, ref)
+            if not good:
+                res["ok"] = False
+                res["log"].append(f"GEMM-fed all-reduce + add + norm mismatch at M={M} N={N} K={K} quant={quant}")
         # one stream only: a launch from another stream declines (the group's own all-reduce serves it)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):

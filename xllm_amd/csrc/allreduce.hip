@@ -20,6 +20,7 @@
 // memory and is advanced by the last block to leave, so the launch is a plain kernel: capturable into a HIP graph, and a
 // TP step needs no eager collective between graph pieces.
 #include "common.h"
+#include "gemm_types.h"
 
 namespace xm {
 
@@ -118,9 +119,21 @@ __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_kernel(ArPeers p
 // Block b owns rows [b * rpb, (b + 1) * rpb); flags, slots and the epoch are shared with the plain kernel (same buffer).
 constexpr int kArNormMaxVec = 4;   // 16-byte chunks per thread: rows up to 512 * 4 * 8 = 16384 elements
 
+// this rank's partial sums as the row-parallel W8A8 GEMM left them: n_slabs K-slice slabs of exact int32 sums (gemm_ws.hip, defer
+// mode) + the dequant operands. Step 1 of the fused kernel then computes the rank's 16-bit partial itself -- r16(sum * a_s[m] *
+// w_s[n] + bias[n]), the expression of ws_slab_epilogue_kernel -- instead of copying one: the TP half-layer is GEMM -> this kernel.
+struct ArSlabs {
+  const int32_t* slabs;   // null: the 16-bit `partial` is the input
+  int n_slabs;
+  int64_t stride;         // elements between slabs (M * H)
+  const float* a_scale;
+  const float* w_scale;
+  const void* bias;
+};
+
 template <typename T, bool QUANT>
 __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_norm_kernel(
-    ArPeers peers, const T* __restrict__ partial, T* __restrict__ residual, const T* __restrict__ weight, float eps,
+    ArPeers peers, ArSlabs sl, const T* __restrict__ partial, T* __restrict__ residual, const T* __restrict__ weight, float eps,
     T* __restrict__ out_norm, int8_t* __restrict__ out_q, float* __restrict__ out_scale, T* __restrict__ out_sum, int M, int H,
     int rows_per_block, int rank, int world, int64_t slot_bytes, uint32_t* __restrict__ epoch_state, int* __restrict__ status,
     long long timeout_ticks) {
@@ -137,7 +150,39 @@ __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_norm_kernel(
   const u32x4* in = reinterpret_cast<const u32x4*>(partial);
   // 1. my rows -> my slot
   u32x4* mine = reinterpret_cast<u32x4*>(peers.base[rank] + kArFlagBytes + (int64_t)buf * slot_bytes);
-  for (int64_t i = (int64_t)r0 * nvec + threadIdx.x; i < (int64_t)r1 * nvec; i += kArThreads) mine[i] = in[i];
+  if (sl.slabs) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const T* bias = reinterpret_cast<const T*>(sl.bias);
+    for (int64_t i = (int64_t)r0 * nvec + threadIdx.x; i < (int64_t)r1 * nvec; i += kArThreads) {
+      const int r = (int)(i / nvec), c = (int)(i - (int64_t)r * nvec);
+      const int32_t* row = sl.slabs + (int64_t)r * H;
+      i32x4 a0 = reinterpret_cast<const i32x4*>(row)[2 * c], a1 = reinterpret_cast<const i32x4*>(row)[2 * c + 1];
+      for (int s0 = 1; s0 < sl.n_slabs; s0 += 7) {   // (at most 8 slices: one pass with every load in flight)
+        i32x4 b0[7], b1[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          const bool ok = s0 + u < sl.n_slabs;
+          const int32_t* p = row + (ok ? s0 + u : 0) * sl.stride;
+          b0[u] = reinterpret_cast<const i32x4*>(p)[2 * c];
+          b1[u] = reinterpret_cast<const i32x4*>(p)[2 * c + 1];
+          if (!ok) { b0[u] = i32x4{0, 0, 0, 0}; b1[u] = i32x4{0, 0, 0, 0}; }
+        }
+        a0 += ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b0[4] + b0[5]) + b0[6]);
+        a1 += ((b1[0] + b1[1]) + (b1[2] + b1[3])) + ((b1[4] + b1[5]) + b1[6]);
+      }
+      const float as = sl.a_scale[r];
+      const float4 w0 = reinterpret_cast<const float4*>(sl.w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(sl.w_scale)[2 * c + 1];
+      const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      RowVec<T> bv, yv;
+      bv.raw = bias ? reinterpret_cast<const uint4*>(bias)[c] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < N; ++j) yv.set(j, (float)av[j] * as * wv[j] + (bias ? bv.get(j) : 0.0f));   // the GEMM's 16-bit output
+      mine[i] = u32x4{yv.raw.x, yv.raw.y, yv.raw.z, yv.raw.w};
+    }
+  } else {
+    for (int64_t i = (int64_t)r0 * nvec + threadIdx.x; i < (int64_t)r1 * nvec; i += kArThreads) mine[i] = in[i];
+  }
   __threadfence_system();
   __syncthreads();
   if ((int)threadIdx.x < world) {
@@ -337,13 +382,12 @@ int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* co
   return hip_check_launch();
 }
 
-int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residual, const void* norm_weight, float eps,
-                                              void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M,
-                                              int64_t H, int dtype, void* const* peer_buffers, int rank, int world,
-                                              size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s,
-                                              void* stream) {
-  if (!partial || !residual || !norm_weight || !peer_buffers || !epoch_state || !status || M < 0 || H <= 0 || world < 1 ||
-      world > kArMaxWorld || rank < 0 || rank >= world)
+static int launch_oneshot_norm(xm::ArSlabs sl, const void* partial, void* residual, const void* norm_weight, float eps,
+                               void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t H, int dtype,
+                               void* const* peer_buffers, int rank, int world, size_t max_message_bytes, uint32_t* epoch_state,
+                               int* status, double timeout_s, void* stream) {
+  if ((!partial && !sl.slabs) || !residual || !norm_weight || !peer_buffers || !epoch_state || !status || M < 0 || H <= 0 ||
+      world < 1 || world > kArMaxWorld || rank < 0 || rank >= world)
     return XM_ERR_INVALID;
   if ((out_q != nullptr) == (out_norm != nullptr)) return XM_ERR_INVALID;  // exactly one output form
   if (out_q && !out_q_scale) return XM_ERR_INVALID;
@@ -368,12 +412,45 @@ int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residua
   hipStream_t s = (hipStream_t)stream;
 #define XM_ARN(T, Q)                                                                                                  \
   hipLaunchKernelGGL((oneshot_allreduce_norm_kernel<T, Q>), dim3((unsigned)grid), dim3(kArThreads), 0, s, peers,     \
-                     (const T*)partial, (T*)residual, (const T*)norm_weight, eps, (T*)out_norm, out_q, out_q_scale,  \
+                     sl, (const T*)partial, (T*)residual, (const T*)norm_weight, eps, (T*)out_norm, out_q, out_q_scale, \
                      (T*)out_sum, (int)M, (int)H, rpb, rank, world, slot_bytes, epoch_state, status, ticks)
   if (dtype == XM_BF16) { if (out_q) XM_ARN(bf16_t, true); else XM_ARN(bf16_t, false); }
   else { if (out_q) XM_ARN(f16_t, true); else XM_ARN(f16_t, false); }
 #undef XM_ARN
   return hip_check_launch();
+}
+
+int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residual, const void* norm_weight, float eps,
+                                              void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M,
+                                              int64_t H, int dtype, void* const* peer_buffers, int rank, int world,
+                                              size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s,
+                                              void* stream) {
+  if (!partial) return XM_ERR_INVALID;
+  return launch_oneshot_norm(xm::ArSlabs{nullptr, 0, 0, nullptr, nullptr, nullptr}, partial, residual, norm_weight, eps, out_norm,
+                             out_q, out_q_scale, out_sum, M, H, dtype, peer_buffers, rank, world, max_message_bytes, epoch_state,
+                             status, timeout_s, stream);
+}
+
+int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
+    const int8_t* a, const int8_t* w_packed, const float* a_scale, const float* w_scale, const void* bias, void* residual,
+    const void* norm_weight, float eps, void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t N,
+    int64_t K, int dtype, void* workspace, size_t ws_bytes, void* const* peer_buffers, int rank, int world,
+    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, void* stream) {
+  if (!a || !w_packed || !a_scale || !w_scale || !workspace || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  if ((size_t)M * N * 2 > max_message_bytes) return XM_ERR_WORKSPACE;
+  if (N % 8 || ((uintptr_t)w_scale % 16) || (bias && (uintptr_t)bias % 16) || M > 512) return XM_ERR_UNSUPPORTED;
+  // the row-parallel GEMM leaves its exact int32 K-slice sums in `workspace` (no dequant pass) ...
+  xm::GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0};
+  epi.defer = 1;
+  int n_slabs = 0;
+  const int rc = xm::launch_gemm_ws_i8(a, w_packed, M, N, K, epi, workspace, ws_bytes, &n_slabs, (hipStream_t)stream);
+  if (rc != XM_OK) return rc;
+  // ... and step 1 of the one-shot kernel turns them into this rank's 16-bit partial on its way into the exchange slot
+  return launch_oneshot_norm(xm::ArSlabs{reinterpret_cast<const int32_t*>(workspace), n_slabs, M * N, a_scale, w_scale, bias},
+                             nullptr, residual, norm_weight, eps, out_norm, out_q, out_q_scale, out_sum, M, N, dtype,
+                             peer_buffers, rank, world, max_message_bytes, epoch_state, status, timeout_s, stream);
 }
 
 }  // extern "C"

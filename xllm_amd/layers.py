@@ -213,6 +213,12 @@ class Qwen2DecoderLayer:
         if not self.fuse or lin.pg is None or lin.pg.world_size() == 1 or lin.pg.oneshot is None or residual is None \
                 or norm_w is None:
             return None
+        if lin.mode == "int8" and lin.weight_packed is not None and pre_quant[0].dim() == 2:
+            # the GEMM's int32 K-slice sums go straight into the one-shot kernel (no dequant pass, round 3)
+            out = lin.pg.matmul_allreduce_add_rms_norm(pre_quant[0], pre_quant[1], lin.weight_packed, lin.w_scale, lin.bias,
+                                                       residual, norm_w, self.args.rms_norm_eps, quantize)
+            if out is not None:
+                return out
         y = lin.forward(None, pre_quant=pre_quant, reduce=False)      # this rank's partial sums, 16 bit (bias on rank 0 only)
         return lin.pg.allreduce_add_rms_norm(y, residual, norm_w, self.args.rms_norm_eps, quantize) if y.dim() == 2 else None
 

@@ -90,6 +90,14 @@ class ProcessGroup:
             return None
         return self.oneshot.allreduce_add_rms_norm(partial, residual, weight, eps, quantize)
 
+    def matmul_allreduce_add_rms_norm(self, a_q, a_scale, w_packed, w_scale, bias, residual, weight, eps: float, quantize: bool):
+        """row-parallel W8A8 linear -> SUM all-reduce -> residual add -> RMSNorm (-> int8 quant) as GEMM + ONE kernel: the one-shot
+        kernel reads the GEMM's int32 K-slice sums directly (OneShotAllReduce.matmul_allreduce_add_rms_norm). None when the
+        one-shot path is off or the shape is outside it (the caller runs linear + allreduce_add_rms_norm)."""
+        if self.oneshot is None or w_packed is None or not self.oneshot._stream_ok():
+            return None
+        return self.oneshot.matmul_allreduce_add_rms_norm(a_q, a_scale, w_packed, w_scale, bias, residual, weight, eps, quantize)
+
     def allreduce_async(self, x: torch.Tensor):
         """ProcessGroup::allreduce_async (process_group.cpp:103-108): returns the c10d Work. With RCCL the collective runs on
         the process group's own HIP stream, fenced against the CURRENT stream by events on both sides (enqueue: the RCCL
@@ -249,6 +257,43 @@ class OneShotAllReduce:
         out = (q, qs) if quantize else n16
         return (out, ysum) if want_sum else out
 
+    def matmul_allreduce_add_rms_norm(self, a_q, a_scale, w_packed, w_scale, bias, residual, weight, eps: float,
+                                      quantize: bool, want_sum: bool = False):
+        """xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm: the row-parallel W8A8 linear on packed weights whose int32
+        K-slice sums are dequantised by step 1 of the one-shot kernel (no dequant pass, no 16-bit partial in memory). Returns like
+        allreduce_add_rms_norm, or None when the GEMM declines the shape (decided by M, N, K alone: the same on every rank;
+        nothing has been written then)."""
+        from . import ops
+        l = self._lib.lib()
+        s = self._bind()
+        M, K = a_q.shape
+        N = w_scale.numel()
+        if residual.shape != (M, N) or not residual.is_contiguous() or not a_q.is_contiguous():
+            raise self._lib.Mi355Error("matmul_allreduce_add_rms_norm: a [M, K] and residual [M, N] contiguous")
+        if M * N * residual.element_size() > self.max_bytes or M > 512 or not ops._prefer_packed(M, N, K):
+            return None
+        ws = ops._slab_workspace(a_q.device)
+        dev = a_q.device
+        q = qs = n16 = ysum = None
+        if quantize:
+            q = torch.empty(M, N, dtype=torch.int8, device=dev)
+            qs = torch.empty(M, dtype=torch.float32, device=dev)
+        else:
+            n16 = torch.empty(M, N, dtype=residual.dtype, device=dev)
+        if want_sum:
+            ysum = torch.empty(M, N, dtype=residual.dtype, device=dev)
+        P = lambda t: 0 if t is None else t.data_ptr()
+        rc = l.xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
+            a_q.data_ptr(), w_packed.data_ptr(), a_scale.data_ptr(), w_scale.data_ptr(), P(bias), residual.data_ptr(),
+            weight.data_ptr(), float(eps), P(n16), P(q), P(qs), P(ysum), M, N, K, self._DT[residual.dtype], ws.data_ptr(),
+            ws.numel(), self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes, self.state.data_ptr(),
+            self.status.data_ptr(), self.timeout_s, s)
+        if rc in (-2, -4):
+            return None
+        self._lib.check(rc, "scaled_matmul_oneshot_allreduce_add_rms_norm")
+        out = (q, qs) if quantize else n16
+        return (out, ysum) if want_sum else out
+
     # ---- health --------------------------------------------------------------------------------------------------------
     def self_test(self) -> bool:
         """one checked message per size class through both kernels (every rank calls it; the caller agrees on the verdict):
@@ -273,6 +318,18 @@ class OneShotAllReduce:
             (n16, ysum) = self.allreduce_add_rms_norm(pat * float(rank + 1), res, w, 1e-6, quantize=False, want_sum=True)
             ok = ok and bool(torch.equal(ysum, pat * float(tri))) and bool(torch.equal(res, pat * float(tri) + 1.0))
             ok = ok and bool(torch.isfinite(n16.float()).all())
+            # the GEMM-fed form: every rank multiplies ones by ones (sum = K) with a_scale = (rank + 1) / K -> partial = rank + 1
+            from . import ops
+            M, K, N = 8, 512, 512
+            a = torch.ones(M, K, dtype=torch.int8, device=self.device)
+            wp = ops.pack_weight_i8(torch.ones(N, K, dtype=torch.int8, device=self.device))
+            a_s = torch.full((M,), float(rank + 1) / K, dtype=torch.float32, device=self.device)
+            w_s = torch.ones(N, dtype=torch.float32, device=self.device)
+            res = torch.ones(M, N, dtype=torch.bfloat16, device=self.device)
+            w = torch.ones(N, dtype=torch.bfloat16, device=self.device)
+            got = self.matmul_allreduce_add_rms_norm(a, a_s, wp, w_s, None, res, w, 1e-6, quantize=False, want_sum=True)
+            if got is not None:    # (None: the packed GEMM is switched off -- the same on every rank)
+                ok = ok and bool((got[1] == float(tri)).all()) and bool((res == float(tri) + 1.0).all())
             torch.cuda.synchronize(self.device)
             ok = ok and int(self.status.item()) == 0
         except Exception:   # noqa: BLE001
