@@ -332,6 +332,8 @@ def main():
         if tp_pg is not None and tp_sz > 1 and not a.no_oneshot_allreduce:
             # the one-shot xGMI all-reduce for the per-layer sums (<= 8 MiB), self-tested at set-up; RCCL when the test fails
             tp_pg.enable_oneshot(dev, 8 << 20)
+            if tp_pg.oneshot is not None:
+                tp_pg.oneshot.timeout_s = 10.0   # bounded waits stay bounded; first launches (code load) may be slow on one rank
             if rank == 0 and tp_pg.oneshot is None:
                 print(f"[bench] one-shot all-reduce not used: {tp_pg.oneshot_note}", file=sys.stderr)
         B = gbatch // dp_sz
@@ -371,6 +373,7 @@ def main():
             hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
             return ops.greedy_argmax(model.logits(hidden))
 
+        sync_all()     # ranks build their shards at different speeds: nobody enters the first collective seconds before a peer
         for _ in range(a.warmup):
             step()
         sync_all()
