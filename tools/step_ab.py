@@ -10,6 +10,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
         ws_waves=N         xllm_mi355_debug_ws_waves (4, 80, 81, 128..131, 0)
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
         attn=s,h,d,e       xllm_mi355_debug_decode_plan: split-KV count, kv heads per workgroup, deep prefetch, exclusive CU
+        idle=before|after,US   an idle gap of US microseconds in front of / behind every decode-attention launch (analysis)
         env:NAME=VALUE     os.environ (only for switches that are read at call time)
     default: python tools/step_ab.py 256 4096 fused=fuse_gu=1 unfused=fuse_gu=0
 """
@@ -45,6 +46,9 @@ def apply(settings):
             _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(n_), ctypes.c_longlong(k_), g_, s_)
         elif k == "attn":                        # attn=splits,hpw,deep,excl (0 = planner / default)
             _lib.lib().xllm_mi355_debug_decode_plan(*(int(x) for x in v.split(",")))
+        elif k == "idle":                        # idle=before|after,US : an idle gap of US microseconds next to every decode-attention launch
+            where, us = v.split(",")
+            IDLE["where"], IDLE["us"] = where, float(us)
         elif k.startswith("env:"):
             os.environ[k[4:]] = v
         else:
@@ -52,7 +56,26 @@ def apply(settings):
     _lib.lib().xllm_mi355_debug_ws_plan(ng, sl)
 
 
+IDLE = {"where": None, "us": 0.0}
+_orig_attn = ops.paged_decode_attention_int8
+
+
+def _attn_with_idle(*a, **kw):
+    import ctypes
+    st = torch.cuda.current_stream().cuda_stream
+    if IDLE["where"] == "before":
+        _lib.lib().xllm_mi355_debug_idle(ctypes.c_double(IDLE["us"]), ctypes.c_void_p(st))
+    out = _orig_attn(*a, **kw)
+    if IDLE["where"] == "after":
+        _lib.lib().xllm_mi355_debug_idle(ctypes.c_double(IDLE["us"]), ctypes.c_void_p(st))
+    return out
+
+
+ops.paged_decode_attention_int8 = _attn_with_idle
+
+
 def reset():
+    IDLE["where"], IDLE["us"] = None, 0.0
     ops._GATE_UP_FUSION = True
     import ctypes
     _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)

@@ -86,6 +86,18 @@ int decode_exclusive_cu() {
 
 using namespace xm;
 
+// analysis (tools/step_ab.py idle=...): ONE wave that does nothing for `us` microseconds (s_sleep loop on the 100-MHz wall clock): a
+// controlled idle gap in front of / behind a kernel of the step, to separate what a kernel costs from the state its predecessor leaves
+__global__ void debug_idle_kernel(long long ticks) {
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_idle(double us, void* stream) {
+  if (us <= 0) return 0;
+  hipLaunchKernelGGL(debug_idle_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(us * 100.0));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // tuning (tools/step_ab.py): the decode kernel's launch plan for the following calls; < 0 = leave as it is, 0 = planner / default
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_decode_plan(int splits, int hpw, int deep, int excl) {
   (void)decode_num_splits(1, 4, 4, 4096); (void)decode_heads_per_wg(1, 4); (void)decode_deep_prefetch(); (void)decode_exclusive_cu();  // env first
