@@ -274,10 +274,9 @@ _PACKED_POLICY = os.environ.get("XLLM_MI355_PACKED", "auto")   # "0" never, "1" 
 
 
 def _prefer_packed(M: int, N: int, K: int) -> bool:
-    """which int8 kernel serves a decode-shaped GEMM (profiles/r02_gemm_ws.txt): the weight-stream kernel on packed weights
-    wins wherever the weight stream is the bound -- every shape at M <= 128, and the few-column / long-K problems (down_proj)
-    up to M = 512; at M = 256 the wide problems stay on the 256 x 256 8-phase kernel (the activation tile then takes most of
-    the LDS ring)."""
+    """which int8 kernel serves a decode-shaped GEMM: since round 3 the weight-stream kernel on packed weights takes every
+    problem of at most 512 rows (profiles/r03_gemm_ws.txt, r03_policy.txt). XLLM_MI355_PACKED = "r2" restores the
+    round-2 policy (M <= 128, and the few-column / long-K problems up to M = 512) as an A/B arm, "0" / "1" = never / always."""
     if _PACKED_POLICY == "0":
         return False
     if _PACKED_POLICY == "1":
