@@ -213,6 +213,8 @@ class Qwen2DecoderLayer:
         if not self.fuse or lin.pg is None or lin.pg.world_size() == 1 or lin.pg.oneshot is None or residual is None \
                 or norm_w is None:
             return None
+        if pre_quant[0].size(0) * lin.weight.size(0) * 2 > lin.pg.oneshot.max_bytes:
+            return None       # (a prefill-sized message: decided before the GEMM runs, the caller takes linear + reduce)
         if lin.mode == "int8" and lin.weight_packed is not None and pre_quant[0].dim() == 2:
             # the GEMM's int32 K-slice sums go straight into the one-shot kernel (no dequant pass, round 3)
             out = lin.pg.matmul_allreduce_add_rms_norm(pre_quant[0], pre_quant[1], lin.weight_packed, lin.w_scale, lin.bias,
