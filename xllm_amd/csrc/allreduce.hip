@@ -64,8 +64,12 @@ __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_kernel(ArPeers p
   if ((int)threadIdx.x < world) {
     const uint32_t* f = reinterpret_cast<const uint32_t*>(peers.base[rank]) + ((int64_t)buf * kArBlocks + b) * kArMaxWorld + threadIdx.x;
     const long long t0 = wall_clock64();
+    // a launch that already finds the status word raised does not wait at all: after ONE timed-out wait every later collective
+    // fails fast (its result is undefined anyway and the host drops the path at its next check), so a dead peer costs one
+    // timeout per step sequence, not one per collective
+    const long long limit = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : timeout_ticks;
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; break; }
+      if (wall_clock64() - t0 > limit) { timed_out = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -195,8 +199,12 @@ __global__ __launch_bounds__(kArThreads) void oneshot_allreduce_norm_kernel(
   if ((int)threadIdx.x < world) {
     const uint32_t* f = reinterpret_cast<const uint32_t*>(peers.base[rank]) + ((int64_t)buf * kArBlocks + b) * kArMaxWorld + threadIdx.x;
     const long long t0 = wall_clock64();
+    // a launch that already finds the status word raised does not wait at all: after ONE timed-out wait every later collective
+    // fails fast (its result is undefined anyway and the host drops the path at its next check), so a dead peer costs one
+    // timeout per step sequence, not one per collective
+    const long long limit = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : timeout_ticks;
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-      if (wall_clock64() - t0 > timeout_ticks) { timed_out = 1; break; }
+      if (wall_clock64() - t0 > limit) { timed_out = 1; break; }
       __builtin_amdgcn_s_sleep(2);
     }
   }
