@@ -21,12 +21,11 @@ SELECT = ("scaled_matmul_int32_exact or splitk_workspace or w8a8_dynamic or matm
     {"XLLM_MI355_WSB_SLICES": "3"},                           # weight-stream 16-bit kernel with a forced K-slice count
     {"XLLM_MI355_WSB": "2"},                                  # ... on every M <= 64 (default policy: M <= 32)
     {"XLLM_MI355_KSTAGGER": "0"},                             # every workgroup walks K from its first tile (round-2 behaviour)
-    {"XLLM_MI355_WS_WAVES": "4", "XLLM_MI355_PACKED": "1"},   # packed kernel on the four-wave 256-row tile, everywhere legal
     {"XLLM_MI355_PACKED": "1"},                               # packed kernel everywhere legal (default tile heights)
     {"XLLM_MI355_PACKED": "1", "XLLM_MI355_WS_ROWS128": "0"},  # ... with the 256-row eight-wave tile for every M > 128 (round-3 first version)
     {"XLLM_MI355_PACKED": "1", "XLLM_MI355_WS_ROWS128": "1", "XLLM_MI355_SLAB_ROPE_VEC": "0"},  # 128-row tiles for every N; scalar RoPE consumer
 ], ids=["p8_forced", "p8_mfma32", "general_only", "skinny_bm256", "wsb_off", "wsb_slices3", "wsb_to_64", "no_kstagger",
-        "ws_four_waves", "packed_everywhere", "packed_rows256", "packed_rows128_all"])
+        "packed_everywhere", "packed_rows256", "packed_rows128_all"])
 def test_gemm_parity_under_kernel_selector(env):
     e = dict(os.environ)
     e.update(env)

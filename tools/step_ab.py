@@ -7,7 +7,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
     python tools/step_ab.py [B] [ctx] [variants...]      variants: name=setting;setting  with settings
         fuse_gu=0|1        ops._GATE_UP_FUSION
         ws_ng=N  ws_sl=N   xllm_mi355_debug_ws_plan
-        ws_waves=N         xllm_mi355_debug_ws_waves (4, 80, 81, 128..131, 0)
+        ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 128..131, 140..142, 0)
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
         attn=s,h,d,e       xllm_mi355_debug_decode_plan: split-KV count, kv heads per workgroup, deep prefetch, exclusive CU
         idle=before|after,US   an idle gap of US microseconds in front of / behind every decode-attention launch (analysis)

@@ -1037,12 +1037,9 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   if constexpr (NWV == 8) {
     if (ws_phase_stagger()) {
       constexpr int ND8 = (2 * WN * NG + 7) / 8 + 4;  // pieces per wave and tile (weights + 4 activation pieces)
-      if (ws_phase_stagger() == 2)   // A/B arm: every request from the matrix phase (first version)
-        hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, 0>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
-                           (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
-      else
-        hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
-                           (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+      // (a first version issued every request from the matrix phase, NRD = 0: 46.0 vs 45.4 us for gate_up at M = 256 -- removed)
+      hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
       return slices;
     }
   }
@@ -1061,7 +1058,8 @@ static int n_shape_plans = 0;
 static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 20480 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
                                   // 3 = N and K <= 8192, 4 = N <= 8192, 0 = never
                                   // (xllm_mi355_debug_ws_waves(128 | 129 | 130 | 131) = 1 | 2 | 3 | 0; XLLM_MI355_WS_ROWS128)
-static int f_waves = -2;          // XLLM_MI355_WS_WAVES / xllm_mi355_debug_ws_waves: 4 = the round-2 four-wave 256-row tile (A/B)
+static int f_waves = -2;          // (env read flag; the round-2 four-wave 256-row tile, XLLM_MI355_WS_WAVES=4, lost the in-step A/B by
+                                  //  0.27 ms and left the library in round 3)
 static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes, bool gu = false) {
   if (f_ng == -2) {
     const char* e = getenv("XLLM_MI355_WS_NG");
@@ -1070,9 +1068,8 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
     f_sl = e ? atoi(e) : -1;
   }
   if (f_waves == -2) {
-    const char* e = getenv("XLLM_MI355_WS_WAVES");
-    f_waves = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_WS_ROWS128");
+    f_waves = -1;
+    const char* e = getenv("XLLM_MI355_WS_ROWS128");
     if (e) f_rows128 = atoi(e);
   }
   WsPlan p;
@@ -1080,7 +1077,6 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
-  else if (f_waves == 4) { p.wm = 4; p.wn = 1; p.mb = 4; }
   else if (f_rows128 == 1 || (f_rows128 == 2 && N <= 20480 && (K <= 8192 || M % 256 == 0)) ||
            (f_rows128 == 3 && N <= 8192 && K <= 8192) || (f_rows128 == 4 && N <= 8192)) {
     // 128-row tiles also above 128 rows for the few-column problems (qkv, o, down: N <= 8192). They need K slices to fill the
@@ -1102,7 +1098,7 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   if (gu) can_slice = false;
   // candidates of the family, narrowest first (a narrower ring slot = more tiles in flight in the same LDS)
   static const int ngs_w1[] = {2, 4, 6, 8, 10}, ngs_w2[] = {1, 2, 3, 4, 5}, ngs_w4[] = {1, 2, 3};
-  const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);
+  const int* ngs = p.wn == 1 ? ngs_w1 : (p.wn == 2 ? ngs_w2 : ngs_w4);   // (wn == 1: no family left since round 3)
   const int n_ngs = p.wn == 4 ? 3 : 5;
   const int g_max = p.wn * ngs[n_ngs - 1] / cap_div;
   const int per_simd = p.waves / 4;  // waves sharing one matrix pipe
@@ -1149,7 +1145,6 @@ int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64
   // of requests in flight to pull its share of the HBM stream, MI355X_MICROARCH.md "ldsdma-fill"); a slot holds the tile's
   // weight fragments (2 KiB per column group) and activation fragments (2 KiB per 16-row block)
   WS_CASE(8, 4, 2, 4, 5, 2) WS_CASE(8, 4, 2, 4, 4, 2) WS_CASE(8, 4, 2, 4, 3, 2) WS_CASE(8, 4, 2, 4, 2, 3) WS_CASE(8, 4, 2, 4, 1, 3)
-  WS_CASE(4, 4, 1, 4, 10, 2) WS_CASE(4, 4, 1, 4, 8, 2) WS_CASE(4, 4, 1, 4, 6, 2) WS_CASE(4, 4, 1, 4, 4, 3) WS_CASE(4, 4, 1, 4, 2, 3)
   WS_CASE(4, 2, 2, 4, 5, 3) WS_CASE(4, 2, 2, 4, 4, 4) WS_CASE(4, 2, 2, 4, 3, 4) WS_CASE(4, 2, 2, 4, 2, 5) WS_CASE(4, 2, 2, 4, 1, 6)
   WS_CASE(4, 1, 4, 4, 3, 4) WS_CASE(4, 1, 4, 4, 2, 5) WS_CASE(4, 1, 4, 4, 1, 8)
   WS_CASE(4, 1, 4, 2, 3, 4) WS_CASE(4, 1, 4, 2, 2, 6) WS_CASE(4, 1, 4, 2, 1, 8)
@@ -1232,14 +1227,13 @@ extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan_
     if (xm::shape_plans[i].N == N && xm::shape_plans[i].K == K) { xm::shape_plans[i].ng = ng; xm::shape_plans[i].slices = slices; return; }
   if (xm::n_shape_plans < 8) xm::shape_plans[xm::n_shape_plans++] = {N, K, ng, slices};
 }
-// tests / tuning: 4 = the four-wave 256-row tile for M > 128 (round 2), anything else = the eight-wave tile (default)
-// 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default)
+// tests / tuning: 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default); 128 .. 131 = tile height above
+// 128 rows; 140 .. 142 = cache policy of the weight stream; 0 = defaults
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_waves(int waves) {
   if (waves == 80 || waves == 81) { xm::f_waves = -1; xm::f_ws8s = waves - 80; return; }
   if (waves >= 128 && waves <= 131) { xm::f_rows128 = waves == 131 ? 0 : waves - 127; return; }
   if (waves >= 140 && waves <= 142) { xm::f_wpolicy = waves - 140; return; }
   if (waves == 0) xm::f_wpolicy = 0;
   if (waves == 0) xm::f_rows128 = 2;
-  xm::f_waves = waves == 4 ? 4 : -1;
   if (waves == 0) xm::f_ws8s = 1;
 }
