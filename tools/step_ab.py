@@ -6,6 +6,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
 
     python tools/step_ab.py [B] [ctx] [variants...]      variants: name=setting;setting  with settings
         fuse_gu=0|1        ops._GATE_UP_FUSION
+        packed=auto|r2|0|1 ops._PACKED_POLICY (r2 = the round-2 policy)
         ws_ng=N  ws_sl=N   xllm_mi355_debug_ws_plan
         ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 128..131, 140..142, 0)
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
@@ -46,6 +47,8 @@ def apply(settings):
             _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(n_), ctypes.c_longlong(k_), g_, s_)
         elif k == "attn":                        # attn=splits,hpw,deep,excl (0 = planner / default)
             _lib.lib().xllm_mi355_debug_decode_plan(*(int(x) for x in v.split(",")))
+        elif k == "packed":                      # packed=auto|r2|0|1 : ops._PACKED_POLICY (which decode GEMMs run on packed weights)
+            ops._PACKED_POLICY = v
         elif k == "idle":                        # idle=before|after,US : an idle gap of US microseconds next to every decode-attention launch
             where, us = v.split(",")
             IDLE["where"], IDLE["us"] = where, float(us)
@@ -76,6 +79,7 @@ ops.paged_decode_attention_int8 = _attn_with_idle
 
 def reset():
     IDLE["where"], IDLE["us"] = None, 0.0
+    ops._PACKED_POLICY = "auto"
     ops._GATE_UP_FUSION = True
     import ctypes
     _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)
