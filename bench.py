@@ -421,7 +421,8 @@ def main():
         sync_all()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         if tp_pg is not None:
-            tp_pg.check()     # the one-shot kernel's bounded waits: a timed-out launch voids the measurement (raises)
+            tp_pg.check_agreed()   # the one-shot kernel's bounded waits: a timed-out launch on ANY rank voids the measurement and
+                                   # raises on EVERY rank (collective), so all ranks take the RCCL re-timing branch together
         ms = elapsed / steps * 1e3
         exposed = 0.0 if tp_sz == 1 else None
         eager_collectives = 0

@@ -208,6 +208,12 @@ XM_API int xllm_mi355_scaled_matmul_packed(const int8_t* a, const int8_t* w_pack
                                            const float* w_scale, const void* bias, void* out, int32_t* acc_out,
                                            int64_t M, int64_t N, int64_t K, int out_dtype, void* workspace,
                                            size_t ws_bytes, void* stream);
+/* Planner hint for the packed-weight GEMMs launched AFTERWARDS BY THE CALLING THREAD (thread-local: a worker thread's hint never
+ * touches another worker's launches; the analogue of an algo preference in a BLAS library -- the reference's hipBLASLt call picks
+ * its algorithm by heuristic, kernels/dcu/scaled_matmul.cpp:242-262). ng = 16-column groups per wave (tile width), slices = K
+ * slices, tile_rows = 128 | 256 for 128 < M <= 512; 0 = leave to the planner. Every combination gives bit-identical int8
+ * results; the parity tests use the hint to cover the tile shapes the planner picks at other problem sizes. */
+XM_API void xllm_mi355_gemm_plan_hint(int ng, int slices, int tile_rows);
 /* xllm_mi355_scaled_matmul_add_rms_norm on packed weights with the explicit workspace (>= 4*M*N bytes required,
  * XM_ERR_WORKSPACE otherwise; more lets the planner slice K). Bit-identical to the unfused operator sequence. */
 XM_API int xllm_mi355_scaled_matmul_add_rms_norm_packed(const int8_t* a, const int8_t* w_packed, const float* a_scale,

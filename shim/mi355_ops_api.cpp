@@ -299,18 +299,17 @@ std::optional<torch::Tensor> packed_weight_for(const torch::Tensor& b) {
 std::optional<torch::Tensor> stream_scratch(std::unordered_map<StreamKey, torch::Tensor, StreamKeyHash>& map,
                                             const torch::Tensor& like, int64_t bytes, bool zero_at_rest) {
   const StreamKey key{(int)like.device().index(), cur_stream()};
-  {
-    std::lock_guard<std::mutex> lock(g_pack_mu);
-    auto it = map.find(key);
-    if (it != map.end()) return it->second;
-  }
+  // ONE critical section for look-up, allocation, registration with the C side and insertion: two threads that miss on the same
+  // (device, stream) must not both register a buffer of which one is then destroyed (round-3 advisor finding: the loser's
+  // pointer stayed registered as the split-K workspace). torch::empty under the lock is fine: first use per stream only.
+  std::lock_guard<std::mutex> lock(g_pack_mu);
+  auto it = map.find(key);
+  if (it != map.end()) return it->second;
   if (capturing()) return std::nullopt;
   torch::Tensor ws = torch::empty({bytes}, like.options().dtype(torch::kUInt8));
   if (zero_at_rest)   // the C side zeroes it (a memset on the null stream) and keys it on the stream
     check(xllm_mi355_set_gemm_workspace_for_stream(cur_stream(), ws.data_ptr(), (size_t)ws.numel()), "set_gemm_workspace_for_stream");
-  std::lock_guard<std::mutex> lock(g_pack_mu);
-  auto ins = map.emplace(key, ws);
-  return ins.first->second;
+  return map.emplace(key, ws).first->second;
 }
 }  // namespace
 

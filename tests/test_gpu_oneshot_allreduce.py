@@ -176,3 +176,51 @@ def test_oneshot_allreduce_protocol(distinct):
         assert ret[r]["ok"], ret[r]["log"]
         assert ret[r].get("declines_other_stream") is True
     assert ret[0].get("timeout_reported") is True
+
+
+def _worker_asymmetric_failure(rank, world, port, ret, where):
+    """rank 1 alone fails during the set-up (`where` = export | open | selftest); both ranks must come out with the one-shot
+    path OFF, the same note, and a working fallback all-reduce -- no hang, no mismatched collectives (round-3 advisor finding)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xllm_amd import _lib, parallel
+    res = {"ok": True, "log": []}
+    try:
+        if rank == 1:
+            l = _lib.lib()
+            if where == "export":
+                class _Fail:   # a callable that reports failure like the C entry point
+                    def __call__(self, *a):
+                        return -3
+                l.xllm_mi355_ipc_get_handle = _Fail()
+            elif where == "open":
+                l.xllm_mi355_ipc_open_handle = lambda *a: -3
+            else:
+                parallel.OneShotAllReduce.self_test = lambda self: False
+        pg = parallel.ProcessGroup(dist.group.WORLD, rank, world)
+        ar = pg.enable_oneshot("cuda:0", max_bytes=1 << 20)
+        res["ar_is_none"] = ar is None
+        res["note"] = pg.oneshot_note
+        x = torch.full((4096,), float(rank + 1), dtype=torch.bfloat16, device="cuda:0")
+        parallel.reduce(x, pg)                           # the group's own all-reduce (gloo here)
+        res["fallback_sum_ok"] = bool((x == 3.0).all())
+        dist.barrier()
+    except Exception as e:   # noqa: BLE001
+        res["ok"] = False
+        res["log"].append(repr(e))
+    ret[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("where", ["export", "open", "selftest"])
+def test_oneshot_setup_failure_on_one_rank_falls_back_on_every_rank(where):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_asymmetric_failure, args=(2, _free_port(), ret, where), nprocs=2, join=True)
+    for r in range(2):
+        assert ret[r]["ok"], ret[r]["log"]
+        assert ret[r]["ar_is_none"] is True and ret[r]["fallback_sum_ok"] is True
+        assert "rank 1" in ret[r]["note"]
+    assert ret[0]["note"] == ret[1]["note"]

@@ -1526,9 +1526,18 @@ def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):
 
 
 # ------------------------------------------------------------------------------------------- weight-stream decode GEMM
-def _ws_plan(ng, slices):
+_HINT = {"ng": 0, "slices": 0, "rows": 0}
+
+
+def _hint():
+    """xllm_mi355_gemm_plan_hint (include/xllm_mi355.h): the calling thread's planner hint for the packed GEMMs"""
     from xllm_amd import _lib
-    _lib.lib().xllm_mi355_debug_ws_plan(int(ng), int(slices))
+    _lib.lib().xllm_mi355_gemm_plan_hint(_HINT["ng"], _HINT["slices"], _HINT["rows"])
+
+
+def _ws_plan(ng, slices):
+    _HINT["ng"], _HINT["slices"] = int(ng), int(slices)
+    _hint()
 
 
 @pytest.fixture
@@ -1569,17 +1578,17 @@ def test_pack_weight_i8_layout():
 
 
 def _ws_waves(n):
-    from xllm_amd import _lib
-    _lib.lib().xllm_mi355_debug_ws_waves(int(n))
+    """tile height for 128 < M <= 512: 131 = the 256-row eight-wave tile, 128 = 128-row tiles, 0 = planner"""
+    _HINT["rows"] = {0: 0, 131: 256, 128: 128}[int(n)]
+    _hint()
 
 
 @pytest.mark.parametrize("M", [129, 200, 256, 257, 512])
-@pytest.mark.parametrize("arm", [80, 81])
-def test_packed_gemm_eight_wave_tiles_exact_on_a_few_column_shape(M, arm):
+def test_packed_gemm_eight_wave_tiles_exact_on_a_few_column_shape(M):
     """round 3 moved 128 < M <= 512 to eight-wave workgroups with the two wave groups one barrier apart (gemm_ws8s_kernel) for
     the wide problems and to 128-row tiles for the few-column ones (N <= 20480: this shape). The 256-row tiles forced onto this
-    shape (arm 131 = XLLM_MI355_WS_ROWS128=0) -- eight waves in phase (80 / XLLM_MI355_WS8_STAGGER=0) and eight waves staggered
-    (81) -- must stay exact. (The round-2 four-wave 256-row tile lost the in-step A/B and left the library.)"""
+    shape (plan hint tile_rows = 256) must stay exact. (The round-2 four-wave 256-row tile and the in-phase eight-wave arm lost
+    their A/Bs and left the library in rounds 3 / 4.)"""
     g = torch.Generator().manual_seed(100 + M)
     N, K = 1936, 1152
     a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
@@ -1592,7 +1601,6 @@ def test_packed_gemm_eight_wave_tiles_exact_on_a_few_column_shape(M, arm):
     ran = 0
     try:
         _ws_waves(131)
-        _ws_waves(arm)
         for ng in (1, 2, 3, 4, 5):
             for slices in (1, 3):
                 _ws_plan(ng, slices)
@@ -1878,9 +1886,9 @@ def test_gate_up_silu_mul_fusion_equals_separate_ops(M, I, K):
         assert out is not None
         assert torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref)
     assert all(float(v.abs().max()) == 0.0 for v in ops._row_amax.values())
-    if M <= 512:      # every width of the tile family, the staggered and the in-phase eight-wave arms
+    if M <= 512:      # every width of the tile family, on the planner's tile height and on the 256-row eight-wave tile
         try:
-            for waves in (0, 80):
+            for waves in (0, 131):
                 _ws_waves(waves)
                 for ng in (1, 2, 3, 4, 5, 6, 8, 10):
                     _ws_plan(ng, 0)
@@ -1892,6 +1900,43 @@ def test_gate_up_silu_mul_fusion_equals_separate_ops(M, I, K):
     # row-major weights only (no packed copy): the 8-phase kernel serves any M
     out = ops.scaled_matmul_silu_mul_quant(a, w, a_s, w_s, torch.bfloat16, None, b_packed=None)
     assert out is not None and torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref)
+
+
+@pytest.mark.parametrize("M", [1, 256, 8192])
+def test_gate_up_act_row_major_only_straight_through_the_c_abi(M):
+    """the round-3 driver-red case, pinned at the C ABI: row-major weights only (w_packed = NULL), M in {1, 256, 8192}. The call
+    must either write act + row maxima that are bit-equal to scaled_matmul -> act_and_mul (and non-zero), or decline with
+    XM_ERR_UNSUPPORTED -- never return XM_OK with nothing written. (Re-run under every GEMM selector by test_zz_gpu_variants.)"""
+    from xllm_amd import _lib
+    g = torch.Generator().manual_seed(77 + M)
+    I, K = 512, 1024
+    N = 2 * I
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-127, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.004 + 0.0005).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.004 + 0.0005).to(DEV)
+    gate_up = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, None)
+    ref = torch.empty(M, I, dtype=torch.bfloat16, device=DEV)
+    ops.act_and_mul(ref, gate_up, "silu")
+    act = torch.full((M, I), float("nan"), dtype=torch.bfloat16, device=DEV)
+    amax = torch.zeros(M, dtype=torch.float32, device=DEV)
+    rc = _lib.lib().xllm_mi355_scaled_matmul_gate_up_act(a.data_ptr(), w.data_ptr(), 0, a_s.data_ptr(), w_s.data_ptr(), 0,
+                                                         act.data_ptr(), amax.data_ptr(), M, N, K, 1, 0, 0,
+                                                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc in (0, -2), rc
+    if rc == 0:
+        assert float(ref.float().abs().max()) > 0
+        assert torch.equal(act, ref)
+        assert torch.equal(amax, ref.float().abs().amax(dim=1))
+    else:   # a decline leaves the outputs untouched
+        assert bool(torch.isnan(act.float()).all()) and float(amax.abs().max()) == 0.0
+    # and the operator the layers call: fused result or None, never zeros
+    out = ops.scaled_matmul_silu_mul_quant(a, w, a_s, w_s, torch.bfloat16, None, b_packed=None)
+    q_ref, s_ref = ops.act_and_mul_dynamic_int8_quant(gate_up, "silu")
+    if out is not None:
+        assert int(out[0].abs().max()) > 0 and torch.equal(out[0], q_ref) and torch.equal(out[1], s_ref)
+    assert rc == 0 or out is None
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -1921,7 +1966,7 @@ def test_gate_up_silu_mul_fusion_16bit_equals_separate_ops(M, I, K, dtype):
             out = ops.matmul_silu_mul(a, w, b, b_packed=wp)
             assert out is not None
             assert_ulp_close(out, ref, dtype, ulps=2.0, min_exact=0.98)
-            for waves in (0, 80):
+            for waves in (0, 131):
                 _ws_waves(waves)
                 for ng in (1, 2, 3, 4, 5, 6, 8, 10):
                     _ws_plan(ng, 0)

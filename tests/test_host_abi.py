@@ -31,6 +31,33 @@ def test_header_symbols_all_exported():
     assert set(_lib.exported_symbols()) <= exported | {"xllm_mi355_strerror"}
 
 
+def test_product_library_has_no_debug_symbols_and_only_the_documented_switches():
+    """round-3 review (#4, #9): the product .so exports no xllm_mi355_debug_* entry point (they live in the -DXM_TUNING
+    flavour), reads the environment only through xm_switch(), and every switch it -- or the Python host side -- reads is a row of
+    the table in DESIGN.md section 4.7 (at most 15 of them)."""
+    import glob
+    _lib = _built()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    assert not re.findall(r"xllm_mi355_debug_\w+", out)
+    csrc = os.path.join(ROOT, "xllm_amd", "csrc")
+    names = set()
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        src = open(f).read()
+        if not f.endswith("common.h"):
+            assert "getenv" not in src, f"{os.path.basename(f)} reads the environment directly"
+        names |= set(re.findall(r'xm_switch\("(\w+)"', src))
+    for f in glob.glob(os.path.join(ROOT, "xllm_amd", "*.py")):
+        names |= set(re.findall(r'os\.environ\.get\("(XLLM_\w+)"', open(f).read()))
+    assert len(names) <= 15, sorted(names)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    table = design[design.index("### 4.7"):]
+    table = table[:table.index("\n## ")] if "\n## " in table else table
+    for n in names:
+        assert f"`{n}`" in table, f"{n} is read by the product but is not a row of DESIGN 4.7"
+    for n in set(re.findall(r"\| `(XLLM_\w+)`", table)):
+        assert n in names, f"DESIGN 4.7 lists {n}, which the product no longer reads"
+
+
 def test_library_loads_without_gpu_and_reports_errors():
     _lib = _built()
     l = _lib.lib()

@@ -6,14 +6,17 @@ changes of round 3 are worth; here every variant is captured from the same weigh
 
     python tools/step_ab.py [B] [ctx] [variants...]      variants: name=setting;setting  with settings
         fuse_gu=0|1        ops._GATE_UP_FUSION
-        packed=auto|r2|0|1 ops._PACKED_POLICY (r2 = the round-2 policy)
-        ws_ng=N  ws_sl=N   xllm_mi355_debug_ws_plan
-        ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 128..131, 140..142, 0)
+        packed=auto|0|1    ops._PACKED_POLICY
+        ws_ng=N  ws_sl=N  ws_rows=128|256   xllm_mi355_gemm_plan_hint (product API, thread-local)
+        ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 140..142, 0)            [tuning flavour]
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
         attn=s,h,d,e       xllm_mi355_debug_decode_plan: split-KV count, kv heads per workgroup, deep prefetch, exclusive CU
         idle=before|after,US   an idle gap of US microseconds in front of / behind every decode-attention launch (analysis)
         env:NAME=VALUE     os.environ (only for switches that are read at call time)
     default: python tools/step_ab.py 256 4096 fused=fuse_gu=1 unfused=fuse_gu=0
+
+The xllm_mi355_debug_* entry points exist only in the tuning flavour of the library (round 4):
+    make -C xllm_amd/csrc tuning && XLLM_MI355_LIB=$PWD/xllm_amd/lib/libxllm_mi355_tuning.so python tools/step_ab.py ...
 """
 import os
 import sys
@@ -28,7 +31,7 @@ import bench  # noqa: E402
 
 
 def apply(settings):
-    ng = sl = 0
+    ng = sl = rows = 0
     for s in settings:
         if not s:
             continue
@@ -39,6 +42,8 @@ def apply(settings):
             ng = int(v)
         elif k == "ws_sl":
             sl = int(v)
+        elif k == "ws_rows":
+            rows = int(v)
         elif k == "ws_waves":
             _lib.lib().xllm_mi355_debug_ws_waves(int(v))
         elif k == "shape":                       # shape=N,K,ng,slices : plan override for that GEMM only
@@ -56,7 +61,7 @@ def apply(settings):
             os.environ[k[4:]] = v
         else:
             raise SystemExit(f"unknown setting {s}")
-    _lib.lib().xllm_mi355_debug_ws_plan(ng, sl)
+    _lib.lib().xllm_mi355_gemm_plan_hint(ng, sl, rows)
 
 
 IDLE = {"where": None, "us": 0.0}
@@ -82,10 +87,11 @@ def reset():
     ops._PACKED_POLICY = "auto"
     ops._GATE_UP_FUSION = True
     import ctypes
-    _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)
-    _lib.lib().xllm_mi355_debug_ws_plan(0, 0)
-    _lib.lib().xllm_mi355_debug_ws_waves(0)
-    _lib.lib().xllm_mi355_debug_decode_plan(0, 0, 0, 0)
+    _lib.lib().xllm_mi355_gemm_plan_hint(0, 0, 0)
+    if hasattr(_lib.lib(), "xllm_mi355_debug_ws_waves"):      # tuning flavour only
+        _lib.lib().xllm_mi355_debug_ws_plan_shape(ctypes.c_longlong(0), ctypes.c_longlong(0), 0, 0)
+        _lib.lib().xllm_mi355_debug_ws_waves(0)
+        _lib.lib().xllm_mi355_debug_decode_plan(0, 0, 0, 0)
 
 
 def main():

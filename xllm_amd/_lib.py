@@ -48,6 +48,7 @@ _SIGS = {
     "xllm_mi355_host_pack_input_buffer": ([C.POINTER(HostBufferEntry), i64, vp, u64], ci),
     "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_gemm_plan_hint": ([ci, ci, ci], None),
     "xllm_mi355_scaled_matmul_rope_cache_packed": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, i64, i64,
                                                     i64, i64, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_oneshot_allreduce_buffer_bytes": ([sz], sz),

@@ -448,7 +448,8 @@ int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (M == 0) return XM_OK;
   if ((size_t)M * N * 2 > max_message_bytes) return XM_ERR_WORKSPACE;
-  if (N % 8 || ((uintptr_t)w_scale % 16) || (bias && (uintptr_t)bias % 16) || M > 512) return XM_ERR_UNSUPPORTED;
+  if (N % 8 || N > 16384 || ((uintptr_t)w_scale % 16) || (bias && (uintptr_t)bias % 16) || M > 512)
+    return XM_ERR_UNSUPPORTED;   // (the fused consumer's envelope, checked before the GEMM is launched: a decline has no side effect)
   // the row-parallel GEMM leaves its exact int32 K-slice sums in `workspace` (no dequant pass) ...
   xm::GemmEpi epi{a_scale, M, w_scale, N, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0};
   epi.defer = 1;

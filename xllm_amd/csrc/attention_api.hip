@@ -20,17 +20,20 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
                          int64_t k_stride, int64_t v_stride, int64_t max_q_len, float scale, int causal,
                          int64_t window_left, hipStream_t s);
 
+// XLLM_MI355_DECODE_SPLITS (product switch, read once): force the grid-level split-KV count -- the parity tests use it to cover
+// the split counts the planner picks at other batch sizes. Tuning arms: 3-stage prefetch (round-1 A/B: 5.87 vs 5.93 TB/s with
+// 2 stages), forced heads per workgroup, exclusive-CU LDS padding.
 static int g_split_override = -2;  // -2: env not read yet; -1: no override
+XM_TUNE_VAR(g_deep, "XLLM_MI355_DECODE_DEEP", 0);
+XM_TUNE_VAR(g_hpw_override, "XLLM_MI355_DECODE_HPW", -1);
+XM_TUNE_VAR(g_excl, "XLLM_MI355_DECODE_EXCL", 0);
 
 // grid-level split-KV count of the decode kernel. Target: ~256 workgroups = ONE per CU (4 waves each, 16-32 KiB
 // in flight per wave): the round-1 sweep (tools/attn_bench.py, profiles/r01_attn_split_sweep.txt) shows that
 // fewer, longer token streams beat more resident waves (no split at B*nkv/hpw >= 256: 5.90 TB/s vs 5.62 TB/s
 // with 2 splits; B=64: 4 splits best), every wave keeping >= 8 tiles of 32 tokens.
 int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len) {
-  if (g_split_override == -2) {
-    const char* e = getenv("XLLM_MI355_DECODE_SPLITS");
-    g_split_override = e ? atoi(e) : -1;
-  }
+  if (g_split_override == -2) g_split_override = xm_switch("XLLM_MI355_DECODE_SPLITS", -1);
   const int nsub = 4 / hpw;
   const int64_t base = batch * (nkv / hpw);
   const int64_t tiles = (max_kv_len + 31) / 32;
@@ -47,45 +50,27 @@ int decode_num_splits(int64_t batch, int64_t nkv, int hpw, int64_t max_kv_len) {
   return (int)n;
 }
 
-static int g_deep = -2;
-bool decode_deep_prefetch() {
-  if (g_deep == -2) {
-    const char* e = getenv("XLLM_MI355_DECODE_DEEP");
-    g_deep = e ? atoi(e) : 0;  // round-1 A/B: 3 stages 5.87 TB/s vs 2 stages 5.93 TB/s (profiles/r01_attn_split_sweep.txt)
-  }
-  return g_deep != 0;
-}
+bool decode_deep_prefetch() { return g_deep != 0; }
 
 // heads per workgroup of the decode kernel (4 waves = hpw kv heads x 4/hpw sub-ranges of the token range, merged in LDS).
 // All kv heads of a token in one workgroup (hpw = 4) read whole token rows and allow the fused int8 epilogue, but give only
 // batch * nkv / 4 workgroups; below ~one workgroup per CU the parallelism has to come from somewhere, and sub-ranges inside
 // the workgroup are free (LDS merge) while grid-level splits pay partial writes + a merge launch. So: the largest hpw that
 // still yields >= 192 workgroups, else hpw = 1 and the rest through grid-level splits.
-static int g_hpw_override = -2;
 int decode_heads_per_wg(int64_t batch, int64_t nkv) {
-  if (g_hpw_override == -2) {
-    const char* e = getenv("XLLM_MI355_DECODE_HPW");
-    g_hpw_override = e ? atoi(e) : -1;
-  }
   if (g_hpw_override > 0 && 4 % g_hpw_override == 0 && nkv % g_hpw_override == 0) return g_hpw_override;
   for (int hpw = 4; hpw > 1; hpw >>= 1)
     if (nkv % hpw == 0 && batch * (nkv / hpw) >= 192) return hpw;
   return 1;
 }
 
-static int g_excl = -2;
-int decode_exclusive_cu() {
-  if (g_excl == -2) {
-    const char* e = getenv("XLLM_MI355_DECODE_EXCL");
-    g_excl = e ? atoi(e) : 0;
-  }
-  return g_excl;
-}
+int decode_exclusive_cu() { return g_excl; }
 
 }  // namespace xm
 
 using namespace xm;
 
+#ifdef XM_TUNING
 // analysis (tools/step_ab.py idle=...): ONE wave that does nothing for `us` microseconds (s_sleep loop on the 100-MHz wall clock): a
 // controlled idle gap in front of / behind a kernel of the step, to separate what a kernel costs from the state its predecessor leaves
 __global__ void debug_idle_kernel(long long ticks) {
@@ -100,12 +85,13 @@ extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_idle(doub
 
 // tuning (tools/step_ab.py): the decode kernel's launch plan for the following calls; < 0 = leave as it is, 0 = planner / default
 extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_decode_plan(int splits, int hpw, int deep, int excl) {
-  (void)decode_num_splits(1, 4, 4, 4096); (void)decode_heads_per_wg(1, 4); (void)decode_deep_prefetch(); (void)decode_exclusive_cu();  // env first
+  (void)decode_num_splits(1, 4, 4, 4096);  // env first
   if (splits >= 0) g_split_override = splits > 0 ? splits : -1;
   if (hpw >= 0) g_hpw_override = hpw > 0 ? hpw : -1;
   if (deep >= 0) g_deep = deep;
   if (excl >= 0) g_excl = excl;
 }
+#endif
 
 extern "C" {
 

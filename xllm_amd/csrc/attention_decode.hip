@@ -503,14 +503,17 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(batch * (nkv / hpw) * nsplit));
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
-  // A/B switch (XLLM_MI355_DECODE_EXCL=1): grids of at most one workgroup per CU reserve enough extra LDS that two
+  // tuning arm (XLLM_MI355_DECODE_EXCL=1, -DXM_TUNING flavour only): grids of at most one workgroup per CU reserve enough extra LDS that two
   // workgroups cannot share a CU, so the dispatcher has to spread them over all 256
   const size_t dyn = (decode_exclusive_cu() && grid.x <= 256) ? 48 * 1024 : 0;
+#ifdef XM_TUNING  /* the three-stage arm (round-1 A/B loser) exists only in the tuning flavour */
   if (block_size % kTile == 0 && decode_deep_prefetch())
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
-  else if (block_size % kTile == 0)
+  else
+#endif
+  if (block_size % kTile == 0)
     hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
                        (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
                        (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);

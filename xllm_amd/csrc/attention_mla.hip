@@ -865,13 +865,11 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
                       size_t workspace_bytes, hipStream_t s) {
   const int64_t hblocks = (n_heads + 15) / 16;
   const int64_t tiles = (max_kv_len + kMlaTile - 1) / kMlaTile;
-  static int split_override = -2, dma_mode = -2;  // XLLM_MI355_MLA_SPLITS / XLLM_MI355_MLA_DMA: tuning overrides, read once
-  if (split_override == -2) {
-    const char* e = getenv("XLLM_MI355_MLA_SPLITS");
-    split_override = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_MLA_DMA");
-    dma_mode = e ? atoi(e) : 1;
-  }
+  // XLLM_MI355_MLA_SPLITS (product switch, read once): force the split-KV count (the parity tests cover the counts the planner
+  // picks at other batch sizes). The register-staged kernel on 64-multiple pages (XLLM_MI355_MLA_DMA=0) lost its A/B: tuning only.
+  static int split_override = -2;
+  if (split_override == -2) split_override = xm_switch("XLLM_MI355_MLA_SPLITS", -1);
+  XM_TUNE_VAR(dma_mode, "XLLM_MI355_MLA_DMA", 1);
   // LDS-DMA kernel: one workgroup per CU (256 resident); register-staged kernel: two per CU (512 resident)
   const bool dma = dma_mode != 0 && block_size % kMlaTile == 0;
   const int64_t resident = dma ? 256 : 512;
@@ -893,10 +891,12 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
       hipLaunchKernelGGL((mla_decode_dma_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
                          part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
                          scale_log2, (int)nsplit, q_seq, q_kvlen);
+#ifdef XM_TUNING
     else if (block_size % kMlaTile == 0)
       hipLaunchKernelGGL((mla_decode_kernel<T, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
                          part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
                          scale_log2, (int)nsplit, q_seq, q_kvlen);
+#endif
     else
       hipLaunchKernelGGL((mla_decode_kernel<T, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
                          part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
@@ -950,18 +950,12 @@ extern "C" int xllm_mi355_mla_prefill(const void* q, const void* k_cache, void* 
   // enough query tokens to fill the chip without a split-KV: the kernel that shares every KV tile between four tokens
   // (XLLM_MI355_MLA_PREFILL = 0: never, 1: whenever the page size allows it; default: by workgroup count)
   static int share_mode = -2;
-  if (share_mode == -2) {
-    const char* e = getenv("XLLM_MI355_MLA_PREFILL");
-    share_mode = e ? atoi(e) : -1;
-  }
+  if (share_mode == -2) share_mode = xm_switch("XLLM_MI355_MLA_PREFILL", -1);
   const int64_t n_groups = (total_q_tokens + 3) / 4, hblocks = (n_heads + 15) / 16;
   if (block_size % kMlaTile == 0 && share_mode != 0 && (share_mode == 1 || n_groups * hblocks >= 128)) {
     const dim3 grid((unsigned)(((n_groups + 7) / 8) * 8 * hblocks));
-    static int p_mode = -2;
-    if (p_mode == -2) {
-      const char* e = getenv("XLLM_MI355_MLA_PREFILL_P");
-      p_mode = e ? atoi(e) : 1;
-    }
+    static int p_mode = -2;   // XLLM_MI355_MLA_PREFILL_P=2: P = hi + lo (fp32-P accuracy), product switch
+    if (p_mode == -2) p_mode = xm_switch("XLLM_MI355_MLA_PREFILL_P", 1);
     if (p_mode == 2) {
       XM_DISPATCH_HALF(dtype, T, {
         hipLaunchKernelGGL((mla_prefill_dma_kernel<T, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache,

@@ -753,11 +753,11 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
   const int wl = window_left < 0 ? -1 : (window_left > 0x3fffffff ? 0x3fffffff : (int)window_left);
   if constexpr (D == 128) {
     // LDS-DMA kernels: a 64-key tile must sit inside one page, and 64 row pitches must fit a 32-bit buffer offset
-    // XLLM_MI355_PREFILL_DMA: 0 = register-staged kernel, 1 = LDS-DMA kernel (default). The ping-pong forms of the DMA kernel
+    // The register-staged kernel below stays the path of head dim 64, pages that are not 64-multiples and > 2 GiB pitches; forcing
+    // it onto head dim 128 (XLLM_MI355_PREFILL_DMA=0) is a tuning arm of the -DXM_TUNING flavour. The ping-pong forms of the DMA kernel
     // (NW = 8: two wave groups alternating MFMA / softmax, round-1 negative result, profiles/r01_prefill_attention.txt) are
     // no longer instantiated in the library (round 3); the template parameter stays in the kernel for whoever revisits it.
-    static int dma_mode = -1;
-    if (dma_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_DMA"); dma_mode = e ? atoi(e) : 1; }  // (A/B, read once)
+    XM_TUNE_VAR(dma_mode, "XLLM_MI355_PREFILL_DMA", 1);
     const int64_t pitch = PAGED ? nkv * D : (k_stride > v_stride ? k_stride : v_stride);
     if (dma_mode && (!PAGED || block_size % kPf2Tile == 0) && pitch * 2 * kPf2Tile < (1ll << 31)) {
       const float sl2 = scale * 1.4426950408889634f;
@@ -768,7 +768,7 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
         // 2.1e-3 from the fp32-P result where the reference's own spec is 2.5e-3 away (profiles/r02_prefill_p.txt).
         // 2 = P = hi + lo (two MFMAs per block: fp32-P accuracy, 1e-4, at 1.34x the time)
         static int p_mode = -1;
-        if (p_mode < 0) { const char* e = getenv("XLLM_MI355_PREFILL_P"); p_mode = e ? atoi(e) : kPfDefaultPMode; }
+        if (p_mode < 0) p_mode = xm_switch("XLLM_MI355_PREFILL_P", kPfDefaultPMode);   // product switch, read once
         if (p_mode == 1)
           hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3((unsigned)(nq * batch * qblocks)),
                              dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table,

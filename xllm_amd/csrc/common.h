@@ -2,12 +2,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/xllm_mi355.h"
 
 namespace xm {
 
 constexpr int kWave = 64;
+
+// ---- run-time switches (host side). The product library reads only the switches of DESIGN section 4.7 through xm_switch()
+// (once per process, cached by the caller). Tuning overrides -- A/B arms whose verdict is recorded, planner constants, sweeps --
+// are XM_TUNE_VAR: compile-time constants here, environment-backed mutable variables only in the -DXM_TUNING flavour of the
+// library that `make tuning` builds for tools/ (lib/libxllm_mi355_tuning.so, never loaded by the product or the tests).
+inline int xm_switch(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#ifdef XM_TUNING
+#define XM_TUNE_VAR(var, name, dflt) static int var = ::xm::xm_switch(name, dflt)
+#else
+#define XM_TUNE_VAR(var, name, dflt) [[maybe_unused]] static constexpr int var = dflt
+#endif
 
 struct bf16_t {
   uint16_t v;

@@ -476,7 +476,9 @@ __global__ __launch_bounds__(256) void f32_splitk_reduce_zero_kernel(float* __re
 }
 
 struct SkinnyPlan { int nt; int splits; };
-static int g_sk_nt = -2, g_sk_splits = -2, g_sk_disable = -2;
+static int g_sk_disable = -2;
+XM_TUNE_VAR(g_sk_nt, "XLLM_MI355_SKINNY_NT", -1);
+XM_TUNE_VAR(g_sk_splits, "XLLM_MI355_SKINNY_SPLITS", -1);
 
 // 16-bit kinds: pick (NT, K slices) by a small cost model instead of the int8 rule below (which is tuned on the W8A8
 // decode shapes and left alone): rounds of 256 workgroups x K steps per slice x relative step cost (the 32 KiB activation
@@ -504,12 +506,6 @@ inline SkinnyPlan plan_skinny_half(int64_t M, int64_t N, int ksteps, bool can_sp
 }
 
 inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) {  // (m_tiles = 1 for every M <= 256)
-  if (g_sk_nt == -2) {
-    const char* e = getenv("XLLM_MI355_SKINNY_NT");
-    g_sk_nt = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_SKINNY_SPLITS");
-    g_sk_splits = e ? atoi(e) : -1;
-  }
   const int64_t m_tiles = (M + SK_BM - 1) / SK_BM;
   const int64_t nt32 = (N + 31) / 32;
   int nt = (int)((nt32 * m_tiles + 255) / 256);  // smallest NT whose grid fits one round of 256 CUs
@@ -528,7 +524,6 @@ inline SkinnyPlan plan_skinny(int64_t M, int64_t N, int ksteps, bool can_split) 
   return SkinnyPlan{nt, splits};
 }
 
-static int g_sk_waves = -2, g_sk_depth = -2;
 
 template <int KIND, int NT, int WV, int DP, int BM = SK_BM>
 int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int splits,
@@ -577,31 +572,13 @@ int launch_skinny_cfg(const void* A, const void* W, int64_t M, int64_t N, int64_
 template <int KIND, int NT>
 int launch_skinny_nt(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int splits,
                      void* workspace, hipStream_t s) {
-  if (g_sk_waves == -2) {
-    const char* e = getenv("XLLM_MI355_SKINNY_WAVES");
-    g_sk_waves = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_SKINNY_DEPTH");
-    g_sk_depth = e ? atoi(e) : -1;
-  }
-  // defaults from the round-1 sweep (tools/gemm_sweep.sh, profiles/r01_gemm_sweep.txt): 8 waves x 32 rows with
-  // 2 register stages wins on every decode shape (two waves per SIMD overlap one wave's MFMAs with the other's
-  // LDS traffic; a third register stage only costs occupancy)
-  // M <= 128: 128-row tile, 4 waves x 32 rows (half the activation stage, half the padded MFMA rows)
-  static int bm128 = -2;  // XLLM_MI355_SKINNY_BM128=0 keeps the 256-row tile (A/B), read once
-  if (bm128 == -2) { const char* e = getenv("XLLM_MI355_SKINNY_BM128"); bm128 = e ? atoi(e) : 1; }
-  if (M <= 128 && bm128) return launch_skinny_cfg<KIND, NT, 4, 2, 128>(A, W, M, N, Kb, epi, splits, workspace, s);
-  int wv = 8, dp = 2;
-  if constexpr (KIND == kI8) {  // tuning overrides are only compiled for the int8 kernels
-    if (g_sk_waves == 4 || g_sk_waves == 8) wv = g_sk_waves;
-    if (g_sk_depth == 2 || g_sk_depth == 3) dp = g_sk_depth;
-    if (NT > 3 && wv == 4) dp = 2;
-    if (wv == 8 && dp == 3) return launch_skinny_cfg<KIND, NT, 8, 3>(A, W, M, N, Kb, epi, splits, workspace, s);
-    if (wv == 8) return launch_skinny_cfg<KIND, NT, 8, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
-    if (dp == 2) return launch_skinny_cfg<KIND, NT, 4, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
-    return launch_skinny_cfg<KIND, NT, 4, 3>(A, W, M, N, Kb, epi, splits, workspace, s);
-  } else {
-    return launch_skinny_cfg<KIND, NT, 8, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
-  }
+  // round-1 sweep (tools/gemm_sweep.sh, profiles/r01_gemm_sweep.txt): 8 waves x 32 rows with 2 register stages wins on every
+  // decode shape (two waves per SIMD overlap one wave's MFMAs with the other's LDS traffic; a third register stage only costs
+  // occupancy) -- the 4-wave and 3-stage forms left the library in round 4.
+  // M <= 128: 128-row tile, 4 waves x 32 rows (half the activation stage, half the padded MFMA rows; the 256-row tile for
+  // M <= 128, XLLM_MI355_SKINNY_BM128=0, lost its A/B and left with them)
+  if (M <= 128) return launch_skinny_cfg<KIND, NT, 4, 2, 128>(A, W, M, N, Kb, epi, splits, workspace, s);
+  return launch_skinny_cfg<KIND, NT, 8, 2>(A, W, M, N, Kb, epi, splits, workspace, s);
 }
 
 template <int KIND>
@@ -632,31 +609,25 @@ template <int KIND>
 int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                 size_t ws_bytes, hipStream_t s) {
   if (M == 0 || N == 0) return XM_OK;
+  // 128x128 / skinny / 8-phase family behind this entry: no gate_up epilogue, no device tile table (those have their own entries)
+  if (!epi_fits(epi, kCapDefer | kCapAccOut | kCapGroupCounts)) return XM_ERR_UNSUPPORTED;
   if (epi.defer) {  // deferred dequant (see xllm_mi355_scaled_matmul_add_rms_norm): decode-shaped int8 problems only
     if (KIND != kI8 || M > 512 || Kb % BKB != 0 || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || !workspace ||
         ws_bytes < (size_t)M * N * 4)
       return XM_ERR_UNSUPPORTED;
     return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
   }
-  if (g_sk_disable == -2) {
-    const char* e = getenv("XLLM_MI355_SKINNY_DISABLE");
-    g_sk_disable = e ? atoi(e) : 0;
-  }
+  if (g_sk_disable == -2) g_sk_disable = xm_switch("XLLM_MI355_SKINNY_DISABLE", 0);   // product switch (general kernel only)
   // decode-shaped problems take the skinny kernel (32-bit buffer offsets: operands < 2 GiB); for the 16-bit / fp8
   // kinds only while the general kernel's 128x128 grid would under-fill the chip (measured at M=256: lm_head
   // 436 vs 553 us, bf16 gate_up 119 vs 146 us in favour of the general kernel)
   // 256x256 8-phase kernel (gemm_p8.hip): XLLM_MI355_P8 = 0 off, 1 forced wherever it is legal, unset = the
   // planner below (round-1 sweep, profiles/r01_gemm_p8.txt): it wins whenever its grid has enough tiles to fill the
   // chip without split-K; small grids stay on the skinny / 128x128 split-K kernels.
-  static int p8 = -2, p8_splits = -1, p8_min_tiles = 50;
-  if (p8 == -2) {
-    const char* e = getenv("XLLM_MI355_P8");
-    p8 = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_P8_SPLITS");
-    p8_splits = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_P8_MIN_TILES");
-    if (e) p8_min_tiles = atoi(e);
-  }
+  static int p8 = -2;   // product switch, read once
+  if (p8 == -2) p8 = xm_switch("XLLM_MI355_P8", -1);
+  XM_TUNE_VAR(p8_splits, "XLLM_MI355_P8_SPLITS", -1);
+  XM_TUNE_VAR(p8_min_tiles, "XLLM_MI355_P8_MIN_TILES", 50);
   if (p8 && Kb % BKB == 0 && (N & 7) == 0 && ((uintptr_t)epi.out & 15) == 0 && M * Kb < (1ll << 31) &&
       N * Kb < (1ll << 31) && !epi.group_counts) {
     int splits = 1;
@@ -726,8 +697,7 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
   } else {
     // K step 64 B + 4 workgroups per CU (4 waves/SIMD) measured +17 % over 128 B + 2 workgroups at M = 8192
     // (profiles/r01_gemm_notes.txt): more independent waves hide the stage -> barrier -> read -> MFMA chain
-    static int kb64 = -2;
-    if (kb64 == -2) { const char* e = getenv("XLLM_MI355_GEMM_KB64"); kb64 = e ? atoi(e) : 1; }
+    XM_TUNE_VAR(kb64, "XLLM_MI355_GEMM_KB64", 1);
     if (kb64 && Kb % 64 == 0)
       hipLaunchKernelGGL((gemm_kernel<KIND, false, 64, 4>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
                          (int)M, (int)N, Kb, m_tiles, n_tiles, per * 2, epi);
@@ -998,11 +968,8 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   }
   // 256x256 8-phase kernel behind a device-built tile table (kept in the tail of the MoE scratch); the 128x128 kernel
   // with its per-workgroup expert walk is the fallback (no scratch registered, shape outside the 8-phase envelope)
-  static int p8_mode = -2;  // XLLM_MI355_GROUP_P8=0: 128x128 kernel only (A/B), read once
-  if (p8_mode == -2) {
-    const char* e = getenv("XLLM_MI355_GROUP_P8");
-    p8_mode = e ? atoi(e) : 1;
-  }
+  static int p8_mode = -2;  // XLLM_MI355_GROUP_P8=0: 128x128 kernel only (product switch: the fallback's parity test), read once
+  if (p8_mode == -2) p8_mode = xm_switch("XLLM_MI355_GROUP_P8", 1);
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   xm_moe_scratch(stream, &scratch, &scratch_bytes);

@@ -438,6 +438,10 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
                    size_t ws_bytes, int splits, hipStream_t s) {
   (void)workspace;
   (void)ws_bytes;
+  // an epilogue mode the selected kernel cannot honour is declined, never silently dropped
+  if (!epi_fits(epi, KIND == kI8 ? (kCapGateUp | kCapGroupTiles | kCapGather | kCapAccOut)
+                                 : (KIND == kFP8 ? 0u : (kCapGroupTiles | kCapGather))))
+    return XM_ERR_UNSUPPORTED;
   if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) ||
       (epi.group_counts && !epi.group_tiles))
     return XM_ERR_UNSUPPORTED;
@@ -452,28 +456,13 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
   const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
-  // tuning selector, read once: XLLM_MI355_P8_MFMA32 = 1 -> int8 on the 32x32x32 kernel (A/B arm of gemm_p8i.hip)
-  static int mfma32 = -2;
-  if (mfma32 == -2) {
-    const char* e = getenv("XLLM_MI355_P8_MFMA32");
-    mfma32 = e ? atoi(e) : 0;
-  }
   if constexpr (KIND == kI8) {
-    // int8: the 16x16x64 specialisation (gemm_p8i.hip) unless the selector asks for the 32x32x32 kernel
-    if (!mfma32 || epi.group_tiles) {  // (the grouped mode lives in the 16x16x64 kernel)
-      if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
-      return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
-    }
-  }
-  if (splits > 1) {
-    if constexpr (KIND == kI8) {
-      if (!epi.acc_out) return XM_ERR_INVALID;  // the caller points acc_out at the zeroed split-K workspace
-      hipLaunchKernelGGL((gemm_p8_kernel<KIND, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
-                         (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
-    } else {
-      return XM_ERR_UNSUPPORTED;
-    }
+    // int8 lives in the 16x16x64 specialisation (gemm_p8i.hip): the only 8-phase kernel with the gate_up epilogue, the grouped
+    // mode and split-K. (The 32x32x32 int8 arm of this file lost its round-1 A/B and left the library in round 4.)
+    if (splits > 1 && !epi.acc_out) return XM_ERR_INVALID;
+    return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
   } else {
+    if (splits > 1) return XM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((gemm_p8_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   }

@@ -432,15 +432,15 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
 }
 
 // same grid / envelope as launch_gemm_p8 (gemm_p8.hip decides which of the two int8 kernels runs)
-int ws_stagger();  // gemm_ws.hip: XLLM_MI355_KSTAGGER
+XM_TUNE_VAR(p8i_kstagger, "XLLM_MI355_KSTAGGER", 1);   // K-walk stagger (round-3 A/B winner; 0 = tuning arm)
 int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
                     int per, int splits, dim3 grid, hipStream_t s) {
   if (splits > 1)
     hipLaunchKernelGGL((gemm_p8i_kernel<true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
-                       (int)N, Kb, m_tiles, n_tiles, per, epi, ws_stagger());
+                       (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);
   else
     hipLaunchKernelGGL((gemm_p8i_kernel<false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W,
-                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi, ws_stagger());
+                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);
   return hip_check_launch();
 }
 

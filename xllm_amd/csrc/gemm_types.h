@@ -92,6 +92,18 @@ struct GemmEpi {
   int w_policy;   // packed kernels, cache policy of the weight stream: 0 = by the launch shape, 1 = nt, 2 = default (tuning arm)
 };
 
+// Epilogue modes a launcher can honour. Every launcher starts with epi_fits(epi, its capabilities): a mode the selected kernel
+// lacks is DECLINED (XM_ERR_UNSUPPORTED) -- never dropped with XM_OK (round-3 review: the removed 32x32x32 int8 arm returned OK
+// with nothing written in gate_up mode).
+enum EpiCap : unsigned { kCapGateUp = 1, kCapDefer = 2, kCapGroupTiles = 4, kCapGather = 8, kCapGroupCounts = 16, kCapAccOut = 32 };
+inline bool epi_fits(const GemmEpi& e, unsigned caps) {
+  const unsigned need = (e.gate_up || e.act_out || e.row_amax ? kCapGateUp : 0u) | (e.defer ? kCapDefer : 0u) |
+                        (e.group_tiles ? kCapGroupTiles : 0u) | (e.gather_rows ? kCapGather : 0u) |
+                        (e.group_counts && !e.group_tiles ? kCapGroupCounts : 0u) | (e.acc_out ? kCapAccOut : 0u);
+  if (!e.out && !e.acc_out && !e.defer && !(e.gate_up && e.act_out)) return false;   // nowhere to write
+  return (need & ~caps) == 0;
+}
+
 __device__ __forceinline__ void store16(void* out, int64_t idx, float v, int out_bf16) {
   if (out_bf16) reinterpret_cast<uint16_t*>(out)[idx] = f32_to_bf16_bits(v);
   else reinterpret_cast<f16_t*>(out)[idx] = (f16_t)v;

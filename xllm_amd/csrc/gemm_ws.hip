@@ -997,22 +997,13 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
 // ------------------------------------------------------------------------------------------------ planner + launch
 struct WsPlan { int waves, wm, wn, mb, ng, slices; };
 
-// XLLM_MI355_KSTAGGER=0: every workgroup walks K from its first tile (A/B arm), read once
-int ws_stagger() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("XLLM_MI355_KSTAGGER"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
-// XLLM_MI355_WS8_STAGGER=0: the eight-wave tile with all waves in phase (A/B arm of gemm_ws8s_kernel), read once;
-// xllm_mi355_debug_ws_waves(80) / (81) switch it from the tests
-static int f_ws8s = -2;
-int ws_phase_stagger() {
-  if (f_ws8s == -2) { const char* e = getenv("XLLM_MI355_WS8_STAGGER"); f_ws8s = e ? atoi(e) : 1; }
-  return f_ws8s;
-}
-
-static int f_wpolicy = 0;   // xllm_mi355_debug_ws_waves(140 | 141 | 142): weight-stream cache policy by shape | nt | default
+// Tuning arms (compiled only into the -DXM_TUNING flavour, `make tuning`; constants in the product library):
+//   XLLM_MI355_KSTAGGER=0     every workgroup walks K from its first tile (round-2 behaviour; lost the round-3 A/B)
+//   XLLM_MI355_WS8_STAGGER=0  the eight-wave tile with all waves in phase (lost the round-3 A/B)
+//   w_policy                  cache policy of the weight stream: 0 by shape (default) | 1 nt | 2 default
+XM_TUNE_VAR(f_kstagger, "XLLM_MI355_KSTAGGER", 1);
+XM_TUNE_VAR(f_ws8s, "XLLM_MI355_WS8_STAGGER", 1);
+XM_TUNE_VAR(f_wpolicy, "XLLM_MI355_WS_WPOLICY", 0);
 template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
@@ -1035,50 +1026,45 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   const int rest = n_tiles * slices;
   const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
   if constexpr (NWV == 8) {
-    if (ws_phase_stagger()) {
-      constexpr int ND8 = (2 * WN * NG + 7) / 8 + 4;  // pieces per wave and tile (weights + 4 activation pieces)
-      // (a first version issued every request from the matrix phase, NRD = 0: 46.0 vs 45.4 us for gate_up at M = 256 -- removed)
-      hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
-                         (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+#ifdef XM_TUNING
+    if (!f_ws8s) {
+      hipLaunchKernelGGL((gemm_ws_kernel<KIND, NWV, WM, WN, MB, NG, DW>), dim3(grid), dim3(NWV * 64), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs, f_kstagger);
       return slices;
     }
+#endif
+    constexpr int ND8 = (2 * WN * NG + 7) / 8 + 4;  // pieces per wave and tile (weights + 4 activation pieces)
+    // (a first version issued every request from the matrix phase, NRD = 0: 46.0 vs 45.4 us for gate_up at M = 256 -- removed)
+    hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+  } else {
+    hipLaunchKernelGGL((gemm_ws_kernel<KIND, NWV, WM, WN, MB, NG, DW>), dim3(grid), dim3(NWV * 64), 0, s, (const uint8_t*)A,
+                       (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs, f_kstagger);
   }
-  hipLaunchKernelGGL((gemm_ws_kernel<KIND, NWV, WM, WN, MB, NG, DW>), dim3(grid), dim3(NWV * 64), 0, s, (const uint8_t*)A,
-                     (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs, ws_stagger());
   return slices;
 }
 
 // (M, N, K) -> tile shape and K slices. The tile height follows M; the width and the slice count are chosen so that the
 // grid comes as close as possible to one workgroup on each of the 256 CUs (two for the small tiles) without exceeding it,
 // with the partial-sum slabs (slices * M * N * 4 bytes written and read back) priced in.
-static int f_ng = -2, f_sl = -2;  // planner overrides: XLLM_MI355_WS_NG / _SLICES, or xllm_mi355_debug_ws_plan (tests, tuning)
+// Planner hint of the CALLING THREAD (xllm_mi355_gemm_plan_hint, include/xllm_mi355.h): tile width (16-column groups per wave),
+// K-slice count and tile height of the following packed-GEMM launches from this thread; 0 = planner. thread_local: a worker
+// thread's hint never races with another worker's launches.
+static thread_local int f_ng = 0, f_sl = 0, f_rows = 0;
+#ifdef XM_TUNING
 struct WsShapePlan { int64_t N, K; int ng, slices; };
 static WsShapePlan shape_plans[8];
 static int n_shape_plans = 0;
-static int f_rows128 = 2;         // 128-row tiles for M > 128: 2 = N <= 20480 and (K <= 8192 or M % 256 == 0) (default), 1 = always,
-                                  // 3 = N and K <= 8192, 4 = N <= 8192, 0 = never
-                                  // (xllm_mi355_debug_ws_waves(128 | 129 | 130 | 131) = 1 | 2 | 3 | 0; XLLM_MI355_WS_ROWS128)
-static int f_waves = -2;          // (env read flag; the round-2 four-wave 256-row tile, XLLM_MI355_WS_WAVES=4, lost the in-step A/B by
-                                  //  0.27 ms and left the library in round 3)
+#endif
+// 128-row tiles for 128 < M <= 512 when N <= 20480 and (K <= 8192 or M % 256 == 0); 256-row eight-wave tiles otherwise
+// (round-3 in-step A/B, profiles/r03_step_ab.txt; the round-2 four-wave 256-row tile left the library in round 3)
 static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws_bytes, bool gu = false) {
-  if (f_ng == -2) {
-    const char* e = getenv("XLLM_MI355_WS_NG");
-    f_ng = e ? atoi(e) : -1;
-    e = getenv("XLLM_MI355_WS_SLICES");
-    f_sl = e ? atoi(e) : -1;
-  }
-  if (f_waves == -2) {
-    f_waves = -1;
-    const char* e = getenv("XLLM_MI355_WS_ROWS128");
-    if (e) f_rows128 = atoi(e);
-  }
   WsPlan p;
   p.waves = 4;
   if (M <= 32) { p.wm = 1; p.wn = 4; p.mb = 2; }
   else if (M <= 64) { p.wm = 1; p.wn = 4; p.mb = 4; }
   else if (M <= 128) { p.wm = 2; p.wn = 2; p.mb = 4; }
-  else if (f_rows128 == 1 || (f_rows128 == 2 && N <= 20480 && (K <= 8192 || M % 256 == 0)) ||
-           (f_rows128 == 3 && N <= 8192 && K <= 8192) || (f_rows128 == 4 && N <= 8192)) {
+  else if (f_rows == 128 || (f_rows != 256 && N <= 20480 && (K <= 8192 || M % 256 == 0))) {
     // 128-row tiles also above 128 rows for the few-column problems (qkv, o, down: N <= 8192). They need K slices to fill the
     // chip; with 2+ m tiles per column range half as many slices do, i.e. half the slab bytes written here and read back by the
     // fused consumer -- at the price of streaming the weights once per m tile (the m tiles of a column range are neighbours in
@@ -1126,11 +1112,13 @@ static WsPlan ws_plan(int64_t M, int64_t N, int64_t K, bool can_slice, size_t ws
   }
   if (f_ng > 0) p.ng = f_ng;
   if (f_sl > 0 && can_slice) p.slices = f_sl;
-  for (int i = 0; i < n_shape_plans; ++i)   // per-shape overrides (tuning: tools/step_ab.py sweeps one GEMM of the step at a time)
+#ifdef XM_TUNING
+  for (int i = 0; i < n_shape_plans; ++i)   // per-shape overrides (tools/step_ab.py sweeps one GEMM of the step at a time)
     if (shape_plans[i].N == N && shape_plans[i].K == K) {
       if (shape_plans[i].ng > 0) p.ng = shape_plans[i].ng;
       if (shape_plans[i].slices > 0 && (can_slice || shape_plans[i].slices == 1)) p.slices = shape_plans[i].slices;
     }
+#endif
   return p;
 }
 
@@ -1156,6 +1144,7 @@ int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64
 template <int KIND>
 static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
                           size_t ws_bytes, int* n_slabs, hipStream_t s) {
+  if (!epi_fits(epi, kCapGateUp | kCapDefer | kCapAccOut)) return XM_ERR_UNSUPPORTED;
   if (M <= 0 || M > 512 || N % 16 != 0 || K % WS_BK != 0 || K / WS_BK < 4 || M * K >= (1ll << 31) || epi.group_counts ||
       ((uintptr_t)A % 16) || ((uintptr_t)Wp % 16) || (epi.out && (uintptr_t)epi.out % 8) ||
       (KIND == kI8 && epi.w_scale && (uintptr_t)epi.w_scale % 16))
@@ -1215,25 +1204,23 @@ extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_ws8(long 
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(xm::ws8_dbg), 64 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
-// tests / tuning: force the tile width (16-column groups per wave) and the K-slice count of the next launches; <= 0 = planner
-extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan(int ng, int slices) {
-  xm::f_ng = ng > 0 ? ng : -1;
-  xm::f_sl = slices > 0 ? slices : -1;
+extern "C" XM_API void xllm_mi355_gemm_plan_hint(int ng, int slices, int tile_rows) {
+  xm::f_ng = ng > 0 ? ng : 0;
+  xm::f_sl = slices > 0 ? slices : 0;
+  xm::f_rows = tile_rows == 128 || tile_rows == 256 ? tile_rows : 0;
 }
+#ifdef XM_TUNING
 // tuning: plan override for ONE problem shape (N, K) of the following launches; N <= 0 clears all of them
-extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_plan_shape(long long N, long long K, int ng, int slices) {
+extern "C" XM_API void xllm_mi355_debug_ws_plan_shape(long long N, long long K, int ng, int slices) {
   if (N <= 0) { xm::n_shape_plans = 0; return; }
   for (int i = 0; i < xm::n_shape_plans; ++i)
     if (xm::shape_plans[i].N == N && xm::shape_plans[i].K == K) { xm::shape_plans[i].ng = ng; xm::shape_plans[i].slices = slices; return; }
   if (xm::n_shape_plans < 8) xm::shape_plans[xm::n_shape_plans++] = {N, K, ng, slices};
 }
-// tests / tuning: 80 / 81 = eight waves with the wave groups in phase / one barrier apart (default); 128 .. 131 = tile height above
-// 128 rows; 140 .. 142 = cache policy of the weight stream; 0 = defaults
-extern "C" __attribute__((visibility("default"))) void xllm_mi355_debug_ws_waves(int waves) {
-  if (waves == 80 || waves == 81) { xm::f_waves = -1; xm::f_ws8s = waves - 80; return; }
-  if (waves >= 128 && waves <= 131) { xm::f_rows128 = waves == 131 ? 0 : waves - 127; return; }
-  if (waves >= 140 && waves <= 142) { xm::f_wpolicy = waves - 140; return; }
-  if (waves == 0) xm::f_wpolicy = 0;
-  if (waves == 0) xm::f_rows128 = 2;
-  if (waves == 0) xm::f_ws8s = 1;
+// tuning: 80 / 81 = eight waves in phase / one barrier apart (default); 140 .. 142 = cache policy of the weight stream; 0 = defaults
+extern "C" XM_API void xllm_mi355_debug_ws_waves(int waves) {
+  if (waves == 80 || waves == 81) xm::f_ws8s = waves - 80;
+  if (waves >= 140 && waves <= 142) xm::f_wpolicy = waves - 140;
+  if (waves == 0) { xm::f_wpolicy = 0; xm::f_ws8s = 1; }
 }
+#endif

@@ -296,14 +296,12 @@ __global__ __launch_bounds__(256) void wsb_reduce_kernel(float* __restrict__ sla
   }
 }
 
-static int g_wsb_mode = -2, g_wsb_slices = -2;
+// XLLM_MI355_WSB (product switch, read once): 0 = never (the tiled kernels take the decode shapes: parity test of that fallback),
+// 1 = default policy, 2 = up to 64 rows. XLLM_MI355_WSB_SLICES (forced K-slice count of the dense form) is a tuning override.
+static int g_wsb_mode = -2;
+XM_TUNE_VAR(g_wsb_slices, "XLLM_MI355_WSB_SLICES", -1);
 static void wsb_env() {
-  if (g_wsb_mode == -2) {
-    const char* e = getenv("XLLM_MI355_WSB");          // 0: never (A/B against the tiled kernels), 1: default policy, 2: up to 64 rows
-    g_wsb_mode = e ? atoi(e) : 1;
-    e = getenv("XLLM_MI355_WSB_SLICES");               // force the K-slice count of the dense form
-    g_wsb_slices = e ? atoi(e) : -1;
-  }
+  if (g_wsb_mode == -2) g_wsb_mode = xm_switch("XLLM_MI355_WSB", 1);
 }
 
 template <typename T, int MB, bool GROUPED>

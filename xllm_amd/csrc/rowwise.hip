@@ -604,8 +604,9 @@ int launch_slab_rope_and_cache(const int32_t* slabs, int n_slabs, const float* a
   const int64_t items = (n_q_heads + n_kv_heads) * (rot_dim / 2) + (n_q_heads + n_kv_heads) * (head_size - rot_dim) +
                         n_kv_heads * head_size;
   const int64_t half = rot_dim / 2, tail = head_size - rot_dim;
-  static int use_vec = -1;
-  if (use_vec < 0) { const char* e = getenv("XLLM_MI355_SLAB_ROPE_VEC"); use_vec = e ? atoi(e) : 1; }   // 0: the scalar kernel (A/B)
+  // (the scalar kernel below is the path of odd head geometries / unaligned tensors; forcing it, XLLM_MI355_SLAB_ROPE_VEC=0, is a
+  // tuning arm of the -DXM_TUNING flavour)
+  XM_TUNE_VAR(use_vec, "XLLM_MI355_SLAB_ROPE_VEC", 1);
   if (use_vec && half % 4 == 0 && tail % 4 == 0 && head_size % 4 == 0 && (!bias || (uintptr_t)bias % 8 == 0) &&
       (uintptr_t)qkv % 8 == 0 && (uintptr_t)k_cache % 8 == 0 && (uintptr_t)v_cache % 8 == 0 && (uintptr_t)cos_sin_cache % 8 == 0) {
     const dim3 gridv((unsigned)M, (unsigned)((items / 4 + 255) / 256));

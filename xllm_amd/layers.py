@@ -373,7 +373,7 @@ class Qwen2Model:
         self.norm_w = (torch.rand(args.hidden_size, device=device, generator=gen) + 0.5).to(dtype)
         self.lm_head = QuantLinear(args.vocab_size, args.hidden_size, False, "16bit", dtype, device, gen,
                                    shard=("col", tp.rank() if tp else 0, tp_size),
-                                   pack16=os.environ.get("XLLM_MI355_PACK_LM_HEAD", "1") == "1")
+                                   pack16=True)
         self.embed = (torch.randn(args.vocab_size, args.hidden_size, device=device, generator=gen)).to(dtype)
         self.cos_sin = build_cos_sin_cache(args, dtype, device, 8192)
 
@@ -645,8 +645,7 @@ class DualBatchDecoder:
             kv_cu_seq_lens=None, kv_seq_lens=md.kv_seq_lens[b:e].contiguous(), slot_mapping=md.slot_mapping[b:e].contiguous(),
             block_table=md.block_table[b:e].contiguous(), max_query_len=1, max_seq_len=md.max_seq_len) for b, e in self.cut]
         self.streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        import os
-        self.chain = os.environ.get("XLLM_DUAL_NOCHAIN", "0") != "1"
+        self.chain = True      # (tools set .chain = False to measure the halves without the cross-stream hand-over)
         for st, (b, e) in zip(self.streams, self.cut):   # split-K partial sums of the two halves must not mix
             ops.set_gemm_workspace_for_stream(st, 32 << 20)
 

@@ -275,14 +275,12 @@ _PACKED_POLICY = os.environ.get("XLLM_MI355_PACKED", "auto")   # "0" never, "1" 
 
 def _prefer_packed(M: int, N: int, K: int) -> bool:
     """which int8 kernel serves a decode-shaped GEMM: since round 3 the weight-stream kernel on packed weights takes every
-    problem of at most 512 rows (profiles/r03_gemm_ws.txt, r03_policy.txt). XLLM_MI355_PACKED = "r2" restores the
-    round-2 policy (M <= 128, and the few-column / long-K problems up to M = 512) as an A/B arm, "0" / "1" = never / always."""
+    problem of at most 512 rows (profiles/r03_gemm_ws.txt, r03_policy.txt). XLLM_MI355_PACKED = "0" / "1" = never /
+    wherever legal (one switch for the int8, fp8 and 16-bit kinds); the round-2 policy arm left in round 4."""
     if _PACKED_POLICY == "0":
         return False
     if _PACKED_POLICY == "1":
         return M <= 512
-    if _PACKED_POLICY == "r2":      # the round-2 policy (A/B)
-        return M <= 128 or (M <= 512 and N <= 8192 and K >= 8192)
     # round 3 (coalesced epilogue, eight-wave tile; profiles/r03_gemm_ws.txt, r03_policy.txt): the packed kernel serves every
     # decode-shaped problem. Stand-alone the two small projections are 3 us slower on it at M = 256 (22.3 / 19.1 us with their
     # slab pass against 19.4 / 17.9), but in the step their slabs feed the fused consumers (RoPE + KV write, add + norm + quant)
@@ -357,6 +355,28 @@ def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None
 
 
 _row_amax = {}
+_row_amax_retired = []
+
+
+def _row_amax_scratch(device, M: int):
+    """zero-at-rest |max| scratch of the gate_up fusion, keyed like _slab_workspace: one buffer per device for the default stream
+    and for captures, one per eagerly-launching side stream (their launches may run concurrently). A buffer is NEVER freed: a
+    captured HIP graph has its address baked in (atomicMax + re-zero on replay), so a buffer a larger M outgrows is retired -- kept
+    alive, still zero at rest -- and a bigger one takes its place for the launches that follow (round-3 advisor finding)."""
+    cur = torch.cuda.current_stream(device)
+    side = cur != torch.cuda.default_stream(device) and not torch.cuda.is_current_stream_capturing()
+    key = (device, cur.cuda_stream if (side or cur.cuda_stream in _private_streams) else 0)
+    amax = _row_amax.get(key)
+    if amax is None or amax.numel() < M:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("row-amax scratch must exist before a graph capture: run one eager step of this shape first")
+        if amax is not None:
+            _row_amax_retired.append(amax)
+        amax = torch.zeros(max(M, 16384), dtype=torch.float32, device=device)     # zero at rest (the quantising pass re-zeroes)
+        _row_amax[key] = amax
+    return amax
+
+
 _GATE_UP_FUSION = os.environ.get("XLLM_MI355_GATE_UP_FUSION", "1") == "1"   # A/B switch of the fusion below
 
 
@@ -371,13 +391,7 @@ def scaled_matmul_silu_mul_quant(a, b, a_scale, b_scale, output_dtype=torch.bflo
     N = b.size(0)
     if not _GATE_UP_FUSION or N % 256 or K % 128 or not a.is_contiguous() or not b.is_contiguous() or M == 0:
         return None
-    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream if torch.cuda.current_stream(a.device).cuda_stream in _private_streams else 0)
-    amax = _row_amax.get(key)
-    if amax is None or amax.numel() < M:
-        if torch.cuda.is_current_stream_capturing():
-            raise Mi355Error("row-amax scratch must exist before a graph capture: run one eager step of this shape first")
-        amax = torch.zeros(max(M, 8192), dtype=torch.float32, device=a.device)     # zero at rest (the quantising pass re-zeroes)
-        _row_amax[key] = amax
+    amax = _row_amax_scratch(a.device, M)
     I = N // 2
     act = torch.empty(M, I, dtype=output_dtype, device=a.device)
     rc = _lib.lib().xllm_mi355_scaled_matmul_gate_up_act(_p(a), _p(b), _p(b_packed), _p(a_scale.reshape(-1)),
@@ -465,7 +479,7 @@ def pack_weight_fp8(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
-_PACKED_FP8_POLICY = os.environ.get("XLLM_MI355_PACKED_FP8", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
+_PACKED_FP8_POLICY = os.environ.get("XLLM_MI355_PACKED", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
 
 
 def _prefer_packed_fp8(M: int, N: int, K: int) -> bool:
@@ -517,7 +531,7 @@ def pack_weight_16(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
-_PACKED_16_POLICY = os.environ.get("XLLM_MI355_PACKED_16", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
+_PACKED_16_POLICY = os.environ.get("XLLM_MI355_PACKED", "auto")   # "0" never, "1" wherever legal (M <= 512), "auto"
 
 
 def _prefer_packed_16(M: int, N: int, K: int) -> bool:

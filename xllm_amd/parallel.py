@@ -28,25 +28,20 @@ class ProcessGroup:
         (`oneshot_note` says why not) -- the group's own all-reduce stays the fallback."""
         if self._world <= 1 or self.oneshot is not None:
             return self.oneshot
-        ar, note = None, "ok"
-        try:
-            ar = OneShotAllReduce(self, device, max_bytes)
-            if ar.refused:
-                note = ar.refused
-            elif self_test and not ar.self_test():
-                note = "self-test failed (a checked message came back wrong or a wait timed out)"
-        except Exception as e:   # noqa: BLE001 -- any set-up failure means: keep RCCL
-            note = f"set-up failed: {e!r}"
+        # OneShotAllReduce() runs the same collectives on every rank whatever fails locally (its `refused` is already agreed over
+        # the group); the self-test verdict is agreed here; close() -- a barrier + unmap -- is then run by EVERY rank or by none.
+        ar = OneShotAllReduce(self, device, max_bytes)
+        note = "ok"
+        if ar.refused:
+            note = ar.refused                      # identical on every rank: nobody enters the self-test
+        elif self_test and not ar.self_test():     # (catches its own exceptions: returns False)
+            note = "self-test failed (a checked message came back wrong or a wait timed out)"
         verdicts = [None] * self._world
         dist.all_gather_object(verdicts, note, group=self.group)
         bad = [f"rank {r}: {v}" for r, v in enumerate(verdicts) if v != "ok"]
         if bad:
-            if ar is not None:
-                try:
-                    ar.close()
-                except Exception:   # noqa: BLE001
-                    pass
-            self.oneshot, self.oneshot_note = None, "; ".join(bad)
+            ar.close()                             # every rank takes this branch together
+            self.oneshot, self.oneshot_note = None, "; ".join(sorted(set(bad)))
         else:
             self.oneshot, self.oneshot_note = ar, "ok"
         return self.oneshot
@@ -69,6 +64,20 @@ class ProcessGroup:
         if self.oneshot is not None:
             self.oneshot.check()
 
+    def check_agreed(self) -> None:
+        """collective form of check(): every rank of the group calls it, the status words are exchanged, and EVERY rank raises if
+        any rank's launch timed out -- so a fall-back that re-times on RCCL is taken by all ranks together (a rank that was waited
+        for sees no timeout of its own; round-3 advisor finding on bench.py)."""
+        if self._world <= 1 or self.oneshot is None:
+            return
+        mine = 0 if int(self.oneshot.status.item()) == 0 else 1
+        flags = [None] * self._world
+        dist.all_gather_object(flags, mine, group=self.group)
+        if any(flags):
+            from . import _lib
+            bad = [r for r, f in enumerate(flags) if f]
+            raise _lib.Mi355Error(f"one-shot all-reduce: a wait for a peer's flag timed out on rank(s) {bad} (result undefined)")
+
     def rank(self) -> int:
         return self._rank
 
@@ -86,7 +95,9 @@ class ProcessGroup:
         """the tensor-parallel half-layer tail in ONE kernel when the one-shot path is on: SUM all-reduce of `partial` [M, H] ->
         residual <- r16(sum + residual) -> RMSNorm (-> per-token int8 quant). Returns (q int8, scale) or the 16-bit norm; None when
         the one-shot kernel does not take the message (the caller then runs allreduce + the row-wise operator)."""
-        if self.oneshot is None or not self.oneshot.takes(partial) or partial.dim() != 2:
+        if self.oneshot is None or partial.dim() != 2 or not self.oneshot.takes(partial):
+            return None
+        if partial.size(1) % 8 != 0 or partial.size(1) > 16384:     # the fused kernel's envelope (H % 8, H <= 16384): not applicable
             return None
         return self.oneshot.allreduce_add_rms_norm(partial, residual, weight, eps, quantize)
 
@@ -154,45 +165,69 @@ class OneShotAllReduce:
         self._stream = None
         world, rank = pg.world_size(), pg.rank()
         total = l.xllm_mi355_oneshot_allreduce_buffer_bytes(self.max_bytes)
-        handle = None
-        with torch.cuda.device(self.device):
-            for first_kind in (0, 1, 2):            # fine-grained, uncached, plain: the first kind that can be exported
-                ptr, kind = C.c_void_p(), C.c_int(first_kind)
-                _lib.check(l.xllm_mi355_ipc_alloc(total, C.byref(ptr), C.byref(kind)), "ipc_alloc")
-                buf = C.create_string_buffer(64)
-                if l.xllm_mi355_ipc_get_handle(ptr, buf) == 0:
-                    handle = bytes(buf.raw)
-                    break
-                l.xllm_mi355_ipc_free(ptr)
-                if kind.value >= 2:
-                    break
+        # Every collective below (object all-gather, barrier) runs UNCONDITIONALLY on every rank: a rank-local failure (no
+        # exportable memory, a peer handle that does not open) is recorded in self.refused and travels with the next exchange,
+        # it never makes this rank skip a collective its peers sit in (round-3 advisor finding: a rank that raised here skipped
+        # the barrier and desynchronised the group instead of falling back to RCCL).
+        handle, err = None, None
+        self.own, self.kind, self._opened = None, -1, []
+        self.peers = (C.c_void_p * world)()
+        try:
+            with torch.cuda.device(self.device):
+                for first_kind in (0, 1, 2):            # fine-grained, uncached, plain: the first kind that can be exported
+                    ptr, kind = C.c_void_p(), C.c_int(first_kind)
+                    _lib.check(l.xllm_mi355_ipc_alloc(total, C.byref(ptr), C.byref(kind)), "ipc_alloc")
+                    buf = C.create_string_buffer(64)
+                    if l.xllm_mi355_ipc_get_handle(ptr, buf) == 0:
+                        handle = bytes(buf.raw)
+                        self.own, self.kind = ptr, kind.value
+                        break
+                    l.xllm_mi355_ipc_free(ptr)
+                    if kind.value >= 2:
+                        break
             if handle is None:
-                raise _lib.Mi355Error("one-shot all-reduce: hipIpcGetMemHandle failed for every memory kind")
-            self.own, self.kind = ptr, kind.value
+                err = "hipIpcGetMemHandle failed for every memory kind"
+        except Exception as e:   # noqa: BLE001
+            err = f"buffer set-up failed: {e!r}"
+        try:
+            dev_id = str(torch.cuda.get_device_properties(self.device).uuid)
+        except Exception:   # noqa: BLE001
+            dev_id = f"{os.uname().nodename}:{self.device.index}"
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (os.getpid(), handle, self.kind, dev_id, err), group=pg.group)
+        export_errs = [f"rank {r}: {e}" for r, (_p, _h, _k, _d, e) in enumerate(everyone) if e or _h is None]
+        if export_errs:
+            self.refused = "; ".join(export_errs)
+        else:
             try:
-                dev_id = str(torch.cuda.get_device_properties(self.device).uuid)
-            except Exception:   # noqa: BLE001
-                dev_id = f"{os.uname().nodename}:{self.device.index}"
-            everyone = [None] * world
-            dist.all_gather_object(everyone, (os.getpid(), handle, self.kind, dev_id), group=pg.group)
-            self.peers = (C.c_void_p * world)()
-            self._opened = []
-            for r, (pid, h, _k, _d) in enumerate(everyone):
-                if r == rank:
-                    self.peers[r] = self.own.value
-                    continue
-                p = C.c_void_p()
-                _lib.check(l.xllm_mi355_ipc_open_handle(h, C.byref(p)), f"ipc_open_handle(rank {r})")
-                self.peers[r] = p.value
-                self._opened.append(p)
-            same_device = len({d for (_p, _h, _k, d) in everyone}) == 1
-            if any(k >= 2 for (_p, _h, k, _d) in everyone) and not same_device:   # the same verdict on every rank
-                self.refused = ("only plain hipMalloc memory could be exported on some rank: not guaranteed visible to a peer "
-                                "GPU while the kernel runs")
-        self.state = torch.zeros(2, dtype=torch.int32, device=self.device)     # epoch, blocks-done counter
-        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
-        torch.cuda.synchronize(self.device)
-        dist.barrier(group=pg.group)    # every rank has every buffer mapped before the first launch
+                with torch.cuda.device(self.device):
+                    for r, (pid, h, _k, _d, _e) in enumerate(everyone):
+                        if r == rank:
+                            self.peers[r] = self.own.value
+                            continue
+                        p = C.c_void_p()
+                        _lib.check(l.xllm_mi355_ipc_open_handle(h, C.byref(p)), f"ipc_open_handle(rank {r})")
+                        self.peers[r] = p.value
+                        self._opened.append(p)
+            except Exception as e:   # noqa: BLE001
+                self.refused = f"peer mapping failed: {e!r}"      # rank-local: agreed below
+            same_device = len({d for (_p, _h, _k, d, _e) in everyone}) == 1
+            if any(k >= 2 for (_p, _h, k, _d, _e) in everyone) and not same_device:   # the same verdict on every rank
+                self.refused = self.refused or ("only plain hipMalloc memory could be exported on some rank: not guaranteed "
+                                                "visible to a peer GPU while the kernel runs")
+        self.state = self.status = None
+        try:
+            self.state = torch.zeros(2, dtype=torch.int32, device=self.device)     # epoch, blocks-done counter
+            self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize(self.device)
+        except Exception as e:   # noqa: BLE001
+            self.refused = self.refused or f"state allocation failed: {e!r}"
+        # agree: either every rank has every buffer mapped before the first launch, or nobody launches
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, self.refused, group=pg.group)
+        bad = [f"rank {r}: {v}" for r, v in enumerate(verdicts) if v]
+        if bad:
+            self.refused = "; ".join(bad)
 
     # ---- which messages ------------------------------------------------------------------------------------------------
     def _stream_ok(self) -> bool:
@@ -272,6 +307,8 @@ class OneShotAllReduce:
             raise self._lib.Mi355Error("matmul_allreduce_add_rms_norm: a [M, K] and residual [M, N] contiguous")
         if M * N * residual.element_size() > self.max_bytes or M > 512 or not ops._prefer_packed(M, N, K):
             return None
+        if N % 8 != 0 or N > 16384:     # the fused consumer's envelope, checked BEFORE the GEMM is launched
+            return None
         ws = ops._slab_workspace(a_q.device)
         dev = a_q.device
         q = qs = n16 = ysum = None
@@ -344,9 +381,11 @@ class OneShotAllReduce:
             raise self._lib.Mi355Error("one-shot all-reduce: a wait for a peer's flag timed out (result undefined)")
 
     def close(self) -> None:
+        """collective: every rank of the group calls it (nobody unmaps while a peer may still read)"""
         l = self._lib.lib()
-        torch.cuda.synchronize(self.device)
-        dist.barrier(group=self.pg.group)   # nobody unmaps while a peer may still read
+        if self.state is not None:
+            torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.pg.group)
         for p in self._opened:
             l.xllm_mi355_ipc_close_handle(p)
         self._opened = []
