@@ -590,6 +590,105 @@ torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, c
   return out;
 }
 
+namespace flash_mla {
+namespace {
+// the input contract of flash_mla_adapter.cpp:48-101 (CHECKs there; TORCH_CHECK here), minus the page == 64 restriction
+void check_dense_inputs(const DenseDecodeParams& p) {
+  TORCH_CHECK(p.q_nope.defined() && p.q_pe.defined() && p.k_cache.defined() && p.seqlens_k.defined() && p.block_table.defined(),
+              "flash_mla: q_nope, q_pe, k_cache, seqlens_k and block_table must be defined");
+  const auto dev = p.k_cache.device();
+  TORCH_CHECK(p.q_nope.device() == dev && p.q_pe.device() == dev && p.seqlens_k.device() == dev && p.block_table.device() == dev,
+              "flash_mla: every tensor must be on the k_cache's device");
+  TORCH_CHECK(p.q_nope.dim() == 4 && p.q_pe.dim() == 4, "flash_mla: q_nope / q_pe must be 4D [B,S_q,H_q,D]");
+  TORCH_CHECK(p.k_cache.dim() == 4 && p.k_cache.size(2) == 1, "flash_mla: k_cache must be 4D [blocks,page,1,D] with one KV head");
+  TORCH_CHECK(p.seqlens_k.dim() == 1 && p.block_table.dim() == 2, "flash_mla: seqlens_k [B], block_table [B,max_blocks]");
+  TORCH_CHECK(p.k_cache.size(3) == p.q_nope.size(3) + p.q_pe.size(3), "flash_mla: k_cache last dim must equal q_nope.dim + q_pe.dim");
+  TORCH_CHECK(p.q_nope.size(0) == p.q_pe.size(0) && p.q_nope.size(1) == p.q_pe.size(1) && p.q_nope.size(2) == p.q_pe.size(2),
+              "flash_mla: q_nope / q_pe batch, seq and head counts must match");
+  TORCH_CHECK(p.seqlens_k.size(0) == p.q_nope.size(0) && p.block_table.size(0) == p.q_nope.size(0), "flash_mla: batch mismatch");
+  TORCH_CHECK(p.head_size_v > 0, "flash_mla: head_size_v must be positive");
+  TORCH_CHECK(p.softmax_scale > 0.0F, "flash_mla: softmax_scale must be set by the MLA attention layer");
+}
+torch::Tensor as_i32(const torch::Tensor& t) { return (t.scalar_type() == torch::kInt32 ? t : t.to(torch::kInt32)).contiguous(); }
+// scratch of the MLA kernels: split-KV partials ((head_size_v + 2) floats per (entry, head, split), at most 32 splits) and, for the
+// prefill form, the per-query (sequence, visible keys) expansion in front of them
+torch::Tensor mla_workspace(const torch::Tensor& like, int64_t entries, int64_t heads, int64_t head_size_v, int64_t q_tokens) {
+  const int64_t idx_bytes = ((q_tokens * 2 * 4) + 255) / 256 * 256;
+  const int64_t part_bytes = entries * heads * 32 * (head_size_v + 2) * 4;
+  return torch::empty({idx_bytes + part_bytes}, like.options().dtype(torch::kUInt8));
+}
+}  // namespace
+
+torch::Tensor dense_decode(DenseDecodeParams& params) {
+  TORCH_CHECK(params.kind == DenseDecodeKind::kQNopePe, "flash_mla: only DenseDecodeKind::kQNopePe (BF16/FP16 split-q) is supported");
+  check_dense_inputs(params);
+  DeviceGuard guard(params.k_cache.device());
+  const int64_t B = params.q_nope.size(0), Sq = params.q_nope.size(1), H = params.q_nope.size(2);
+  const int64_t D = params.k_cache.size(3), page = params.k_cache.size(1);
+  // the kernels take the query as one [.., D] row (nope || pe): one small copy (B * S_q * H * D elements) next to the cache read
+  torch::Tensor q = torch::cat({params.q_nope, params.q_pe}, /*dim=*/-1).contiguous();   // [B, S_q, H, D]
+  torch::Tensor lens = as_i32(params.seqlens_k), bt = as_i32(params.block_table);
+  const int64_t max_kv = bt.size(1) * page;           // upper bound of every kv length: sizes the split-KV plan, never read back
+  auto out = torch::empty({B, Sq, H, params.head_size_v}, q.options());
+  if (B == 0 || Sq == 0) return out;
+  if (Sq == 1) {
+    auto ws = mla_workspace(q, B, H, params.head_size_v, 0);
+    check(xllm_mi355_mla_decode(p(q), p(params.k_cache), p(out), lens.data_ptr<int32_t>(), bt.data_ptr<int32_t>(), bt.size(1), B, H,
+                                D, params.head_size_v, page, params.k_cache.size(0), max_kv, params.softmax_scale, dt(q),
+                                ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+          "flash_mla::dense_decode");
+    return out;
+  }
+  // S_q > 1: every sequence brings S_q query tokens, packed in batch order
+  auto cu_q = torch::arange(0, (B + 1) * Sq, Sq, lens.options());
+  auto ws = mla_workspace(q, B * Sq, H, params.head_size_v, B * Sq);
+  check(xllm_mi355_mla_prefill(p(q), p(params.k_cache), p(out), cu_q.data_ptr<int32_t>(), lens.data_ptr<int32_t>(),
+                               bt.data_ptr<int32_t>(), bt.size(1), B, B * Sq, H, D, params.head_size_v, page, params.k_cache.size(0),
+                               max_kv, params.softmax_scale, params.is_causal ? 1 : 0, dt(q), ws.data_ptr(), (size_t)ws.numel(),
+                               cur_stream()),
+        "flash_mla::dense_decode (S_q > 1)");
+  return out;
+}
+
+torch::Tensor prefill_paged(const torch::Tensor& q_nope, const torch::Tensor& q_pe, const torch::Tensor& k_cache,
+                            const torch::Tensor& q_cu_seq_lens, const torch::Tensor& kv_seq_lens, const torch::Tensor& block_table,
+                            int64_t head_size_v, double softmax_scale, bool is_causal) {
+  TORCH_CHECK(q_nope.dim() == 3 && q_pe.dim() == 3 && q_nope.size(0) == q_pe.size(0) && q_nope.size(1) == q_pe.size(1),
+              "flash_mla::prefill_paged: q_nope [T, H, kv_lora], q_pe [T, H, rope]");
+  TORCH_CHECK(k_cache.dim() == 4 && k_cache.size(2) == 1 && k_cache.size(3) == q_nope.size(2) + q_pe.size(2),
+              "flash_mla::prefill_paged: k_cache [blocks, page, 1, kv_lora + rope]");
+  TORCH_CHECK(q_cu_seq_lens.dim() == 1 && kv_seq_lens.dim() == 1 && q_cu_seq_lens.size(0) == kv_seq_lens.size(0) + 1 &&
+                  block_table.dim() == 2 && block_table.size(0) == kv_seq_lens.size(0),
+              "flash_mla::prefill_paged: q_cu_seq_lens [B + 1], kv_seq_lens [B], block_table [B, max_blocks]");
+  TORCH_CHECK(head_size_v > 0 && softmax_scale > 0.0, "flash_mla::prefill_paged: head_size_v and softmax_scale must be positive");
+  DeviceGuard guard(k_cache.device());
+  const int64_t T = q_nope.size(0), H = q_nope.size(1), B = kv_seq_lens.size(0), D = k_cache.size(3), page = k_cache.size(1);
+  torch::Tensor q = torch::cat({q_nope, q_pe}, /*dim=*/-1).contiguous();
+  torch::Tensor cu = as_i32(q_cu_seq_lens), lens = as_i32(kv_seq_lens), bt = as_i32(block_table);
+  auto out = torch::empty({T, H, head_size_v}, q.options());
+  if (T == 0 || B == 0) return out;
+  auto ws = mla_workspace(q, T, H, head_size_v, T);
+  check(xllm_mi355_mla_prefill(p(q), p(k_cache), p(out), cu.data_ptr<int32_t>(), lens.data_ptr<int32_t>(), bt.data_ptr<int32_t>(),
+                               bt.size(1), B, T, H, D, head_size_v, page, k_cache.size(0), bt.size(1) * page, (float)softmax_scale,
+                               is_causal ? 1 : 0, dt(q), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+        "flash_mla::prefill_paged");
+  return out;
+}
+
+void store_latent_cache(const torch::Tensor& latent_cache, const torch::Tensor& slot_mapping, const torch::Tensor& k_cache) {
+  TORCH_CHECK(latent_cache.dim() == 2 && k_cache.dim() == 4 && k_cache.size(2) == 1 && k_cache.size(3) == latent_cache.size(1) &&
+                  slot_mapping.dim() == 1 && slot_mapping.size(0) == latent_cache.size(0),
+              "flash_mla::store_latent_cache: latent [T, D], slots [T], k_cache [blocks, page, 1, D]");
+  DeviceGuard guard(k_cache.device());
+  torch::Tensor rows = latent_cache.contiguous(), slots = as_i32(slot_mapping);
+  const int64_t T = rows.size(0), D = rows.size(1);
+  check(xllm_mi355_reshape_paged_cache(slots.data_ptr<int32_t>(), p(rows), nullptr, p(k_cache), nullptr, T, /*n_kv_heads=*/1,
+                                       /*head_dim=*/D, /*block_size=*/k_cache.size(1), /*n_blocks=*/k_cache.size(0),
+                                       /*k_stride=*/D, /*v_stride=*/0, (int)rows.element_size(), cur_stream()),
+        "flash_mla::store_latent_cache");
+}
+}  // namespace flash_mla
+
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& indptr, const torch::Tensor& indices) {
   DeviceGuard guard(indptr.device());
   const int64_t B = indptr.size(0) - 1, total = indices.size(0);

@@ -123,6 +123,44 @@ torch::Tensor group_gemm_w8a8(const torch::Tensor& input, const torch::Tensor& a
 torch::Tensor mla_decode(const torch::Tensor& q, const torch::Tensor& k_cache, const torch::Tensor& seqlens_k,
                          const torch::Tensor& block_table, int64_t head_size_v, double softmax_scale, int64_t max_kv_len);
 
+// ---- flash_mla adapter: kernels/dcu/flash_mla_adapter.h:33-53, the interface layers/dcu/deepseek_v2_attention.cpp:189-210 binds.
+// Under USE_MI355 that layer file includes this header instead of kernels/dcu/flash_mla_adapter.h and reaches it through
+// `namespace dcu = mi355` (patches/xllm-use-mi355.patch), so `kernel::dcu::flash_mla::dense_decode(params)` compiles unchanged.
+namespace flash_mla {
+enum class DenseDecodeKind {
+  kQNopePe,
+};
+// q_nope [B, S_q, H_q, kv_lora_rank], q_pe [B, S_q, H_q, qk_rope_head_dim], k_cache [num_blocks, page, 1, kv_lora_rank + rope],
+// seqlens_k [B] int32, block_table [B, max_blocks] int32 (flash_mla_adapter.h:33-50, member for member)
+struct DenseDecodeParams {
+  torch::Tensor q_nope;
+  torch::Tensor q_pe;
+  torch::Tensor k_cache;
+  torch::Tensor seqlens_k;
+  torch::Tensor block_table;
+  int64_t head_size_v = 0;
+  float softmax_scale = -1.0F;
+  bool is_causal = false;
+  DenseDecodeKind kind = DenseDecodeKind::kQNopePe;
+};
+// Returns [B, S_q, H_q, head_size_v]. S_q == 1: xllm_mi355_mla_decode; S_q > 1 (multi-token decode): xllm_mi355_mla_prefill over
+// the cache with q_cu = S_q * arange(B + 1) -- query i of a sequence sees seqlens_k - S_q + i + 1 keys when is_causal, all of
+// them otherwise (the flash kernels' bottom-right alignment). Pages of any size (the closed flash_mla.so requires 64,
+// flash_mla_adapter.cpp:79-82; 64-multiples take the LDS-DMA kernels here). No host sync: graph-capturable; the launch plan is
+// sized from block_table.size(1) * page, an upper bound of every sequence length.
+torch::Tensor dense_decode(DenseDecodeParams& params);
+// DeepseekV2AttentionImpl::prefill_sdpa (deepseek_v2_attention.cpp:212-262) without the host loop over sequences: the latent rows
+// were written to the paged cache by store_latent_cache just before (:300-303), so prefill -- and chunked prefill, which the
+// reference CHECK-fails on (:270-271) -- read them back through the block table. q_nope [T, H, kv_lora], q_pe [T, H, rope],
+// q_cu_seq_lens [B + 1], kv_seq_lens [B], block_table [B, max_blocks]; returns [T, H, head_size_v].
+torch::Tensor prefill_paged(const torch::Tensor& q_nope, const torch::Tensor& q_pe, const torch::Tensor& k_cache,
+                            const torch::Tensor& q_cu_seq_lens, const torch::Tensor& kv_seq_lens,
+                            const torch::Tensor& block_table, int64_t head_size_v, double softmax_scale, bool is_causal);
+// DeepseekV2AttentionImpl::store_latent_cache (:170-178) as one kernel (index_copy_ with int64 slots in the reference): rows with
+// slot < 0 (graph padding) are skipped
+void store_latent_cache(const torch::Tensor& latent_cache, const torch::Tensor& slot_mapping, const torch::Tensor& k_cache);
+}  // namespace flash_mla
+
 torch::Tensor build_block_table_from_paged_kv(const torch::Tensor& paged_kv_indptr,
                                               const torch::Tensor& paged_kv_indices);
 

@@ -26,6 +26,25 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("group_gemm_gather", &k::group_gemm_gather);
   m.def("group_gemm_w8a8", [](const torch::Tensor& x, const torch::Tensor& as, const torch::Tensor& w, const torch::Tensor& bs, const torch::Tensor& c, std::optional<torch::Tensor> idx, int64_t div) { return k::group_gemm_w8a8(x, as, w, bs, c, torch::kBFloat16, idx, div); });
   m.def("mla_decode", &k::mla_decode);
+  // kernel::dcu::flash_mla::dense_decode(DenseDecodeParams&) exactly as DeepseekV2AttentionImpl::decode_flash_mla fills the struct
+  // (layers/dcu/deepseek_v2_attention.cpp:189-210): q views [B, 1, H, .], k_cache, kv_seq_lens, block_table, kv_lora, scale, causal
+  m.def("flash_mla_dense_decode", [](const torch::Tensor& q_nope, const torch::Tensor& q_pe, const torch::Tensor& k_cache,
+                                     const torch::Tensor& seqlens_k, const torch::Tensor& block_table, int64_t head_size_v,
+                                     double scale, bool is_causal) {
+    k::flash_mla::DenseDecodeParams params;
+    params.q_nope = q_nope;
+    params.q_pe = q_pe;
+    params.k_cache = k_cache;
+    params.seqlens_k = seqlens_k;
+    params.block_table = block_table;
+    params.head_size_v = head_size_v;
+    params.softmax_scale = (float)scale;
+    params.is_causal = is_causal;
+    params.kind = k::flash_mla::DenseDecodeKind::kQNopePe;
+    return k::flash_mla::dense_decode(params);
+  });
+  m.def("flash_mla_prefill_paged", &k::flash_mla::prefill_paged);
+  m.def("flash_mla_store_latent_cache", &k::flash_mla::store_latent_cache);
   m.def("rejection_sample", &k::rejection_sample);
   m.def("scaled_quantize", [](const torch::Tensor& x) {
     return k::scaled_quantize(x, torch::Tensor(), std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, "none", 1.0, false, torch::kInt8);

@@ -1,4 +1,7 @@
-"""GPU parity at BASELINE.json's FULL sizes (cfg3: Qwen2-7B, batch 256, ctx 4096; prefill chunks of 4096 tokens).
+"""GPU parity at BASELINE.json's FULL sizes: cfg3 (Qwen2-7B W8A8, batch 256, ctx 4096; prefill chunks of 4096 tokens) and, since
+round 4, cfg2 (bf16, batch 64, ctx 2048: decode attention + the packed 16-bit linears at their real shapes), cfg4 (DeepSeek-V3 MLA,
+one TP = 8 rank: batch 128, ctx 8192, 16 heads, pages of 64, fed by the fp8 q_b projection) and cfg5 (Qwen3-MoE W8A8: 8192 tokens,
+128 experts top-8, moe_I 768: gate -> index -> grouped GEMM -> SiLU.mul + quant -> grouped GEMM -> combine).
 
 The oracle cannot finish these shapes in seconds, so every test combines
   * an oracle check on a SAMPLE of the units (sequences / rows / queries) of the full-size launch, and
@@ -36,21 +39,23 @@ def _paged_cache(gen, n_seqs, ctx, extra=7):
     return n_blocks, perm
 
 
-def test_paged_decode_full_size_sample_and_properties():
-    g = torch.Generator().manual_seed(100)
-    gd = torch.Generator(device=DEV).manual_seed(100)
+@pytest.mark.parametrize("B,CTX", [(256, 4096), (64, 2048)], ids=["cfg3_b256_ctx4096", "cfg2_b64_ctx2048"])
+def test_paged_decode_full_size_sample_and_properties(B, CTX):
+    g = torch.Generator().manual_seed(100 + B)
+    gd = torch.Generator(device=DEV).manual_seed(100 + B)
     n_blocks, table = _paged_cache(g, B, CTX)
     kc = torch.empty(n_blocks, BS, NKV, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
     vc = torch.empty(n_blocks, BS, NKV, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
     q = torch.empty(B, NQ, D, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
     kv_lens = torch.full((B,), CTX, dtype=torch.int32)
-    kv_lens[5], kv_lens[77], kv_lens[200] = CTX - 1, 1, 2049          # ragged tails inside the full-size batch
+    i1, i2 = (77, 200) if B == 256 else (33, 50)
+    kv_lens[5], kv_lens[i1], kv_lens[i2] = CTX - 1, 1, CTX // 2 + 1   # ragged tails inside the full-size batch
     scale = 1.0 / math.sqrt(D)
     tbl_d, len_d = table.to(DEV), kv_lens.to(DEV)
     out = ops.paged_attention(q, kc, vc, None, len_d, tbl_d, 1, CTX, scale)
     assert torch.isfinite(out.float()).all()
     # (1) oracle on a sample of sequences (their pages gathered into a compact cache)
-    sample = [0, 5, 77, 200, 255]
+    sample = [0, 5, i1, i2, B - 1]
     pages = table.size(1)
     ids = table[sample].reshape(-1).long()
     kc_s, vc_s = kc[ids.to(DEV)].cpu(), vc[ids.to(DEV)].cpu()
@@ -203,7 +208,7 @@ def test_prefill_full_size_causality_and_sample():
     e_ref = rel_l2(ref1, ref)
     strict = os.environ.get("XLLM_MI355_PREFILL_P") == "2"
     assert rel_l2(out[S - tail:S], ref) <= (1e-3 if strict else max(1e-3, 1.25 * e_ref))
-    if not strict and os.environ.get("XLLM_MI355_PREFILL_DMA", "1") != "0":
+    if not strict:
         # round 3: at BASELINE's context length the default kernel holds the ABSOLUTE 1e-3 against the oracle with its own cast
         # point (un-normalised 64-key-tile P rounded to bf16; oracle p_round="flash")
         ref2 = orc.attention_varlen(q[S - tail:S].cpu().contiguous(), k[:S].cpu().contiguous(), v[:S].cpu().contiguous(),
@@ -241,3 +246,185 @@ def test_mla_prefill_8192_tokens_against_the_flash_cast_point_oracle():
             for m in (False, True, "flash")]
     got = out[S - tail:].reshape(tail, -1)
     assert_p16_attention_close(got, refs[0].view(tail, -1), refs[1].view(tail, -1), refs[2].view(tail, -1))
+
+
+# ------------------------------------------------------------------------------------------------ cfg2 (round 4)
+@pytest.mark.parametrize("name,N,K", [("qkv", 4608, H), ("o", H, H), ("gate_up", 2 * I, H), ("down", H, I),
+                                      ("lm_head", 152064, H)])
+def test_cfg2_packed_16bit_linears_at_qwen2_7b_shapes(name, N, K):
+    """cfg2 = Qwen2-7B bf16, batch 64: every linear of the step at its real shape on the kernel the policy picks at M = 64 (packed
+    16-bit weight stream, gemm_ws.hip kBF16; a15 / dcu::matmul = F::linear, kernels/dcu/matmul.cpp:20-25): (a) sampled rows against
+    the oracle's fp32 sum (<= 1 bf16 ulp of the fp64 value + the accumulation term), (b) every row against the fp64 product on the
+    GPU, (c) linear checksums of the WHOLE output, (d) the row-major kernel (another summation order) within 2 ulp, (e) with bias."""
+    gd = torch.Generator(device=DEV).manual_seed(N + K)
+    M = 64
+    a = (torch.randn(M, K, device=DEV, generator=gd) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=gd) / math.sqrt(K)).bfloat16()
+    bias = (torch.randn(N, device=DEV, generator=gd) * 0.1).bfloat16() if name == "qkv" else None   # Qwen2: qkv carries a bias
+    wp = ops.pack_weight_16(w)
+    assert wp is not None and ops._prefer_packed_16(M, N, K)
+    out = ops.matmul(a, w, bias, b_packed=wp)
+    a64, w64 = a.double(), w.double()
+    ref = a64 @ w64.T + (bias.double() if bias is not None else 0.0)
+    mag = a64.abs() @ w64.abs().T + (bias.double().abs() if bias is not None else 0.0)
+    err = (out.double() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2.0 ** -20 * mag + 1e-30).all(), float((err / mag).max())
+    rows = [0, 17, 63]
+    orc_rows = orc.matmul(a[rows].cpu(), w.cpu(), None if bias is None else bias.cpu())
+    got = out[rows].cpu()
+    assert (got == orc_rows).float().mean() >= 0.98                      # two fp32 summation orders: a few last-bit flips
+    assert ((got.float() - orc_rows.float()).abs() <= 2.0 ** -7 * orc_rows.float().abs() + 1e-30).all()
+    o64 = out.double()
+    tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -20 * mag.sum(0) + 1e-9
+    tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -20 * mag.sum(1) + 1e-9
+    assert ((o64.sum(0) - ref.sum(0)).abs() <= tol_c).all() and ((o64.sum(1) - ref.sum(1)).abs() <= tol_r).all()
+    rm = ops.matmul(a, w, bias)                                           # row-major weights: the unpacked kernels
+    assert ((rm.double() - o64).abs() <= 2.0 ** -7 * ref.abs() + 2.0 ** -19 * mag).all()
+
+
+# ------------------------------------------------------------------------------------------------ cfg4 (round 4)
+def test_cfg4_mla_decode_full_size_fed_by_the_fp8_rank_linear():
+    """cfg4 = DeepSeek-V3 MLA, one TP = 8 rank: batch 128, ctx 8192, 16 heads, pages of 64 tokens, latent cache [n, 64, 1, 576]
+    (flash_mla::dense_decode semantics, kernels/dcu/flash_mla_adapter.cpp:104-160; layers/dcu/deepseek_v2_attention.cpp:189-210).
+    The query comes from the rank's fp8 q_b projection (N = 16 * 192, K = 1536; per-tensor dynamic activation scale,
+    linear.cpp:137-182) -> DeepSeek RoPE layout on q_pe -> absorption by w_kc, all on the GPU at the full shape:
+      (a) the fp8 linear against the fp64 product of the dequantised operands, every row;
+      (b) decode attention of sampled sequences (ragged tails: 1, 63, 64, 65, ctx - 1, ctx) against the oracle on the same query;
+      (c) page-permutation invariance (bitwise), independence of the sequences (another split plan: 2e-4), constant-value rows
+          come back (softmax weights are a convex combination), padded kv_len = 0 rows give zeros."""
+    from xllm_amd import layers
+    g = torch.Generator().manual_seed(404)
+    gd = torch.Generator(device=DEV).manual_seed(404)
+    Bq, S, Hh, bs, KVL, ROPE, NOPE, QL = 128, 8192, 16, 64, 512, 64, 128, 1536
+    pages = S // bs
+    nb = Bq * pages + 5
+    table = torch.randperm(nb, generator=g)[: Bq * pages].to(torch.int32).view(Bq, pages)
+    kc = torch.empty(nb, bs, 1, KVL + ROPE, dtype=torch.bfloat16, device=DEV).normal_(generator=gd)
+    kv_lens = torch.full((Bq,), S, dtype=torch.int32)
+    ragged = {3: 1, 9: 63, 20: 64, 41: 65, 77: S - 1, 100: S // 2 + 7}
+    for i, L in ragged.items():
+        kv_lens[i] = L
+    # ---- the rank's fp8 q_b projection
+    q_a = (torch.randn(Bq, QL, device=DEV, generator=gd) * 1.5).bfloat16()
+    wq = (torch.randn(Hh * (NOPE + ROPE), QL, device=DEV, generator=gd) * 0.05)
+    w_s = (wq.abs().amax() / 448.0).reshape(1).float()
+    wq8 = (wq / w_s).to(torch.float8_e4m3fn)
+    a8, a_s = ops.fp8_scaled_quantize(q_a)
+    q = ops.fp8_scaled_matmul(a8, wq8, a_s, w_s, torch.bfloat16)
+    ref_q = (a8.double() * a_s.double()) @ (wq8.double() * w_s.double()).T
+    mag_q = (a8.double().abs() * a_s.double()) @ (wq8.double().abs() * w_s.double()).T
+    assert ((q.double() - ref_q).abs() <= 2.0 ** -8 * ref_q.abs() + 2.0 ** -17 * mag_q + 1e-9).all()
+    assert rel_l2(q, ref_q) <= 2e-2                                          # north_star's fp8 bar (met by a wide margin)
+    # ---- q_pe in DeepSeek's layout + RoPE, q_nope absorbed by w_kc
+    q = q.view(Bq, Hh, NOPE + ROPE)
+    inv_freq = 1.0 / torch.pow(torch.tensor(1e4), torch.arange(0, ROPE, 2, dtype=torch.float32) / ROPE)
+    fr = torch.outer(torch.arange(S, dtype=torch.float32), inv_freq)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], -1).bfloat16().to(DEV)
+    pos = (kv_lens - 1).long().to(DEV)
+    q_pe = layers.to_deepseek_rope_layout(q[..., NOPE:].contiguous())
+    ops.rotary_embedding(pos, q_pe, None, cos_sin, True, head_size=ROPE)
+    w_kc = (torch.randn(Hh, NOPE, KVL, device=DEV, generator=gd) / math.sqrt(NOPE)).bfloat16()
+    q_abs = torch.bmm(q[..., :NOPE].contiguous().transpose(0, 1), w_kc).transpose(0, 1)
+    q_in = torch.cat([q_abs, q_pe], -1).contiguous()                          # [B, 16, 576]
+    scale = 192 ** -0.5
+    tbl_d, len_d = table.to(DEV), kv_lens.to(DEV)
+    out = ops.mla_decode(q_in, kc, len_d, tbl_d, KVL, scale, S)
+    assert torch.isfinite(out.float()).all() and out.shape == (Bq, Hh, KVL)
+    # (b) oracle on sampled sequences (their pages gathered into a compact cache)
+    sample = [0, 3, 9, 20, 41, 77, 100, Bq - 1]
+    ids = table[sample].reshape(-1).long()
+    kc_s = kc[ids.to(DEV)].cpu()
+    tbl_s = torch.arange(len(sample) * pages, dtype=torch.int32).view(len(sample), pages)
+    ref = orc.paged_attention(q_in[sample].cpu(), kc_s, kc_s, torch.arange(len(sample) + 1, dtype=torch.int32),
+                              kv_lens[sample], tbl_s, scale, dv=KVL)
+    assert rel_l2(out[sample], ref) <= 1e-3
+    for j, b in enumerate(sample):
+        assert rel_l2(out[b], ref[j]) <= 1.5e-3, (b, int(kv_lens[b]))
+    # (c) invariants
+    perm2 = torch.randperm(nb, generator=g)
+    inv = torch.empty_like(perm2)
+    inv[perm2] = torch.arange(nb)
+    out2 = ops.mla_decode(q_in, kc[perm2.to(DEV)], len_d, inv[table.long()].to(torch.int32).to(DEV), KVL, scale, S)
+    assert torch.equal(out2, out)
+    out3 = ops.mla_decode(q_in[sample].contiguous(), kc, len_d[sample].contiguous(), tbl_d[sample].contiguous(), KVL, scale, S)
+    assert rel_l2(out3, out[sample]) <= 2e-4
+    # padded rows (graph buckets: kv_len = 0, block-table row 0): zeros, live rows untouched
+    len_p = len_d.clone()
+    len_p[100:] = 0
+    tbl_p = tbl_d.clone()
+    tbl_p[100:] = 0
+    out_p = ops.mla_decode(q_in, kc, len_p, tbl_p, KVL, scale, S)
+    assert torch.equal(out_p[:100], out[:100]) and int((out_p[100:] != 0).sum()) == 0
+    vconst = torch.randn(KVL, generator=g).bfloat16().to(DEV)
+    kc[..., :KVL] = vconst
+    out4 = ops.mla_decode(q_in, kc, len_d, tbl_d, KVL, scale, S)
+    want = vconst.float().expand(Bq, Hh, KVL)
+    assert ((out4.float() - want).abs() <= 2.0 ** -7 * want.abs() + 1e-6).all()
+
+
+# ------------------------------------------------------------------------------------------------ cfg5 (round 4)
+def test_cfg5_qwen3_moe_w8a8_expert_path_full_size():
+    """cfg5 = Qwen3-MoE W8A8, a chunked-prefill step of T = 8192 tokens, 128 experts top-8, hidden 2048, moe_I 768
+    (FusedMoEImpl::forward_experts, layers/dcu/fused_moe.cpp:217-337, with the W8A8 grouped GEMM of GroupGemmParams.a_scale /
+    b_scale, param.h:374-394): gate top-k -> moe_compute_index -> per-token int8 quant -> grouped GEMM w13 (expand fused into the
+    A staging) -> SiLU.mul + per-row int8 quant -> grouped GEMM w2 -> weighted combine.
+      * index data bit-exact properties on the whole launch: sizes == bincount, src_dst / dst_src inverse permutations, the sorted
+        expert ids non-decreasing;
+      * sampled tokens: EVERY stage of their top-8 rows against the oracle, bit for bit (int32 sums are exact, the dequant
+        expression is the oracle's), the combined output to 1 bf16 ulp;
+      * whole output: permuting the tokens permutes the output rows, bit for bit (every row's arithmetic is independent of where
+        the sort puts it); int64 checksums of the quantised activations (a checksum of checksums across the expand)."""
+    from xllm_amd import layers
+    T, Hd, Im, E, topk = 8192, 2048, 768, 128, 8
+    gd = torch.Generator(device=DEV).manual_seed(55)
+    moe = layers.FusedMoE(Hd, Im, E, topk, torch.bfloat16, DEV, gd, mode="int8")
+    x = torch.randn(T, Hd, device=DEV, generator=gd).bfloat16()
+    logits = (torch.randn(T, E, device=DEV, generator=gd) * 2).bfloat16()
+    # ---- the operator chain of FusedMoE.forward_experts(mode = "int8"), stage by stage
+    weights, ids = ops.moe_active_topk(logits, topk, 1, 1, True, None, "softmax", 1.0)
+    src_dst, dst_src, sizes = ops.moe_compute_index(ids, E)
+    R = T * topk
+    assert torch.equal(sizes.cpu().long(), torch.bincount(ids.reshape(-1).long().cpu(), minlength=E))
+    assert torch.equal(dst_src[src_dst.long()].cpu(), torch.arange(R, dtype=torch.int32))
+    sorted_e = ids.reshape(-1)[dst_src.long()]
+    assert bool((sorted_e[1:] >= sorted_e[:-1]).all())
+    xq, xs = ops.scaled_quantize(x)
+    h13 = ops.group_gemm_w8a8(xq, xs, moe.w13_q, moe.w13_s, sizes, torch.bfloat16, row_index=dst_src, index_div=topk)
+    aq, a_s = ops.act_and_mul_dynamic_int8_quant(h13, "silu")
+    h2 = ops.group_gemm_w8a8(aq, a_s, moe.w2_q, moe.w2_s, sizes, torch.bfloat16)
+    out = ops.moe_combine_sorted(h2, src_dst, weights, T, topk, None)
+    assert torch.equal(out, moe.forward_experts(x, logits))                     # the layer is that chain
+    assert torch.isfinite(out.float()).all()
+    # ---- sampled tokens against the oracle, every stage
+    sample = [0, 1, 4095, 7000, T - 1]
+    w_ref, id_ref = orc.moe_fused_topk(logits[sample].cpu(), topk, True, None, "softmax")
+    assert torch.equal(id_ref.sort(-1).values, ids[sample].cpu().sort(-1).values)
+    xq_r, xs_r = orc.scaled_quantize(x[sample].cpu())
+    assert torch.equal(xq[sample].cpu(), xq_r) and torch.equal(xs[sample].cpu(), xs_r)
+    w13_q, w13_s, w2_q, w2_s = moe.w13_q.cpu(), moe.w13_s.cpu(), moe.w2_q.cpu(), moe.w2_s.cpu()
+    for j, t in enumerate(sample):
+        rows_h2 = []
+        for k in range(topk):
+            e = int(ids[t, k])
+            pos = int(src_dst[t * topk + k])
+            r13 = orc.scaled_matmul(xq_r[j:j + 1], w13_q[e], xs_r[j:j + 1], w13_s[e], torch.bfloat16, None)
+            assert torch.equal(h13[pos].cpu(), r13[0]), (t, k, "w13")
+            act = torch.empty(1, Im, dtype=torch.bfloat16)
+            orc.act_and_mul(act, r13, "silu")
+            aq_r, as_r = orc.scaled_quantize(act)
+            assert torch.equal(aq[pos].cpu(), aq_r[0]) and float(a_s[pos]) == float(as_r[0]), (t, k, "act quant")
+            r2 = orc.scaled_matmul(aq_r, w2_q[e], as_r, w2_s[e], torch.bfloat16, None)
+            assert torch.equal(h2[pos].cpu(), r2[0]), (t, k, "w2")
+            rows_h2.append(r2[0].float() * float(weights[t, k]))
+        terms = torch.stack(rows_h2)
+        want, mag = terms.sum(0), terms.abs().sum(0)
+        got = out[t].float().cpu()
+        assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 2.0 ** -20 * mag + 1e-9).all(), t   # one bf16 rounding of an fp32 sum
+    # ---- whole output: a permutation of the tokens permutes the rows (bitwise)
+    perm = torch.randperm(T, device=DEV, generator=gd)
+    out_p = moe.forward_experts(x[perm].contiguous(), logits[perm].contiguous())
+    assert torch.equal(out_p, out[perm])
+    # ---- checksum of checksums: the expanded int8 rows the first GEMM consumed, summed per expert-sorted position, equal the
+    #      token rows they came from (int64, exact) -- the gather inside the A staging moved the right bytes
+    tok = (dst_src.long() // topk)
+    assert int(xq[tok].sum(dtype=torch.int64)) == int((xq.sum(1, dtype=torch.int64)[tok]).sum())

@@ -27,7 +27,8 @@ def test_shim_builds_and_exposes_reference_operator_names():
     for name in ("rms_norm", "fused_add_rms_norm", "act_and_mul", "reshape_paged_cache", "rotary_embedding", "matmul",
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
                  "random_sample", "rejection_sample", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
-                 "moe_combine_result", "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode"):
+                 "moe_combine_result", "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode",
+                 "flash_mla_dense_decode", "flash_mla_prefill_paged", "flash_mla_store_latent_cache"):
         assert hasattr(m, name)
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
@@ -35,7 +36,7 @@ def test_shim_builds_and_exposes_reference_operator_names():
                 "fused_add_rms_norm_static_fp8_quant", "fp8_scaled_matmul", "fused_qk_norm_rope", "scaled_quantize",
                 "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
                 "update_llm_decode_metadata", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
-                "moe_combine_result", "group_gemm_gather", "mla_decode"):
+                "moe_combine_result", "group_gemm_gather", "mla_decode", "dense_decode", "prefill_paged", "store_latent_cache"):
         assert sym + "(" in hdr, sym
 
 
@@ -258,3 +259,74 @@ def test_shim_two_threads_two_streams_share_no_scratch():
     for t in ts:
         t.join()
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_shim_flash_mla_adapter_drives_the_reference_call_sequence():
+    """kernel::dcu::flash_mla::dense_decode(DenseDecodeParams&) with the struct of kernels/dcu/flash_mla_adapter.h:33-53, filled the
+    way DeepseekV2AttentionImpl::decode_flash_mla fills it (layers/dcu/deepseek_v2_attention.cpp:189-210: separate q_nope / q_pe
+    viewed [B, 1, H, .], returns [B, 1, H, kv_lora]), against the ctypes path and the oracle; S_q = 2 (multi-token decode, causal
+    and not) against the oracle's bottom-right alignment; the latent store and the paged prefill that replace store_latent_cache /
+    prefill_sdpa (:170-178, :212-262); int64 metadata is accepted like the reference's .to(kInt32)."""
+    from oracle import oracle as orc
+    from xllm_amd import ops
+    m = _shim()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(19)
+    B, H, bs, KVL, ROPE = 5, 16, 64, 512, 64
+    kv_lens = [300, 64, 1, 129, 1000]
+    pages = [(L + bs - 1) // bs for L in kv_lens]
+    nb = sum(pages) + 3
+    perm = torch.randperm(nb, generator=g).tolist()
+    blocks, used = [], 0
+    for n in pages:
+        blocks.append(perm[used:used + n]); used += n
+    md = orc.build_batch_metadata(kv_lens, [1] * B, blocks, bs)
+    kc = torch.randn(nb, bs, 1, KVL + ROPE, generator=g).bfloat16()
+    q_nope = torch.randn(B, H, KVL, generator=g).bfloat16()
+    q_pe = torch.randn(B, H, ROPE, generator=g).bfloat16()
+    scale = 192 ** -0.5
+    lens_d, bt_d, kc_d = md["kv_seq_lens"].to(dev), md["block_tables"].to(dev), kc.to(dev)
+    out = m.flash_mla_dense_decode(q_nope.to(dev).view(B, 1, H, KVL), q_pe.to(dev).view(B, 1, H, ROPE), kc_d, lens_d, bt_d, KVL,
+                                   scale, False)
+    assert out.shape == (B, 1, H, KVL)
+    q_in = torch.cat([q_nope, q_pe], -1)
+    ref = orc.paged_attention(q_in, kc, kc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"], scale, dv=KVL)
+    assert ((out.view(B, -1).float().cpu() - ref.view(B, -1).float()).norm() / ref.float().norm()).item() <= 1e-3
+    # the ctypes path planned with the same upper bound of the lengths gives the same bits
+    direct = ops.mla_decode(q_in.to(dev), kc_d, lens_d, bt_d, KVL, scale, bt_d.size(1) * bs)
+    assert torch.equal(out.view(B, H, KVL), direct)
+    out64 = m.flash_mla_dense_decode(q_nope.to(dev).view(B, 1, H, KVL), q_pe.to(dev).view(B, 1, H, ROPE), kc_d, lens_d.long(),
+                                     bt_d.long(), KVL, scale, False)
+    assert torch.equal(out64, out)
+    # S_q = 2: the last two tokens of every sequence are queries (sequences of length 1 cannot: use lens >= 2)
+    lens2 = [max(L, 2) for L in kv_lens]
+    md2 = orc.build_batch_metadata(lens2, [2] * B, [b + ([perm[used]] if len(b) * bs < L else []) for b, L in zip(blocks, lens2)], bs)
+    q2n = torch.randn(B, 2, H, KVL, generator=g).bfloat16()
+    q2p = torch.randn(B, 2, H, ROPE, generator=g).bfloat16()
+    for causal in (True, False):
+        o2 = m.flash_mla_dense_decode(q2n.to(dev), q2p.to(dev), kc_d, md2["kv_seq_lens"].to(dev), md2["block_tables"].to(dev), KVL,
+                                      scale, causal)
+        assert o2.shape == (B, 2, H, KVL)
+        r2 = orc.paged_attention(torch.cat([q2n, q2p], -1).view(B * 2, H, KVL + ROPE), kc, kc, md2["q_cu_seq_lens"],
+                                 md2["kv_seq_lens"], md2["block_tables"], scale, causal=causal, dv=KVL)
+        assert ((o2.view(B * 2, -1).float().cpu() - r2.view(B * 2, -1).float()).norm() / r2.float().norm()).item() <= 2.5e-3
+    # store_latent_cache + paged prefill (the USE_MI355 branch of DeepseekV2AttentionImpl::forward)
+    q_lens = [40, 64, 1, 129, 77]
+    md3 = orc.build_batch_metadata(kv_lens, [min(a, b) for a, b in zip(q_lens, kv_lens)], blocks, bs)
+    T = int(md3["q_cu_seq_lens"][-1])
+    latent = torch.randn(T, KVL + ROPE, generator=g).bfloat16()
+    kc_ref = kc.clone()
+    orc.reshape_paged_cache(md3["new_cache_slots"], latent.view(T, 1, -1), None, kc_ref, None)
+    kc_w = kc.to(dev)
+    slots = md3["new_cache_slots"].clone()
+    m.flash_mla_store_latent_cache(latent.to(dev), slots.to(dev).long(), kc_w)          # int64 slots, as the reference passes
+    assert torch.equal(kc_w.cpu().view(torch.int16), kc_ref.view(torch.int16))
+    qn = torch.randn(T, H, KVL, generator=g).bfloat16()
+    qp = torch.randn(T, H, ROPE, generator=g).bfloat16()
+    o3 = m.flash_mla_prefill_paged(qn.to(dev), qp.to(dev), kc_w, md3["q_cu_seq_lens"].to(dev), md3["kv_seq_lens"].to(dev),
+                                   md3["block_tables"].to(dev), KVL, scale, True)
+    r3 = orc.paged_attention(torch.cat([qn, qp], -1), kc_ref, kc_ref, md3["q_cu_seq_lens"], md3["kv_seq_lens"], md3["block_tables"],
+                             scale, causal=True, dv=KVL)
+    assert o3.shape == (T, H, KVL)
+    assert ((o3.view(T, -1).float().cpu() - r3.view(T, -1).float()).norm() / r3.float().norm()).item() <= 2.5e-3

@@ -61,6 +61,35 @@ namespace dcu = mi355;
     return head + sep + rest
 
 
+def edit_deepseek_v2_attention(src: str) -> str:
+    """DeepseekV2AttentionImpl: (1) flash_mla::dense_decode comes from the MI355 shim (same DenseDecodeParams, same call site);
+    (2) prefill reads the latent rows back from the paged cache (no host loop over sequences, no .cpu())"""
+    a = '#include "kernels/dcu/flash_mla_adapter.h"\n'
+    assert a in src
+    src = src.replace(a, '#if defined(USE_MI355)\n'
+                         '// kernel::dcu::flash_mla::{DenseDecodeParams, dense_decode} of kernels/dcu/flash_mla_adapter.h, served by the MI355X\n'
+                         '// backend: decode_flash_mla below compiles unchanged\n'
+                         '#include "kernels/mi355/mi355_ops_api.h"\n'
+                         'namespace xllm::kernel {\nnamespace dcu = mi355;\n}  // namespace xllm::kernel\n'
+                         '#else\n' + a + '#endif\n', 1)
+    b = '  if (is_prefill) {\n    return prefill_sdpa(q_nope_absorbed, q_pe, latent_normed, attn_metadata);\n  }\n'
+    assert b in src
+    src = src.replace(b, '  if (is_prefill) {\n'
+                         '#if defined(USE_MI355)\n'
+                         '    // the latent rows of this step are already in the paged cache (store_latent_cache above): one kernel over the\n'
+                         '    // block table instead of the per-sequence SDPA loop on the host -- graph-capturable, no device-to-host copy\n'
+                         '    if (k_cache.defined() && attn_metadata.slot_mapping.defined() &&\n'
+                         '        attn_metadata.block_table.defined()) {\n'
+                         '      return project_output(kernel::mi355::flash_mla::prefill_paged(\n'
+                         '          q_nope_absorbed, q_pe, k_cache, attn_metadata.q_cu_seq_lens,\n'
+                         '          attn_metadata.kv_seq_lens, attn_metadata.block_table, kv_lora_rank_,\n'
+                         '          softmax_scale_, attn_metadata.is_causal));\n'
+                         '    }\n'
+                         '#endif\n'
+                         '    return prefill_sdpa(q_nope_absorbed, q_pe, latent_normed, attn_metadata);\n  }\n', 1)
+    return src
+
+
 EDITS = {
     "CMakeLists.txt": lambda s: s.replace(
         'option(USE_DCU "Enable DCU support" OFF)\n',
@@ -90,7 +119,20 @@ EDITS = {
     "xllm/core/layers/CMakeLists.txt": lambda s: s.replace(
         "elseif(USE_DCU)\n  add_subdirectory(dcu)\n",
         "elseif(USE_DCU)\n  add_subdirectory(dcu)\nelseif(USE_MI355)\n"
-        "  add_subdirectory(mi355)  # ${MI355_ROOT}/shim/mi355_attention.{h,cpp} as layers/mi355/attention.{h,cpp}\n", 1),
+        "  # layers/mi355/ = ${MI355_ROOT}/shim/layers_mi355/CMakeLists.txt + ${MI355_ROOT}/shim/mi355_attention.{h,cpp} as\n"
+        "  # attention.{h,cpp}; the target also compiles ../dcu/{fused_moe,deepseek_v2_attention,deepseek_v2_decoder_layer_impl}.cpp\n"
+        "  add_subdirectory(mi355)\n", 1),
+    # the routed-expert layer and the MLA attention / decoder layer of the DCU backend (layers/dcu/{fused_moe,deepseek_v2_attention,
+    # deepseek_v2_decoder_layer_impl}.cpp) are host code over kernel::* operators and flash_mla::dense_decode: a USE_MI355 build
+    # compiles THOSE files (layers/mi355/CMakeLists.txt lists them) and keeps layers/common/fused_moe.* out, exactly as USE_DCU does
+    "xllm/core/layers/common/CMakeLists.txt": lambda s: s.replace(
+        "$<BOOL:${USE_CUDA}>,$<BOOL:${USE_DCU}>>>:fused_moe.h>", "$<BOOL:${USE_CUDA}>,$<BOOL:${USE_DCU}>,$<BOOL:${USE_MI355}>>>:fused_moe.h>", 1).replace(
+        "$<BOOL:${USE_CUDA}>,$<BOOL:${USE_DCU}>>>:fused_moe.cpp>", "$<BOOL:${USE_CUDA}>,$<BOOL:${USE_DCU}>,$<BOOL:${USE_MI355}>>>:fused_moe.cpp>", 1).replace(
+        "    $<$<BOOL:${USE_DCU}>:dcu_layers>\n", "    $<$<BOOL:${USE_DCU}>:dcu_layers>\n    $<$<BOOL:${USE_MI355}>:mi355_layers>\n", 1),
+    "xllm/core/layers/qwen3_moe_decoder_layer.h": add_to_dcu_conditions,      # -> layers/dcu/fused_moe.h (FusedMoEImpl)
+    "xllm/models/llm/deepseek_v2.h": add_to_dcu_conditions,                   # -> layers/dcu/deepseek_v2_decoder_layer_impl.h
+    "xllm/models/models.h": add_to_dcu_conditions,                            # the model list of the DCU build (deepseek_v2, qwen3_moe, ...)
+    "xllm/core/layers/dcu/deepseek_v2_attention.cpp": edit_deepseek_v2_attention,
     "xllm/core/kernels/ops_api.cpp": edit_ops_api,
     "xllm/core/layers/common/attention.h": lambda s: s.replace(
         '#elif defined(USE_DCU)\n#include "layers/dcu/attention.h"\n',
@@ -119,7 +161,8 @@ def main():
         chunks += difflib.unified_diff(old.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel, n=3)
     header = ("# xllm-use-mi355.patch -- generated by tools/make_reference_patch.py against the reference tree; apply with\n"
               "#   git apply xllm-use-mi355.patch   (then: ln -s $MI355_ROOT/shim xllm/core/kernels/mi355, and\n"
-              "#   xllm/core/layers/mi355/{attention.h,attention.cpp,CMakeLists.txt} from $MI355_ROOT/shim/mi355_attention.*;\n"
+              "#   xllm/core/layers/mi355/{attention.h,attention.cpp} from $MI355_ROOT/shim/mi355_attention.*, CMakeLists.txt from\n"
+              "#   $MI355_ROOT/shim/layers_mi355/ -- it also compiles layers/dcu/{fused_moe,deepseek_v2_attention,deepseek_v2_decoder_layer_impl}.cpp;\n"
               "#   configure with -DUSE_MI355=ON -DMI355_ROOT=...). See INTEGRATION.md section 3.\n")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
