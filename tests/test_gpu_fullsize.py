@@ -273,7 +273,8 @@ def test_cfg2_packed_16bit_linears_at_qwen2_7b_shapes(name, N, K):
     orc_rows = orc.matmul(a[rows].cpu(), w.cpu(), None if bias is None else bias.cpu())
     got = out[rows].cpu()
     assert (got == orc_rows).float().mean() >= 0.98                      # two fp32 summation orders: a few last-bit flips
-    assert ((got.float() - orc_rows.float()).abs() <= 2.0 ** -7 * orc_rows.float().abs() + 1e-30).all()
+    # (two fp32 summation orders differ by the accumulation term; near-cancelled sums are far below one ulp of their terms)
+    assert ((got.double() - orc_rows.double()).abs() <= 2.0 ** -7 * orc_rows.double().abs() + 2.0 ** -19 * mag[rows].cpu()).all()
     o64 = out.double()
     tol_c = 6 * 2.0 ** -9 * o64.pow(2).sum(0).sqrt() + 2.0 ** -20 * mag.sum(0) + 1e-9
     tol_r = 6 * 2.0 ** -9 * o64.pow(2).sum(1).sqrt() + 2.0 ** -20 * mag.sum(1) + 1e-9
@@ -337,6 +338,7 @@ def test_cfg4_mla_decode_full_size_fed_by_the_fp8_rank_linear():
     tbl_s = torch.arange(len(sample) * pages, dtype=torch.int32).view(len(sample), pages)
     ref = orc.paged_attention(q_in[sample].cpu(), kc_s, kc_s, torch.arange(len(sample) + 1, dtype=torch.int32),
                               kv_lens[sample], tbl_s, scale, dv=KVL)
+    ref = ref.view(len(sample), Hh, KVL)
     assert rel_l2(out[sample], ref) <= 1e-3
     for j, b in enumerate(sample):
         assert rel_l2(out[b], ref[j]) <= 1.5e-3, (b, int(kv_lens[b]))
