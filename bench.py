@@ -371,7 +371,7 @@ def main():
 
         def step():
             hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
-            return ops.greedy_argmax(model.logits(hidden))
+            return model.greedy_tokens(hidden)     # lm_head + Sampler::greedy_sample in one pass (round 4); [B, V] logits never written
 
         sync_all()     # ranks build their shards at different speeds: nobody enters the first collective seconds before a peer
         for _ in range(a.warmup):
@@ -756,7 +756,7 @@ def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, d
 
     def chunk():
         hidden = model.forward(tokens, positions, md, kv_caches)
-        return ops.greedy_argmax(model.logits(hidden.index_select(0, last)))
+        return model.greedy_tokens(hidden.index_select(0, last))
 
     chunk()
     sync_all()

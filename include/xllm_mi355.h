@@ -308,6 +308,20 @@ XM_API int xllm_mi355_fp8_scaled_matmul_packed(const uint8_t* a, const uint8_t* 
 XM_API int xllm_mi355_pack_weight_16(const void* w, void* packed, int64_t N, int64_t K, void* stream);
 XM_API int xllm_mi355_matmul_packed(const void* a, const void* w_packed, const void* bias, void* out, int64_t M, int64_t N,
                                     int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream);
+/* lm_head + greedy sampling in one pass (round 4): out_idx[m] = argmax_n r16(a[m] . w[n] + bias[n]) -- the token
+ * Sampler::greedy_sample picks from the logits of the (never quantised) lm_head (framework/sampling/sampler.cpp:160-168: argmax(-1);
+ * layers/common/linear.cpp:512-520) -- without writing the [M, N] logits: every wave of the packed 16-bit GEMM reduces the 16-bit
+ * ROUNDED values of its columns to a (max, first index) pair per row and a finishing launch reduces the pairs (argmax commutes
+ * with the column tiling; torch.argmax order: NaN above every number, the first index among equals). out_val (optional, may be
+ * NULL) receives the winning logit as float -- with a column-sharded lm_head the ranks then exchange [B] (value, index) pairs
+ * instead of all-gathering [B, V / tp] logits (linear.cpp:712-714). The token ids equal xllm_mi355_greedy_argmax of
+ * xllm_mi355_matmul_packed's output from the same launch plan bit for bit (the same fp32 sums, the same rounding).
+ * workspace >= xllm_mi355_matmul_argmax_workspace_bytes(M, N) (= 8 * M * max(N / 16, 1024) bytes), XM_ERR_WORKSPACE otherwise; envelope of
+ * xllm_mi355_matmul_packed (M <= 512, N % 16 == 0, K % 64 == 0), XM_ERR_UNSUPPORTED outside it. */
+XM_API size_t xllm_mi355_matmul_argmax_workspace_bytes(int64_t M, int64_t N);
+XM_API int xllm_mi355_matmul_argmax_packed(const void* a, const void* w_packed, const void* bias, int64_t* out_idx, float* out_val,
+                                           int64_t M, int64_t N, int64_t K, int dtype, void* workspace, size_t ws_bytes,
+                                           void* stream);
 /* The gate_up linear of the dense MLP on packed 16-bit weights with SiLU * mul in its epilogue (dense_mlp.cpp:97-116 with an
  * unquantised layer: gate_up_proj -> kernel::act_and_mul, kernels/cuda/activation.cu:49-120): w_packed = pack_weight_16 of the
  * [N = 2 I, K] weight (gate rows first), act_out [M, I] = r16(r16(silu(gate)) * up) with gate / up = r16(sum_fp32 + bias) --

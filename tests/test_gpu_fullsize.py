@@ -430,3 +430,28 @@ def test_cfg5_qwen3_moe_w8a8_expert_path_full_size():
     #      token rows they came from (int64, exact) -- the gather inside the A staging moved the right bytes
     tok = (dst_src.long() // topk)
     assert int(xq[tok].sum(dtype=torch.int64)) == int((xq.sum(1, dtype=torch.int64)[tok]).sum())
+
+
+def test_lm_head_fused_greedy_argmax_full_size():
+    """the step's tail at its real shape (B = 256 rows x Qwen2-7B's 152064-column lm_head, K = 3584): token ids of the fused
+    lm_head + argmax == greedy_argmax of the logits the same plan writes (bit for bit), == the argmax of the fp64 logits wherever
+    their top-2 margin exceeds one bf16 ulp, and the scratch the launch needs is 1/4 of the logits it avoids writing"""
+    gd = torch.Generator(device=DEV).manual_seed(152064)
+    M, N, K = 256, 152064, H
+    a = (torch.randn(M, K, device=DEV, generator=gd)).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=gd) / math.sqrt(K)).bfloat16()
+    wp = ops.pack_weight_16(w)
+    from xllm_amd import _lib
+    _lib.lib().xllm_mi355_gemm_plan_hint(0, 1, 0)
+    try:
+        logits = ops.matmul(a, w, None, b_packed=wp)
+    finally:
+        _lib.lib().xllm_mi355_gemm_plan_hint(0, 0, 0)
+    got, val = ops.matmul_argmax(a, wp, N, None, want_value=True)
+    assert torch.equal(got, ops.greedy_argmax(logits))
+    assert torch.equal(val, logits.float().gather(1, got.view(-1, 1)).view(-1))
+    ref = a.double() @ w.double().T
+    top2 = ref.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > top2[:, 0].abs() * 2.0 ** -7
+    assert torch.equal(got[clear], ref.argmax(-1)[clear]) and int(clear.sum()) >= 200
+    assert _lib.lib().xllm_mi355_matmul_argmax_workspace_bytes(M, N) * 4 <= M * N * 2

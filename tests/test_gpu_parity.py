@@ -1953,6 +1953,89 @@ def test_greedy_argmax_equals_torch(B, V, dtype):
     assert torch.equal(ops.greedy_argmax(sl).cpu(), torch.argmax(sl.float().cpu(), dim=-1))
 
 
+@pytest.mark.parametrize("M", [1, 17, 64, 128, 200, 256, 512])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_matmul_argmax_equals_matmul_then_greedy_argmax(M, dtype):
+    """lm_head + Sampler::greedy_sample in one pass (xllm_mi355_matmul_argmax_packed, round 4): the token ids are
+    greedy_argmax(matmul_packed(...)) of the SAME tile plan bit for bit (same fp32 sums, same 16-bit rounding), on every width
+    of the tile family and both tile heights, with ties (first index wins: duplicated weight rows), a NaN row, a bias, ragged N;
+    against the oracle's logits wherever its top-2 margin exceeds one 16-bit ulp (round-3 review, next #5); the winning value
+    (what tensor-parallel ranks exchange) is the max logit."""
+    g = torch.Generator().manual_seed(7 * M + (dtype == torch.float16))
+    N, K = 1936, 576
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    w[1500] = w[300]                      # identical columns: a tie wherever they win -> the lower index
+    w[1935] = w[7]
+    bias = (torch.randn(N, generator=g) * 0.2).to(dtype)
+    bias[1500], bias[1935] = bias[300], bias[7]
+    if M > 2:
+        a[2, 5] = float("nan")            # a NaN row: every logit NaN -> index 0
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    wp = ops.pack_weight_16(wd)
+    old = ops._PACKED_16_POLICY
+    ran = 0
+    try:
+        ops._PACKED_16_POLICY = "1"
+        for rows in ((0,) if M <= 128 else (0, 131)):
+            _ws_waves(rows)
+            for b in (None, bd):
+                for ng in (0, 1, 2, 3, 4, 5, 6, 8, 10):
+                    _ws_plan(ng, 1)                                              # (the fused form never slices K)
+                    logits = ops.matmul(ad, wd, b, b_packed=wp)
+                    got = ops.matmul_argmax(ad, wp, N, b, want_value=True)
+                    if got is None:          # this width is not in the tile family of this M (the caller's two operators serve)
+                        assert ng not in (0, 1, 2)
+                        continue
+                    idx, val = got
+                    want = ops.greedy_argmax(logits)
+                    assert torch.equal(idx, want), (rows, ng, b is not None)
+                    top = logits.float().gather(1, want.view(-1, 1)).view(-1)
+                    ok = (val == top) | (torch.isnan(val) & torch.isnan(top))
+                    assert bool(ok.all())
+                    ran += 1
+        _ws_plan(0, 0)
+        _ws_waves(0)
+        # the planner's own choice, against the oracle where the decision is not within one ulp
+        idx = ops.matmul_argmax(ad, wp, N, bd)
+        ref = orc.matmul(a, w, bias).float()
+        ref_idx = torch.argmax(ref, -1)
+        top2 = ref.topk(2, -1).values
+        ulp = top2[:, 0].abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+        clear = (top2[:, 0] - top2[:, 1]) > ulp
+        clear &= ~torch.isnan(ref).any(-1)
+        assert torch.equal(idx.cpu()[clear], ref_idx[clear]) and int(clear.sum()) >= (M * 3) // 5
+        if M > 2:
+            assert int(idx[2]) == 0
+    finally:
+        ops._PACKED_16_POLICY = old
+        _ws_plan(0, 0)
+        _ws_waves(0)
+    assert ran >= 6
+
+
+def test_model_greedy_tokens_equal_argmax_of_logits():
+    """Qwen2Model.greedy_tokens (the fused lm_head + argmax the engine and the bench call) == greedy_argmax(logits(hidden)) on the
+    model's own lm_head at a decode batch, and the engine's graph replays it"""
+    from xllm_amd import layers
+    args = layers.ModelArgs(1024, 1, 16, 4, 64, 2048, 32000, 1e-6, 1e6, 4096)
+    model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=3, n_layers=1)
+    gd = torch.Generator(device=DEV).manual_seed(5)
+    for B in (1, 64, 256):
+        hidden = torch.randn(B, 1024, device=DEV, generator=gd).bfloat16()
+        _ws_plan(0, 1)
+        want = ops.greedy_argmax(model.logits(hidden))
+        _ws_plan(0, 0)
+        got = model.greedy_tokens(hidden)
+        assert got.dtype == torch.int64 and torch.equal(got, want), B
+    old = ops._GREEDY_FUSION
+    try:
+        ops._GREEDY_FUSION = False
+        assert torch.equal(model.greedy_tokens(hidden), ops.greedy_argmax(model.logits(hidden)))
+    finally:
+        ops._GREEDY_FUSION = old
+
+
 # ------------------------------------------------------------------------------------------- 16-bit weight-stream GEMM, packed
 @pytest.mark.parametrize("M", [1, 16, 33, 64, 100, 128, 200, 256, 512])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

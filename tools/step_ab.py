@@ -6,6 +6,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
 
     python tools/step_ab.py [B] [ctx] [variants...]      variants: name=setting;setting  with settings
         fuse_gu=0|1        ops._GATE_UP_FUSION
+        greedy=0|1         ops._GREEDY_FUSION (lm_head + argmax in one pass, round 4)
         packed=auto|0|1    ops._PACKED_POLICY
         ws_ng=N  ws_sl=N  ws_rows=128|256   xllm_mi355_gemm_plan_hint (product API, thread-local)
         ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 140..142, 0)            [tuning flavour]
@@ -38,6 +39,8 @@ def apply(settings):
         k, v = s.split("=", 1)
         if k == "fuse_gu":
             ops._GATE_UP_FUSION = v == "1"
+        elif k == "greedy":
+            ops._GREEDY_FUSION = v == "1"
         elif k == "ws_ng":
             ng = int(v)
         elif k == "ws_sl":
@@ -86,6 +89,7 @@ def reset():
     IDLE["where"], IDLE["us"] = None, 0.0
     ops._PACKED_POLICY = "auto"
     ops._GATE_UP_FUSION = True
+    ops._GREEDY_FUSION = True
     import ctypes
     _lib.lib().xllm_mi355_gemm_plan_hint(0, 0, 0)
     if hasattr(_lib.lib(), "xllm_mi355_debug_ws_waves"):      # tuning flavour only
@@ -117,7 +121,7 @@ def main():
     positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
 
     def step():
-        return ops.greedy_argmax(model.logits(model.forward(tokens, positions, md, kv)))
+        return model.greedy_tokens(model.forward(tokens, positions, md, kv))
 
     graphs, outs = [], []
     for spec in specs:

@@ -95,6 +95,8 @@ _SIGS = {
     "xllm_mi355_pack_weight_16": ([vp, vp, i64, i64, vp], ci),
     "xllm_mi355_matmul_packed": ([vp, vp, vp, vp, i64, i64, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_matmul_gate_up_act": ([vp, vp, vp, vp, i64, i64, i64, ci, vp, sz, vp], ci),
+    "xllm_mi355_matmul_argmax_workspace_bytes": ([i64, i64], sz),
+    "xllm_mi355_matmul_argmax_packed": ([vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_prefill_attention": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, ci, i64,
                                       ci, vp], ci),
     "xllm_mi355_paged_decode_attention_int8": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,

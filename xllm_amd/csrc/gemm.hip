@@ -928,6 +928,19 @@ int xllm_mi355_matmul_gate_up_act(const void* a, const void* w_packed, const voi
   return launch_gemm_ws_h16(a, w_packed, M, N, K * 2, epi, workspace, ws_bytes, (hipStream_t)stream);
 }
 
+size_t xllm_mi355_matmul_argmax_workspace_bytes(int64_t M, int64_t N) {
+  return M > 0 && N > 0 ? (size_t)M * (size_t)(N / 16 > 1024 ? N / 16 : 1024) * 8 : 0;
+}
+
+int xllm_mi355_matmul_argmax_packed(const void* a, const void* w_packed, const void* bias, int64_t* out_idx, float* out_val, int64_t M,
+                                    int64_t N, int64_t K, int dtype, void* workspace, size_t ws_bytes, void* stream) {
+  if (!a || !w_packed || !out_idx || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (M == 0) return XM_OK;
+  GemmEpi epi{nullptr, 0, nullptr, 0, bias, nullptr, nullptr, dtype == XM_BF16, nullptr, 0};
+  return launch_gemm_ws_h16_argmax(a, w_packed, M, N, K * 2, epi, out_idx, out_val, workspace, ws_bytes, (hipStream_t)stream);
+}
+
 int xllm_mi355_matmul(const void* a, const void* w, const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                       int dtype, void* stream) {
   if (!a || !w || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;

@@ -90,17 +90,34 @@ struct GemmEpi {
   void* act_out;
   float* row_amax;
   int w_policy;   // packed kernels, cache policy of the weight stream: 0 = by the launch shape, 1 = nt, 2 = default (tuning arm)
+  // round 4: greedy sampling fused into the lm_head GEMM (Sampler::greedy_sample = argmax(-1), framework/sampling/sampler.cpp:
+  // 160-168; the logits of ColumnParallelLinear lm_head, linear.cpp:512-520). Every wave reduces the 16-bit-rounded results of
+  // its NG column groups to one (max, first index) pair per row and writes it to slot `nt * WN + wn` of the partial arrays
+  // [M][argmax_slots]; xllm_mi355_matmul_argmax_packed's finishing launch reduces the slots. The [M, N] logits are never written
+  // (epi.out may be null). argmax commutes with the column tiling; NaN > everything and the first index wins, as torch.argmax.
+  float* argmax_val;
+  int32_t* argmax_idx;
+  int argmax_slots;
 };
+
+// torch.argmax order: NaN above every number, the first index among equals
+__device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn || bn) return vn && (!bn || i < bi);
+  return v > bv || (v == bv && i < bi);
+}
 
 // Epilogue modes a launcher can honour. Every launcher starts with epi_fits(epi, its capabilities): a mode the selected kernel
 // lacks is DECLINED (XM_ERR_UNSUPPORTED) -- never dropped with XM_OK (round-3 review: the removed 32x32x32 int8 arm returned OK
 // with nothing written in gate_up mode).
-enum EpiCap : unsigned { kCapGateUp = 1, kCapDefer = 2, kCapGroupTiles = 4, kCapGather = 8, kCapGroupCounts = 16, kCapAccOut = 32 };
+enum EpiCap : unsigned { kCapGateUp = 1, kCapDefer = 2, kCapGroupTiles = 4, kCapGather = 8, kCapGroupCounts = 16, kCapAccOut = 32,
+                         kCapArgmax = 64 };
 inline bool epi_fits(const GemmEpi& e, unsigned caps) {
   const unsigned need = (e.gate_up || e.act_out || e.row_amax ? kCapGateUp : 0u) | (e.defer ? kCapDefer : 0u) |
                         (e.group_tiles ? kCapGroupTiles : 0u) | (e.gather_rows ? kCapGather : 0u) |
-                        (e.group_counts && !e.group_tiles ? kCapGroupCounts : 0u) | (e.acc_out ? kCapAccOut : 0u);
-  if (!e.out && !e.acc_out && !e.defer && !(e.gate_up && e.act_out)) return false;   // nowhere to write
+                        (e.group_counts && !e.group_tiles ? kCapGroupCounts : 0u) | (e.acc_out ? kCapAccOut : 0u) |
+                        (e.argmax_val || e.argmax_idx ? kCapArgmax : 0u);
+  if (!e.out && !e.acc_out && !e.defer && !(e.gate_up && e.act_out) && !(e.argmax_val && e.argmax_idx)) return false;   // nowhere to write
   return (need & ~caps) == 0;
 }
 
@@ -206,6 +223,8 @@ int launch_gemm_ws_fp8(const void* A, const void* Wp, int64_t M, int64_t N, int6
                        size_t ws_bytes, hipStream_t s);
 int launch_gemm_ws_h16(const void* A, const void* Wp, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, void* workspace,
                        size_t ws_bytes, hipStream_t s);
+int launch_gemm_ws_h16_argmax(const void* A, const void* Wp, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int64_t* out_idx,
+                              float* out_val, void* workspace, size_t ws_bytes, hipStream_t s);
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s);
 
 // gemm_wsb.hip: weight-stream GEMM for 16-bit weights at decode shapes (dense M <= 64, grouped with few rows per expert)

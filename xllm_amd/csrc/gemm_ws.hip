@@ -290,7 +290,7 @@ struct WsAcc<kF16> { using type = f32x4_t; };
 template <int KIND, int MB, int NG>
 __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB][NG], const GemmEpi& epi,
                                             int32_t* __restrict__ slabs, int slice, int n_slices, int M, int N, int m_base,
-                                            int g0, int g_live, int wn, int lane, uint8_t* lds, int wave) {
+                                            int g0, int g_live, int wn, int lane, uint8_t* lds, int wave, int part_slot = 0) {
   using acc_t = typename WsAcc<KIND>::type;
   const int g4 = lane >> 4, ml = lane & 15;
   const int gw = wn * NG;  // first column group of the wave inside the workgroup tile
@@ -319,6 +319,11 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
   const bool has_bias = epi.bias != nullptr, out_bf16 = epi.out_bf16 != 0;
   const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
   const bool wide = epi.out && (((uintptr_t)epi.out & 15) == 0);  // (N % 16 == 0: every row segment is then 16-byte aligned)
+  const bool amax = (KIND == kBF16 || KIND == kF16) && epi.argmax_val != nullptr;   // fused greedy sampling (GemmEpi::argmax_*)
+  float best_v[MB];
+  int best_i[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { best_v[mb] = -__builtin_inff(); best_i[mb] = 0x7fffffff; }
   constexpr int ROWB = NG * 32, PITCH = ROWB + 16, CH = ROWB / 16;  // 16-bit tile of the wave: [MB * 16 rows][NG * 32 B + 16]
   uint8_t* const tb = lds + wave * (MB * 16 * PITCH);
   float asv[MB];
@@ -353,7 +358,7 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
       const int m = m_base + mb * 16 + ml;
       if (epi.acc_out && live && m < M)
         *reinterpret_cast<acc_t*>(epi.acc_out + (int64_t)m * N + n) = acc[mb][ng];  // raw sums (tests, one slab)
-      if (!epi.out) continue;
+      if (!epi.out && !amax) continue;
       float v[4];
       if constexpr (KIND == kI8) {
 #pragma unroll
@@ -368,8 +373,39 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
       uint2 pk;
       if (out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }
       else { pk.x = pack2x16<false>(v[0], v[1]); pk.y = pack2x16<false>(v[2], v[3]); }
+      if constexpr (KIND == kBF16 || KIND == kF16) {
+        if (amax && live) {   // the values argmax sees are the 16-bit logits the plain epilogue would have stored
+          const unsigned h[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float lv;
+            if (out_bf16) lv = bf16_bits_to_f32(h[e]);
+            else { const uint16_t hb = (uint16_t)h[e]; f16_t hv; __builtin_memcpy(&hv, &hb, 2); lv = (float)hv; }
+            if (n + e < N && argmax_better(lv, n + e, best_v[mb], best_i[mb])) { best_v[mb] = lv; best_i[mb] = n + e; }
+          }
+        }
+      }
+      if (!epi.out) continue;
       if (wide) *reinterpret_cast<uint2*>(tb + (mb * 16 + ml) * PITCH + ng * 32 + g4 * 8) = pk;
       else if (live && m < M) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)m * N + n) = pk;
+    }
+  }
+  if constexpr (KIND == kBF16 || KIND == kF16) {
+    if (amax) {   // the four lanes (g4) of a row hold disjoint columns: two xor steps, then one pair per (row, wave)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(best_v[mb], o);
+          const int oi = __shfl_xor(best_i[mb], o);
+          if (argmax_better(ov, oi, best_v[mb], best_i[mb])) { best_v[mb] = ov; best_i[mb] = oi; }
+        }
+        const int m = m_base + mb * 16 + ml;
+        if (g4 == 0 && m < M) {
+          epi.argmax_val[(int64_t)m * epi.argmax_slots + part_slot] = best_v[mb];
+          epi.argmax_idx[(int64_t)m * epi.argmax_slots + part_slot] = best_i[mb];
+        }
+      }
     }
   }
   if (!wide) return;
@@ -684,7 +720,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
       return;
     }
   }
-  ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
+  ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave, nt * WN + wn);
 }
 
 // ------------------------------------------------------------------------------------------------ staggered eight-wave tile
@@ -937,7 +973,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   if constexpr (KIND != kFP8) {
     if (gu) ws_epilogue_gate_up<KIND, MB, NG, WM, WN, NWV>(acc, epi, M, N, m_tile0, wm, wn, lane, tid, ga0, ga_live, n_groups_act, lds);
   }
-  if (!gu) ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave);
+  if (!gu) ws_epilogue<KIND, MB, NG>(acc, epi, slabs, slice, n_slices, M, N, m_base, g0, g_live, wn, lane, lds, wave, nt * WN + wn);
 #ifdef WS8_TIMING
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been accepted
@@ -1004,6 +1040,7 @@ struct WsPlan { int waves, wm, wn, mb, ng, slices; };
 XM_TUNE_VAR(f_kstagger, "XLLM_MI355_KSTAGGER", 1);
 XM_TUNE_VAR(f_ws8s, "XLLM_MI355_WS8_STAGGER", 1);
 XM_TUNE_VAR(f_wpolicy, "XLLM_MI355_WS_WPOLICY", 0);
+static thread_local int g_argmax_slots_used = 0;   // slots the last argmax-mode launch of this thread filled (read by its caller)
 template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
                          int32_t* slabs, hipStream_t s) {
@@ -1015,7 +1052,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   if (gu && (G % 2 != 0 || KIND == kFP8)) return -1;
   const int n_groups = gu ? (int)(N / 32) : (int)(N / 16);
   const int KT = (int)(K / WS_BK);
-  if (gu) slices = 1;
+  if (gu || epi.argmax_val) slices = 1;
   int per = (KT + slices - 1) / slices;
   slices = (KT + per - 1) / per;  // no empty slice
   // at least ceil(n_groups / G) column tiles; more (narrower, balanced) ones while the grid still fits one round of 256 CUs
@@ -1025,6 +1062,10 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   if (fit > n_tiles) n_tiles = fit < n_groups ? fit : n_groups;
   const int rest = n_tiles * slices;
   const unsigned grid = (unsigned)(((rest + 7) / 8) * 8 * m_tiles);
+  if (epi.argmax_val) {   // one partial slot per (column tile, wave column): the caller's arrays must hold them
+    if (n_tiles * WN > epi.argmax_slots) return -2;
+    g_argmax_slots_used = n_tiles * WN;
+  }
   if constexpr (NWV == 8) {
 #ifdef XM_TUNING
     if (!f_ws8s) {
@@ -1144,7 +1185,9 @@ int ws_dispatch(const WsPlan& p, const void* A, const void* Wp, int64_t M, int64
 template <int KIND>
 static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, GemmEpi epi, void* workspace,
                           size_t ws_bytes, int* n_slabs, hipStream_t s) {
-  if (!epi_fits(epi, kCapGateUp | kCapDefer | kCapAccOut)) return XM_ERR_UNSUPPORTED;
+  if (!epi_fits(epi, kCapGateUp | kCapDefer | kCapAccOut | ((KIND == kBF16 || KIND == kF16) ? kCapArgmax : 0u)))
+    return XM_ERR_UNSUPPORTED;
+  if (epi.argmax_val && (!epi.argmax_idx || epi.argmax_slots <= 0 || epi.gate_up || epi.defer || epi.acc_out)) return XM_ERR_INVALID;
   if (M <= 0 || M > 512 || N % 16 != 0 || K % WS_BK != 0 || K / WS_BK < 4 || M * K >= (1ll << 31) || epi.group_counts ||
       ((uintptr_t)A % 16) || ((uintptr_t)Wp % 16) || (epi.out && (uintptr_t)epi.out % 8) ||
       (KIND == kI8 && epi.w_scale && (uintptr_t)epi.w_scale % 16))
@@ -1152,7 +1195,7 @@ static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, i
   if (N * K >= (1ll << 31) * 16ll) return XM_ERR_UNSUPPORTED;
   const bool need_slab = epi.defer != 0;
   if (need_slab && (KIND != kI8 || !workspace || ws_bytes < (size_t)M * N * 4)) return XM_ERR_WORKSPACE;
-  const bool can_slice = workspace && ws_bytes >= (size_t)2 * M * N * 4;
+  const bool can_slice = !epi.argmax_val && workspace && ws_bytes >= (size_t)2 * M * N * 4;
   if (epi.gate_up && (KIND == kFP8 || N % 32 != 0 || !epi.act_out || ((uintptr_t)epi.act_out % 16) || N * K >= (1ll << 31) ||
                       (KIND == kI8 && (!epi.row_amax || !epi.a_scale || !epi.w_scale))))
     return XM_ERR_UNSUPPORTED;
@@ -1164,6 +1207,7 @@ static int launch_gemm_ws(const void* A, const void* Wp, int64_t M, int64_t N, i
     e2.out = nullptr;
   }
   const int slices = ws_dispatch<KIND>(p, A, Wp, M, N, K, e2, slabs, s);
+  if (slices == -2) return XM_ERR_WORKSPACE;
   if (slices < 0) return XM_ERR_UNSUPPORTED;
   if (n_slabs) *n_slabs = slices;
   if (slices > 1 && !need_slab) {
@@ -1187,6 +1231,54 @@ int launch_gemm_ws_h16(const void* A, const void* Wp, int64_t M, int64_t N, int6
                        size_t ws_bytes, hipStream_t s) {
   if (epi.out_bf16) return launch_gemm_ws<kBF16>(A, Wp, M, N, Kb, epi, workspace, ws_bytes, nullptr, s);
   return launch_gemm_ws<kF16>(A, Wp, M, N, Kb, epi, workspace, ws_bytes, nullptr, s);
+}
+
+// finishing launch of the fused greedy sampling: one workgroup per row reduces the row's partial (max, first index) pairs
+__global__ __launch_bounds__(256) void argmax_finish_kernel(const float* __restrict__ val, const int32_t* __restrict__ idx, int slots,
+                                                           int pitch, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int j = tid; j < slots; j += 256) {
+    const float v = val[(int64_t)m * pitch + j];
+    const int i = idx[(int64_t)m * pitch + j];
+    if (argmax_better(v, i, bv, bi)) { bv = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o);
+    const int oi = __shfl_xor(bi, o);
+    if (argmax_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (argmax_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    out_idx[m] = bi == 0x7fffffff ? 0 : bi;
+    if (out_val) out_val[m] = bv;
+  }
+}
+
+// matmul + argmax(-1) on packed 16-bit weights: workspace = [M][slots] floats, then [M][slots] int32 (slots = N / 16, the bound)
+int launch_gemm_ws_h16_argmax(const void* A, const void* Wp, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int64_t* out_idx,
+                              float* out_val, void* workspace, size_t ws_bytes, hipStream_t s) {
+  // slots of a launch = column tiles x waves across a tile: <= N / 16 / NG for the wide problems, <= 256 tiles x 4 waves otherwise
+  const int64_t slots = N / 16 > 1024 ? N / 16 : 1024;
+  if (!workspace || ws_bytes < (size_t)M * slots * 8) return XM_ERR_WORKSPACE;
+  epi.out = nullptr;
+  epi.argmax_val = reinterpret_cast<float*>(workspace);
+  epi.argmax_idx = reinterpret_cast<int32_t*>(epi.argmax_val + M * slots);
+  epi.argmax_slots = (int)slots;
+  g_argmax_slots_used = 0;
+  const int rc = epi.out_bf16 ? launch_gemm_ws<kBF16>(A, Wp, M, N, Kb, epi, nullptr, 0, nullptr, s)
+                              : launch_gemm_ws<kF16>(A, Wp, M, N, Kb, epi, nullptr, 0, nullptr, s);
+  if (rc != XM_OK) return rc;
+  hipLaunchKernelGGL(argmax_finish_kernel, dim3((unsigned)M), dim3(256), 0, s, epi.argmax_val, epi.argmax_idx, g_argmax_slots_used,
+                     (int)slots, out_idx, out_val);
+  return hip_check_launch();
 }
 
 int launch_pack_weight_i8(const void* W, void* Wp, int64_t N, int64_t K, hipStream_t s) {

@@ -11,7 +11,7 @@
 // segment, and only that 16-KiB segment is re-read (L2 hit) for the in-segment scan. The prefix sums are fp32 like
 // the reference's, in a different association order: the selected index can differ from the reference's only when u
 // lies within fp32 summation error of a CDF step (tests bound it with an fp64 CDF).
-#include "common.h"
+#include "gemm_types.h"
 
 namespace xm {
 
@@ -222,11 +222,7 @@ __global__ __launch_bounds__(256) void rejection_sample_kernel(
 // NaN is larger than every number (the first NaN wins).
 template <typename T>
 __device__ __forceinline__ float argmax_key(T v) { return to_f32(v); }
-__device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) {
-  const bool vn = v != v, bn = bv != bv;
-  if (vn || bn) return vn && (!bn || i < bi);
-  return v > bv || (v == bv && i < bi);
-}
+// (argmax_better: gemm_types.h -- shared with the lm_head GEMM's fused argmax epilogue)
 template <typename T>
 __global__ __launch_bounds__(1024) void greedy_argmax_kernel(const T* __restrict__ logits, int64_t* __restrict__ out, int d) {
   constexpr int VEC = 16 / sizeof(T);

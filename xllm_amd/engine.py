@@ -75,9 +75,9 @@ class DecodeEngine:
         self._tokens64.copy_(self.dst["tokens"])
         self._pos64.copy_(self.dst["positions"])
         hidden = self.model.forward(self._tokens64, self._pos64, self.md, self.kv_caches)
-        logits = self.model.logits(hidden)
         if self.temperature <= 0.0:
-            return ops.greedy_argmax(logits).to(torch.int32)
+            return self.model.greedy_tokens(hidden).to(torch.int32)   # lm_head + argmax in one pass, no [B, V] logits
+        logits = self.model.logits(hidden)
         probs = torch.softmax(logits.float() / self.temperature, dim=-1)
         return ops.random_sample(probs, uniform=self._uniform)
 

@@ -400,6 +400,31 @@ class Qwen2Model:
         y = self.lm_head.forward(hidden)
         return parallel.gather(y, self.tp)
 
+    def greedy_tokens(self, hidden):
+        """lm_head -> Sampler::greedy_sample (argmax(-1), sampler.cpp:160-168) as ONE pass: the packed lm_head GEMM reduces its
+        columns to (max logit, first index) per row in its epilogue and the [B, V] logits are never written
+        (ops.matmul_argmax, round 4). Tensor parallel: every rank reduces its own column shard and the ranks exchange [B] (value,
+        global index) pairs instead of all-gathering [B, V / tp] logits (linear.cpp:712-714) -- argmax commutes with the gather;
+        ties go to the lowest global index, i.e. torch.argmax of the gathered logits. Token ids int64 [B], bit-equal to
+        greedy_argmax(logits(hidden)). Falls back to exactly that outside the packed kernel's envelope."""
+        lm = self.lm_head
+        tp_size = self.tp.world_size() if self.tp else 1
+        if lm.mode == "16bit" and lm.weight_packed is not None and hidden.dim() == 2 and ops._GREEDY_FUSION:
+            got = ops.matmul_argmax(hidden, lm.weight_packed, lm.weight.size(0), lm.bias, want_value=tp_size > 1)
+            if got is not None:
+                if tp_size == 1:
+                    return got
+                idx, val = got
+                idx = idx + self.tp.rank() * lm.weight.size(0)                 # shard-local -> global column
+                vals = self.tp.allgather(val)                                   # [W, B]
+                idxs = self.tp.allgather(idx)
+                nan = torch.isnan(vals)                                         # torch.argmax: NaN above every number
+                key = torch.where(nan, torch.full_like(vals, float("inf")), vals)
+                best = key.max(0, keepdim=True).values
+                cand = torch.where(key == best, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
+                return cand.min(0).values
+        return ops.greedy_argmax(self.logits(hidden))
+
 
 def to_deepseek_rope_layout(t: torch.Tensor) -> torch.Tensor:
     """deepseek_v2_attention.cpp:35-46: [.., d] viewed as [.., d/2, 2], transposed to [.., 2, d/2]: even dims first"""

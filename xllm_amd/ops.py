@@ -590,6 +590,39 @@ def matmul_silu_mul(a, b, bias=None, b_packed=None):
     return act
 
 
+_argmax_ws = {}
+_GREEDY_FUSION = os.environ.get("XLLM_MI355_GREEDY_FUSION", "1") == "1"   # 0: lm_head -> logits -> greedy_argmax as two operators
+
+
+def matmul_argmax(a, b_packed, N: int, bias=None, want_value: bool = False):
+    """lm_head + Sampler::greedy_sample in one pass (xllm_mi355_matmul_argmax_packed, round 4): token ids int64 [M] =
+    argmax_n r16(a . w[n] + bias[n]) with torch.argmax's order, the [M, N] logits never written. a [M, K] 16-bit contiguous,
+    b_packed = pack_weight_16(w [N, K]). want_value: also the winning logit (float32 [M]) -- what a column-sharded lm_head exchanges
+    instead of its logits. None outside the packed kernel's envelope (M > 512, N % 16, ...): the caller runs matmul + greedy_argmax."""
+    _need_cuda(a, b_packed)
+    M, K = a.shape
+    if b_packed is None or M == 0 or M > 512 or N % 16 or not a.is_contiguous():
+        return None
+    need = _lib.lib().xllm_mi355_matmul_argmax_workspace_bytes(M, N)
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream if torch.cuda.current_stream(a.device).cuda_stream in _private_streams else 0)
+    ws = _argmax_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise Mi355Error("matmul_argmax scratch must exist before a graph capture: run one eager step of this shape first")
+        if ws is not None:
+            _retired_ws.append(ws)           # a captured graph may still write it
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        _argmax_ws[key] = ws
+    idx = torch.empty(M, dtype=torch.int64, device=a.device)
+    val = torch.empty(M, dtype=torch.float32, device=a.device) if want_value else None
+    rc = _lib.lib().xllm_mi355_matmul_argmax_packed(_p(a), _p(b_packed), _p(bias), _p(idx), _p(val), M, N, K, _dt(a), _p(ws),
+                                                    ws.numel(), _stream())
+    if rc in (-2, -4):
+        return None
+    check(rc, "matmul_argmax_packed")
+    return (idx, val) if want_value else idx
+
+
 # ------------------------------------------------------------------------------------------------ attention
 _attn_ws = {}
 _retired_ws = []   # outgrown scratch buffers stay allocated: a captured HIP graph may still launch kernels that write them
