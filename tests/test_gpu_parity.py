@@ -2026,14 +2026,17 @@ def test_model_greedy_tokens_equal_argmax_of_logits():
         _ws_plan(0, 1)
         want = ops.greedy_argmax(model.logits(hidden))
         _ws_plan(0, 0)
-        got = model.greedy_tokens(hidden)
-        assert got.dtype == torch.int64 and torch.equal(got, want), B
-    old = ops._GREEDY_FUSION
-    try:
-        ops._GREEDY_FUSION = False
-        assert torch.equal(model.greedy_tokens(hidden), ops.greedy_argmax(model.logits(hidden)))
-    finally:
-        ops._GREEDY_FUSION = old
+        old = ops._GREEDY_FUSION
+        try:
+            ops._GREEDY_FUSION = "1"
+            got = model.greedy_tokens(hidden)
+            assert got.dtype == torch.int64 and torch.equal(got, want), B
+            ops._GREEDY_FUSION = "0"
+            assert torch.equal(model.greedy_tokens(hidden), ops.greedy_argmax(model.logits(hidden)))
+            ops._GREEDY_FUSION = "auto"      # one GPU: the two operators (measured tie); tensor parallel: the fused form
+            assert torch.equal(model.greedy_tokens(hidden), ops.greedy_argmax(model.logits(hidden)))
+        finally:
+            ops._GREEDY_FUSION = old
 
 
 # ------------------------------------------------------------------------------------------- 16-bit weight-stream GEMM, packed

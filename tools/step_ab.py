@@ -40,7 +40,7 @@ def apply(settings):
         if k == "fuse_gu":
             ops._GATE_UP_FUSION = v == "1"
         elif k == "greedy":
-            ops._GREEDY_FUSION = v == "1"
+            ops._GREEDY_FUSION = v
         elif k == "ws_ng":
             ng = int(v)
         elif k == "ws_sl":
@@ -89,7 +89,7 @@ def reset():
     IDLE["where"], IDLE["us"] = None, 0.0
     ops._PACKED_POLICY = "auto"
     ops._GATE_UP_FUSION = True
-    ops._GREEDY_FUSION = True
+    ops._GREEDY_FUSION = "auto"
     import ctypes
     _lib.lib().xllm_mi355_gemm_plan_hint(0, 0, 0)
     if hasattr(_lib.lib(), "xllm_mi355_debug_ws_waves"):      # tuning flavour only

@@ -92,8 +92,9 @@ struct GemmEpi {
   int w_policy;   // packed kernels, cache policy of the weight stream: 0 = by the launch shape, 1 = nt, 2 = default (tuning arm)
   // round 4: greedy sampling fused into the lm_head GEMM (Sampler::greedy_sample = argmax(-1), framework/sampling/sampler.cpp:
   // 160-168; the logits of ColumnParallelLinear lm_head, linear.cpp:512-520). Every wave reduces the 16-bit-rounded results of
-  // its NG column groups to one (max, first index) pair per row and writes it to slot `nt * WN + wn` of the partial arrays
-  // [M][argmax_slots]; xllm_mi355_matmul_argmax_packed's finishing launch reduces the slots. The [M, N] logits are never written
+  // its NG column groups to one (max, first index) pair per row and writes it to slot `nt * WN + wn` of the partial array
+  // uint2 [argmax_slots][M] at argmax_val (argmax_idx only marks the mode); xllm_mi355_matmul_argmax_packed's finishing launch
+  // reduces the slots. The [M, N] logits are never written
   // (epi.out may be null). argmax commutes with the column tiling; NaN > everything and the first index wins, as torch.argmax.
   float* argmax_val;
   int32_t* argmax_idx;

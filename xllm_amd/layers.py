@@ -406,10 +406,13 @@ class Qwen2Model:
         (ops.matmul_argmax, round 4). Tensor parallel: every rank reduces its own column shard and the ranks exchange [B] (value,
         global index) pairs instead of all-gathering [B, V / tp] logits (linear.cpp:712-714) -- argmax commutes with the gather;
         ties go to the lowest global index, i.e. torch.argmax of the gathered logits. Token ids int64 [B], bit-equal to
-        greedy_argmax(logits(hidden)). Falls back to exactly that outside the packed kernel's envelope."""
+        greedy_argmax(logits(hidden)). Falls back to exactly that outside the packed kernel's envelope. Policy
+        (ops._GREEDY_FUSION): on by default under tensor parallelism only -- on one GPU the fused form TIES with the two operators
+        (the GEMM is not store-bound: 333 vs 326 us stand-alone, +0.01 ms in the step; profiles/r04_lm_head_ab.txt)."""
         lm = self.lm_head
         tp_size = self.tp.world_size() if self.tp else 1
-        if lm.mode == "16bit" and lm.weight_packed is not None and hidden.dim() == 2 and ops._GREEDY_FUSION:
+        fuse = ops._GREEDY_FUSION == "1" or (ops._GREEDY_FUSION == "auto" and tp_size > 1)
+        if fuse and lm.mode == "16bit" and lm.weight_packed is not None and hidden.dim() == 2:
             got = ops.matmul_argmax(hidden, lm.weight_packed, lm.weight.size(0), lm.bias, want_value=tp_size > 1)
             if got is not None:
                 if tp_size == 1:

@@ -591,7 +591,9 @@ def matmul_silu_mul(a, b, bias=None, b_packed=None):
 
 
 _argmax_ws = {}
-_GREEDY_FUSION = os.environ.get("XLLM_MI355_GREEDY_FUSION", "1") == "1"   # 0: lm_head -> logits -> greedy_argmax as two operators
+# lm_head + greedy argmax in one pass: "auto" = under tensor parallelism only (it replaces the [B, V / tp] logits all-gather by [B]
+# pairs; on one GPU it ties with the two operators: profiles/r04_lm_head_ab.txt), "1" always, "0" never
+_GREEDY_FUSION = os.environ.get("XLLM_MI355_GREEDY_FUSION", "auto")
 
 
 def matmul_argmax(a, b_packed, N: int, bias=None, want_value: bool = False):
