@@ -402,6 +402,37 @@ XM_API int xllm_mi355_rotary_embedding_and_cache(const int64_t* positions, void*
                                                  int64_t block_size, int64_t n_blocks, int is_neox, int dtype,
                                                  void* stream);
 
+/* ---- logits processors in front of the sampler (N3; framework/sampling/logits_utils.cpp:24-155, Sampler::forward
+ * sampler.cpp:33-116). logits [batch, vocab] with `row_stride` elements between rows, dtype XM_F32 / XM_BF16 / XM_F16, modified
+ * IN PLACE like the reference's functions. None of them reads a device value on the host: graph-capturable.
+ *
+ * xllm_mi355_apply_penalties: apply_frequency_presence_penalties (:24-36) when frequency_penalties / presence_penalties [batch]
+ * are given (both or neither), then apply_repetition_penalties (:38-52) when repetition_penalties [batch] is given.
+ * unique_token_ids int64 [batch, n_unique] / unique_token_counts int32 [batch, n_unique] = the padded per-sequence tables of
+ * SamplingParameters (sampling_params.cpp:127-134). Every (row, u) is computed from the row as it was before the call (the
+ * reference's gather-then-scatter), so repeated padding ids are harmless; ids outside [0, vocab) are skipped.
+ * workspace >= 4 * batch * n_unique bytes (xllm_mi355_apply_penalties_workspace_bytes). */
+XM_API size_t xllm_mi355_apply_penalties_workspace_bytes(int64_t batch, int64_t n_unique);
+XM_API int xllm_mi355_apply_penalties(void* logits, int64_t batch, int64_t vocab, int64_t row_stride, int dtype,
+                                      const int64_t* unique_token_ids, const int32_t* unique_token_counts, int64_t n_unique,
+                                      const float* frequency_penalties, const float* presence_penalties,
+                                      const float* repetition_penalties, void* workspace, size_t workspace_bytes, void* stream);
+/* apply_temperatures (:54-64): logits[b, :] /= (temperatures[b] == 0 ? 1 : temperatures[b]). */
+XM_API int xllm_mi355_apply_temperatures(void* logits, int64_t batch, int64_t vocab, int64_t row_stride, int dtype,
+                                         const float* temperatures, void* stream);
+/* apply_top_k_top_p (:92-155): temperatures (optional, applied first), then top-k and / or top-p masking with -inf; top_k int64
+ * [batch], top_p float [batch], either may be NULL.
+ *   one of them given ("else" branch, :121-153 -- what a CUDA / DCU build of the reference runs): top_k <= 0 disables the row's
+ *     top-k; top-p masks sorted rank i when cumsum(softmax(sorted))[i] - prob[i] > top_p (rank 0 always survives);
+ *   both given: apply_top_k_top_p_torch_impl (:66-90): k = clamp(top_k, 1, vocab), top-p masks rank i > 0 when cumsum[i] > top_p.
+ *     (On a CUDA / DCU build the reference's both-given case falls through an NPU / MLU-only #if, :107-120, and applies nothing;
+ *     this backend applies the torch_impl rule the file ships for it.)
+ * No sort: radix selection on an order-preserving key finds the k-th logit, the same descent over fixed-point probability mass
+ * finds where the cumulative probability crosses p; ties at a boundary rank by column index (a stable descending sort). The
+ * result equals the reference's wherever p is not within fp32 summation error of a cumulative-probability step. */
+XM_API int xllm_mi355_apply_top_k_top_p(void* logits, int64_t batch, int64_t vocab, int64_t row_stride, int dtype,
+                                        const float* temperatures, const int64_t* top_k, const float* top_p, void* stream);
+
 /* flash_mla::dense_decode (kernels/dcu/flash_mla_adapter.h:40-50): q [B, H, 576] = [q_nope*W_kc || q_pe],
  * k_cache [n_blocks, block_size, 1, 576]; out [B, H, head_size_v] = softmax(scale q k^T) k[:, :512]. */
 XM_API int xllm_mi355_mla_decode(const void* q, const void* k_cache, void* out,

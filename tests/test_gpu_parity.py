@@ -2241,3 +2241,138 @@ def test_gate_up_fusion_declines_outside_its_envelope():
     w = torch.zeros(2 * 96, 512, dtype=torch.int8, device=DEV)          # I = 96: not a multiple of the 128-column act tile
     s1, s2 = torch.ones(8, device=DEV), torch.ones(192, device=DEV)
     assert ops.scaled_matmul_silu_mul_quant(a, w, s1, s2) is None
+
+
+# ------------------------------------------------------------------------------------------- N3: logits processors
+def _osm():
+    from oracle import sampling as osm
+    return osm
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_apply_penalties_bit_exact(dtype):
+    """apply_frequency_presence_penalties + apply_repetition_penalties (logits_utils.cpp:24-52) through Sampler::forward's order
+    (sampler.cpp:35-48): bit-exact against the oracle's torch restatement for fp32 logits (the dtype the reference's own
+    gather / scatter_ pipeline accepts); padded id tables (repeated id 0, count 0), one pair absent at a time"""
+    osm = _osm()
+    g = torch.Generator().manual_seed(41)
+    B, V, U = 7, 5000, 37
+    logits = (torch.randn(B, V, generator=g) * 3).to(dtype)
+    ids = torch.stack([torch.randperm(V, generator=g)[:U] for _ in range(B)])
+    cnt = torch.randint(1, 6, (B, U), generator=g, dtype=torch.int32)
+    lens = torch.randint(0, U + 1, (B,), generator=g)
+    for b in range(B):
+        ids[b, lens[b]:] = 0
+        cnt[b, lens[b]:] = 0
+    freq, pres = torch.rand(B, generator=g) * 2 - 0.5, torch.rand(B, generator=g) * 2 - 0.5
+    rep = torch.rand(B, generator=g) * 1.5 + 0.5
+    for use_fp, use_rep in ((True, True), (True, False), (False, True)):
+        ref = logits.clone().float()
+        if use_fp:
+            osm.apply_frequency_presence_penalties(ref, ids, cnt, freq, pres)
+            if dtype != torch.float32:
+                ref = ref.to(dtype).float()         # (16-bit logits: the kernel rounds to the logits dtype after each in-place op)
+        if use_rep:
+            osm.apply_repetition_penalties(ref, ids, rep)
+        got = logits.clone().to(DEV)
+        ops.apply_penalties(got, ids.to(DEV), cnt.to(DEV), freq.to(DEV) if use_fp else None, pres.to(DEV) if use_fp else None,
+                            rep.to(DEV) if use_rep else None)
+        if dtype == torch.float32:
+            assert torch.equal(got.cpu(), ref), (use_fp, use_rep)
+        else:
+            assert_ulp_close(got, ref.to(dtype), dtype, ulps=1.0, min_exact=0.999)
+    noop = logits.clone().to(DEV)
+    ops.apply_penalties(noop, ids.to(DEV), cnt.to(DEV))
+    assert torch.equal(noop.cpu(), logits)
+
+
+def _mask_mismatch_is_a_boundary_case(ref_row_sorted_probs, p, rank_a, rank_b, exclusive):
+    """two top-p cut ranks may differ only when p is within fp32 summation error of the cumulative probability between them"""
+    cum = ref_row_sorted_probs.double().cumsum(-1)
+    lo, hi = min(rank_a, rank_b), max(rank_a, rank_b)
+    pref = cum - ref_row_sorted_probs.double() if exclusive else cum
+    return bool(((pref[lo:hi + 1] - p).abs() <= 2e-5).any())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [1000, 152064])
+def test_apply_top_k_top_p_matches_the_sorting_reference(V, dtype):
+    """apply_top_k_top_p (logits_utils.cpp:92-155) without a sort: temperature only, top-k only (k <= 0 disables, k >= V keeps all,
+    ties at the k-th value by column index), top-p only (exclusive prefix), both (clamped k, inclusive prefix, rank 0 forced) --
+    the surviving set equals the oracle's (stable descending torch.sort + softmax + cumsum) except where p sits within fp32
+    summation error of a cumulative-probability step; surviving values are bit-equal (temperature division included); identical
+    run to run"""
+    osm = _osm()
+    g = torch.Generator().manual_seed(V + (dtype == torch.bfloat16))
+    B = 9
+    logits = (torch.randn(B, V, generator=g) * 2.5).to(dtype)
+    logits[1, 7] = logits[1, 900] = logits[1, 13] = logits[1].max()            # ties at the top
+    logits[2] = logits[2].float().round().to(dtype)                            # many ties everywhere
+    temps = torch.tensor([1.0, 0.7, 0.0, 1.3, 2.0, 0.5, 1.0, 0.9, 1.1])
+    top_k = torch.tensor([50, 2, 5, 0, V + 5, 1, 300, -1, 17], dtype=torch.int64)
+    top_p = torch.tensor([0.9, 0.5, 0.95, 0.0, 1.0, 0.3, 0.999, 0.75, 0.6])
+    cases = [("temp", temps, None, None), ("k", None, top_k, None), ("p", None, None, top_p), ("temp+k", temps, top_k, None),
+             ("temp+p", temps, None, top_p), ("both", None, top_k, top_p), ("temp+both", temps, top_k, top_p)]
+    for name, t, k, p in cases:
+        ref = osm.apply_top_k_top_p(logits.clone().float(), None if t is None else t.clone(), k, p)
+        base = logits.clone().float()
+        if t is not None:
+            osm.apply_temperatures(base, t.clone())
+        if dtype != torch.float32:
+            base = base.to(dtype).float()
+            # 16-bit logits: the oracle masks the rows the kernel sees (temperature applied and rounded to the dtype first)
+            ref = osm.apply_top_k_top_p(base.clone(), None, k, p)
+        got = logits.clone().to(DEV)
+        ops.apply_top_k_top_p(got, None if t is None else t.to(DEV), None if k is None else k.to(DEV), None if p is None else p.to(DEV))
+        got2 = logits.clone().to(DEV)
+        ops.apply_top_k_top_p(got2, None if t is None else t.to(DEV), None if k is None else k.to(DEV), None if p is None else p.to(DEV))
+        assert torch.equal(got, got2), name                                      # deterministic
+        got = got.float().cpu()
+        gm, rm = torch.isinf(got) & (got < 0), torch.isinf(ref) & (ref < 0)
+        assert torch.equal(got[~gm], base[~gm]), name                            # survivors keep their (temperature-scaled) value
+        for b in range(B):
+            if torch.equal(gm[b], rm[b]):
+                continue
+            assert p is not None, (name, b, int(gm[b].sum()), int(rm[b].sum()))  # top-k alone is exact
+            # same top-k set; the top-p cut may move by the ranks whose prefix is within summation error of p
+            srt, idx = base[b].sort(dim=-1, descending=True, stable=True)
+            if k is not None:
+                kk = int(k[b])
+                kk = max(1, min(kk, V)) if p is not None and k is not None and name.endswith("both") else (V if kk <= 0 else min(kk, V))
+                srt[kk:] = float("-inf")
+            probs = srt.softmax(-1)
+            n_got, n_ref = int((~gm[b]).sum()), int((~rm[b]).sum())
+            assert torch.equal(~gm[b][idx][:n_got], torch.ones(n_got, dtype=torch.bool)), (name, b)   # a PREFIX of the sorted order
+            assert _mask_mismatch_is_a_boundary_case(probs, float(p[b]), n_got - 1, n_ref - 1, exclusive=not name.endswith("both")), \
+                (name, b, n_got, n_ref)
+        assert int((~gm).sum(-1).min()) >= 1, name                               # at least one survivor per row
+
+
+def test_sampler_pipeline_penalties_temperature_top_k_top_p_then_random_sample():
+    """Sampler::forward's non-greedy path (sampler.cpp:33-125) end to end on kernels: penalties -> temperatures + top-k + top-p ->
+    softmax (fp32) -> random_sample: the processed logits equal the oracle's and the sampled token is one of the survivors"""
+    osm = _osm()
+    g = torch.Generator().manual_seed(77)
+    B, V, U = 16, 32000, 20
+    logits = (torch.randn(B, V, generator=g) * 3)
+    ids = torch.randint(0, V, (B, U), generator=g)
+    cnt = torch.randint(0, 4, (B, U), generator=g, dtype=torch.int32)
+    freq, pres, rep = torch.rand(B, generator=g), torch.rand(B, generator=g), torch.rand(B, generator=g) + 0.8
+    temps, top_k = torch.rand(B, generator=g) + 0.5, torch.randint(1, 100, (B,), generator=g)
+    ref = logits.clone()
+    # (a token id may repeat inside a row of this random table: the oracle's scatter_ order would then be unspecified -- dedupe)
+    for b in range(B):
+        u, first = torch.unique(ids[b], return_inverse=False, return_counts=False), None
+        ids[b, :u.numel()] = u
+        ids[b, u.numel():] = u[0]
+        cnt[b, u.numel():] = cnt[b, 0]
+    osm.apply_frequency_presence_penalties(ref, ids, cnt, freq, pres)
+    osm.apply_repetition_penalties(ref, ids, rep)
+    ref = osm.apply_top_k_top_p(ref, temps.clone(), top_k, None)
+    got = logits.clone().to(DEV)
+    ops.apply_penalties(got, ids.to(DEV), cnt.to(DEV), freq.to(DEV), pres.to(DEV), rep.to(DEV))
+    ops.apply_top_k_top_p(got, temps.to(DEV), top_k.to(DEV), None)
+    assert torch.equal(got.cpu(), ref)
+    probs = torch.softmax(got, -1, dtype=torch.float32)
+    tok = ops.random_sample(probs, seed=3, offset=0).long().cpu()
+    assert bool(torch.isfinite(ref.gather(1, tok.view(-1, 1))).all())

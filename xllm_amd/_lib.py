@@ -118,6 +118,10 @@ _OPTIONAL = {
     "xllm_mi355_philox_uniform": ([vp, i64, u64, u64, vp], ci),
     "xllm_mi355_rejection_sample": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp], ci),
     "xllm_mi355_greedy_argmax": ([vp, vp, i64, i64, ci, vp], ci),
+    "xllm_mi355_apply_penalties_workspace_bytes": ([i64, i64], sz),
+    "xllm_mi355_apply_penalties": ([vp, i64, i64, i64, ci, vp, vp, i64, vp, vp, vp, vp, sz, vp], ci),
+    "xllm_mi355_apply_temperatures": ([vp, i64, i64, i64, ci, vp, vp], ci),
+    "xllm_mi355_apply_top_k_top_p": ([vp, i64, i64, i64, ci, vp, vp, vp, vp], ci),
     "xllm_mi355_moe_fused_topk": ([vp, ci, i64, i64, i64, ci, vp, ci, vp, vp, vp], ci),
     "xllm_mi355_moe_grouped_topk": ([vp, ci, i64, i64, i64, i64, i64, ci, vp, ci, f32, vp, vp, vp], ci),
     "xllm_mi355_set_moe_workspace": ([vp, sz], ci),

@@ -953,6 +953,50 @@ def random_sample(probs, uniform=None, seed: int = 0, offset: int = 0):
     return out.view(probs.shape[:-1])
 
 
+def _logits_2d(logits):
+    _need_cuda(logits)
+    if logits.dim() != 2 or logits.stride(1) != 1 or logits.dtype not in _DT:
+        raise Mi355Error("logits: [batch, vocab] float32 / bfloat16 / float16 with unit column stride")
+    return logits.size(0), logits.size(1), logits.stride(0)
+
+
+def apply_penalties(logits, unique_token_ids, unique_token_counts, frequency_penalties=None, presence_penalties=None,
+                    repetition_penalties=None):
+    """apply_frequency_presence_penalties + apply_repetition_penalties (framework/sampling/logits_utils.cpp:24-52), in place on
+    logits [B, V]; the order and the cast points of Sampler::forward (sampler.cpp:35-48)"""
+    B, V, stride = _logits_2d(logits)
+    if frequency_penalties is None and repetition_penalties is None:
+        return logits
+    U = unique_token_ids.size(1)
+    ws = torch.empty(max(B * U, 1), dtype=torch.float32, device=logits.device)
+    ids = unique_token_ids.to(torch.int64).contiguous()
+    cnt = unique_token_counts.to(torch.int32).contiguous() if unique_token_counts is not None else None
+    f32c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    check(_lib.lib().xllm_mi355_apply_penalties(_p(logits), B, V, stride, _dt(logits), _p(ids), _p(cnt), U, _p(f32c(frequency_penalties)),
+                                                _p(f32c(presence_penalties)), _p(f32c(repetition_penalties)), _p(ws), ws.numel() * 4,
+                                                _stream()), "apply_penalties")
+    return logits
+
+
+def apply_temperatures(logits, temperatures):
+    """apply_temperatures (logits_utils.cpp:54-64), in place"""
+    B, V, stride = _logits_2d(logits)
+    check(_lib.lib().xllm_mi355_apply_temperatures(_p(logits), B, V, stride, _dt(logits), _p(temperatures.to(torch.float32).contiguous()),
+                                                   _stream()), "apply_temperatures")
+    return logits
+
+
+def apply_top_k_top_p(logits, temperatures=None, top_k=None, top_p=None):
+    """apply_top_k_top_p (logits_utils.cpp:92-155), in place: temperatures, then top-k and / or top-p masking with -inf
+    (sort-free: radix selection over keys and over fixed-point probability mass, xllm_mi355_apply_top_k_top_p)"""
+    B, V, stride = _logits_2d(logits)
+    f32c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    k = None if top_k is None else top_k.to(torch.int64).contiguous()
+    check(_lib.lib().xllm_mi355_apply_top_k_top_p(_p(logits), B, V, stride, _dt(logits), _p(f32c(temperatures)), _p(k), _p(f32c(top_p)),
+                                                  _stream()), "apply_top_k_top_p")
+    return logits
+
+
 def greedy_argmax(logits: torch.Tensor) -> torch.Tensor:
     """Sampler::greedy_sample (framework/sampling/sampler.cpp:160-168): argmax over the last dim of [B, V] logits -> int64 [B];
     first index of the maximum, NaN above everything (torch.argmax)"""
