@@ -2268,19 +2268,26 @@ def test_apply_penalties_bit_exact(dtype):
     rep = torch.rand(B, generator=g) * 1.5 + 0.5
     for use_fp, use_rep in ((True, True), (True, False), (False, True)):
         ref = logits.clone().float()
-        if use_fp:
-            osm.apply_frequency_presence_penalties(ref, ids, cnt, freq, pres)
-            if dtype != torch.float32:
-                ref = ref.to(dtype).float()         # (16-bit logits: the kernel rounds to the logits dtype after each in-place op)
-        if use_rep:
-            osm.apply_repetition_penalties(ref, ids, rep)
+        if dtype == torch.float32:
+            if use_fp:
+                osm.apply_frequency_presence_penalties(ref, ids, cnt, freq, pres)
+            if use_rep:
+                osm.apply_repetition_penalties(ref, ids, rep)
+        else:
+            # 16-bit logits: the same expressions with the in-place operators' cast points written out (sub_ twice, then the
+            # where(...) result stored into the 16-bit tensor): fp32 arithmetic, rounded to the logits dtype after each of them
+            rt = lambda t: t.to(dtype).float()
+            sc = ref.gather(1, ids)
+            if use_fp:
+                sc = rt(sc - cnt * freq.unsqueeze(1))
+                sc = rt(sc - (cnt > 0) * pres.unsqueeze(1))
+            if use_rep:
+                sc = rt(torch.where(sc < 0, sc * rep.unsqueeze(1), sc / rep.unsqueeze(1)))
+            ref.scatter_(1, ids, sc)
         got = logits.clone().to(DEV)
         ops.apply_penalties(got, ids.to(DEV), cnt.to(DEV), freq.to(DEV) if use_fp else None, pres.to(DEV) if use_fp else None,
                             rep.to(DEV) if use_rep else None)
-        if dtype == torch.float32:
-            assert torch.equal(got.cpu(), ref), (use_fp, use_rep)
-        else:
-            assert_ulp_close(got, ref.to(dtype), dtype, ulps=1.0, min_exact=0.999)
+        assert torch.equal(got.float().cpu(), ref), (use_fp, use_rep)
     noop = logits.clone().to(DEV)
     ops.apply_penalties(noop, ids.to(DEV), cnt.to(DEV))
     assert torch.equal(noop.cpu(), logits)

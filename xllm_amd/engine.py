@@ -13,7 +13,8 @@ and stop-condition handling of the reference are out of scope): every step
      cumulative lengths, paged-KV triple, dense block table + per-sequence lengths),
   4. replays ONE captured HIP graph: embedding -> L decoder layers (KV write included) -> lm_head -> sampler,
   5. reads the sampled tokens back (the only host sync of the step).
-Sampling: greedy argmax, or temperature sampling through ops.random_sample with the step's uniforms drawn OUTSIDE the
+Sampling: greedy argmax, or temperature (+ top-k / top-p: ops.apply_top_k_top_p, the logits processors of
+framework/sampling/logits_utils.cpp as kernels) sampling through ops.random_sample with the step's uniforms drawn OUTSIDE the
 graph (ops.philox_uniform with offset = step), so a replay never repeats random numbers.
 """
 from __future__ import annotations
@@ -29,7 +30,7 @@ from .attention import AttentionMetadata
 class DecodeEngine:
     def __init__(self, model, kv_caches, block_size: int, seq_lens: Sequence[int], block_ids_per_seq: Sequence[Sequence[int]],
                  last_tokens: torch.Tensor, max_seq_len: int, temperature: float = 0.0, seed: int = 0,
-                 use_graph: bool = True):
+                 use_graph: bool = True, top_k: Optional[int] = None, top_p: Optional[float] = None):
         """seq_lens[b] tokens of sequence b are already in the cache (the prompt was prefilled); last_tokens[b] is the
         token the next step feeds; block_ids_per_seq[b] are the sequence's pre-assigned pages; max_seq_len bounds every
         sequence's length over the engine's life (the attention launch plan is frozen in the graph)."""
@@ -59,6 +60,10 @@ class DecodeEngine:
         self._tokens64 = torch.zeros(B, dtype=torch.int64, device=self.dev)
         self._pos64 = torch.zeros(B, dtype=torch.int64, device=self.dev)
         self._uniform = torch.zeros(B, dtype=torch.float32, device=self.dev)
+        # per-sequence sampling parameters (SamplingParameters: temperatures / top_k / top_p tensors, sampling_params.cpp:33-110)
+        self._temps = torch.full((B,), float(temperature), dtype=torch.float32, device=self.dev)
+        self._top_k = None if top_k is None else torch.full((B,), int(top_k), dtype=torch.int64, device=self.dev)
+        self._top_p = None if top_p is None else torch.full((B,), float(top_p), dtype=torch.float32, device=self.dev)
         self._next_host = last_tokens.to(torch.int32).cpu()
         self.md = AttentionMetadata(
             q_cu_seq_lens=torch.arange(B + 1, dtype=torch.int32, device=self.dev), kv_cu_seq_lens=self.dst["kv_seq_lens"],
@@ -77,8 +82,11 @@ class DecodeEngine:
         hidden = self.model.forward(self._tokens64, self._pos64, self.md, self.kv_caches)
         if self.temperature <= 0.0:
             return self.model.greedy_tokens(hidden).to(torch.int32)   # lm_head + argmax in one pass, no [B, V] logits
-        logits = self.model.logits(hidden)
-        probs = torch.softmax(logits.float() / self.temperature, dim=-1)
+        # Sampler::forward's random path (sampler.cpp:100-125): temperatures -> top-k -> top-p (apply_top_k_top_p, one sort-free
+        # kernel) -> softmax in fp32 -> random_sample
+        logits = self.model.logits(hidden).float()
+        ops.apply_top_k_top_p(logits, self._temps, self._top_k, self._top_p)
+        probs = torch.softmax(logits, dim=-1)
         return ops.random_sample(probs, uniform=self._uniform)
 
     @property
