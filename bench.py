@@ -362,12 +362,16 @@ def main():
         return dict(model=model, md=md, n_blocks=n_blocks, kv_caches=kv_caches, tokens=tokens, positions=positions, B=B,
                     tp_pg=tp_pg, tp_size=tp_sz, dp_size=dp_sz, nkv_l=nkv_l)
 
-    def time_decode(w, steps):
+    def time_decode(w, steps, overlap_arm=False):
         """warm up, capture (one graph without collectives, piecewise graphs around eager collectives, or -- one-shot kernel --
-        one graph WITH them), time `steps` replays; returns the timing record and the eager step function"""
+        one graph WITH them), time `steps` replays; returns the timing record and the eager step function.
+        overlap_arm: tensor parallel with the per-layer all-reduces on RCCL's own stream under the dual micro-batch executor
+        (north_star's "RCCL all-reduce overlapped with the next GEMM on a side HIP stream": the next GEMM is the OTHER half's,
+        parallel_state_async.cpp:72-84 / enable_multi_stream_parallel), launched eagerly (collectives from two streams do not go
+        through the piecewise capture)"""
         model, md, kv_caches, tokens, positions, B = w["model"], w["md"], w["kv_caches"], w["tokens"], w["positions"], w["B"]
         tp_sz, tp_pg = w["tp_size"], w["tp_pg"]
-        dual = layers.DualBatchDecoder(model, md, B) if (a.dual and world == 1 and not a.no_fuse and mode == "int8") else None
+        dual = layers.DualBatchDecoder(model, md, B) if ((a.dual and world == 1 or overlap_arm) and not a.no_fuse and mode == "int8") else None
 
         def step():
             hidden = dual.forward(tokens, positions, kv_caches) if dual is not None else model.forward(tokens, positions, md, kv_caches)
@@ -381,8 +385,8 @@ def main():
         # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
         graph = None
         # no collective inside the step (one GPU, or data-parallel replicas): ONE graph; tensor parallel: piecewise graphs
-        use_graph = (not a.no_graph) and (tp_sz == 1 or (a.graph and a.backend == "nccl"))
-        piecewise = (not a.no_graph) and tp_sz > 1 and not use_graph
+        use_graph = (not a.no_graph) and not overlap_arm and (tp_sz == 1 or (a.graph and a.backend == "nccl"))
+        piecewise = (not a.no_graph) and not overlap_arm and tp_sz > 1 and not use_graph
         if piecewise:
             # TP > 1: one graph per run of kernels between two EAGER collectives (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo
             # never run inside a capture. With the one-shot kernel the per-layer sums are kernels INSIDE the pieces: the only eager
@@ -502,6 +506,30 @@ def main():
         layouts = {layout: {"ms_per_step": round(ms_per_step, 4), "tokens_per_s": round(tok_s, 2),
                             "collectives_per_step": collectives_per_step, "allreduce": allreduce_kind,
                             "exposed_comm_ms": exposed_comm_ms}}
+        # the two other exchange designs of the SAME tensor-parallel layout, from the same lease (round-3 review, next #8): the
+        # group's own all-reduce (RCCL) in stream between piecewise graphs, and RCCL on its own stream under the dual micro-batch
+        # executor (the overlap north_star describes). Each arm is optional: a failure is recorded, never fatal. Every rank runs
+        # the same code, so the collectives of an arm are issued in the same order everywhere.
+        saved_oneshot = tp_pg.oneshot if tp_pg is not None else None
+        for arm, overlap in ((layout + "_rccl", False), (layout + "_rccl_overlap", True)):
+            if saved_oneshot is None and not overlap:
+                layouts[arm] = {"same_as": layout}          # the headline already ran on the group's own all-reduce
+                continue
+            try:
+                tp_pg.oneshot = None
+                ra = time_decode(w, a.steps, overlap_arm=overlap)
+                layouts[arm] = {"ms_per_step": round(ra["ms_per_step"], 4), "tokens_per_s": round(ra["tok_s"], 2),
+                                "collectives_per_step": collectives_per_step, "allreduce": tp_pg.allreduce_kind(),
+                                "exposed_comm_ms": ra["exposed_comm_ms"], "micro_batches": 2 if overlap else 1,
+                                "hip_graph": ("piecewise" if ra["piecewise"] else bool(ra["graph"])) if ra["graph"] is not None else False}
+                if ra.get("dual") is not None:
+                    ra["dual"].close()
+                del ra
+            except Exception as e:  # noqa: BLE001
+                layouts[arm] = {"error": repr(e)}
+            finally:
+                tp_pg.oneshot = saved_oneshot
+        torch.cuda.empty_cache()
         try:
             w2 = build(1)
             r2 = time_decode(w2, a.steps)

@@ -253,3 +253,28 @@ def test_oneshot_setup_failure_is_agreed_and_leaves_the_group_usable():
     assert ret[0]["none"] and ret[1]["none"]
     assert ret[0]["note"] == ret[1]["note"] and "rank 0" in ret[0]["note"] and "rank 1" in ret[0]["note"]
     assert ret[0]["sum"] == 3.0 and ret[1]["sum"] == 3.0 and ret[0]["kind"] == "gloo"
+
+
+def _argmax_merge(rank, world):
+    """column-sharded greedy sampling: per-shard (max, global first index) pairs merged over the group == torch.argmax of the
+    gathered logits, with ties across shards (lowest global column), a NaN in one shard, +inf next to a NaN, all -inf"""
+    from xllm_amd import parallel
+    pg = parallel.ProcessGroup(dist.group.WORLD, rank, world)
+    g = torch.Generator().manual_seed(5)                            # the same full logits on every rank
+    B, V = 12, 64
+    full = torch.randn(B, V, generator=g)
+    full[0, 3] = full[0, 40] = 9.0                                  # a tie across the two shards
+    full[1, 50] = float("nan")
+    full[2, 10] = float("inf"); full[2, 60] = float("nan")          # NaN beats +inf
+    full[3] = float("-inf")
+    full[4, 33] = full[4, 35] = 7.5                                 # a tie inside shard 1
+    shard = full[:, rank * (V // world):(rank + 1) * (V // world)]
+    idx = torch.argmax(shard, -1)
+    val = shard.gather(1, idx.view(-1, 1)).view(-1)
+    got = parallel.argmax_merge(val, idx + rank * (V // world), pg)
+    return got.tolist(), torch.argmax(full, -1).tolist()
+
+
+def test_sharded_greedy_argmax_pairs_merge_like_argmax_of_the_gathered_logits():
+    for got, want in _run(_argmax_merge):
+        assert got == want

@@ -418,14 +418,7 @@ class Qwen2Model:
                 if tp_size == 1:
                     return got
                 idx, val = got
-                idx = idx + self.tp.rank() * lm.weight.size(0)                 # shard-local -> global column
-                vals = self.tp.allgather(val)                                   # [W, B]
-                idxs = self.tp.allgather(idx)
-                nan = torch.isnan(vals)                                         # torch.argmax: NaN above every number
-                key = torch.where(nan, torch.full_like(vals, float("inf")), vals)
-                best = key.max(0, keepdim=True).values
-                cand = torch.where(key == best, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
-                return cand.min(0).values
+                return parallel.argmax_merge(val, idx + self.tp.rank() * lm.weight.size(0), self.tp)   # shard-local -> global column
         return ops.greedy_argmax(self.logits(hidden))
 
 
@@ -664,7 +657,10 @@ class DualBatchDecoder:
     W8A8 fused decode path, TP = 1 only."""
 
     def __init__(self, model: "Qwen2Model", md: AttentionMetadata, batch: int):
-        assert model.tp is None and all(l.fuse for l in model.layers)
+        # tensor parallel (round 4): allowed -- each half's row-parallel linears reduce through the group's own all-reduce (RCCL runs
+        # it on its own stream, fenced against the half's stream), which is what lets the OTHER half's GEMMs overlap the transfer.
+        # The one-shot kernel is bound to one stream (OneShotAllReduce), so launches from the two half-streams decline it by design.
+        assert all(l.fuse for l in model.layers)
         self.model, self.B = model, batch
         h = batch // 2
         self.cut = [(0, h), (h, batch)]

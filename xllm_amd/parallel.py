@@ -543,6 +543,23 @@ def finish_reduce(ctx: ReduceAsyncCtx) -> torch.Tensor:
     return ctx.tensor
 
 
+def argmax_merge(val: torch.Tensor, idx: torch.Tensor, pg: Optional[ProcessGroup]) -> torch.Tensor:
+    """greedy sampling over a column-sharded lm_head without gathering the logits: every rank holds, per row, the maximum of ITS
+    shard (val float32 [B]) and its GLOBAL column (idx int64 [B]); the ranks exchange the [B] pairs and pick, per row, the best
+    value -- NaN above every number, the lowest global column among equals -- i.e. torch.argmax of the gathered [B, V] logits
+    (parallel_state::gather + Sampler::greedy_sample, linear.cpp:712-714, sampler.cpp:160-168; argmax commutes with the gather)"""
+    if pg is None or pg.world_size() == 1:
+        return idx
+    vals = pg.allgather(val)                                        # [W, B]
+    idxs = pg.allgather(idx)
+    key = torch.where(torch.isnan(vals), torch.full_like(vals, float("inf")), vals)
+    nan_rows = torch.isnan(vals).any(0, keepdim=True)
+    key = torch.where(nan_rows & ~torch.isnan(vals), torch.full_like(vals, float("-inf")), key)   # a NaN beats +inf too
+    best = key.max(0, keepdim=True).values
+    cand = torch.where(key == best, idxs, torch.full_like(idxs, torch.iinfo(torch.int64).max))
+    return cand.min(0).values
+
+
 def gather(x: torch.Tensor, pg: Optional[ProcessGroup], dim: int = -1) -> torch.Tensor:
     """parallel_state::gather (parallel_state.cpp:89-102): all-gather-base then cat along `dim`."""
     if pg is None or pg.world_size() == 1:
