@@ -75,6 +75,8 @@ def parse():
                    help="also run the SAME decode step through the C++ libtorch shim (shim/: the reference's operator signatures, "
                         "what a -DUSE_MI355 build of xLLM calls) in the reference's operator order, and print its ms_per_step "
                         "beside the headline")
+    p.add_argument("--no-pmc", action="store_true",
+                   help="skip the live rocprofv3 --pmc passes behind roofline.traffic (then the committed record is quoted)")
     p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
@@ -83,6 +85,48 @@ def parse():
     p.add_argument("--emulate-dp", type=int, default=0,
                    help="single GPU: run ONE replica's share of the batch of a DP=k job (tuning aid, with --emulate-tp)")
     return p.parse_args()
+
+
+def live_pmc_traffic(B, ctx, nq, nkv, launches=4, timeout_s=240):
+    """roofline.traffic measured in this run: rocprofv3 --kernel-trace --pmc <counter> (one counter per pass) around
+    tools/attn_pmc_probe.py, per-dispatch sums of the paged_decode kernel read back from the rocpd database. gfx950 correction of
+    MI355X_MICROARCH.md's HBM section: FETCH_SIZE (KiB) reports half the bytes of a wide coalesced streaming read -> doubled;
+    WRITE_SIZE (KiB) as reported. Returns (bytes per launch, provenance) or (None, None) when rocprofv3 is unavailable / fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    probe = os.path.join(ROOT, "tools", "attn_pmc_probe.py")
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            tmp = tempfile.mkdtemp(prefix="xm_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "--", sys.executable, probe, str(B), str(ctx),
+                                str(nq), str(nkv), str(launches)], cwd="/tmp", env=env, timeout=timeout_s, check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+                if not dbs:
+                    return None, None
+                cur = sqlite3.connect(dbs[0]).cursor()
+                row = cur.execute("select sum(value), count(*) from counters_collection where counter_name = ? and "
+                                  "kernel_name like '%paged_decode_kernel%'", (counter,)).fetchone()
+                if not row or not row[1]:
+                    return None, None
+                got[counter] = float(row[0]) / float(row[1])          # KiB per dispatch
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        traffic = int(2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024)
+        return traffic, (f"rocprofv3 --pmc in this run (tools/attn_pmc_probe.py, {launches} launches per counter pass): FETCH_SIZE "
+                         f"{got['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction) + WRITE_SIZE {got['WRITE_SIZE']:.0f} KiB per dispatch")
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] live PMC pass failed ({e!r}); quoting the committed record instead", file=sys.stderr)
+        return None, None
 
 
 def build_metadata(B, ctx, block_size, device, seed):
@@ -491,8 +535,13 @@ def main():
     attn_bytes = B * (ctx * nkv_l * d * 2 * 2 + 2 * nq_l * d * 2)
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
     traffic, traffic_source = None, None
+    if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_pmc:
+        # HBM bytes per launch of the dominant kernel from the PMC counters, collected IN THIS RUN (round-3 review, weak #12): two
+        # rocprofv3 passes (one counter each, as MI355X_MICROARCH.md prescribes) over tools/attn_pmc_probe.py = the same kernel at
+        # the same shape in a child process
+        traffic, traffic_source = live_pmc_traffic(B, ctx, nq_l, nkv_l)
     pmc = os.path.join(ROOT, "profiles", "decode_attn_pmc.json")
-    if os.path.exists(pmc) and world == 1 and tp_size == 1 and a.config == "cfg3":
+    if traffic is None and os.path.exists(pmc) and world == 1 and tp_size == 1 and a.config == "cfg3":
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             traffic_source = "profiles/decode_attn_pmc.json (rocprofv3 --pmc passes of an earlier run, not this run)"
