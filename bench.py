@@ -13,11 +13,17 @@ the global batch of 256 sequences is FIXED ("scaling": "strong") and the layout 
          o_proj and down_proj, all-gather of logits; linear.cpp:1518-1520, 712-714); Qwen2-7B has 28 heads, so TP is 1, 2 or 4
          (qwen2_attention.cpp:54-65). The 56 per-layer sums run on the one-shot all-reduce kernel of csrc/allreduce.hip (self-tested
          at set-up, fused with the residual add + RMSNorm + int8 quant that follows; RCCL when the self-test fails --
-         config.allreduce says which), the logits all-gather on RCCL;
+         config.allreduce says which); greedy sampling reduces every rank's lm_head shard to [B] (max, index) pairs in the GEMM
+         epilogue and exchanges THOSE instead of all-gathering the logits (round 4). `layouts` also carries the two other
+         exchange designs of the same layout from the same launch: <layout>_rccl (the group's own all-reduce in stream, piecewise
+         graphs) and <layout>_rccl_overlap (RCCL on its own stream under the dual micro-batch executor, eager);
   tp4dp2 (headline for N = 8) TP = 4 inside two replicas (what the reference would run on 8 GPUs);
   dp     N replicas of the model (7.6 GB of int8 weights fit a 288 GB GPU many times over), 256 / N sequences each, NO data-path
          exchange. A legitimate deployment answer for this path, measured in the same run and reported in `layouts` beside the
          headline (never substituted for it); --layout dp makes it the headline.
+
+roofline.traffic (N = 1) is measured in the same run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the dominant kernel
+at the bench's shape in a child process (tools/attn_pmc_probe.py; --no-pmc quotes the committed record instead).
 
 Prints ONE JSON line on rank 0.
 """
