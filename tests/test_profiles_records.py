@@ -8,7 +8,8 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RECORDS = os.path.join(ROOT, "profiles", "r03_model_parity.jsonl")
+import glob as _glob
+RECORDS = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r0*_model_parity.jsonl")))[-1]    # the latest round's records
 
 # the bars of tests/test_gpu_model_parity.py (kept literal here on purpose: changing a bar has to be done in two places)
 FLOAT_BAR, FP8_BAR = 1e-3, 2e-2
@@ -51,3 +52,24 @@ def test_committed_free_running_records_stay_inside_their_controls():
             assert max(errs) <= 5e-2 and sorted(errs)[len(errs) // 2 - 1] <= 1e-3, (r["test"], r["mode"], errs)
         if "hip_vs_fp32_truth" in r:
             assert max(r["hip_vs_fp32_truth"]) <= 1.25 * max(r["oracle_vs_fp32_truth"])
+
+
+def test_full_gpu_suite_record_is_for_this_tree():
+    """round-3 review (next #1d): the round's last GPU run is the FULL `pytest -m gpu` on the tree that is submitted. Its log
+    (profiles/r04_pytest_gpu.txt, written by tools/r04/final_gpu_suite.sh) starts with the digest of the sources it ran on
+    (kernels, C ABI, host mirror, shim, oracle, tests: tools/source_digest.py); this test fails when any of them changed since,
+    when the run was not green, or when it ran fewer tests than the suite holds."""
+    import re
+    import subprocess
+    import sys
+    rec = os.path.join(ROOT, "profiles", "r04_pytest_gpu.txt")
+    assert os.path.exists(rec), "no committed record of the full GPU suite for this round"
+    text = open(rec).read()
+    m = re.search(r"^# source-digest: ([0-9a-f]{64})$", text, flags=re.M)
+    assert m, "the record does not carry a source digest"
+    now = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "source_digest.py")]).decode().strip()
+    assert m.group(1) == now, ("kernels / host code / tests changed after the last full GPU run: re-run tools/r04/final_gpu_suite.sh "
+                               "on the GPU box and commit its log as profiles/r04_pytest_gpu.txt")
+    assert re.search(r"^# pytest rc=0$", text, flags=re.M), "the recorded GPU run was not green"
+    res = re.search(r"(\d+) passed", text)
+    assert res and int(res.group(1)) >= 400 and " failed" not in text.split("# pytest rc")[0].splitlines()[-1]

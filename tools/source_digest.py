@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One digest over every source the GPU suite exercises (kernels, C ABI, host mirror, shim, oracle, tests): the committed record
+of the last full `pytest -m gpu` run carries it, and tests/test_profiles_records.py compares it with the tree (round-3 review:
+the submitted HEAD must be the tree the full GPU suite ran on). Documentation, profiles and tools are not part of it."""
+import glob
+import hashlib
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERNS = ["xllm_amd/csrc/*.hip", "xllm_amd/csrc/*.h", "xllm_amd/csrc/Makefile", "xllm_amd/*.py", "include/*.h", "shim/*.cpp", "shim/*.h",
+            "shim/build_shim.py", "shim/stub/**/*.h", "oracle/*.py", "oracle/*.c", "oracle/Makefile", "tests/*.py", "tests/golden/*",
+            "__graft_entry__.py"]
+
+
+def files():
+    out = set()
+    for pat in PATTERNS:
+        out.update(p for p in glob.glob(os.path.join(ROOT, pat), recursive=True) if os.path.isfile(p))
+    return sorted(out)
+
+
+def digest() -> str:
+    h = hashlib.sha256()
+    for p in files():
+        h.update(os.path.relpath(p, ROOT).encode() + b"\0")
+        h.update(open(p, "rb").read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+if __name__ == "__main__":
+    print(digest())
