@@ -9,7 +9,7 @@ changes of round 3 are worth; here every variant is captured from the same weigh
         greedy=0|1         ops._GREEDY_FUSION (lm_head + argmax in one pass, round 4)
         packed=auto|0|1    ops._PACKED_POLICY
         ws_ng=N  ws_sl=N  ws_rows=128|256   xllm_mi355_gemm_plan_hint (product API, thread-local)
-        ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 140..142, 0)            [tuning flavour]
+        ws_waves=N         xllm_mi355_debug_ws_waves (80, 81, 140..142, 150 | 151 = slab stores plain | non-temporal, 0)   [tuning flavour]
         shape=N,K,ng,sl    xllm_mi355_debug_ws_plan_shape: tile width / K slices of ONE GEMM of the step
         attn=s,h,d,e       xllm_mi355_debug_decode_plan: split-KV count, kv heads per workgroup, deep prefetch, exclusive CU
         idle=before|after,US   an idle gap of US microseconds in front of / behind every decode-attention launch (analysis)

@@ -141,6 +141,15 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
   x8 k0[2][KK], k1[2][KK], k2[2][KK];
   u32x4 v0[NV], v1[NV], v2[NV];
 
+  // The KV stream is read exactly ONCE per launch: NON-TEMPORAL loads (global_load_dwordx4 ... nt). Round 4, tools/attn_ab.py on
+  // one box, alternating libraries: 355 -> 329 us per launch at cfg3 = 6.05 -> 6.53 TB/s (0.756 -> 0.817 of 8 TB/s) -- above the
+  // 6.25-6.47 TB/s "read ceiling" earlier rounds measured with ordinary loads (tools/hbm_read_bench.hip): a streaming read that
+  // allocates in the L2 pays for evicting 2 GB of lines nobody will hit. -DXM_ATTN_TEMPORAL_LOADS restores the old loads (A/B).
+#ifndef XM_ATTN_TEMPORAL_LOADS
+#define XM_KV_LOAD(P) __builtin_nontemporal_load(P)
+#else
+#define XM_KV_LOAD(P) (*(P))
+#endif
   auto page_of_tile = [&](int tile) -> int {  // UNIFORM only: scalar page id of a tile (clamped)
     int idx = (tile * kTile) / block_size;
     const int last = (kv_len - 1) / block_size;
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
       else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
       const T* kp = kc + rowi * row_elems + (int64_t)kvh * D + g * 8;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) kr[blk][kk] = *reinterpret_cast<const x8*>(kp + kk * 32);
+      for (int kk = 0; kk < KK; ++kk) kr[blk][kk] = XM_KV_LOAD(reinterpret_cast<const x8*>(kp + kk * 32));
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
       int64_t rowi;
       if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
       else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
-      vr[i] = *reinterpret_cast<const u32x4*>(vc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8);
+      vr[i] = XM_KV_LOAD(reinterpret_cast<const u32x4*>(vc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8));
     }
   };
   auto page_clamped = [&](int tile) -> int {

@@ -288,7 +288,11 @@ typedef unsigned mu32x2_t __attribute__((ext_vector_type(2)));
 //     f = row bit1 -> bit1, bit2 -> bit2, bit3 -> bit0 -- distinct over the 16 consecutive rows a K fragment read touches
 //     AND over the 8 rows x 2 chunks a transposed V read touches;
 //   * wave w DMAs rows 16w..16w+15 -- exactly the rows it scores, so QK^T needs only the wave's own vmcnt, no barrier.
-template <typename T>
+//   * NT (round 4): a pure decode launch with one head block per sequence reads every latent byte ONCE -> non-temporal DMA
+//     (cfg4: 211 -> 193-197 us = 0.716 -> 0.77-0.78 of 8 TB/s). With several head blocks per sequence (128 heads: 8 workgroups
+//     share a sequence's tiles through the L2) or several query tokens per sequence (the per-token prefill form) the L2 re-use
+//     is the point: nt costs 16 % there (1248 -> 1445 us), so those launches keep ordinary loads.
+template <typename T, bool NT>
 __global__ __launch_bounds__(256, 1) void mla_decode_dma_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, T* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_ml, const int32_t* __restrict__ seqlens, const int32_t* __restrict__ block_table,
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_dma_kernel(
         const_cast<T*>(kc + row0 * kMlaD), 0, rows * ROWB, 0x00020000);
     const lds_ptr_t dst = lds3 + buf * BUFB + wave * (NDMA * 1024);
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + i * 1024, 16, voff[i], 0, 0, 0);
+    for (int i = 0; i < NDMA; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst + i * 1024, 16, voff[i], 0, 0, NT ? 2 : 0);   // aux 2 = nt
   };
 
   // fragment read offsets inside a tile buffer (per lane, constant over tiles)
@@ -887,8 +891,12 @@ static int launch_mla(const void* q, const void* k_cache, void* out, const int32
   const float scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid((unsigned)(entries * hblocks * nsplit));
   XM_DISPATCH_HALF(dtype, T, {
-    if (dma)
-      hipLaunchKernelGGL((mla_decode_dma_kernel<T>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+    if (dma && hblocks == 1 && !q_seq)   // every latent byte is read once: non-temporal DMA
+      hipLaunchKernelGGL((mla_decode_dma_kernel<T, true>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
+                         part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
+                         scale_log2, (int)nsplit, q_seq, q_kvlen);
+    else if (dma)
+      hipLaunchKernelGGL((mla_decode_dma_kernel<T, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)k_cache, (T*)out,
                          part_o, part_ml, seqlens_k, block_table, (int)max_blocks, (int)n_heads, (int)block_size,
                          scale_log2, (int)nsplit, q_seq, q_kvlen);
 #ifdef XM_TUNING

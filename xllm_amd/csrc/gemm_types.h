@@ -99,6 +99,7 @@ struct GemmEpi {
   float* argmax_val;
   int32_t* argmax_idx;
   int argmax_slots;
+  int slab_nt;   // packed kernels: K-slice slabs leave with non-temporal stores (round 4, see ws_epilogue)
 };
 
 // torch.argmax order: NaN above every number, the first index among equals

@@ -309,8 +309,19 @@ __device__ __forceinline__ void ws_epilogue(typename WsAcc<KIND>::type (&acc)[MB
         const int idx = i * 64 + lane, row = idx / CH, c = idx % CH;
         const uint4 v = *reinterpret_cast<const uint4*>(tb + row * PITCH + c * 16);
         const int m = m_base + mb * 16 + row;
-        if (m < M && gw + (c >> 2) < g_live)
-          *reinterpret_cast<uint4*>(slab + (int64_t)m * N + (g0 + gw) * 16 + c * 4) = v;
+        if (m < M && gw + (c >> 2) < g_live) {
+          uint4* const dst = reinterpret_cast<uint4*>(slab + (int64_t)m * N + (g0 + gw) * 16 + c * 4);
+          // non-temporal: the slabs are read once by the fused consumer and dead afterwards; as ordinary stores they sit DIRTY in
+          // the L2 (up to 19 MB after the qkv GEMM) and are written back while the decode-attention kernel streams the KV cache
+          // (tools/attn_dirty_l2.py: +10 us on that launch after 17 MB of dirty lines)
+          if (epi.slab_nt) {
+            typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+            const nt_u32x4 nv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<nt_u32x4*>(dst));
+          } else {
+            *dst = v;
+          }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the block is rewritten by the next row block
     }
@@ -1040,6 +1051,7 @@ struct WsPlan { int waves, wm, wn, mb, ng, slices; };
 XM_TUNE_VAR(f_kstagger, "XLLM_MI355_KSTAGGER", 1);
 XM_TUNE_VAR(f_ws8s, "XLLM_MI355_WS8_STAGGER", 1);
 XM_TUNE_VAR(f_wpolicy, "XLLM_MI355_WS_WPOLICY", 0);
+XM_TUNE_VAR(f_slab_nt, "XLLM_MI355_SLAB_NT", 1);   // non-temporal slab stores: -0.09 … -0.125 ms per step (profiles/r04_step_ab_nt.txt)
 static thread_local int g_argmax_slots_used = 0;   // slots the last argmax-mode launch of this thread filled (read by its caller)
 template <int KIND, int NWV, int WM, int WN, int MB, int NG, int DW>
 int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K, int slices, GemmEpi epi,
@@ -1049,6 +1061,7 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
   // gate_up mode: a tile holds G / 2 ACT groups (their gate and their up columns); the split is over the N / 32 act groups
   const bool gu = epi.gate_up != 0;
   epi.w_policy = f_wpolicy;
+  epi.slab_nt = f_slab_nt;
   if (gu && (G % 2 != 0 || KIND == kFP8)) return -1;
   const int n_groups = gu ? (int)(N / 32) : (int)(N / 16);
   const int KT = (int)(K / WS_BK);
@@ -1340,6 +1353,7 @@ extern "C" XM_API void xllm_mi355_debug_ws_plan_shape(long long N, long long K, 
 extern "C" XM_API void xllm_mi355_debug_ws_waves(int waves) {
   if (waves == 80 || waves == 81) xm::f_ws8s = waves - 80;
   if (waves >= 140 && waves <= 142) xm::f_wpolicy = waves - 140;
-  if (waves == 0) { xm::f_wpolicy = 0; xm::f_ws8s = 1; }
+  if (waves == 150 || waves == 151) xm::f_slab_nt = waves - 150;
+  if (waves == 0) { xm::f_wpolicy = 0; xm::f_ws8s = 1; xm::f_slab_nt = 1; }
 }
 #endif

@@ -358,14 +358,21 @@ _row_amax = {}
 _row_amax_retired = []
 
 
+def _scratch_key(device):
+    """which scratch buffer a launch on the CURRENT stream uses (the keying of _slab_workspace): one per device for the default
+    stream and for graph captures (a capture orders its launches explicitly), one of its own for every stream that launches
+    eagerly next to it (their kernels may run concurrently) and for the streams registered as private (dual micro-batch executor)"""
+    cur = torch.cuda.current_stream(device)
+    side = cur != torch.cuda.default_stream(device) and not torch.cuda.is_current_stream_capturing()
+    return (device, cur.cuda_stream if (side or cur.cuda_stream in _private_streams) else 0)
+
+
 def _row_amax_scratch(device, M: int):
     """zero-at-rest |max| scratch of the gate_up fusion, keyed like _slab_workspace: one buffer per device for the default stream
     and for captures, one per eagerly-launching side stream (their launches may run concurrently). A buffer is NEVER freed: a
     captured HIP graph has its address baked in (atomicMax + re-zero on replay), so a buffer a larger M outgrows is retired -- kept
     alive, still zero at rest -- and a bigger one takes its place for the launches that follow (round-3 advisor finding)."""
-    cur = torch.cuda.current_stream(device)
-    side = cur != torch.cuda.default_stream(device) and not torch.cuda.is_current_stream_capturing()
-    key = (device, cur.cuda_stream if (side or cur.cuda_stream in _private_streams) else 0)
+    key = _scratch_key(device)
     amax = _row_amax.get(key)
     if amax is None or amax.numel() < M:
         if torch.cuda.is_current_stream_capturing():
@@ -606,7 +613,7 @@ def matmul_argmax(a, b_packed, N: int, bias=None, want_value: bool = False):
     if b_packed is None or M == 0 or M > 512 or N % 16 or not a.is_contiguous():
         return None
     need = _lib.lib().xllm_mi355_matmul_argmax_workspace_bytes(M, N)
-    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream if torch.cuda.current_stream(a.device).cuda_stream in _private_streams else 0)
+    key = _scratch_key(a.device)
     ws = _argmax_ws.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
