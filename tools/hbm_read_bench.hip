@@ -1,9 +1,15 @@
 // hbm_read_bench.hip -- the read-only HBM ceiling the paged-decode kernel is priced against: a 2.15-GB buffer (the
 // KV bytes of one cfg3 layer) streamed once by 16-B loads, for several (waves per CU, loads in flight per lane) points.
-// build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 -o /tmp/hbm tools/hbm_read_bench.hip && /tmp/hbm
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 [-DHBM_NT] -o /tmp/hbm tools/hbm_read_bench.hip && /tmp/hbm [small]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// -DHBM_NT: non-temporal loads (global_load_dwordx4 ... nt) -- round 4: what the decode-attention kernel now uses for its KV stream
+#ifdef HBM_NT
+#define LD(X) __builtin_nontemporal_load(&(X))
+#else
+#define LD(X) (X)
+#endif
 
 template <int UNROLL>
 __global__ __launch_bounds__(256) void k(const u32x4* __restrict__ p, size_t n_vec, unsigned* sink) {
@@ -12,7 +18,7 @@ __global__ __launch_bounds__(256) void k(const u32x4* __restrict__ p, size_t n_v
   for (size_t base = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x; base + 256 * (UNROLL - 1) < n_vec; base += stride) {
     u32x4 v[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) v[i] = p[base + (size_t)i * 256];
+    for (int i = 0; i < UNROLL; ++i) v[i] = LD(p[base + (size_t)i * 256]);
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
   }
@@ -29,7 +35,7 @@ __global__ __launch_bounds__(256) void kp(const u32x4* __restrict__ p, size_t n_
   for (size_t base = threadIdx.x; base + 256 * (UNROLL - 1) < per; base += 256 * UNROLL) {
     u32x4 v[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) v[i] = q[base + (size_t)i * 256];
+    for (int i = 0; i < UNROLL; ++i) v[i] = LD(q[base + (size_t)i * 256]);
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
   }
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void ks(const u32x4* __restrict__ p, size_t n_
   for (size_t r0 = 0; r0 + 16 * UNROLL <= rows; r0 += 16 * UNROLL) {
     u32x4 v[UNROLL];
 #pragma unroll
-    for (int i = 0; i < UNROLL; ++i) v[i] = q[(r0 + i * 16 + threadIdx.x / 16) * (NH * 16) + head * 16 + threadIdx.x % 16];
+    for (int i = 0; i < UNROLL; ++i) v[i] = LD(q[(r0 + i * 16 + threadIdx.x / 16) * (NH * 16) + head * 16 + threadIdx.x % 16]);
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
   }

@@ -16,6 +16,17 @@
 
 #include "gemm_types.h"
 
+// Output stores of the 8-phase int8 kernel: when the [M, N] output is larger than the L2 (prefill: [8192, 37888] bf16 = 620 MB,
+// read once by the next operator) they are NON-TEMPORAL (GemmEpi::out_nt, set by the launcher) so that they do not evict the
+// operand panels the super-block re-uses. Round 4, GEMM_DIST=gauss tools/gemm_bench.py 8192 int8, alternating libraries on one box:
+// gate_up 911 -> 884 us (2.44 -> 2.52 POP/s), qkv 127.3 -> 123.8, o 89.5 -> 88.4, down 414.4 -> 413.5 (profiles/r04_p8i_nt.txt).
+// Decode-sized outputs (a few MB, consumed from the L2 by the next kernel) keep ordinary stores.
+#define P8I_STORE(PTR, VAL)                                          \
+  do {                                                               \
+    if (epi.out_nt) __builtin_nontemporal_store((VAL), (PTR));       \
+    else *(PTR) = (VAL);                                             \
+  } while (0)
+
 namespace xm {
 
 constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
@@ -109,7 +120,7 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
         const u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
         const int mr = m0 + wr * 128 + mp * 32 + i * 8 + rrow;
         if (mr < M && n_st < N)
-          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st) = row16;
+          P8I_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st), row16);
       }
     }
   }
@@ -176,7 +187,10 @@ __device__ __forceinline__ void p8i_epilogue_gate_up(i32x4_t (&acc)[8][4], uint8
     const int idx = i * 64 + lane, row = idx >> 2, c = idx & 3;
     const uint4 v = *reinterpret_cast<const uint4*>(tb + row * PITCH + c * 16);
     const int m = m0 + wr * 128 + row;
-    if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + ncol0 + c * 8) = v;
+    if (m < M) {
+      const u32x4 nv = {v.x, v.y, v.z, v.w};
+      P8I_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.act_out) + (int64_t)m * I + ncol0 + c * 8), nv);
+    }
   }
   __builtin_amdgcn_s_barrier();
   if (tid < 256) {
@@ -435,6 +449,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
 XM_TUNE_VAR(p8i_kstagger, "XLLM_MI355_KSTAGGER", 1);   // K-walk stagger (round-3 A/B winner; 0 = tuning arm)
 int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, GemmEpi epi, int m_tiles, int n_tiles,
                     int per, int splits, dim3 grid, hipStream_t s) {
+  // 16-bit output (or the fused act [M, N / 2]) beyond the 32 MB of L2: streamed out (see P8I_STORE)
+  epi.out_nt = (M * (epi.gate_up ? N / 2 : N) * 2 > (48ll << 20)) ? 1 : 0;
   if (splits > 1)
     hipLaunchKernelGGL((gemm_p8i_kernel<true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
                        (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);

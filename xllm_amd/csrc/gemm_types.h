@@ -100,6 +100,7 @@ struct GemmEpi {
   int32_t* argmax_idx;
   int argmax_slots;
   int slab_nt;   // packed kernels: K-slice slabs leave with non-temporal stores (round 4, see ws_epilogue)
+  int out_nt;    // 8-phase int8 kernel: non-temporal output stores (outputs larger than the L2; set by launch_gemm_p8i)
 };
 
 // torch.argmax order: NaN above every number, the first index among equals

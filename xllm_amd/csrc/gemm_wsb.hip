@@ -70,12 +70,25 @@ struct WsbGroup {
 // (scalar base + 32-bit lane offset: the K walk lives in SGPRs, one VGPR per row pointer)
 #define WSB_LD(DST, VOFF, SBASE, OFF) \
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=v"(DST) : "v"(VOFF), "s"(SBASE))
+// Non-temporal weight loads were TRIED here in round 4 (-DWSB_W_NT=1) and LOSE by 15-20 % (bf16 layer at M = 16: 12.0 / 10.6 / 59.0 /
+// 30.5 -> 14.0 / 12.3 / 71.5 / 36.4 us, cfg4-slice 1.02 -> 1.19 ms; profiles/r04_wsb_nt.txt): a lane reads 16 bytes of a row-major
+// weight row per instruction, so a 128-byte line is consumed by EIGHT consecutive K steps -- it has to stay cached in between.
+// (nt pays where one instruction consumes whole lines: the KV stream of attention_decode.hip, the packed fragments of gemm_ws.hip.)
+#ifndef WSB_W_NT
+#define WSB_W_NT 0
+#endif
+#if WSB_W_NT
+#define WSB_LDW(DST, VOFF, SBASE, OFF) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF " nt" : "=v"(DST) : "v"(VOFF), "s"(SBASE))
+#else
+#define WSB_LDW(DST, VOFF, SBASE, OFF) WSB_LD(DST, VOFF, SBASE, OFF)
+#endif
 
 __device__ __forceinline__ void wsb_issue_w(wsb_u32x4 (&wr)[4][2], const uint32_t (&woff)[4], const char* base) {
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    WSB_LD(wr[nb][0], woff[nb], base, 0);
-    WSB_LD(wr[nb][1], woff[nb], base, 16);
+    WSB_LDW(wr[nb][0], woff[nb], base, 0);
+    WSB_LDW(wr[nb][1], woff[nb], base, 16);
   }
 }
 template <int MB>
