@@ -177,8 +177,11 @@ __device__ __forceinline__ void p8_epilogue_impl(typename MmaTraits<KIND>::acc_t
       for (int i = 0; i < 4; ++i) {
         const u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
         const int mr = m0 + wr * 128 + mb * 32 + i * 8 + rrow;
-        if (mr < M && n_st < N)
-          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st) = row16;
+        if (mr < M && n_st < N) {
+          u32x4* const dst = reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st);
+          if (epi.out_nt) __builtin_nontemporal_store(row16, dst);   // outputs beyond the L2 are streamed out (gemm_p8i.hip, round 4)
+          else *dst = row16;
+        }
       }
     }
   }
@@ -463,6 +466,7 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
     return launch_gemm_p8i(A, W, M, N, Kb, epi, m_tiles, n_tiles, per, splits, grid, s);
   } else {
     if (splits > 1) return XM_ERR_UNSUPPORTED;
+    epi.out_nt = (M * N * 2 > (48ll << 20)) ? 1 : 0;
     hipLaunchKernelGGL((gemm_p8_kernel<KIND, false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A,
                        (const uint8_t*)W, (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi);
   }

@@ -55,11 +55,25 @@ __global__ __launch_bounds__(256) void build_block_table_kernel(const int32_t* _
 //          1 -> fp8 e4m3: v = float(r16(x*inv))*float(w); q = sat(clamp(v * (1/scale)))
 //          2 -> int8 per token of y (the 16-bit norm output), scale[t] = amax/127
 // ------------------------------------------------------------------------------------------------
+// 16-byte row IO with an optional non-temporal hint (round 4): prefill-sized tensors (beyond the 32 MB of L2, every byte touched
+// once per operator) are streamed; decode-sized ones are consumed from the L2 by the next kernel and keep ordinary accesses
+typedef unsigned rw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 rw_ld16(const void* p, bool nt) {
+  const rw_u32x4* q = reinterpret_cast<const rw_u32x4*>(p);
+  const rw_u32x4 v = nt ? __builtin_nontemporal_load(q) : *q;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void rw_st16(void* p, const uint4& v, bool nt) {
+  const rw_u32x4 w = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_nontemporal_store(w, reinterpret_cast<rw_u32x4*>(p));
+  else *reinterpret_cast<rw_u32x4*>(p) = w;
+}
+
 template <typename T, bool ADD, int QUANT>
 __global__ __launch_bounds__(kRowThreads) void rms_norm_kernel(
     void* __restrict__ out, T* __restrict__ input, T* __restrict__ residual,
     const T* __restrict__ weight, const float* __restrict__ fp8_scale, float* __restrict__ q_scale,
-    float eps, int hidden, int64_t in_stride, bool write_input) {
+    float eps, int hidden, int64_t in_stride, bool write_input, bool nt = false) {
   constexpr int N = RowVec<T>::N;
   __shared__ float smem[32];
   const int64_t t = blockIdx.x;
@@ -72,13 +86,13 @@ __global__ __launch_bounds__(kRowThreads) void rms_norm_kernel(
   for (int i = 0; i < kMaxVec; ++i) {
     const int c = threadIdx.x + i * kRowThreads;
     if (c < nvec) {
-      xv[i].raw = reinterpret_cast<const uint4*>(in_row)[c];
+      xv[i].raw = rw_ld16(reinterpret_cast<const uint4*>(in_row) + c, nt);
       if constexpr (ADD) {
         RowVec<T> rv;
-        rv.raw = reinterpret_cast<const uint4*>(res_row)[c];
+        rv.raw = rw_ld16(reinterpret_cast<const uint4*>(res_row) + c, nt);
 #pragma unroll
         for (int j = 0; j < N; ++j) xv[i].set(j, xv[i].get(j) + rv.get(j));  // r16(x + r)
-        reinterpret_cast<uint4*>(res_row)[c] = xv[i].raw;
+        rw_st16(reinterpret_cast<uint4*>(res_row) + c, xv[i].raw, nt);
       }
 #pragma unroll
       for (int j = 0; j < N; ++j) { float x = xv[i].get(j); ss += x * x; }
@@ -334,7 +348,8 @@ int launch_rms_norm(void* out, void* input, void* residual, const void* weight, 
                       (!ADD || (uintptr_t)residual % 16 == 0) && ((uintptr_t)out % 16 == 0);
   if (vec_ok)
     hipLaunchKernelGGL((rms_norm_kernel<T, ADD, QUANT>), dim3(T_), dim3(kRowThreads), 0, s, out, (T*)input,
-                       (T*)residual, (const T*)weight, fp8_scale, q_scale, eps, (int)H, in_stride, write_input);
+                       (T*)residual, (const T*)weight, fp8_scale, q_scale, eps, (int)H, in_stride, write_input,
+                       T_ * H * (int64_t)sizeof(T) > (48ll << 20));
   else
     hipLaunchKernelGGL((rms_norm_generic_kernel<T, ADD, QUANT>), dim3(T_), dim3(kRowThreads), 0, s, out,
                        (T*)input, (T*)residual, (const T*)weight, fp8_scale, q_scale, eps, (int)H, in_stride,
@@ -1367,15 +1382,18 @@ static int launch_actq(int8_t* out_q, float* out_scale, const void* input, int64
 // and puts the row's entry of row_amax back to zero. Bit-identical to act_and_mul -> scaled_quantize.
 template <typename T>
 __global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __restrict__ act, float* __restrict__ row_amax,
-                                                                    int8_t* __restrict__ out_q, float* __restrict__ out_s, int d) {
+                                                                    int8_t* __restrict__ out_q, float* __restrict__ out_s, int d,
+                                                                    int nt) {
+  // nt (round 4): prefill-sized tensors (beyond the L2, each byte touched once) are streamed with non-temporal loads / stores
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const int64_t t = blockIdx.x;
   const float amax = row_amax[t];
   const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(act + t * (int64_t)d);
   for (int c = threadIdx.x; c < nvec; c += 512) {
-    const u32x4 v = x[c];
+    const u32x4 v = nt ? __builtin_nontemporal_load(&x[c]) : x[c];
     uint32_t pk[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1389,7 +1407,10 @@ __global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __
       }
       pk[h] = wq;
     }
-    *reinterpret_cast<uint2*>(out_q + t * (int64_t)d + (int64_t)c * 8) = make_uint2(pk[0], pk[1]);
+    u32x2* const dst = reinterpret_cast<u32x2*>(out_q + t * (int64_t)d + (int64_t)c * 8);
+    const u32x2 qv2 = {pk[0], pk[1]};
+    if (nt) __builtin_nontemporal_store(qv2, dst);
+    else *dst = qv2;
   }
   __syncthreads();                       // every thread has read row_amax[t]
   if (threadIdx.x == 0) { out_s[t] = amax / 127.0f; row_amax[t] = 0.0f; }
@@ -1404,7 +1425,8 @@ int xllm_mi355_quantize_with_row_amax(const void* act, float* row_amax, int8_t* 
   if (n_tokens == 0) return XM_OK;
   XM_DISPATCH_HALF(dtype, T,
                    hipLaunchKernelGGL((quantize_with_row_amax_kernel<T>), dim3((unsigned)n_tokens), dim3(512), 0,
-                                      (hipStream_t)stream, (const T*)act, row_amax, out_q, out_scale, (int)d));
+                                      (hipStream_t)stream, (const T*)act, row_amax, out_q, out_scale, (int)d,
+                                      (n_tokens * d * 2 > (48ll << 20)) ? 1 : 0));
   return hip_check_launch();
 }
 
