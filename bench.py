@@ -135,6 +135,48 @@ def live_pmc_traffic(B, ctx, nq, nkv, launches=4, timeout_s=240):
         return None, None
 
 
+def live_mfma_busy(kind, timeout_s=240):
+    """north_star's "MFMA util on the quant GEMM", measured in this run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (one
+    pass) over a few launches of the gate_up GEMM at M = 8192 in a child process (tools/gemm_one.py for int8 with per-row-quantised
+    Gaussian operands, tools/fp8_gemm_one.py for fp8). busy = MFMA-busy cycles / (active cycles per XCD x 1024 SIMDs), the granted
+    clock = active cycles per XCD / kernel duration. Returns a dict or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tool = os.path.join(ROOT, "tools", "gemm_one.py" if kind == "int8" else "fp8_gemm_one.py")
+    tmp = tempfile.mkdtemp(prefix="xm_mfma_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", GEMM_DIST="gauss", GEMM_LAUNCHES="6")
+        subprocess.run([exe, "--kernel-trace", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "-d", tmp, "--", sys.executable,
+                        tool, "8192", "37888", "3584"], cwd="/tmp", env=env, timeout=timeout_s, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if not dbs:
+            return None
+        cur = sqlite3.connect(dbs[0]).cursor()
+        vals = {}
+        for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            row = cur.execute("select sum(value), count(*) from counters_collection where counter_name = ? and kernel_name like "
+                              "'%gemm_p8%'", (c,)).fetchone()
+            if not row or not row[1]:
+                return None
+            vals[c] = float(row[0]) / float(row[1])
+        dur = cur.execute("select avg(end - start) from kernels where name like '%gemm_p8%'").fetchone()[0]
+        cycles = vals["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
+        return {"mfma_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * 1024.0), 4),
+                "clock_ghz": round(cycles / float(dur), 3) if dur else None, "us_under_pmc": round(float(dur) / 1e3, 1) if dur else None}
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] live MFMA-busy pass ({kind}) failed ({e!r}); quoting the committed record instead", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def build_metadata(B, ctx, block_size, device, seed):
     """BatchInputBuilder-shaped decode metadata (framework/batch/batch_input_builder.cpp:739-830, 904-938)."""
     pages = (ctx + block_size - 1) // block_size
@@ -602,7 +644,7 @@ def main():
 
     gemm_info = None
     if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_gemm:
-        gemm_info = gemm_leg(dev)
+        gemm_info = gemm_leg(dev, live_pmc=not a.no_pmc)
 
     shim_info = None
     if a.via_shim and world == 1 and tp_size == 1 and mode == "int8":
@@ -661,19 +703,29 @@ def main():
 
 
 
-def gemm_leg(dev):
+def gemm_leg(dev, live_pmc=True):
     """the quantised GEMM by itself (north_star: ">= 60 % fp8 MFMA util on quant GEMM at TP = 1"): Qwen2-7B gate_up
     (N = 37888, K = 3584) at the prefill M = 8192 and at a decode M = 128, int8 and fp8, timed with HIP events over a
     100-launch graph (weights rotate over 4 copies = 543 MB > Infinity Cache). `frac_of_peak` is achieved / 5 PFLOP/s (the
     dense 8-bit MFMA peak, MI355X_MICROARCH.md); at M = 128 the bound is the weight stream, so `frac_of_hbm` is given too.
-    `mfma_busy` is a PMC figure (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE x SIMDs) and cannot be read inside a run: it is
-    quoted from the committed profile with its source."""
+    `mfma_busy` is a PMC figure (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE x SIMDs): since round 4 it is MEASURED IN THIS RUN by a
+    rocprofv3 --pmc pass over the same GEMM in a child process (live_mfma_busy); the committed record is quoted only when that
+    pass is unavailable."""
     from xllm_amd import ops
     N, K = 37888, 3584
     out = {"shape": f"gate_up N={N} K={K}", "peak_tops": 5000.0, "hbm_peak_gbs": HBM_PEAK_GBS,
            "mfma_busy": {"int8_M8192": 0.638, "fp8_M8192": 0.700, "int8_M8192_clock_ghz": 1.57,
                          "source": "profiles/r03_prefill.txt (int8, round 3) and profiles/r01_gemm_p8_pmc.txt (fp8): rocprofv3 --pmc "
                                    "passes of earlier runs, not measured in this run"}}
+    if live_pmc:
+        li, lf = live_mfma_busy("int8"), live_mfma_busy("fp8")
+        if li is not None and lf is not None:
+            out["mfma_busy"] = {"int8_M8192": li["mfma_busy"], "fp8_M8192": lf["mfma_busy"], "int8_M8192_clock_ghz": li["clock_ghz"],
+                                "fp8_M8192_clock_ghz": lf["clock_ghz"], "int8_us_under_pmc": li["us_under_pmc"],
+                                "fp8_us_under_pmc": lf["us_under_pmc"],
+                                "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE in this run (tools/gemm_one.py "
+                                          "GEMM_DIST=gauss / tools/fp8_gemm_one.py, 8192 x 37888 x 3584): busy = MFMA-busy cycles / "
+                                          "(active cycles per XCD x 1024 SIMDs)"}
     g = torch.Generator(device=dev).manual_seed(3)
     copies = 4
     for kind in ("int8", "fp8"):
