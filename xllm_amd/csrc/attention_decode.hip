@@ -65,7 +65,8 @@ constexpr int kTile = 32;         // tokens per tile (= K dim of the PV MFMA)
 constexpr float kNegBig = -1e30f;  // finite "-inf" for the running max (log2 domain)
 
 // D = head dim (K and V), UNIFORM: block_size % 32 == 0 so a tile lives in one page
-template <typename T, int D, bool UNIFORM, bool DEEP>
+// KROWS: how the K tile is fetched (see issue_loads) -- chosen by the launch plan, bit-identical results either way
+template <typename T, int D, bool UNIFORM, bool DEEP, bool KROWS>
 __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc, T* __restrict__ out,
     float* __restrict__ part_o, float* __restrict__ part_ml, const int32_t* __restrict__ cu_q,
@@ -162,16 +163,36 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
   auto issue_loads = [&](int tile, int page, x8 (&kr)[2][KK], u32x4 (&vr)[NV]) {
     tile = tile < my_hi ? tile : my_hi - 1;
     const int t0 = tile * kTile;
+    if constexpr (KROWS) {
+      // K like V: an instruction fetches WHOLE head rows (64 / CH token rows x 2 D bytes) and compute_tile() re-lays the tile
+      // through the wave's LDS. For a wave whose head is a strided 2D-byte slice of the token rows and whose workgroup does not
+      // hold the row's other heads (hpw < nkv: small batches, DP replicas) this is the faster fetch -- round 4, alternating
+      // libraries on one box (profiles/r04_attn_krows.txt): cfg2 54.5 -> 50.2 us, B = 128 / 64 / 32 at ctx 4096 177 -> 167,
+      // 99.5 -> 92.5, 57.8 -> 52.4 us; with all kv heads of a row in the workgroup (hpw == nkv: the B = 256 headline, TP shards)
+      // the direct operand-layout fetch below ties or wins by 0.6 %, so the plan picks per launch.
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      int tok = t0 + blk * 16 + p16;
-      tok = tok < kv_len ? tok : kv_len - 1;
-      int64_t rowi;
-      if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
-      else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
-      const T* kp = kc + rowi * row_elems + (int64_t)kvh * D + g * 8;
+      for (int j = 0; j < 2 * KK; ++j) {
+        int tok = t0 + j * TPI + lane / CH;
+        tok = tok < kv_len ? tok : kv_len - 1;
+        int64_t rowi;
+        if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
+        else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
+        kr[j / KK][j % KK] = XM_KV_LOAD(reinterpret_cast<const x8*>(kc + rowi * row_elems + (int64_t)kvh * D + (lane % CH) * 8));
+      }
+    } else {
+      // K straight into the MFMA A-operand layout: lane (p16, g) holds K[token blk*16 + p16][(kk*4+g)*8 .. +7] (64-byte pieces of
+      // 16 token rows per instruction)
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) kr[blk][kk] = XM_KV_LOAD(reinterpret_cast<const x8*>(kp + kk * 32));
+      for (int blk = 0; blk < 2; ++blk) {
+        int tok = t0 + blk * 16 + p16;
+        tok = tok < kv_len ? tok : kv_len - 1;
+        int64_t rowi;
+        if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
+        else rowi = (int64_t)bt_row[tok / block_size] * block_size + (tok % block_size);
+        const T* kp = kc + rowi * row_elems + (int64_t)kvh * D + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kr[blk][kk] = XM_KV_LOAD(reinterpret_cast<const x8*>(kp + kk * 32));
+      }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -209,6 +230,25 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     const int t0 = tile * kTile;
     const bool partial = (t0 + kTile > kv_len) || (t0 < t_lo);
 
+    // ---- KROWS: K tile -> wave-private LDS (row major, padded rows) -> MFMA A-operand fragments. The same buffer takes the V
+    //      tile next: the LDS serves a wave's requests in order, so the V writes below cannot overtake these reads.
+    x8 kf[2][KK];
+    if constexpr (KROWS) {
+#pragma unroll
+      for (int j = 0; j < 2 * KK; ++j)
+        *reinterpret_cast<x8*>(my_lds + (j * TPI + lane / CH) * RSB + (lane % CH) * 16) = kr[j / KK][j % KK];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+          kf[blk][kk] = *reinterpret_cast<const x8*>(my_lds + (blk * 16 + p16) * RSB + (kk * 4 + g) * 16);
+    } else {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[blk][kk] = kr[blk][kk];
+    }
+
     // ---- V tile -> wave-private LDS (row major, padded rows); invalid rows zeroed (0 * NaN guard)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -224,7 +264,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     for (int blk = 0; blk < 2; ++blk) {
       s[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) s[blk] = TR::mfma(kr[blk][kk], qf[kk], s[blk]);
+      for (int kk = 0; kk < KK; ++kk) s[blk] = TR::mfma(kf[blk][kk], qf[kk], s[blk]);
     }
     // ---- online softmax (log2 domain), lane-local except the 2 cross-group maxima
     float mx = kNegBig;
@@ -515,21 +555,23 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   // tuning arm (XLLM_MI355_DECODE_EXCL=1, -DXM_TUNING flavour only): grids of at most one workgroup per CU reserve enough extra LDS that two
   // workgroups cannot share a CU, so the dispatcher has to spread them over all 256
   const size_t dyn = (decode_exclusive_cu() && grid.x <= 256) ? 48 * 1024 : 0;
+  const bool krows = hpw < nkv;   // the wave's head is a strided slice of rows whose other heads are elsewhere (see issue_loads)
+#define XM_DECODE_LAUNCH(UNI_, DEEP_, KROWS_, DYN_)                                                                        \
+  hipLaunchKernelGGL((paged_decode_kernel<T, D, UNI_, DEEP_, KROWS_>), grid, dim3(256), DYN_, s, (const T*)q, (const T*)kc, \
+                     (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,        \
+                     (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode)
 #ifdef XM_TUNING  /* the three-stage arm (round-1 A/B loser) exists only in the tuning flavour */
-  if (block_size % kTile == 0 && decode_deep_prefetch())
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, true>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
-                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
+  if (block_size % kTile == 0 && decode_deep_prefetch()) XM_DECODE_LAUNCH(true, true, false, dyn);
   else
 #endif
-  if (block_size % kTile == 0)
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, true, false>), grid, dim3(256), dyn, s, (const T*)q, (const T*)kc,
-                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
-  else
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, false, false>), grid, dim3(256), 0, s, (const T*)q, (const T*)kc,
-                       (const T*)vc, (T*)out, part_o, part_ml, cu_q, kv_lens, block_table, (int)max_blocks, (int)nq,
-                       (int)nkv, (int)block_size, q_stride, scale_log2, nsplit, hpw, wl, kq, kqs, part_mode);
+  if (block_size % kTile == 0) {
+    if (krows) XM_DECODE_LAUNCH(true, false, true, dyn);
+    else XM_DECODE_LAUNCH(true, false, false, dyn);
+  } else {
+    if (krows) XM_DECODE_LAUNCH(false, false, true, 0);
+    else XM_DECODE_LAUNCH(false, false, false, 0);
+  }
+#undef XM_DECODE_LAUNCH
   if (finish) {
     const int vpt = (int)((nq * D + 255) / 256);
 #define XM_FINISH(V_)                                                                                                   \

@@ -432,6 +432,53 @@ __global__ __launch_bounds__(256) void rope_and_cache_kernel(
   }
 }
 
+// The same operator with 16-byte accesses (round 4): NeoX layout, rot_dim == head_size, 16-bit T, head_size % 16 == 0, 16-byte
+// aligned rows. A work item is (head, 8-element block j of the first half): x = row[j], y = row[half + j], both rotated with the
+// expressions of rope_and_cache_kernel (bit-identical), written back and -- for k -- into the cache row. The scalar kernel moved
+// 2 bytes per access: 39 us for the 159 MB of a Qwen2-7B prefill chunk (4 TB/s); nt = prefill-sized tensors are streamed.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_and_cache_vec_kernel(
+    const int64_t* __restrict__ positions, T* __restrict__ q, T* __restrict__ k, const T* __restrict__ v,
+    const T* __restrict__ cache, const int32_t* __restrict__ slot_ids, T* __restrict__ kc, T* __restrict__ vc,
+    int64_t q_stride, int64_t k_stride, int64_t v_stride, int head_size, int nq, int nk, int64_t block_size,
+    int64_t n_blocks, bool nt) {
+  static_assert(sizeof(T) == 2, "16-bit rows");
+  const int64_t t = blockIdx.x;
+  const int half = head_size >> 1, hb = half >> 3;
+  const T* cp = cache + positions[t] * head_size;
+  const int64_t slot = slot_ids[t];
+  const bool store = slot >= 0 && slot / block_size < n_blocks;
+  T* kc_row = kc + slot * (int64_t)nk * head_size;
+  T* vc_row = vc + slot * (int64_t)nk * head_size;
+  const int total = (nq + nk) * hb;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / hb, j0 = (i - h * hb) * 8;
+    const bool is_k = h >= nq;
+    T* arr = is_k ? k + t * k_stride + (int64_t)(h - nq) * head_size : q + t * q_stride + (int64_t)h * head_size;
+    RowVec<T> x, y, c, sn, nx, ny;
+    x.raw = rw_ld16(arr + j0, nt);
+    y.raw = rw_ld16(arr + half + j0, nt);
+    c.raw = *reinterpret_cast<const uint4*>(cp + j0);
+    sn.raw = *reinterpret_cast<const uint4*>(cp + half + j0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xf = x.get(e), yf = y.get(e), cf = c.get(e), sf = sn.get(e);
+      nx.set(e, r16<T>(xf * cf) - r16<T>(yf * sf));
+      ny.set(e, r16<T>(yf * cf) + r16<T>(xf * sf));
+    }
+    rw_st16(arr + j0, nx.raw, nt);
+    rw_st16(arr + half + j0, ny.raw, nt);
+    if (is_k && store) {
+      rw_st16(kc_row + (h - nq) * head_size + j0, nx.raw, nt);
+      rw_st16(kc_row + (h - nq) * head_size + half + j0, ny.raw, nt);
+    }
+  }
+  if (!store) return;
+  const int nv = nk * head_size / 8;
+  const T* vs = v + t * v_stride;
+  for (int i = threadIdx.x; i < nv; i += 256) rw_st16(vc_row + i * 8, rw_ld16(vs + i * 8, nt), nt);
+}
+
 // N1 fusion across the GEMM boundary: the qkv projection's dequant epilogue + RoPE + KV write in ONE pass over the token's row.
 // The packed-weight GEMM (gemm_ws.hip) leaves exact int32 K-slice slabs; this kernel adds them, applies the scaled_matmul
 // epilogue (r16(acc * a_s[t] * w_s[n] + bias[n]): the 16-bit qkv row the reference's linear would have written,
@@ -933,9 +980,11 @@ __global__ __launch_bounds__(512) void act_and_mul_i8_kernel(int8_t* __restrict_
 // per-token int8 quant (reference: kernels/dcu/scaled_quantize.hip:29-109)
 // the row is read once (register cache up to 16 KiB/row of 16-bit data at 512 threads, else re-read)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512) void scaled_quantize_i8_kernel(const T* __restrict__ x, int8_t* __restrict__ out,
-                                                                 float* __restrict__ scales, int K, bool vec) {
+// TH threads per row: 512 for a few long rows (decode: latency), 128 when there are thousands of short ones (prefill: a 7-KiB row per
+// 512-thread workgroup left ~7 MB in flight chip-wide and the kernel at 4 TB/s -- round 4); nt = prefill-sized input, streamed
+template <typename T, int TH>
+__global__ __launch_bounds__(TH) void scaled_quantize_i8_kernel(const T* __restrict__ x, int8_t* __restrict__ out,
+                                                                float* __restrict__ scales, int K, bool vec, bool nt) {
   __shared__ float red[32];
   constexpr int N = RowVec<T>::N;
   constexpr int kCache = 4;
@@ -948,14 +997,14 @@ __global__ __launch_bounds__(512) void scaled_quantize_i8_kernel(const T* __rest
     RowVec<T> xv[kCache];
 #pragma unroll
     for (int i = 0; i < kCache; ++i) {
-      const int c = threadIdx.x + i * 512;
+      const int c = threadIdx.x + i * TH;
       if (c < nvec) {
-        xv[i].raw = reinterpret_cast<const uint4*>(xr)[c];
+        xv[i].raw = rw_ld16(reinterpret_cast<const uint4*>(xr) + c, nt);
 #pragma unroll
         for (int j = 0; j < N; ++j) amax = fmaxf(amax, fabsf(xv[i].get(j)));
       }
     }
-    for (int c = threadIdx.x + kCache * 512; c < nvec; c += 512) {
+    for (int c = threadIdx.x + kCache * TH; c < nvec; c += TH) {
       RowVec<T> v;
       v.raw = reinterpret_cast<const uint4*>(xr)[c];
 #pragma unroll
@@ -981,10 +1030,10 @@ __global__ __launch_bounds__(512) void scaled_quantize_i8_kernel(const T* __rest
     };
 #pragma unroll
     for (int i = 0; i < kCache; ++i) {
-      const int c = threadIdx.x + i * 512;
+      const int c = threadIdx.x + i * TH;
       if (c < nvec) emit(xv[i], c);
     }
-    for (int c = threadIdx.x + kCache * 512; c < nvec; c += 512) {
+    for (int c = threadIdx.x + kCache * TH; c < nvec; c += TH) {
       RowVec<T> v;
       v.raw = reinterpret_cast<const uint4*>(xr)[c];
       emit(v, c);
@@ -1269,6 +1318,18 @@ int xllm_mi355_rotary_embedding_and_cache(const int64_t* positions, void* q, voi
     return XM_ERR_INVALID;
   if (n_tokens == 0) return XM_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (is_neox && rot_dim == head_size && head_size % 16 == 0 && (dtype == XM_BF16 || dtype == XM_F16) && q_stride % 8 == 0 &&
+      k_stride % 8 == 0 && v_stride % 8 == 0 &&
+      ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_sin_cache | (uintptr_t)k_cache | (uintptr_t)v_cache) % 16 == 0) {
+    // prefill-sized rows (beyond the 32 MB of L2, every byte touched once): streamed
+    const bool nt = n_tokens * (n_q_heads + 2 * n_kv_heads) * head_size * 2 > (48ll << 20);
+    XM_DISPATCH_HALF(dtype, T, {
+      hipLaunchKernelGGL((rope_and_cache_vec_kernel<T>), dim3(n_tokens), dim3(256), 0, s, positions, (T*)q, (T*)k, (const T*)v,
+                         (const T*)cos_sin_cache, slot_ids, (T*)k_cache, (T*)v_cache, q_stride, k_stride, v_stride,
+                         (int)head_size, (int)n_q_heads, (int)n_kv_heads, block_size, n_blocks, nt);
+    });
+    return hip_check_launch();
+  }
   XM_DISPATCH_FLOAT(dtype, T, {
     if (is_neox)
       hipLaunchKernelGGL((rope_and_cache_kernel<T, true>), dim3(n_tokens), dim3(256), 0, s, positions, (T*)q, (T*)k,
@@ -1392,25 +1453,38 @@ __global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __
   const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(act + t * (int64_t)d);
-  for (int c = threadIdx.x; c < nvec; c += 512) {
-    const u32x4 v = nt ? __builtin_nontemporal_load(&x[c]) : x[c];
-    uint32_t pk[2];
+  // four 16-byte loads of a thread in flight before the first is consumed (round 4: one at a time left the prefill launch -- 465 MB
+  // in and out -- at 5.6 TB/s)
+  for (int c0 = threadIdx.x; c0 < nvec; c0 += 4 * 512) {
+    u32x4 vv[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint32_t wq = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t word = v[h * 2 + (e >> 1)];
-        const float r = half_bits_to_f32<T>((e & 1) ? (word >> 16) : (word & 0xffffu));
-        const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(r * qinv)));
-        wq |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
-      }
-      pk[h] = wq;
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * 512;
+      if (c < nvec) vv[u] = nt ? __builtin_nontemporal_load(&x[c]) : x[c];
     }
-    u32x2* const dst = reinterpret_cast<u32x2*>(out_q + t * (int64_t)d + (int64_t)c * 8);
-    const u32x2 qv2 = {pk[0], pk[1]};
-    if (nt) __builtin_nontemporal_store(qv2, dst);
-    else *dst = qv2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * 512;
+      if (c >= nvec) break;
+      const u32x4 v = vv[u];
+      uint32_t pk[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t wq = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t word = v[h * 2 + (e >> 1)];
+          const float r = half_bits_to_f32<T>((e & 1) ? (word >> 16) : (word & 0xffffu));
+          const float qv = fmaxf(-127.0f, fminf(127.0f, rintf(r * qinv)));
+          wq |= ((uint32_t)(int)qv & 0xffu) << (8 * e);
+        }
+        pk[h] = wq;
+      }
+      u32x2* const dst = reinterpret_cast<u32x2*>(out_q + t * (int64_t)d + (int64_t)c * 8);
+      const u32x2 qv2 = {pk[0], pk[1]};
+      if (nt) __builtin_nontemporal_store(qv2, dst);
+      else *dst = qv2;
+    }
   }
   __syncthreads();                       // every thread has read row_amax[t]
   if (threadIdx.x == 0) { out_s[t] = amax / 127.0f; row_amax[t] = 0.0f; }
@@ -1468,8 +1542,13 @@ int xllm_mi355_scaled_quantize(const void* x, int8_t* out, float* out_scale, int
   XM_DISPATCH_FLOAT(dtype, T, {
     constexpr int N = Vec16B<T>::N;
     const bool vec = (K % N == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0);
-    hipLaunchKernelGGL((scaled_quantize_i8_kernel<T>), dim3(M), dim3(512), 0, s, (const T*)x, out, out_scale,
-                       (int)K, vec);
+    const bool nt = M * K * (int64_t)sizeof(T) > (48ll << 20);
+    if (vec && M >= 1024 && K / N <= 4 * 128)
+      hipLaunchKernelGGL((scaled_quantize_i8_kernel<T, 128>), dim3(M), dim3(128), 0, s, (const T*)x, out, out_scale,
+                         (int)K, vec, nt);
+    else
+      hipLaunchKernelGGL((scaled_quantize_i8_kernel<T, 512>), dim3(M), dim3(512), 0, s, (const T*)x, out, out_scale,
+                         (int)K, vec, nt);
   });
   return hip_check_launch();
 }
