@@ -189,6 +189,20 @@ XM_API int xllm_mi355_scaled_quantize(const void* x, int8_t* out, float* out_sca
 XM_API int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_scale,
                                     const float* w_scale, const void* bias, void* out, int32_t* acc_out,
                                     int64_t M, int64_t N, int64_t K, int out_dtype, void* stream);
+/* kernel::scaled_matmul with ScaledMatmulParams::c, alpha = beta = 1 (kernels/param.h:852-866: "Result: alpha * (a @ b) +
+ * beta * c"; the DCU backend of the reference drops c, alpha and beta -- kernels/dcu/scaled_matmul.cpp:112-113, 264-265 -- the
+ * MLU backend honours them). out[m,n] = r16( y + c[m,n] ) with y = the 16-bit result of xllm_mi355_scaled_matmul: the GEMM's
+ * rounding first, then a 16-bit add, so that out is bit-identical to scaled_matmul followed by the residual add of
+ * fused_add_rms_norm (fused_layernorm with residual, ops_api.h:43). c [M,N] in the out dtype; out may alias c (in-place
+ * residual update: the row-parallel o_proj / down_proj of a prefill chunk, whose norm pass then reads one tensor instead of two).
+ * Served by the 8-phase kernel's dequant epilogue (prefill shapes); XM_ERR_UNSUPPORTED where a split-K or decode-shaped kernel
+ * would take the problem -- the caller then runs scaled_matmul and adds in a second pass (xllm_amd/ops.py does). */
+XM_API int xllm_mi355_scaled_matmul_add(const int8_t* a, const int8_t* w, const float* a_scale, const float* w_scale,
+                                        const void* bias, const void* c, void* out, int64_t M, int64_t N, int64_t K,
+                                        int out_dtype, void* stream);
+/* out[i] = r16(a[i] + b[i]) over n 16-bit elements (16-byte aligned; out may alias a or b): the second pass of the addend form
+ * above where no GEMM epilogue takes it (torch's `add` on 16-bit tensors: f32 add, one rounding). */
+XM_API int xllm_mi355_add16(void* out, const void* a, const void* b, int64_t n, int dtype, void* stream);
 
 /* ---- pre-packed int8 weights (decode-shaped GEMMs, M <= 512) -------------------------------------------------
  * A decode GEMM streams every weight byte once; the weight-stream kernel (xllm_amd/csrc/gemm_ws.hip) wants them in

@@ -340,8 +340,8 @@ void clear_packed_weight_cache() {
 
 torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, const std::optional<torch::Tensor>& a_scale,
                             const torch::Tensor& b_scale, torch::ScalarType output_dtype,
-                            const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& /*c*/,
-                            const std::string& /*act_mode*/, int64_t quant_bit_size, double /*alpha*/, double /*beta*/,
+                            const std::optional<torch::Tensor>& bias, const std::optional<torch::Tensor>& c,
+                            const std::string& /*act_mode*/, int64_t quant_bit_size, double alpha, double beta,
                             bool /*use_hp_active*/, int64_t a_quant_bit_size,
                             const std::optional<torch::Tensor>& /*a_calib*/,
                             const std::optional<torch::Tensor>& /*b_calib*/,
@@ -356,6 +356,24 @@ torch::Tensor scaled_matmul(const torch::Tensor& a, const torch::Tensor& b, cons
   torch::Tensor out = output.has_value() ? *output : torch::empty({M, N}, a.options().dtype(output_dtype));
   auto as = a_scale->reshape({-1}).contiguous();
   auto bs = b_scale.reshape({-1}).contiguous();
+  // ScaledMatmulParams::c (param.h:852-866): honoured for alpha = beta = 1 -- the reference's DCU backend drops c silently
+  // (kernels/dcu/scaled_matmul.cpp:112-113); any other alpha / beta is refused rather than ignored
+  const bool has_c = c.has_value() && c->defined();
+  if (has_c) {
+    TORCH_CHECK(alpha == 1.0 && beta == 1.0, "mi355 scaled_matmul: c is supported with alpha = beta = 1 only");
+    TORCH_CHECK(c->dim() == 2 && c->size(0) == M && c->size(1) == N && c->scalar_type() == output_dtype && c->is_contiguous(),
+                "scaled_matmul: c must be a contiguous [M, N] tensor of the output dtype");
+    const int rc = xllm_mi355_scaled_matmul_add(a.data_ptr<int8_t>(), b.data_ptr<int8_t>(), as.data_ptr<float>(),
+                                                bs.data_ptr<float>(), p(bias), c->data_ptr(), p(out), M, N, K,
+                                                dt(output_dtype), cur_stream());
+    if (rc == 0) return out;
+    TORCH_CHECK(rc == XM_ERR_UNSUPPORTED, "scaled_matmul (c): ", xllm_mi355_strerror(rc));
+    // no epilogue takes the addend at this shape: the plain product into a temporary, then one 16-bit add
+    torch::Tensor y = scaled_matmul(a, b, a_scale, b_scale, output_dtype, bias, std::nullopt, "none", quant_bit_size, 1.0, 1.0,
+                                    false, a_quant_bit_size, std::nullopt, std::nullopt, std::nullopt);
+    check(xllm_mi355_add16(out.data_ptr(), y.data_ptr(), c->data_ptr(), M * N, dt(output_dtype), cur_stream()), "add16");
+    return out;
+  }
   if (prefer_packed(M, N, K)) {   // decode shapes: the weight-stream kernel on the packed copy; declines fall through
     if (auto wp = packed_weight_for(b)) {
       auto ws = stream_scratch(g_slab_ws, a, kSlabBytes, false);   // (none inside a capture that was not warmed up: unsliced)

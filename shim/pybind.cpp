@@ -52,6 +52,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("scaled_matmul", [](const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& as, const torch::Tensor& bs, std::optional<torch::Tensor> bias) {
     return k::scaled_matmul(a, b, as, bs, torch::kBFloat16, bias, std::nullopt, "none", 8, 1.0, 0.0, false, 8, std::nullopt, std::nullopt, std::nullopt);
   });
+  m.def("scaled_matmul_c", [](const torch::Tensor& a, const torch::Tensor& b, const torch::Tensor& as, const torch::Tensor& bs,
+                              std::optional<torch::Tensor> bias, const torch::Tensor& c, double alpha, double beta,
+                              std::optional<torch::Tensor> output) {
+    return k::scaled_matmul(a, b, as, bs, c.scalar_type(), bias, c, "none", 8, alpha, beta, false, 8, std::nullopt, std::nullopt, output);
+  });
   m.def("packed_weight_cache_size", &k::packed_weight_cache_size);
   m.def("pack_w8a8_weight", &k::pack_w8a8_weight);
   m.def("invalidate_packed_weight", &k::invalidate_packed_weight);

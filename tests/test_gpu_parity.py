@@ -280,6 +280,35 @@ def test_scaled_matmul_int32_exact_and_epilogue(M, N, K):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("M,N,K,dt", [(2048, 3584, 3584, torch.bfloat16), (8192, 3584, 1024, torch.bfloat16),
+                                        (2049, 520, 512, torch.float16), (256, 3584, 3584, torch.bfloat16),
+                                        (1030, 130, 512, torch.bfloat16), (64, 512, 18944, torch.float16)])
+def test_scaled_matmul_with_addend_is_matmul_then_16bit_add(M, N, K, dt):
+    """ScaledMatmulParams::c with alpha = beta = 1 (kernels/param.h:852-866): out = r16(r16(a @ b ...) + c). The prefill shapes take
+    the addend in the 8-phase kernel's dequant epilogue (xllm_mi355_scaled_matmul_add), the others run the product and one add pass:
+    both bit-identical to the oracle's scaled_matmul followed by a 16-bit add, in place (output = c) and out of place."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-127, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+    a_s = (torch.rand(M, generator=g) * 0.05 + 0.01).to(DEV)
+    w_s = (torch.rand(N, generator=g) * 0.02 + 0.01).to(DEV)
+    bias = torch.randn(N, generator=g).to(dt).to(DEV)
+    c = (torch.randn(M, N, generator=g) * 3).to(dt).to(DEV)
+    y = ops.scaled_matmul(a, w, a_s, w_s, dt, bias)                      # the operator without c (parity-tested above)
+    want = (y.float() + c.float()).to(dt)                                # torch's 16-bit add: f32 sum, one rounding
+    if M * N * K <= 256 * 3584 * 3584:                                   # ... and the oracle end to end where it finishes quickly
+        ref = orc.scaled_matmul(a.cpu(), w.cpu(), a_s.cpu(), w_s.cpu(), dt, bias.cpu())
+        assert torch.equal((ref.float() + c.cpu().float()).to(dt), want.cpu())
+    out = ops.scaled_matmul(a, w, a_s, w_s, dt, bias, c=c)
+    assert torch.equal(out, want)
+    assert torch.equal(ops.add_(y, c), want)
+    c_in_place = c.clone()
+    got = ops.scaled_matmul(a, w, a_s, w_s, dt, bias, output=c_in_place, c=c_in_place)
+    assert got.data_ptr() == c_in_place.data_ptr() and torch.equal(c_in_place, want)
+    with pytest.raises(ops.Mi355Error):
+        ops.scaled_matmul(a, w, a_s, w_s, dt, bias, c=c, beta=0.5)
+
+
 def test_splitk_workspace_invariant_across_shapes():
     """split-K paths (prefill-sized and decode-sized) share one workspace that must be all-zero between calls"""
     g = torch.Generator().manual_seed(4)
@@ -1111,6 +1140,34 @@ def test_model_step_fused_equals_reference_operator_order():
         positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=DEV)
         outs.append(model.logits(model.forward(tokens, positions, md, caches)).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_model_prefill_fused_equals_reference_operator_order():
+    """the prefill chunk too: RoPE + KV write in one pass (16-byte accesses since round 4), norm + quant fused, gate_up with SiLU.mul
+    in its epilogue -- hidden states and caches bit-identical to the reference operator order"""
+    from xllm_amd import attention, layers
+    from xllm_amd.attention import KVCache
+    args = layers.ModelArgs(1024, 3, 16, 4, 128, 2048, 4096, 1e-6, 1e6, 4096)
+    bs, lens = 128, [1024, 768, 512]            # T = 2304
+    pages = [L // bs for L in lens]
+    table, used = [], 0
+    for n in pages:
+        table.append(list(range(used, used + n))); used += n
+    bi = attention.build_batch_input([0] * len(lens), lens, table, bs)
+    md = attention.build_attention_metadata(bi, is_prefill=True, is_chunked_prefill=False, device=torch.device(DEV))
+    T = sum(lens)
+    outs = []
+    for fuse in (True, False):
+        model = layers.Qwen2Model(args, "int8", torch.bfloat16, DEV, seed=11, fuse=fuse, n_layers=3)
+        g = torch.Generator(device=DEV).manual_seed(7)
+        caches = [KVCache(torch.zeros(used, bs, 4, 128, device=DEV, dtype=torch.bfloat16),
+                          torch.zeros(used, bs, 4, 128, device=DEV, dtype=torch.bfloat16)) for _ in model.layers]
+        tokens = torch.randint(0, args.vocab_size, (T,), device=DEV, generator=g)
+        hidden = model.forward(tokens, bi.positions.to(DEV).long(), md, caches)
+        outs.append((hidden.clone(), [c.k_cache.clone() for c in caches], [c.v_cache.clone() for c in caches]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)
 
 
 def _padded_decode_metadata(live_lens, B_pad, blocks, bs):

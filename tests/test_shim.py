@@ -76,6 +76,18 @@ def test_shim_matches_oracle_and_ctypes_path():
     big = torch.randint(-127, 128, (600, H), generator=g, dtype=torch.int8).to(dev)     # M = 600: the row-major kernels
     sb = torch.rand(600, generator=g).to(dev) * 0.01
     assert torch.equal(m.scaled_matmul(big, wqd, sb, ws.to(dev), None), ops.scaled_matmul(big, wqd, sb, ws.to(dev), torch.bfloat16))
+    # ScaledMatmulParams::c (param.h:852-866), alpha = beta = 1: product + 16-bit add, at a decode shape (second pass) and a
+    # prefill shape (the 8-phase kernel's epilogue), in place; another alpha / beta is refused, not ignored
+    for rows, (aq, asc) in ((9, (q, s)), (600, (big, sb))):
+        cc = torch.randn(rows, 256, generator=g).bfloat16().to(dev)
+        base = m.scaled_matmul(aq, wqd, asc, ws.to(dev), None)
+        want = (base.float() + cc.float()).bfloat16()
+        assert torch.equal(m.scaled_matmul_c(aq, wqd, asc, ws.to(dev), None, cc, 1.0, 1.0, None), want)
+        inplace = cc.clone()
+        assert torch.equal(m.scaled_matmul_c(aq, wqd, asc, ws.to(dev), None, inplace, 1.0, 1.0, inplace), want)
+        assert torch.equal(ops.scaled_matmul(aq, wqd, asc, ws.to(dev), torch.bfloat16, None, c=cc), want)
+    with pytest.raises(RuntimeError):
+        m.scaled_matmul_c(q, wqd, s, ws.to(dev), None, cc[:9].contiguous(), 1.0, 0.5, None)
     # AttentionImpl::forward (decode): KV write + paged attention
     B, nq, nkv, d, bs = 3, 28, 4, 128, 128
     kv_lens = [300, 129, 517]

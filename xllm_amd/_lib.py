@@ -77,6 +77,8 @@ _SIGS = {
     "xllm_mi355_act_and_mul_dynamic_int8_quant_live": ([vp, vp, vp, i64, i64, ci, ci, vp, i64, vp], ci),
     "xllm_mi355_scaled_quantize": ([vp, vp, vp, i64, i64, ci, vp], ci),
     "xllm_mi355_scaled_matmul": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_scaled_matmul_add": ([vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp], ci),
+    "xllm_mi355_add16": ([vp, vp, vp, i64, ci, vp], ci),
     "xllm_mi355_set_gemm_workspace": ([vp, sz], ci),
     "xllm_mi355_set_gemm_workspace_for_stream": ([vp, vp, sz], ci),
     "xllm_mi355_scaled_matmul_add_rms_norm": ([vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, i64, i64, ci, vp], ci),

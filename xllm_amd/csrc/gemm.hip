@@ -610,7 +610,8 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
                 size_t ws_bytes, hipStream_t s) {
   if (M == 0 || N == 0) return XM_OK;
   // 128x128 / skinny / 8-phase family behind this entry: no gate_up epilogue, no device tile table (those have their own entries)
-  if (!epi_fits(epi, kCapDefer | kCapAccOut | kCapGroupCounts)) return XM_ERR_UNSUPPORTED;
+  if (!epi_fits(epi, kCapDefer | kCapAccOut | kCapGroupCounts | kCapAddend)) return XM_ERR_UNSUPPORTED;
+  if (epi.addend && (KIND != kI8 || epi.defer)) return XM_ERR_UNSUPPORTED;   // (only the un-split 8-phase int8 kernel below honours it)
   if (epi.defer) {  // deferred dequant (see xllm_mi355_scaled_matmul_add_rms_norm): decode-shaped int8 problems only
     if (KIND != kI8 || M > 512 || Kb % BKB != 0 || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) || !workspace ||
         ws_bytes < (size_t)M * N * 4)
@@ -643,6 +644,7 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
     const bool long_k_few_tiles = KIND == kI8 && tiles < 100 && Kb >= 8192 && can_split;
     if (p8 == 1 || (tiles >= p8_min_tiles && !long_k_few_tiles)) {
       if (splits > 1) {
+        if (epi.addend) return XM_ERR_UNSUPPORTED;
         GemmEpi e2 = epi;
         e2.acc_out = reinterpret_cast<int32_t*>(workspace);
         const int rc = launch_gemm_p8<KIND>(A, W, M, N, Kb, e2, workspace, ws_bytes, splits, s);
@@ -658,6 +660,7 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
       return launch_gemm_p8<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, 1, s);
     }
   }
+  if (epi.addend) return XM_ERR_UNSUPPORTED;   // the kernels below have no addend epilogue: the caller adds in a second pass
   const bool skinny_pays = KIND == kI8 || ((M + BM - 1) / BM) * ((N + BN - 1) / BN) < 256;
   if (M <= 512 && Kb % BKB == 0 && M * Kb < (1ll << 31) && N * Kb < (1ll << 31) && skinny_pays && !g_sk_disable)
     return launch_skinny<KIND>(A, W, M, N, Kb, epi, workspace, ws_bytes, s);
@@ -760,6 +763,21 @@ int xllm_mi355_scaled_matmul(const int8_t* a, const int8_t* w, const float* a_sc
   if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16)) return XM_ERR_UNSUPPORTED;  // K step = 128 B
   GemmEpi epi{a_scale, M, w_scale, N, bias, out, acc_out, out_dtype == XM_BF16, nullptr, 0};
+  void* ws;
+  size_t ws_bytes;
+  gemm_ws_for(stream, &ws, &ws_bytes);
+  return launch_gemm<kI8>(a, w, M, N, K, epi, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int xllm_mi355_scaled_matmul_add(const int8_t* a, const int8_t* w, const float* a_scale, const float* w_scale,
+                                 const void* bias, const void* c, void* out, int64_t M, int64_t N, int64_t K, int out_dtype,
+                                 void* stream) {
+  if (!a || !w || !a_scale || !w_scale || !c || !out || M < 0 || N < 0 || K <= 0) return XM_ERR_INVALID;
+  if (out_dtype != XM_BF16 && out_dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (K % 128 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)w % 16) || ((uintptr_t)c % 16) || ((uintptr_t)out % 16) || N % 8)
+    return XM_ERR_UNSUPPORTED;
+  GemmEpi epi{a_scale, M, w_scale, N, bias, out, nullptr, out_dtype == XM_BF16, nullptr, 0};
+  epi.addend = c;
   void* ws;
   size_t ws_bytes;
   gemm_ws_for(stream, &ws, &ws_bytes);

@@ -442,13 +442,14 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   (void)workspace;
   (void)ws_bytes;
   // an epilogue mode the selected kernel cannot honour is declined, never silently dropped
-  if (!epi_fits(epi, KIND == kI8 ? (kCapGateUp | kCapGroupTiles | kCapGather | kCapAccOut)
+  if (!epi_fits(epi, KIND == kI8 ? (kCapGateUp | kCapGroupTiles | kCapGather | kCapAccOut | kCapAddend)
                                  : (KIND == kFP8 ? 0u : (kCapGroupTiles | kCapGather))))
     return XM_ERR_UNSUPPORTED;
   if (Kb % P8_BK != 0 || (N & 7) != 0 || ((uintptr_t)epi.out & 15) || M * Kb >= (1ll << 31) || N * Kb >= (1ll << 31) ||
       (epi.group_counts && !epi.group_tiles))
     return XM_ERR_UNSUPPORTED;
   if (epi.group_tiles && (splits > 1 || KIND == kFP8)) return XM_ERR_UNSUPPORTED;
+  if (epi.addend && (splits > 1 || epi.gate_up || epi.group_tiles || !epi.out)) return XM_ERR_UNSUPPORTED;   // plain dequant epilogue only
   // grouped: M = total rows; every expert may add one partial tile (the table has that many slots)
   const int m_tiles = (int)((M + P8_BM - 1) / P8_BM) + (epi.group_tiles ? epi.n_groups : 0);
   const int n_tiles = (int)((N + P8_BN - 1) / P8_BN);

@@ -33,7 +33,7 @@ constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 128, P8_THREADS = 512;
 constexpr int P8_SLOT = 128 * P8_BK;  // one half-tile: 16 KiB
 
 // epilogue of the 16x16 accumulator layout: acc[mb][nb] (mb = 16-row block 0..7, nb = 16-column block 0..3)
-template <bool SPLITK, bool OUT_BF16>
+template <bool SPLITK, bool OUT_BF16, bool ADDEND>
 __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds, int M, int N, int m0, int n0, int wr,
                                              int wc, int wave, int lane, const GemmEpi& epi) {
   const int g4 = lane >> 4, ml = lane & 15;
@@ -62,6 +62,22 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
   } else {
     const bool has_bias = epi.bias != nullptr;
     const uint16_t* bias16 = reinterpret_cast<const uint16_t*>(epi.bias);
+    // GemmEpi::addend: the lane's 16 row segments are requested up front (a load issued next to its store put one memory
+    // latency per segment on the epilogue's critical path: prefill chunk 55.97 -> 56.75 ms, tools/prefill_ab.py)
+    u32x4 cadd[ADDEND ? 4 : 1][4];
+    if constexpr (ADDEND) {
+      const int n_ld = n0 + wc * 64 + (lane & 7) * 8;
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mr = m0 + wr * 128 + mp * 32 + i * 8 + (lane >> 3);
+          cadd[mp][i] = u32x4{0u, 0u, 0u, 0u};
+          if (mr < M && n_ld < N)
+            cadd[mp][i] = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(epi.addend) + (int64_t)mr * N + n_ld));
+        }
+    }
     float wsv[4][4], bsv[4][4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -117,10 +133,24 @@ __device__ __forceinline__ void p8i_epilogue(i32x4_t (&acc)[8][4], uint8_t* lds,
       if (!epi.out) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
+        u32x4 row16 = *reinterpret_cast<const u32x4*>(blk + (i * 8 + rrow) * 128 + rcol);
         const int mr = m0 + wr * 128 + mp * 32 + i * 8 + rrow;
-        if (mr < M && n_st < N)
+        if (mr < M && n_st < N) {
+          if constexpr (ADDEND) {   // GemmEpi::addend: rT(y + c) on the 16-bit result y (8 columns of one row per lane)
+            const u32x4 c16 = cadd[mp][i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t yw = row16[e], cw = c16[e];
+              auto cvt = [](uint32_t h) -> float {
+                if constexpr (OUT_BF16) return bf16_bits_to_f32((uint16_t)h);
+                else { const uint16_t b = (uint16_t)h; f16_t hv; __builtin_memcpy(&hv, &b, 2); return (float)hv; }
+              };
+              const float y0 = cvt(yw & 0xffffu), y1 = cvt(yw >> 16), c0 = cvt(cw & 0xffffu), c1 = cvt(cw >> 16);
+              row16[e] = pack2x16<OUT_BF16>(y0 + c0, y1 + c1);
+            }
+          }
           P8I_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(epi.out) + (int64_t)mr * N + n_st), row16);
+        }
       }
     }
   }
@@ -199,7 +229,9 @@ __device__ __forceinline__ void p8i_epilogue_gate_up(i32x4_t (&acc)[8][4], uint8
   }
 }
 
-template <bool SPLITK>
+// ADDEND: GemmEpi::addend in the dequant epilogue -- its own instantiation, so the plain kernel's code is untouched (with a run-time
+// branch the plain gate_up GEMM at M = 8192 measured +0.45 %: profiles/r04_gemm_addend.txt)
+template <bool SPLITK, bool ADDEND = false>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A_in,
                                                                 const uint8_t* __restrict__ W_in, int M_in, int N,
                                                                 int64_t Kb, int m_tiles, int n_tiles,
@@ -441,8 +473,8 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
       return;
     }
   }
-  if (epi.out_bf16) p8i_epilogue<SPLITK, true>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
-  else p8i_epilogue<SPLITK, false>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
+  if (epi.out_bf16) p8i_epilogue<SPLITK, true, ADDEND>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
+  else p8i_epilogue<SPLITK, false, ADDEND>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
 }
 
 // same grid / envelope as launch_gemm_p8 (gemm_p8.hip decides which of the two int8 kernels runs)
@@ -454,6 +486,9 @@ int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t 
   if (splits > 1)
     hipLaunchKernelGGL((gemm_p8i_kernel<true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W, (int)M,
                        (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);
+  else if (epi.addend)
+    hipLaunchKernelGGL((gemm_p8i_kernel<false, true>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                       (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);
   else
     hipLaunchKernelGGL((gemm_p8i_kernel<false>), grid, dim3(P8_THREADS), 0, s, (const uint8_t*)A, (const uint8_t*)W,
                        (int)M, (int)N, Kb, m_tiles, n_tiles, per, epi, p8i_kstagger);

@@ -101,6 +101,11 @@ struct GemmEpi {
   int argmax_slots;
   int slab_nt;   // packed kernels: K-slice slabs leave with non-temporal stores (round 4, see ws_epilogue)
   int out_nt;    // 8-phase int8 kernel: non-temporal output stores (outputs larger than the L2; set by launch_gemm_p8i)
+  // round 4: ScaledMatmulParams::c with alpha = beta = 1 (kernels/param.h:852-866, "alpha * (a @ b) + beta * c"): a 16-bit [M, N]
+  // addend folded into the dequant epilogue, out = rT(rT(acc * a_scale * w_scale + bias) + addend) -- the 16-bit GEMM result,
+  // then a 16-bit add, i.e. bit-identical to scaled_matmul followed by the residual add of fused_add_rms_norm. May alias `out`
+  // (every element is read by the lane that then writes it). 8-phase int8 kernel only.
+  const void* addend;
 };
 
 // torch.argmax order: NaN above every number, the first index among equals
@@ -114,12 +119,12 @@ __device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) 
 // lacks is DECLINED (XM_ERR_UNSUPPORTED) -- never dropped with XM_OK (round-3 review: the removed 32x32x32 int8 arm returned OK
 // with nothing written in gate_up mode).
 enum EpiCap : unsigned { kCapGateUp = 1, kCapDefer = 2, kCapGroupTiles = 4, kCapGather = 8, kCapGroupCounts = 16, kCapAccOut = 32,
-                         kCapArgmax = 64 };
+                         kCapArgmax = 64, kCapAddend = 128 };
 inline bool epi_fits(const GemmEpi& e, unsigned caps) {
   const unsigned need = (e.gate_up || e.act_out || e.row_amax ? kCapGateUp : 0u) | (e.defer ? kCapDefer : 0u) |
                         (e.group_tiles ? kCapGroupTiles : 0u) | (e.gather_rows ? kCapGather : 0u) |
                         (e.group_counts && !e.group_tiles ? kCapGroupCounts : 0u) | (e.acc_out ? kCapAccOut : 0u) |
-                        (e.argmax_val || e.argmax_idx ? kCapArgmax : 0u);
+                        (e.argmax_val || e.argmax_idx ? kCapArgmax : 0u) | (e.addend ? kCapAddend : 0u);
   if (!e.out && !e.acc_out && !e.defer && !(e.gate_up && e.act_out) && !(e.argmax_val && e.argmax_idx)) return false;   // nowhere to write
   return (need & ~caps) == 0;
 }

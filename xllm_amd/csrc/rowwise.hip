@@ -1490,7 +1490,35 @@ __global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __
   if (threadIdx.x == 0) { out_s[t] = amax / 127.0f; row_amax[t] = 0.0f; }
 }
 
+// out = rT(a + b), 16-bit tensors of n elements (the second pass of scaled_matmul with an addend where no GEMM epilogue takes it)
+template <typename T>
+__global__ __launch_bounds__(256) void add16_kernel(T* __restrict__ out, const T* a, const T* b, int64_t n) {
+  const int64_t nvec = n / 8;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nvec; c += (int64_t)gridDim.x * 256) {
+    RowVec<T> x, y, r;
+    x.raw = reinterpret_cast<const uint4*>(a)[c];
+    y.raw = reinterpret_cast<const uint4*>(b)[c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.set(j, x.get(j) + y.get(j));
+    reinterpret_cast<uint4*>(out)[c] = r.raw;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += 256) out[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+
 extern "C" {
+
+int xllm_mi355_add16(void* out, const void* a, const void* b, int64_t n, int dtype, void* stream) {
+  if (!out || !a || !b || n < 0) return XM_ERR_INVALID;
+  if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
+  if (((uintptr_t)out | (uintptr_t)a | (uintptr_t)b) % 16) return XM_ERR_UNSUPPORTED;
+  if (n == 0) return XM_OK;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  XM_DISPATCH_HALF(dtype, T, hipLaunchKernelGGL((add16_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                                (T*)out, (const T*)a, (const T*)b, n));
+  return hip_check_launch();
+}
 
 int xllm_mi355_quantize_with_row_amax(const void* act, float* row_amax, int8_t* out_q, float* out_scale, int64_t n_tokens,
                                       int64_t d, int dtype, void* stream) {

@@ -323,10 +323,44 @@ def release_stream_workspaces(stream: "torch.cuda.Stream") -> None:
     check(_lib.lib().xllm_mi355_set_gemm_workspace_for_stream(stream.cuda_stream, 0, 0), "release gemm workspace")
 
 
+def add_(a, b, out=None):
+    """out = r16(a + b) for contiguous 16-bit tensors of one shape (xllm_mi355_add16; out may be a or b)"""
+    _need_cuda(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16) \
+            or not a.is_contiguous() or not b.is_contiguous():
+        raise Mi355Error("add_: two contiguous 16-bit tensors of one shape and dtype")
+    out = out if out is not None else torch.empty_like(a)
+    check(_lib.lib().xllm_mi355_add16(_p(out), _p(a), _p(b), a.numel(), _DT[a.dtype], _stream()), "add16")
+    return out
+
+
 def scaled_matmul(a, b, a_scale, b_scale, output_dtype=torch.bfloat16, bias=None, output=None, acc_out=None,
-                  quant_bit_size: int = 8, a_quant_bit_size: int = 8, b_packed=None):
+                  quant_bit_size: int = 8, a_quant_bit_size: int = 8, b_packed=None, c=None, alpha: float = 1.0,
+                  beta: float = 1.0):
     """dcu::scaled_matmul (dcu_ops_api.h, scaled_matmul.cpp:103-300): a [M,K] int8, b [N,K] int8,
-    a_scale [M]/[M,1] f32, b_scale [N]/[N,1] f32, optional bias [N] (output dtype)."""
+    a_scale [M]/[M,1] f32, b_scale [N]/[N,1] f32, optional bias [N] (output dtype).
+    c (ScaledMatmulParams::c, kernels/param.h:852-866, alpha = beta = 1 only): out = r16(r16(a @ b ...) + c), the 16-bit GEMM
+    result then a 16-bit add -- in the GEMM epilogue where the 8-phase kernel takes the shape (xllm_mi355_scaled_matmul_add), as a
+    second pass (ops.add_) elsewhere; `output` may be c itself (in-place residual update)."""
+    if c is not None:
+        if alpha != 1.0 or beta != 1.0:
+            raise Mi355Error("scaled_matmul: c is supported with alpha = beta = 1 only")
+        _need_cuda(a, b, a_scale, b_scale, c)
+        M, K = a.shape
+        N = b.size(0)
+        if c.shape != (M, N) or c.dtype != output_dtype or not c.is_contiguous():
+            raise Mi355Error("scaled_matmul: c must be a contiguous [M, N] tensor of the output dtype")
+        out = output if output is not None else torch.empty(M, N, dtype=output_dtype, device=a.device)
+        rc = -2
+        if a.is_contiguous() and b.is_contiguous() and M > 0:
+            _ensure_gemm_workspace(a.device)
+            rc = _lib.lib().xllm_mi355_scaled_matmul_add(_p(a), _p(b), _p(a_scale.reshape(-1)), _p(b_scale.reshape(-1)), _p(bias),
+                                                         _p(c), _p(out), M, N, K, _DT[output_dtype], _stream())
+        if rc != -2:
+            check(rc, "scaled_matmul_add")
+            return out
+        y = scaled_matmul(a, b, a_scale, b_scale, output_dtype, bias, None, None, quant_bit_size, a_quant_bit_size, b_packed)
+        return add_(y, c, out)
     _need_cuda(a, b, a_scale, b_scale)
     if quant_bit_size != 8 or a_quant_bit_size != 8:
         raise Mi355Error("scaled_matmul only supports w8a8 quantization")  # scaled_matmul.cpp:120-121
