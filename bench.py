@@ -672,6 +672,8 @@ def main():
                        "layout": layout if world > 1 else "single", "collectives_per_step": collectives_per_step,
                        "allreduce": allreduce_kind,
                        "allreduce_note": (tp_pg.oneshot_note if (tp_pg is not None and tp_size > 1 and world > 1) else None),
+                       "allreduce_grid_limit": (getattr(getattr(tp_pg, "oneshot", None), "grid_limit", None)
+                                                if (tp_pg is not None and tp_size > 1 and world > 1) else None),
                        "eager_collectives_per_step": r["eager_collectives"] if tp_size > 1 else 0,
                        "exposed_comm_ms": exposed_comm_ms,
                        "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,

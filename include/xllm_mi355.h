@@ -671,12 +671,15 @@ XM_API int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, v
  * 16-bit RMSNorm OR out_q [M, H] int8 + out_q_scale [M] = its per-token quantisation. out_sum (optional, may be NULL) receives y.
  * Bit-identical to xllm_mi355_oneshot_allreduce followed by xllm_mi355_fused_add_rms_norm / xllm_mi355_rms_norm_dynamic_int8_quant
  * with a residual. Same buffers, epoch and status as xllm_mi355_oneshot_allreduce (the two may be mixed freely on one stream);
- * every rank calls it with the same M, H. H % 8 == 0, H <= 16384, M * H * 2 <= max_message_bytes (XM_ERR_WORKSPACE otherwise). */
+ * every rank calls it with the same M, H. H % 8 == 0, H <= 16384, M * H * 2 <= max_message_bytes (XM_ERR_WORKSPACE otherwise).
+ * grid_limit: the most blocks a launch may use (whole rows per block), 0 = 64, at most 256. Every block waits for its peers'
+ * blocks, so all ranks' grids must be co-resident: one rank per GPU may pass 256 (a 256-row decode message then has one row per
+ * block -- one dependent exchange + norm chain instead of four), ranks sharing a GPU must keep 64. The same value on every rank. */
 XM_API int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residual, const void* norm_weight, float eps,
                                                      void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum,
                                                      int64_t M, int64_t H, int dtype, void* const* peer_buffers, int rank,
                                                      int world, size_t max_message_bytes, uint32_t* epoch_state, int* status,
-                                                     double timeout_s, void* stream);
+                                                     double timeout_s, int grid_limit, void* stream);
 
 /* The same with the row-parallel W8A8 linear in front of it (linear.cpp:481-507 + 1518-1520): the packed-weight GEMM of
  * xllm_mi355_scaled_matmul_packed leaves this rank's exact int32 K-slice sums in `workspace` and step 1 of the one-shot kernel
@@ -689,7 +692,7 @@ XM_API int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
     const int8_t* a, const int8_t* w_packed, const float* a_scale, const float* w_scale, const void* bias, void* residual,
     const void* norm_weight, float eps, void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t N,
     int64_t K, int dtype, void* workspace, size_t ws_bytes, void* const* peer_buffers, int rank, int world,
-    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, void* stream);
+    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, int grid_limit, void* stream);
 
 #ifdef __cplusplus
 }

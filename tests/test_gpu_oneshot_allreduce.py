@@ -65,7 +65,7 @@ def _worker(rank, world, port, ret, distinct):
             res["log"].append("staged (non-contiguous) message mismatch")
         # the fused tensor-parallel tail: all-reduce + residual add + RMSNorm (+ int8 quant) in one kernel == the three operators
         from xllm_amd import ops
-        for (M, H, quant) in ((256, 3584, True), (256, 3584, False), (5, 512, True), (70, 7168, False), (1, 128, True)):
+        def fused_case(M, H, quant):
             part = (_msg(rank, 300 + M, M * H, torch.bfloat16) * 0.5).view(M, H).cuda()
             g0 = torch.Generator().manual_seed(M * 7 + H)
             resid0 = torch.randn(M, H, generator=g0).bfloat16().cuda()
@@ -87,7 +87,18 @@ def _worker(rank, world, port, ret, distinct):
                 good = torch.equal(got, n_ref)
             if not good:
                 res["ok"] = False
-                res["log"].append(f"fused all-reduce + add + norm mismatch at M={M} H={H} quant={quant}")
+                res["log"].append(f"fused all-reduce + add + norm mismatch at M={M} H={H} quant={quant} grid_limit={ar.grid_limit}")
+
+        for case in ((256, 3584, True), (256, 3584, False), (5, 512, True), (70, 7168, False), (1, 128, True)):
+            fused_case(*case)
+        # grid_limit = 256 (what a one-rank-per-GPU set-up chooses: ONE row per block for a decode message, flag rows beyond the
+        # first 64) -- on a shared GPU at row counts whose two grids still fit the chip together (every block waits for its peer's)
+        res["grid_limit"] = ar.grid_limit
+        chosen = ar.grid_limit
+        ar.grid_limit = 256
+        for case in ((100, 3584, True), (96, 1024, False), (65, 512, True)):
+            fused_case(*case)
+        ar.grid_limit = chosen
         # the same tail fed by the row-parallel W8A8 GEMM's int32 K-slice sums (no dequant pass, no 16-bit partial in memory)
         # == packed scaled_matmul -> all-reduce + add + norm (+ quant), bit for bit; rank 0 carries the bias
         for (M, N, K, quant) in ((256, 3584, 1792, True), (256, 3584, 4736, False), (32, 3584, 896, True), (130, 512, 1024, True)):
@@ -175,6 +186,7 @@ def test_oneshot_allreduce_protocol(distinct):
     for r in range(2):
         assert ret[r]["ok"], ret[r]["log"]
         assert ret[r].get("declines_other_stream") is True
+        assert ret[r].get("grid_limit") == (256 if distinct else 0)    # one row per block only with a GPU per rank
     assert ret[0].get("timeout_reported") is True
 
 

@@ -59,10 +59,10 @@ _SIGS = {
     "xllm_mi355_ipc_close_handle": ([vp], ci),
     "xllm_mi355_oneshot_allreduce": ([vp, i64, ci, C.POINTER(vp), ci, ci, sz, vp, vp, C.c_double, vp], ci),
     "xllm_mi355_oneshot_allreduce_add_rms_norm": ([vp, vp, vp, f32, vp, vp, vp, vp, i64, i64, ci, C.POINTER(vp), ci, ci, sz, vp, vp,
-                                                   C.c_double, vp], ci),
+                                                   C.c_double, ci, vp], ci),
     "xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm": (
         [vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i64, i64, i64, ci, vp, sz, C.POINTER(vp), ci, ci, sz, vp, vp,
-         C.c_double, vp], ci),
+         C.c_double, ci, vp], ci),
     "xllm_mi355_decode_metadata_update": ([C.POINTER(DecodeMetadata), vp], ci),
     "xllm_mi355_reshape_paged_cache": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_build_block_table_from_paged_kv": ([vp, vp, i32, i32, vp, vp], ci),

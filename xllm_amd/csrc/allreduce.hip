@@ -25,8 +25,15 @@
 namespace xm {
 
 constexpr int kArMaxWorld = 8;
-constexpr int kArBlocks = 64;                                  // grid upper bound = flag rows per slot
-constexpr size_t kArFlagBytes = 2 * kArBlocks * kArMaxWorld * sizeof(uint32_t);   // 4 KiB
+// flag rows per slot = the largest grid of a launch. 256 since round 4 (was 64): with `grid_limit` = 256 the fused add + norm
+// kernel gives a decode-step message of 256 rows ONE row per block, so step 3 -- peer loads over xGMI, two block-wide reductions,
+// the stores -- is one dependent chain per block instead of four in a row (round-3 review, next #8.iii). The CALLER picks the
+// limit (0 = 64): every block spin-waits for its peers' blocks, so all ranks' grids must be co-resident -- one rank per GPU may
+// use 256, ranks that SHARE a GPU (the two-process protocol test) must stay at 64 (256 blocks of 512 threads of one rank fill the
+// chip with waiting blocks: measured time-out, round 3). The plain kernel keeps its 64 blocks of >= 16 KiB.
+constexpr int kArBlocks = 256;
+constexpr int kArPlainBlocks = 64;
+constexpr size_t kArFlagBytes = 2 * kArBlocks * kArMaxWorld * sizeof(uint32_t);   // 16 KiB
 constexpr int kArThreads = 512;
 
 struct ArPeers {
@@ -376,7 +383,7 @@ int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* co
   const int64_t n_vec = (int64_t)(bytes / 16);
   // enough blocks to keep the incoming links busy, few enough that the flag traffic stays negligible: >= 16 KiB per block
   int64_t grid = (n_vec * 16 + 16383) / 16384;
-  grid = grid < 1 ? 1 : (grid > kArBlocks ? kArBlocks : grid);
+  grid = grid < 1 ? 1 : (grid > kArPlainBlocks ? kArPlainBlocks : grid);
   const int64_t slot_bytes = (int64_t)((max_message_bytes + 255) / 256 * 256);
   const long long ticks = (long long)((timeout_s > 0 ? timeout_s : 2.0) * 1e8);   // wall_clock64: 100 MHz
   hipStream_t s = (hipStream_t)stream;
@@ -393,7 +400,7 @@ int xllm_mi355_oneshot_allreduce(void* inout, int64_t count, int dtype, void* co
 static int launch_oneshot_norm(xm::ArSlabs sl, const void* partial, void* residual, const void* norm_weight, float eps,
                                void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t H, int dtype,
                                void* const* peer_buffers, int rank, int world, size_t max_message_bytes, uint32_t* epoch_state,
-                               int* status, double timeout_s, void* stream) {
+                               int* status, double timeout_s, int grid_limit, void* stream) {
   if ((!partial && !sl.slabs) || !residual || !norm_weight || !peer_buffers || !epoch_state || !status || M < 0 || H <= 0 ||
       world < 1 || world > kArMaxWorld || rank < 0 || rank >= world)
     return XM_ERR_INVALID;
@@ -412,8 +419,10 @@ static int launch_oneshot_norm(xm::ArSlabs sl, const void* partial, void* residu
     peers.base[p] = p < world ? (char*)peer_buffers[p] : nullptr;
     if (p < world && !peers.base[p]) return XM_ERR_INVALID;
   }
-  // whole rows per block; at most kArBlocks blocks (one flag row each)
-  const int rpb = (int)((M + kArBlocks - 1) / kArBlocks);
+  // whole rows per block; at most `grid_limit` (<= kArBlocks) blocks (one flag row each)
+  if (grid_limit < 0 || grid_limit > kArBlocks) return XM_ERR_INVALID;
+  const int max_blocks = grid_limit > 0 ? grid_limit : kArPlainBlocks;
+  const int rpb = (int)((M + max_blocks - 1) / max_blocks);
   const int grid = (int)((M + rpb - 1) / rpb);
   const int64_t slot_bytes = (int64_t)((max_message_bytes + 255) / 256 * 256);
   const long long ticks = (long long)((timeout_s > 0 ? timeout_s : 2.0) * 1e8);
@@ -432,18 +441,18 @@ int xllm_mi355_oneshot_allreduce_add_rms_norm(const void* partial, void* residua
                                               void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M,
                                               int64_t H, int dtype, void* const* peer_buffers, int rank, int world,
                                               size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s,
-                                              void* stream) {
+                                              int grid_limit, void* stream) {
   if (!partial) return XM_ERR_INVALID;
   return launch_oneshot_norm(xm::ArSlabs{nullptr, 0, 0, nullptr, nullptr, nullptr}, partial, residual, norm_weight, eps, out_norm,
                              out_q, out_q_scale, out_sum, M, H, dtype, peer_buffers, rank, world, max_message_bytes, epoch_state,
-                             status, timeout_s, stream);
+                             status, timeout_s, grid_limit, stream);
 }
 
 int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
     const int8_t* a, const int8_t* w_packed, const float* a_scale, const float* w_scale, const void* bias, void* residual,
     const void* norm_weight, float eps, void* out_norm, int8_t* out_q, float* out_q_scale, void* out_sum, int64_t M, int64_t N,
     int64_t K, int dtype, void* workspace, size_t ws_bytes, void* const* peer_buffers, int rank, int world,
-    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, void* stream) {
+    size_t max_message_bytes, uint32_t* epoch_state, int* status, double timeout_s, int grid_limit, void* stream) {
   if (!a || !w_packed || !a_scale || !w_scale || !workspace || M < 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
   if (dtype != XM_BF16 && dtype != XM_F16) return XM_ERR_UNSUPPORTED;
   if (M == 0) return XM_OK;
@@ -459,7 +468,7 @@ int xllm_mi355_scaled_matmul_oneshot_allreduce_add_rms_norm(
   // ... and step 1 of the one-shot kernel turns them into this rank's 16-bit partial on its way into the exchange slot
   return launch_oneshot_norm(xm::ArSlabs{reinterpret_cast<const int32_t*>(workspace), n_slabs, M * N, a_scale, w_scale, bias},
                              nullptr, residual, norm_weight, eps, out_norm, out_q, out_q_scale, out_sum, M, N, dtype,
-                             peer_buffers, rank, world, max_message_bytes, epoch_state, status, timeout_s, stream);
+                             peer_buffers, rank, world, max_message_bytes, epoch_state, status, timeout_s, grid_limit, stream);
 }
 
 }  // extern "C"

@@ -1453,17 +1453,20 @@ __global__ __launch_bounds__(512) void quantize_with_row_amax_kernel(const T* __
   const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
   const int nvec = d / 8;
   const u32x4* x = reinterpret_cast<const u32x4*>(act + t * (int64_t)d);
-  // four 16-byte loads of a thread in flight before the first is consumed (round 4: one at a time left the prefill launch -- 465 MB
-  // in and out -- at 5.6 TB/s)
-  for (int c0 = threadIdx.x; c0 < nvec; c0 += 4 * 512) {
-    u32x4 vv[4];
+  // six 16-byte loads of a thread in flight before the first is consumed: a row of up to 24576 elements (Qwen2-7B: 18944) is ONE
+  // round trip to memory per workgroup. (Round 4: the prefill launch -- 310 MB in, 155 MB out, nothing of it cache-resident --
+  // takes 80-83 us = 5.6-5.8 TB/s with one, four or six loads in flight: that is what a 2:1 read/write stream gets from this
+  // HBM, not a latency problem; the 7 TB/s of rms_norm in the chunk owes part of its bytes to the Infinity Cache.)
+  constexpr int U = 6;
+  for (int c0 = threadIdx.x; c0 < nvec; c0 += U * 512) {
+    u32x4 vv[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int c = c0 + u * 512;
       if (c < nvec) vv[u] = nt ? __builtin_nontemporal_load(&x[c]) : x[c];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int c = c0 + u * 512;
       if (c >= nvec) break;
       const u32x4 v = vv[u];

@@ -163,6 +163,7 @@ class OneShotAllReduce:
         self.device = torch.device(device)
         self.refused = None
         self._stream = None
+        self.grid_limit = 0          # 0 = the library's 64 blocks; raised below when every rank has a GPU of its own
         world, rank = pg.world_size(), pg.rank()
         total = l.xllm_mi355_oneshot_allreduce_buffer_bytes(self.max_bytes)
         # Every collective below (object all-gather, barrier) runs UNCONDITIONALLY on every rank: a rank-local failure (no
@@ -212,6 +213,11 @@ class OneShotAllReduce:
             except Exception as e:   # noqa: BLE001
                 self.refused = f"peer mapping failed: {e!r}"      # rank-local: agreed below
             same_device = len({d for (_p, _h, _k, d, _e) in everyone}) == 1
+            # one rank per GPU: the fused kernel may use 256 blocks (one row per block for a 256-row decode message); ranks that
+            # share a GPU keep 64 -- every block waits for its peers' blocks, so all grids must be co-resident (csrc/allreduce.hip).
+            # `everyone` is the same list on every rank, so is the choice.
+            if len({d for (_p, _h, _k, d, _e) in everyone}) == world:
+                self.grid_limit = 256
             if any(k >= 2 for (_p, _h, k, _d, _e) in everyone) and not same_device:   # the same verdict on every rank
                 self.refused = self.refused or ("only plain hipMalloc memory could be exported on some rank: not guaranteed "
                                                 "visible to a peer GPU while the kernel runs")
@@ -287,7 +293,7 @@ class OneShotAllReduce:
         rc = l.xllm_mi355_oneshot_allreduce_add_rms_norm(
             pc.data_ptr(), residual.data_ptr(), weight.data_ptr(), float(eps), P(n16), P(q), P(qs), P(ysum), M, H,
             self._DT[partial.dtype], self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes, self.state.data_ptr(),
-            self.status.data_ptr(), self.timeout_s, s)
+            self.status.data_ptr(), self.timeout_s, self.grid_limit, s)
         self._lib.check(rc, "oneshot_allreduce_add_rms_norm")
         out = (q, qs) if quantize else n16
         return (out, ysum) if want_sum else out
@@ -324,7 +330,7 @@ class OneShotAllReduce:
             a_q.data_ptr(), w_packed.data_ptr(), a_scale.data_ptr(), w_scale.data_ptr(), P(bias), residual.data_ptr(),
             weight.data_ptr(), float(eps), P(n16), P(q), P(qs), P(ysum), M, N, K, self._DT[residual.dtype], ws.data_ptr(),
             ws.numel(), self.peers, self.pg.rank(), self.pg.world_size(), self.max_bytes, self.state.data_ptr(),
-            self.status.data_ptr(), self.timeout_s, s)
+            self.status.data_ptr(), self.timeout_s, self.grid_limit, s)
         if rc in (-2, -4):
             return None
         self._lib.check(rc, "scaled_matmul_oneshot_allreduce_add_rms_norm")
