@@ -2,6 +2,8 @@
 # the round's LAST GPU run: the full suite on exactly the tree that is submitted. The log starts with the digest of the sources
 # it ran on (tools/source_digest.py); profiles/r04_pytest_gpu.txt is a copy of it and tests/test_profiles_records.py holds the
 # committed tree to that digest.
+# (Serial on purpose: `pytest -n 3` (pytest-xdist) was tried at the end of round 4 and is SLOWER -- 201 tests in 420 s against 430 in
+# 527 s serial: the oracle's OpenMP teams and the full-size tests' host work contend for the box's cores.)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r4final
 O=gpurun_out/r4final/pytest_gpu.txt
