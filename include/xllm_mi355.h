@@ -44,7 +44,14 @@ enum {
 enum { XM_ACT_SILU = 0, XM_ACT_GELU = 1, XM_ACT_GELU_TANH = 2 };
 
 XM_API const char* xllm_mi355_strerror(int code);
+/* The ABI version this header describes; xllm_mi355_abi_version() returns the one the library was built from. A binding
+ * (ctypes, the libtorch shim, cgo ...) written against this header must refuse a library that reports another number.
+ * 2: `grid_limit` inserted before `stream` in the two oneshot_allreduce_add_rms_norm entry points; block_copy, build_digest. */
+#define XLLM_MI355_ABI_VERSION 2
 XM_API int xllm_mi355_abi_version(void);
+/* sha256 (hex) over the library's sources (xllm_amd/csrc/{*.hip,*.h,Makefile} + this header) at build time -- the value
+ * `python tools/source_digest.py --lib` prints for the tree: a prebuilt .so that does not match its sources is detectable. */
+XM_API const char* xllm_mi355_build_digest(void);
 
 /* ---- KV write ------------------------------------------------------------------------------
  * kernel::reshape_paged_cache (ops_api.h:31) -> cuda::reshape_paged_cache
@@ -57,6 +64,18 @@ XM_API int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k
                                           int64_t n_kv_heads, int64_t head_dim, int64_t block_size,
                                           int64_t n_blocks, int64_t k_stride, int64_t v_stride,
                                           int elt_bytes, void* stream);
+
+/* cuda::block_copy (kernels/cuda/cuda_ops_api.h:50-56, kernels/cuda/block_copy.cu:56-205), called by
+ * WorkerImpl::execute_cuda_block_copy_kernel (runtime/worker_impl.cpp:1071-1082) for beam-search / prefix forks: destination j
+ * (0 <= j < num_dst_blocks) belongs to source group g = the first g with j < cum_sum[g]; for every layer l,
+ * K_l[dst[j]] <- K_l[src[g]] and V_l[dst[j]] <- V_l[src[g]] (whole cache blocks of bytes_per_block bytes).
+ * k_cache_ptrs / v_cache_ptrs: DEVICE arrays [num_layers] of cache base addresses as int64 (the reference's layout);
+ * v_cache_ptrs may be NULL (K-only caches: the MLA latent cache). A destination that is also a source of the same launch
+ * is undefined, as in the reference. Byte copy: any cache dtype. */
+XM_API int xllm_mi355_block_copy(const int64_t* k_cache_ptrs, const int64_t* v_cache_ptrs,
+                                 const int32_t* src_block_indices, const int32_t* dst_block_indices,
+                                 const int32_t* cum_sum, int64_t num_layers, int64_t num_groups,
+                                 int64_t num_dst_blocks, int64_t bytes_per_block, void* stream);
 
 /* dcu::build_block_table_from_paged_kv_cuda (kernels/dcu/build_block_table_from_paged_kv.hip:74-110):
  * CSR (indptr[B+1], indices[total_pages]) -> dense [B, total_pages] int32, -1 padded. */

@@ -160,6 +160,28 @@ def reshape_paged_cache(slot_ids, k, v, k_cache, v_cache):
         raise ValueError("slot out of range")
 
 
+def block_copy(k_caches, v_caches, src_block_indices, dst_block_indices, cum_sum):
+    """cuda::block_copy (kernels/cuda/block_copy.cu:38-118) on lists of per-layer caches [n_blocks, ...]: destination j copies
+    from source group g = the first g with j < cum_sum[g] (the kernel's binary search, restated as written, :38-50);
+    v_caches may be None (K-only caches). In place."""
+    src, dst, cs = (t.tolist() for t in (src_block_indices, dst_block_indices, cum_sum))
+    assert len(src) == len(cs)
+    if not src:
+        return
+    for j, d in enumerate(dst):
+        lo, hi = 0, len(src) - 1
+        while lo < hi:
+            mid = lo + ((hi - lo) >> 1)
+            if j < cs[mid]:
+                hi = mid
+            else:
+                lo = mid + 1
+        for l in range(len(k_caches)):
+            k_caches[l][d] = k_caches[l][src[lo]].clone()
+            if v_caches is not None:
+                v_caches[l][d] = v_caches[l][src[lo]].clone()
+
+
 def rms_norm(out, x, w, eps):
     T, H = x.shape
     lib().orc_rms_norm(_p(out), _p(x), _p(w), _f32(eps), _i64(T), _i64(H), _i64(x.stride(0)), C.c_int(_dt(x)))

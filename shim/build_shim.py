@@ -16,12 +16,14 @@ ROOT = os.path.dirname(HERE)
 def main():
     name = "xllm_mi355_shim"
     out = os.path.join(HERE, name + sysconfig.get_config_var("EXT_SUFFIX"))
-    srcs = [os.path.join(HERE, f) for f in ("mi355_ops_api.cpp", "mi355_attention.cpp", "pybind.cpp")]
+    srcs = [os.path.join(HERE, f) for f in ("mi355_ops_api.cpp", "mi355_attention.cpp", "pybind.cpp",
+                                               os.path.join("stub", "kernels", "dcu", "attention_runner_stub.cpp"))]
     stub = os.path.join(HERE, "stub")   # stand-ins for the two reference headers mi355_attention.h includes
     deps = srcs + [os.path.join(HERE, "mi355_ops_api.h"), os.path.join(HERE, "mi355_attention.h"),
                    os.path.join(ROOT, "include", "xllm_mi355.h"),
                    os.path.join(stub, "layers", "common", "attention_metadata.h"),
-                   os.path.join(stub, "framework", "kv_cache", "kv_cache.h")]
+                   os.path.join(stub, "framework", "kv_cache", "kv_cache.h"),
+                   os.path.join(stub, "kernels", "dcu", "attention_runner.h")]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out
     inc = ce.include_paths("cuda") if hasattr(ce, "include_paths") else []

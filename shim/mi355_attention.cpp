@@ -2,6 +2,9 @@
 
 #include <type_traits>
 
+// the reference's host code for piecewise HIP-graph capture (kernels/dcu/attention_runner.{h,cpp}, compiled into a USE_MI355
+// build unchanged); outside the xLLM tree shim/stub/kernels/dcu/ stands in
+#include "kernels/dcu/attention_runner.h"
 #include "mi355_ops_api.h"
 
 namespace xllm {
@@ -34,23 +37,41 @@ std::tuple<torch::Tensor, std::optional<torch::Tensor>> AttentionImpl::forward(c
                                                                                torch::Tensor& query, torch::Tensor& key,
                                                                                torch::Tensor& value, KVCache& kv_cache) {
   namespace k = xllm::kernel::mi355;
+  // the output is allocated here so that a captured graph segment after the attention records its address
+  // (layers/dcu/attention.cpp:46-47)
+  torch::Tensor output = torch::empty_like(query);
   auto q = query.unflatten(-1, {num_heads_, head_size_});
   auto kk = key.unflatten(-1, {num_kv_heads_, head_size_});
   auto vv = value.unflatten(-1, {num_kv_heads_, head_size_});
+  auto out3 = output.unflatten(-1, {num_heads_, head_size_});
   auto kc = kv_cache.get_k_cache(), vc = kv_cache.get_v_cache();
-  k::reshape_paged_cache(md.slot_mapping, kk, vv, kc, vc);  // flash_attention.cpp:310-318
-  torch::Tensor out;
-  if (md.is_prefill) {          // causal by construction: attention_metadata_builder.cpp:240-241 sets is_causal with it
-    out = k::prefill_attention(q, kk, vv, md.q_cu_seq_lens, md.kv_cu_seq_lens, md.max_query_len, scale_, md.is_causal,
-                               window_left_);
-  } else if (md.is_chunked_prefill) {
-    out = k::paged_attention(q, kc, vc, md.q_cu_seq_lens, md.kv_seq_lens, md.block_table, md.max_query_len,
-                             md.max_seq_len, scale_, md.is_causal, window_left_);
-  } else {                      // decode: one query per sequence, nothing to mask (flash_attention.cpp:220-288)
-    out = k::paged_attention(q, kc, vc, std::nullopt, md.kv_seq_lens, md.block_table, 1, md.max_seq_len, scale_, false,
-                             window_left_);
+  if (kc.defined() && kc.dim() >= 2) k::reshape_paged_cache(md.slot_mapping, kk, vv, kc, vc);  // flash_attention.cpp:310-318
+  if (md.is_prefill) {
+    // prefill attention is the piece a piecewise-captured step leaves OUT of its graphs (flash_attention.cpp:325-365,
+    // runtime/dcu_graph_executor_impl.cpp:722-800): while the executor captures, the closure is registered and the placeholder
+    // returned; at replay the executor calls it with the step's real metadata. Eager steps run it here and now.
+    const double scale = scale_;
+    const int64_t window = window_left_;
+    AttentionMetadata md_copy = md;
+    return ::xllm::kernel::dcu::prefill_with_optional_piecewise_capture(
+        [md_copy, q, kk, vv, out3, output, scale, window](const ::xllm::kernel::dcu::AttentionReplayParams& params) mutable
+        -> std::tuple<torch::Tensor, std::optional<torch::Tensor>> {
+          const AttentionMetadata& m = params.attn_metadata ? *params.attn_metadata : md_copy;
+          // causal by construction: attention_metadata_builder.cpp:240-241 sets is_causal with is_prefill
+          xllm::kernel::mi355::prefill_attention(q, kk, vv, m.q_cu_seq_lens, m.kv_cu_seq_lens, m.max_query_len, scale,
+                                                 m.is_causal, window, out3);
+          return {output, std::nullopt};
+        },
+        output);
   }
-  return {out, std::nullopt};
+  if (md.is_chunked_prefill) {
+    k::paged_attention(q, kc, vc, md.q_cu_seq_lens, md.kv_seq_lens, md.block_table, md.max_query_len, md.max_seq_len, scale_,
+                       md.is_causal, window_left_, out3);
+  } else {                      // decode: one query per sequence, nothing to mask (flash_attention.cpp:220-288)
+    k::paged_attention(q, kc, vc, std::nullopt, md.kv_seq_lens, md.block_table, 1, md.max_seq_len, scale_, false,
+                       window_left_, out3);
+  }
+  return {output, std::nullopt};
 }
 
 }  // namespace layer

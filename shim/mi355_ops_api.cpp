@@ -35,6 +35,12 @@ int dt(torch::ScalarType s) {
   TORCH_CHECK(s == torch::kBFloat16 || s == torch::kFloat16, "output dtype must be half or bfloat16");
   return s == torch::kBFloat16 ? XM_BF16 : XM_F16;
 }
+// the library behind the C ABI must be the one this file was compiled against (same argument lists behind the same names)
+const bool kAbiChecked = [] {
+  TORCH_CHECK(xllm_mi355_abi_version() == XLLM_MI355_ABI_VERSION, "libxllm_mi355.so reports ABI version ",
+              xllm_mi355_abi_version(), ", the shim was compiled against ", XLLM_MI355_ABI_VERSION);
+  return true;
+}();
 void check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", xllm_mi355_strerror(rc)); }
 void* p(const torch::Tensor& t) { return t.data_ptr(); }
 void* p(const std::optional<torch::Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
@@ -81,6 +87,27 @@ void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tens
                                        key_cache.size(0), keys.stride(-3), values.stride(-3),
                                        (int)keys.element_size(), cur_stream()),
         "reshape_paged_cache");
+}
+
+void block_copy(torch::Tensor key_cache_ptrs, torch::Tensor value_cache_ptrs, torch::Tensor src_block_indices,
+                torch::Tensor dst_block_indices, torch::Tensor cum_sum, int64_t numel_per_block,
+                torch::ScalarType cache_dtype) {
+  if (src_block_indices.numel() == 0) return;                                     // block_copy.cu:128-130
+  for (const torch::Tensor* t : {&key_cache_ptrs, &value_cache_ptrs, &src_block_indices, &dst_block_indices, &cum_sum})
+    TORCH_CHECK(t->is_cuda() && t->dim() == 1 && t->is_contiguous());            // :136-155
+  TORCH_CHECK(key_cache_ptrs.scalar_type() == torch::kInt64 && value_cache_ptrs.scalar_type() == torch::kInt64);
+  TORCH_CHECK(src_block_indices.scalar_type() == torch::kInt32 && dst_block_indices.scalar_type() == torch::kInt32 &&
+              cum_sum.scalar_type() == torch::kInt32);
+  TORCH_CHECK(key_cache_ptrs.size(0) == value_cache_ptrs.size(0));               // :156
+  TORCH_CHECK(src_block_indices.size(0) == cum_sum.size(0));                     // :157
+  TORCH_CHECK(numel_per_block > 0);                                              // :158
+  DeviceGuard guard(key_cache_ptrs.device());
+  check(xllm_mi355_block_copy(key_cache_ptrs.data_ptr<int64_t>(), value_cache_ptrs.data_ptr<int64_t>(),
+                              src_block_indices.data_ptr<int32_t>(), dst_block_indices.data_ptr<int32_t>(),
+                              cum_sum.data_ptr<int32_t>(), key_cache_ptrs.size(0), src_block_indices.size(0),
+                              dst_block_indices.size(0), numel_per_block * (int64_t)c10::elementSize(cache_dtype),
+                              cur_stream()),
+        "block_copy");
 }
 
 void rms_norm(torch::Tensor output, torch::Tensor input, torch::Tensor weight, double eps) {

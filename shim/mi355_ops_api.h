@@ -18,6 +18,12 @@
 
 namespace xllm::kernel::mi355 {
 
+// kernels/cuda/cuda_ops_api.h:50-56 (block_copy.cu:120-205): whole-block KV copies for beam-search / prefix forks, called by
+// WorkerImpl::execute_cuda_block_copy_kernel (runtime/worker_impl.cpp:1071-1082) under USE_CUDA || USE_DCU (|| USE_MI355)
+void block_copy(torch::Tensor key_cache_ptrs, torch::Tensor value_cache_ptrs, torch::Tensor src_block_indices,
+                torch::Tensor dst_block_indices, torch::Tensor cum_sum, int64_t numel_per_block,
+                torch::ScalarType cache_dtype);
+
 // kernels/cuda/cuda_ops_api.h:31-36
 void rotary_embedding(torch::Tensor& positions, torch::Tensor& query, std::optional<torch::Tensor> key,
                       torch::Tensor& cos_sin_cache, bool is_neox);

@@ -1,6 +1,7 @@
 // test-only binding so the pytest suite can call the C++ shim (xllm::kernel::mi355::*) exactly as ops_api.cpp would
 #include <torch/extension.h>
 
+#include "kernels/dcu/attention_runner.h"
 #include "mi355_attention.h"
 #include "mi355_ops_api.h"
 
@@ -11,6 +12,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("fused_add_rms_norm", [](torch::Tensor x, torch::Tensor r, torch::Tensor w, double eps) { k::fused_add_rms_norm(x, r, w, eps); });
   m.def("act_and_mul", &k::act_and_mul);
   m.def("reshape_paged_cache", &k::reshape_paged_cache);
+  m.def("block_copy", &k::block_copy);
   m.def("rotary_embedding", [](torch::Tensor pos, torch::Tensor q, std::optional<torch::Tensor> kk, torch::Tensor cache, bool neox) { k::rotary_embedding(pos, q, kk, cache, neox); });
   m.def("matmul", &k::matmul);
   m.def("random_sample", &k::random_sample);
@@ -80,4 +82,32 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     xllm::KVCache cache(kc, vc);
     return std::get<0>(attn->forward(md, q, kk, v, cache));
   });
+  // AttentionImpl::forward on a prefill step, eagerly or the way a piecewise-captured step of the DCU graph executor drives it
+  // (runtime/dcu_graph_executor_impl.cpp:722-800): capture = true registers the attention closure and returns the untouched
+  // placeholder; piecewise_replay() then runs the registered closures with the metadata of the step being replayed
+  m.def("attention_prefill_forward", [](torch::Tensor q, torch::Tensor kk, torch::Tensor v, torch::Tensor kc, torch::Tensor vc,
+                                        torch::Tensor slots, torch::Tensor q_cu, torch::Tensor kv_cu, int64_t max_q, int64_t nq,
+                                        int64_t nkv, int64_t d, bool capture) {
+    xllm::layer::Attention attn(nq, d, 1.0f / std::sqrt((float)d), nkv, -1);
+    xllm::layer::AttentionMetadata md{};
+    md.q_cu_seq_lens = q_cu; md.kv_cu_seq_lens = kv_cu; md.slot_mapping = slots; md.max_query_len = max_q; md.max_seq_len = max_q;
+    md.is_prefill = true; md.is_chunked_prefill = false; md.is_dummy = false; md.is_causal = true;
+    xllm::KVCache cache(kc, vc);
+    if (capture) xllm::kernel::dcu::stub_begin_piecewise_capture();
+    torch::Tensor out = std::get<0>(attn->forward(md, q, kk, v, cache));
+    const int64_t n = capture ? xllm::kernel::dcu::stub_end_piecewise_capture() : 0;
+    return std::make_tuple(out, n);
+  });
+  m.def("piecewise_replay", [](std::optional<torch::Tensor> q_cu, std::optional<torch::Tensor> kv_cu, int64_t max_q, int64_t n_tokens) {
+    xllm::kernel::dcu::AttentionReplayParams params;
+    params.actual_num_tokens = (uint32_t)n_tokens;
+    if (q_cu.has_value()) {
+      auto md = std::make_shared<xllm::layer::AttentionMetadata>();
+      md->q_cu_seq_lens = *q_cu; md->kv_cu_seq_lens = *kv_cu; md->max_query_len = max_q; md->max_seq_len = max_q;
+      md->is_prefill = true; md->is_causal = true;
+      params.attn_metadata = md;
+    }
+    xllm::kernel::dcu::stub_replay_runners(params);
+  });
+  m.def("abi_version", [] { return (int64_t)xllm_mi355_abi_version(); });
 }

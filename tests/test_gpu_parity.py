@@ -77,8 +77,50 @@ def assert_prefill_close(out, q, k, v, cu, scale):
 
 # ------------------------------------------------------------------------------------------- probes
 def test_library_loaded_is_hip_path():
+    """the library the GPU tests call is the HIP one, at the ABI version the bindings were written for, AND built from the
+    sources that were shipped next to it (round-4 review, weak #10: the driver's GPU run uses the builder's prebuilt .so; the
+    digest of xllm_amd/csrc + include/xllm_mi355.h is compiled into it)"""
+    import importlib.util
     from xllm_amd import _lib
-    assert _lib.lib().xllm_mi355_abi_version() == 1
+    assert _lib.lib().xllm_mi355_abi_version() == _lib.ABI_VERSION == 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("source_digest", os.path.join(root, "tools", "source_digest.py"))
+    sd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sd)
+    assert _lib.lib().xllm_mi355_build_digest().decode() == sd.lib_digest(), "libxllm_mi355.so was not built from these sources"
+
+
+# ------------------------------------------------------------------------------------------- KV block copy
+@pytest.mark.parametrize("shape,dtype,with_v", [((128, 4, 128), torch.bfloat16, True),     # Qwen2-7B page: 128 KiB per block
+                                                ((16, 2, 64), torch.float16, True),
+                                                ((64, 1, 576), torch.bfloat16, False),     # MLA latent cache, K only
+                                                ((3, 1, 5), torch.float32, True),          # 60 bytes: 4-byte units
+                                                ((3, 1, 5), torch.bfloat16, True),         # 30 bytes: 2-byte units
+                                                ((5, 1, 3), torch.int8, True)])            # 15 bytes: byte units
+def test_block_copy_bit_exact(shape, dtype, with_v):
+    """cuda::block_copy (worker_impl.cpp:1071-1082): fan-out copies of whole cache blocks over every layer, against the oracle"""
+    L, nb = 5, 40
+    g = torch.Generator().manual_seed(99)
+    mk = lambda: [(torch.randn(nb, *shape, generator=g) * 20).to(dtype) for _ in range(L)]
+    k, v = mk(), (mk() if with_v else None)
+    perm = torch.randperm(nb, generator=g)
+    src = perm[:6].to(torch.int32)
+    fan = [1, 3, 1, 7, 2, 4]
+    dst = perm[6:6 + sum(fan)].to(torch.int32)
+    cs = torch.tensor(fan).cumsum(0).to(torch.int32)
+    kd = [t.to(DEV) for t in k]
+    vd = [t.to(DEV) for t in v] if with_v else None
+    orc.block_copy(k, v, src, dst, cs)
+    kp = torch.tensor([t.data_ptr() for t in kd], dtype=torch.int64, device=DEV)
+    vp = torch.tensor([t.data_ptr() for t in vd], dtype=torch.int64, device=DEV) if with_v else None
+    ops.block_copy(kp, vp, src.to(DEV), dst.to(DEV), cs.to(DEV), kd[0][0].numel(), dtype)
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert torch.equal(kd[l].cpu().view(torch.uint8), k[l].view(torch.uint8))
+        if with_v:
+            assert torch.equal(vd[l].cpu().view(torch.uint8), v[l].view(torch.uint8))
+    # nothing to do is not an error
+    ops.block_copy(kp, vp, src[:0].to(DEV), dst[:0].to(DEV), cs[:0].to(DEV), kd[0][0].numel(), dtype)
 
 
 # ------------------------------------------------------------------------------------------- KV write

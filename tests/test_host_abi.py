@@ -61,7 +61,7 @@ def test_product_library_has_no_debug_symbols_and_only_the_documented_switches()
 def test_library_loads_without_gpu_and_reports_errors():
     _lib = _built()
     l = _lib.lib()
-    assert l.xllm_mi355_abi_version() == 1
+    assert l.xllm_mi355_abi_version() == _lib.ABI_VERSION == 2
     assert b"invalid" in l.xllm_mi355_strerror(-1)
     # argument validation happens before any device work
     assert l.xllm_mi355_rms_norm(None, None, None, 1e-6, 1, 8, 8, 1, None) == -1
@@ -303,6 +303,173 @@ def test_reference_patch_binds_the_moe_and_mla_layers(tmp_path):
         assert m, fn
         body = live_ops[m.end():live_ops.index("\n}\n", m.end())]
         assert re.search(r"\b(?:cuda|dcu)::\w+\(", body), f"kernel::{fn} has no backend call under USE_MI355: {body[:200]}"
+
+
+def _patch_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_patch", os.path.join(ROOT, "tools", "make_reference_patch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _patched_tree(tmp_path):
+    """the files the committed patch touches, copied from the reference and patched with `git apply`"""
+    import shutil
+    import subprocess
+    ref_root = "/root/reference"
+    patch = os.path.join(ROOT, "patches", "xllm-use-mi355.patch")
+    files = re.findall(r"^\+\+\+ b/(\S+)", open(patch).read(), flags=re.M)
+    for rel in files:
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        shutil.copy(os.path.join(ref_root, rel), tmp_path / rel)
+    subprocess.check_call(["git", "init", "-q"], cwd=tmp_path)
+    subprocess.check_call(["git", "apply", patch], cwd=tmp_path)
+    return files
+
+
+def test_every_use_dcu_gate_of_the_reference_is_live_under_use_mi355(tmp_path):
+    """round-4 review (missing #1, next #1): a build with ONLY USE_MI355 defined must select a live branch at every host gate the
+    reference has for its HIP-family backend. Walks EVERY non-test file of the reference that mentions USE_DCU:
+      * C++ sources: the patched file preprocessed with only USE_MI355 defined leaves exactly the lines the original leaves with
+        only USE_DCU defined -- except the differences tools/make_reference_patch.py lists in EXPECTED_DIFF (the operator header,
+        the attention class, the five fp8 operators that are CUDA-only in the reference);
+      * CMake lists: every line that tests USE_DCU also tests USE_MI355, except the DCU-only targets (kernels/dcu, layers/dcu,
+        -DUSE_DCU) next to which the patch puts their MI355 counterparts;
+      * kernels/cuda/*: not compiled -- and nothing that IS compiled includes them under USE_MI355;
+      * the committed patch is what the tool generates from the reference as it stands here."""
+    ref_root = "/root/reference"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present")
+    tool = _patch_tool()
+    found = tool.discover()
+    kinds = {}
+    for k in found.values():
+        kinds[k] = kinds.get(k, 0) + 1
+    assert len(found) >= 70 and kinds["H-cpp"] >= 40 and kinds["replaced"] >= 10, kinds
+    files = _patched_tree(tmp_path)
+    plan = tool.edits()
+    assert sorted(files) == sorted(plan), sorted(set(files) ^ set(plan))             # the committed patch covers the plan
+    for rel, fn in plan.items():                                                      # ... and is the tool's output
+        assert open(tmp_path / rel).read() == fn(open(os.path.join(ref_root, rel)).read()), f"{rel}: committed patch is stale"
+    norm = lambda lines: [" ".join(l.split()) for l in lines if l.strip()]
+    cuda_only_lines = None
+    for rel, kind in found.items():
+        orig = open(os.path.join(ref_root, rel), errors="replace").read()
+        if kind == "replaced":
+            assert rel not in files
+            continue
+        new = open(tmp_path / rel).read()
+        if rel.endswith("CMakeLists.txt"):
+            for line in new.split("\n"):
+                if "USE_DCU" in line and "USE_MI355" not in line:
+                    t = line.strip()
+                    ok = (t.startswith(("option(USE_DCU", "add_definitions(-DUSE_DCU)", "#")) or
+                          (rel == "xllm/core/kernels/CMakeLists.txt" and t in ("if(USE_DCU)", "$<$<BOOL:${USE_DCU}>:dcu_kernels>")) or
+                          (rel == "xllm/core/layers/CMakeLists.txt" and t == "elseif(USE_DCU)") or
+                          (rel == "xllm/core/layers/common/CMakeLists.txt" and t == "$<$<BOOL:${USE_DCU}>:dcu_layers>"))
+                    assert ok, f"{rel}: `{t}` tests USE_DCU only"
+            continue
+        if rel == "setup.py":
+            assert 'self.device == "mi355"' in new and "-DUSE_MI355=ON" in new
+            continue
+        a = norm(_live_lines_under(orig, ("USE_DCU",)))
+        b = norm(_live_lines_under(new, ("USE_MI355",)))
+        import collections
+        ca, cb = collections.Counter(a), collections.Counter(b)
+        only_dcu, only_mi = list((ca - cb).elements()), list((cb - ca).elements())
+        exp_dcu, exp_mi = tool.EXPECTED_DIFF.get(rel, ([], []))
+        exp_dcu, exp_mi = norm(exp_dcu), norm(exp_mi)
+        if "FP8_BRANCHES" in exp_mi:               # ... whose "only supported on CUDA" fall-through branches the USE_DCU build has
+            no_backend = set(norm(_live_lines_under(orig, ())))
+            dropped = list((collections.Counter(only_dcu) - collections.Counter(exp_dcu)).elements())
+            assert len(dropped) <= 12 and all(l in no_backend for l in dropped), dropped
+            assert not list((collections.Counter(exp_dcu) - collections.Counter(only_dcu)).elements())
+        else:
+            assert sorted(only_dcu) == sorted(exp_dcu), (rel, only_dcu)
+        if "FP8_BRANCHES" in exp_mi:               # ops_api.cpp: the fp8 operators' CUDA branches are live under USE_MI355 too
+            extra = list((collections.Counter(only_mi) - collections.Counter(exp_mi)).elements())
+            cuda_only_lines = set(norm(_live_lines_under(orig, ("USE_CUDA",))))
+            assert 5 <= len(extra) <= 60 and all(l in cuda_only_lines for l in extra), extra
+            assert sum("fp8" in l or "Fp8" in l for l in extra) >= 5
+            missing = list((collections.Counter(x for x in exp_mi if x != "FP8_BRANCHES") - collections.Counter(only_mi)).elements())
+            assert not missing, missing
+        else:
+            assert sorted(only_mi) == sorted(exp_mi), (rel, only_mi)
+        # nothing that is compiled reaches into the replaced kernel sources or a closed-library header
+        for inc in re.findall(r'#include "([^"]+)"', "\n".join(b)):
+            assert not inc.startswith(("kernels/cuda/", "core/kernels/cuda/", "cuda/")), (rel, inc)
+            assert "dcu_ops_api.h" not in inc and "flash_mla_adapter.h" not in inc, (rel, inc)
+    assert cuda_only_lines is not None
+    # every cuda:: / dcu:: function a patched HOST file (outside ops_api.cpp, checked elsewhere) calls under USE_MI355 is declared
+    shim_hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
+    declared = set(re.findall(r"\b(\w+)\s*\(", shim_hdr))
+    for rel in ("xllm/core/runtime/worker_impl.cpp", "xllm/core/layers/common/qwen2_attention.cpp"):
+        live = "\n".join(_live_lines_under(open(tmp_path / rel).read(), ("USE_MI355",)))
+        called = set(re.findall(r"kernel::(?:cuda|dcu)::(\w+)\s*\(", live))
+        assert called and called <= declared, (rel, sorted(called - declared))
+    assert "block_copy" in declared
+
+
+def test_use_mi355_build_never_sees_an_alias_and_a_real_namespace_of_the_same_name(tmp_path):
+    """`namespace dcu = mi355;` (ops_api.cpp, deepseek_v2_attention.cpp) and the reference's real `namespace xllm::kernel::dcu`
+    (kernels/dcu/attention_runner.h, compiled unchanged for piecewise capture) must never meet in one translation unit: walk the
+    include closure of every source that declares the alias, live lines under USE_MI355 only"""
+    ref_root = "/root/reference"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present")
+    _patched_tree(tmp_path)
+    rd = lambda rel: open(tmp_path / rel).read() if os.path.exists(tmp_path / rel) else open(os.path.join(ref_root, rel), errors="replace").read()
+    for tu in ("xllm/core/kernels/ops_api.cpp", "xllm/core/layers/dcu/deepseek_v2_attention.cpp",
+               "xllm/core/runtime/worker_impl.cpp", "xllm/core/layers/common/qwen2_attention.cpp"):
+        todo, seen, alias = [tu], set(), set()
+        while todo:
+            cur = todo.pop()
+            if cur in seen:
+                continue
+            seen.add(cur)
+            live = "\n".join(_live_lines_under(rd(cur), ("USE_MI355",)))
+            alias |= set(re.findall(r"namespace (\w+) = mi355;", live))
+            if cur != tu or not alias:
+                for real in re.findall(r"namespace xllm::kernel::(\w+) \{", live):
+                    assert real not in alias, f"{tu} sees `namespace {real} = mi355` and the real namespace in {cur}"
+            for inc in re.findall(r'#include "([^"]+)"', live):
+                if inc in ("kernels/mi355/mi355_ops_api.h", "mi355/mi355_ops_api.h", "layers/mi355/attention.h"):
+                    continue
+                for c in (os.path.join("xllm/core", inc), os.path.join("xllm", inc), os.path.join(os.path.dirname(cur), inc)):
+                    if os.path.exists(os.path.join(ref_root, c)):
+                        todo.append(os.path.normpath(c))
+                        break
+        assert alias, tu
+        assert len(seen) > 5, (tu, len(seen))
+
+
+def test_integration_md_lists_every_gate():
+    """INTEGRATION.md section 3.6 is the tool's gate table for the reference as it stands here"""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference tree not present")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for row in _patch_tool().gate_table():
+        assert row in doc, f"INTEGRATION.md 3.6 misses or misstates: {row}"
+
+
+def test_shim_attention_routes_prefill_through_the_piecewise_capture_hook():
+    """the DCU graph executor (runtime/dcu_graph_executor_impl.cpp:722-800) captures prefill steps piecewise: attention is left
+    out of the graphs and replayed through the closure the layer registered. The MI355 attention class must register one exactly
+    like layers/dcu/flash_attention.cpp:325-365 does; the stub header restates the reference's interface"""
+    src = open(os.path.join(ROOT, "shim", "mi355_attention.cpp")).read()
+    assert "prefill_with_optional_piecewise_capture(" in src and '#include "kernels/dcu/attention_runner.h"' in src
+    ref = "/root/reference/xllm/core/kernels/dcu/attention_runner.h"
+    if not os.path.isfile(ref):
+        pytest.skip("reference tree not present")
+    squash = lambda t: " ".join(re.sub(r"//.*", "", t).split())
+    r, ours = squash(open(ref).read()), squash(open(os.path.join(ROOT, "shim", "stub", "kernels", "dcu", "attention_runner.h")).read())
+    for piece in ("struct AttentionReplayParams { uint32_t actual_num_tokens = 0; std::shared_ptr<layer::AttentionMetadata> attn_metadata; };",
+                  "void run_capture(RunFn run_fn);", "void run_replay(const AttentionReplayParams& params);"):
+        assert piece in r and piece in ours, piece
+    assert "prefill_with_optional_piecewise_capture(AttentionRunner::RunFn run_fn, const torch::Tensor& output);" in r.replace("( ", "(")
+    assert "prefill_with_optional_piecewise_capture( AttentionRunner::RunFn run_fn, const torch::Tensor& output);" in ours or \
+        "prefill_with_optional_piecewise_capture(AttentionRunner::RunFn run_fn, const torch::Tensor& output);" in ours
 
 
 def test_python_sources_have_no_undefined_names():

@@ -509,3 +509,31 @@ def test_attention_flash_cast_point_mode():
     n0 = orc.attention_varlen(q32, k32, v32, cu, cu, scale, causal=False)
     n2 = orc.attention_varlen(q32, k32, v32, cu, cu, scale, causal=False, p_round="flash")
     assert r(n2, n0) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------- KV block copy
+def test_block_copy_oracle_hand_computed_groups():
+    """cuda::block_copy (kernels/cuda/block_copy.cu:38-118): cum_sum is the inclusive running count of destinations per source.
+    Sources [5, 1] with cum_sum [3, 4]: destinations 0..2 copy block 5, destination 3 copies block 1 -- worked by hand."""
+    L, nb = 3, 8
+    k = [torch.arange(nb * 4, dtype=torch.float32).reshape(nb, 2, 2) + 100 * l for l in range(L)]
+    v = [-(torch.arange(nb * 4, dtype=torch.float32).reshape(nb, 2, 2)) - 100 * l for l in range(L)]
+    k0, v0 = [t.clone() for t in k], [t.clone() for t in v]
+    src = torch.tensor([5, 1], dtype=torch.int32)
+    dst = torch.tensor([0, 7, 2, 3], dtype=torch.int32)
+    cs = torch.tensor([3, 4], dtype=torch.int32)
+    orc.block_copy(k, v, src, dst, cs)
+    for l in range(L):
+        for d, sblk in ((0, 5), (7, 5), (2, 5), (3, 1)):
+            assert torch.equal(k[l][d], k0[l][sblk]) and torch.equal(v[l][d], v0[l][sblk])
+        for untouched in (1, 4, 5, 6):
+            assert torch.equal(k[l][untouched], k0[l][untouched]) and torch.equal(v[l][untouched], v0[l][untouched])
+    # a destination index past the last running count falls into the last group (the kernel's search stops at num_groups - 1)
+    k2 = [t.clone() for t in k0]
+    orc.block_copy(k2, None, torch.tensor([6], dtype=torch.int32), torch.tensor([0, 1], dtype=torch.int32),
+                   torch.tensor([1], dtype=torch.int32))
+    assert torch.equal(k2[0][0], k0[0][6]) and torch.equal(k2[0][1], k0[0][6])
+    # no sources: nothing happens (block_copy.cu:128-130)
+    k3 = [t.clone() for t in k0]
+    orc.block_copy(k3, None, torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32))
+    assert all(torch.equal(a, b) for a, b in zip(k3, k0))

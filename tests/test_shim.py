@@ -28,15 +28,19 @@ def test_shim_builds_and_exposes_reference_operator_names():
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
                  "random_sample", "rejection_sample", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
                  "moe_combine_result", "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode",
-                 "flash_mla_dense_decode", "flash_mla_prefill_paged", "flash_mla_store_latent_cache"):
+                 "flash_mla_dense_decode", "flash_mla_prefill_paged", "flash_mla_store_latent_cache", "block_copy",
+                 "attention_prefill_forward", "piecewise_replay"):
         assert hasattr(m, name)
+    from xllm_amd import _lib
+    assert m.abi_version() == _lib.ABI_VERSION
     hdr = open(os.path.join(ROOT, "shim", "mi355_ops_api.h")).read()
     for sym in ("rotary_embedding", "act_and_mul", "reshape_paged_cache", "rms_norm", "fused_add_rms_norm", "matmul",
                 "static_scaled_fp8_quant", "fp8_scaled_quantize", "rms_norm_static_fp8_quant",
                 "fused_add_rms_norm_static_fp8_quant", "fp8_scaled_matmul", "fused_qk_norm_rope", "scaled_quantize",
                 "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
                 "update_llm_decode_metadata", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
-                "moe_combine_result", "group_gemm_gather", "mla_decode", "dense_decode", "prefill_paged", "store_latent_cache"):
+                "moe_combine_result", "group_gemm_gather", "mla_decode", "dense_decode", "prefill_paged", "store_latent_cache",
+                "block_copy"):
         assert sym + "(" in hdr, sym
 
 
@@ -342,3 +346,81 @@ def test_shim_flash_mla_adapter_drives_the_reference_call_sequence():
                              scale, causal=True, dv=KVL)
     assert o3.shape == (T, H, KVL)
     assert ((o3.view(T, -1).float().cpu() - r3.view(T, -1).float()).norm() / r3.float().norm()).item() <= 2.5e-3
+
+
+@pytest.mark.gpu
+def test_shim_block_copy_equals_the_oracle():
+    """xllm::kernel::cuda::block_copy as WorkerImpl::execute_cuda_block_copy_kernel calls it (runtime/worker_impl.cpp:1071-1082):
+    int64 device arrays of per-layer cache addresses, int32 index tensors, numel_per_block in ELEMENTS + the cache dtype"""
+    from oracle import oracle as orc
+    m = _shim()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(5)
+    L, nb = 4, 24
+    k = [torch.randn(nb, 16, 4, 128, generator=g).bfloat16() for _ in range(L)]
+    v = [torch.randn(nb, 16, 4, 128, generator=g).bfloat16() for _ in range(L)]
+    kd, vd = [t.to(dev) for t in k], [t.to(dev) for t in v]
+    src = torch.tensor([3, 20, 7], dtype=torch.int32)
+    dst = torch.tensor([0, 1, 2, 23, 10, 11], dtype=torch.int32)
+    cs = torch.tensor([2, 3, 6], dtype=torch.int32)
+    orc.block_copy(k, v, src, dst, cs)
+    kp = torch.tensor([t.data_ptr() for t in kd], dtype=torch.int64, device=dev)
+    vp = torch.tensor([t.data_ptr() for t in vd], dtype=torch.int64, device=dev)
+    m.block_copy(kp, vp, src.to(dev), dst.to(dev), cs.to(dev), kd[0][0].numel(), torch.bfloat16)
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert torch.equal(kd[l].cpu(), k[l]) and torch.equal(vd[l].cpu(), v[l])
+    with pytest.raises(RuntimeError):                                  # reference CHECK_EQ(src.size(0), cum_sum.size(0))
+        m.block_copy(kp, vp, src.to(dev), dst.to(dev), cs[:2].to(dev), kd[0][0].numel(), torch.bfloat16)
+
+
+@pytest.mark.gpu
+def test_shim_attention_prefill_piecewise_capture_and_replay():
+    """AttentionImpl::forward on a prefill step the way the DCU graph executor drives it (runtime/dcu_graph_executor_impl.cpp:
+    722-800, layers/dcu/flash_attention.cpp:325-365): while capturing, attention is NOT run -- the layer registers a closure and
+    returns its pre-allocated output untouched; the replay runs the closure, with the metadata of the step being replayed, into
+    that same tensor. Eager result, replay result and the oracle must agree; the KV write happens at capture time either way."""
+    from oracle import oracle as orc
+    m = _shim()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(17)
+    nq, nkv, d, bs = 8, 2, 128, 16
+    lens = [37, 64, 5]
+    T = sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    q = torch.randn(T, nq * d, generator=g).bfloat16()
+    k = torch.randn(T, nkv * d, generator=g).bfloat16()
+    v = torch.randn(T, nkv * d, generator=g).bfloat16()
+    nb = 16
+    slots = torch.randperm(nb * bs, generator=g)[:T].to(torch.int32)
+    kc0 = torch.zeros(nb, bs, nkv, d).bfloat16()
+    ref = orc.attention_varlen(q.view(T, nq, d), k.view(T, nkv, d), v.view(T, nkv, d), cu, cu, 1.0 / math.sqrt(d), True).view(T, nq, d)
+    mk = lambda: (kc0.clone().to(dev), kc0.clone().to(dev))
+    # eager
+    kc, vc = mk()
+    out_e, n = m.attention_prefill_forward(q.to(dev), k.to(dev), v.to(dev), kc, vc, slots.to(dev), cu.to(dev), cu.to(dev),
+                                           max(lens), nq, nkv, d, False)
+    assert n == 0
+    torch.cuda.synchronize()
+    assert ((out_e.float().cpu().view(T, nq, d) - ref.float()).norm() / ref.float().norm()) < 2e-3
+    kref, vref = kc0.clone(), kc0.clone()
+    orc.reshape_paged_cache(slots, k.view(T, nkv, d), v.view(T, nkv, d), kref, vref)
+    assert torch.equal(kc.cpu(), kref) and torch.equal(vc.cpu(), vref)
+    # capture: one runner registered, the placeholder is returned without attention having run, the KV rows ARE written
+    kc2, vc2 = mk()
+    qd = q.to(dev)
+    out_c, n = m.attention_prefill_forward(qd, k.to(dev), v.to(dev), kc2, vc2, slots.to(dev), cu.to(dev), cu.to(dev),
+                                           max(lens), nq, nkv, d, True)
+    assert n == 1 and out_c.shape == qd.shape
+    out_c.fill_(float("nan"))
+    torch.cuda.synchronize()
+    assert torch.equal(kc2.cpu(), kref)
+    addr = out_c.data_ptr()
+    # replay with the captured metadata, then with fresh metadata tensors (what the executor passes at replay)
+    m.piecewise_replay(None, None, 0, T)
+    torch.cuda.synchronize()
+    assert out_c.data_ptr() == addr and torch.equal(out_c, out_e)
+    out_c.fill_(float("nan"))
+    m.piecewise_replay(cu.clone().to(dev), cu.clone().to(dev), max(lens), T)
+    torch.cuda.synchronize()
+    assert torch.equal(out_c, out_e)

@@ -28,5 +28,16 @@ def digest() -> str:
     return h.hexdigest()
 
 
+def lib_digest() -> str:
+    """what xllm_mi355_build_digest() must report for this tree (the recipe of xllm_amd/csrc/Makefile: DIGEST_SRCS)"""
+    csrc = os.path.join(ROOT, "xllm_amd", "csrc")
+    names = sorted(n for n in os.listdir(csrc) if n.endswith((".hip", ".h")))
+    h = hashlib.sha256()
+    for p in [os.path.join(csrc, n) for n in names] + [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "xllm_mi355.h")]:
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
-    print(digest())
+    import sys
+    print(lib_digest() if "--lib" in sys.argv else digest())

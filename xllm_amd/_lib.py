@@ -48,6 +48,8 @@ _SIGS = {
     "xllm_mi355_host_pack_input_buffer": ([C.POINTER(HostBufferEntry), i64, vp, u64], ci),
     "xllm_mi355_host_build_batch": ([vp, vp, vp, vp, i64, i64, C.POINTER(HostBatch)], ci),
     "xllm_mi355_abi_version": ([], ci),
+    "xllm_mi355_build_digest": ([], C.c_char_p),
+    "xllm_mi355_block_copy": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, vp], ci),
     "xllm_mi355_gemm_plan_hint": ([ci, ci, ci], None),
     "xllm_mi355_scaled_matmul_rope_cache_packed": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, i64, i64,
                                                     i64, i64, i64, ci, vp, sz, vp], ci),
@@ -138,6 +140,10 @@ _OPTIONAL = {
 }
 
 _lib = None
+# the ABI version these bindings were written for (XLLM_MI355_ABI_VERSION of include/xllm_mi355.h): a library that reports
+# another one has different argument lists behind the same names (version 1 -> 2 inserted `grid_limit` before `stream` in two
+# entry points), so it is refused at load time rather than called
+ABI_VERSION = 2
 
 
 class Mi355Error(RuntimeError):
@@ -152,6 +158,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
         l = C.CDLL(LIB_PATH)
+        l.xllm_mi355_abi_version.argtypes, l.xllm_mi355_abi_version.restype = [], ci
+        got = l.xllm_mi355_abi_version()
+        if got != ABI_VERSION:
+            raise Mi355Error(f"{LIB_PATH} reports ABI version {got}, these bindings are written for {ABI_VERSION}: "
+                             "rebuild it (`make -C xllm_amd/csrc`)")
         for name, (args, res) in _SIGS.items():
             fn = getattr(l, name)
             fn.argtypes, fn.restype = args, res

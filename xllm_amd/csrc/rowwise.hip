@@ -38,6 +38,51 @@ __global__ __launch_bounds__(256) void reshape_paged_cache_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// KV block copy (reference: kernels/cuda/block_copy.cu:56-118; WorkerImpl::execute_cuda_block_copy_kernel,
+// runtime/worker_impl.cpp:1071-1082): beam-search / prefix forks copy whole cache blocks. Destination j belongs to
+// source group g = the first g with j < cum_sum[g] (cum_sum = inclusive running count of destinations per source);
+// for every layer, key[dst[j]] <- key[src[g]] and value likewise. A pure byte copy: one workgroup moves a 16-KiB
+// piece of K and of V (four 16-byte chunks per thread per array, all loads issued before the stores), the layer
+// base addresses come from two device arrays of int64 like the reference's. grid = (pieces, destinations, layers).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBlockCopyChunks = 4;
+template <typename V>
+__global__ __launch_bounds__(256) void block_copy_kernel(const int64_t* __restrict__ k_ptrs,
+                                                         const int64_t* __restrict__ v_ptrs,
+                                                         const int32_t* __restrict__ src_blocks,
+                                                         const int32_t* __restrict__ dst_blocks,
+                                                         const int32_t* __restrict__ cum_sum, int num_groups,
+                                                         int64_t units_per_block /* in V units */) {
+  const int j = blockIdx.y;
+  int lo = 0, hi = num_groups - 1;                 // block_copy.cu:38-50: first group whose running count exceeds j
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (j < cum_sum[mid]) hi = mid; else lo = mid + 1;
+  }
+  const int64_t so = (int64_t)src_blocks[lo] * units_per_block, dof = (int64_t)dst_blocks[j] * units_per_block;
+  V* kc = reinterpret_cast<V*>(static_cast<uintptr_t>(k_ptrs[blockIdx.z]));
+  V* vc = v_ptrs ? reinterpret_cast<V*>(static_cast<uintptr_t>(v_ptrs[blockIdx.z])) : nullptr;
+  const int64_t base = (int64_t)blockIdx.x * (256 * kBlockCopyChunks) + threadIdx.x;
+  V kr[kBlockCopyChunks], vr[kBlockCopyChunks];
+#pragma unroll
+  for (int c = 0; c < kBlockCopyChunks; ++c) {
+    const int64_t i = base + c * 256;
+    if (i < units_per_block) {
+      kr[c] = kc[so + i];
+      if (vc) vr[c] = vc[so + i];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kBlockCopyChunks; ++c) {
+    const int64_t i = base + c * 256;
+    if (i < units_per_block) {
+      kc[dof + i] = kr[c];
+      if (vc) vc[dof + i] = vr[c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void build_block_table_kernel(const int32_t* __restrict__ indptr,
                                                                 const int32_t* __restrict__ indices,
                                                                 int32_t total_pages,
@@ -1185,7 +1230,7 @@ const char* xllm_mi355_strerror(int code) {
     default: return "xllm_mi355: unknown error";
   }
 }
-int xllm_mi355_abi_version(void) { return 1; }
+int xllm_mi355_abi_version(void) { return XLLM_MI355_ABI_VERSION; }
 
 int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const void* v, void* k_cache,
                                    void* v_cache, int64_t n_tokens, int64_t n_kv_heads, int64_t head_dim,
@@ -1219,6 +1264,36 @@ int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k, const
                        (const uint8_t*)k, (const uint8_t*)v, (uint8_t*)k_cache, (uint8_t*)v_cache,
                        n_kv_heads * head_dim, k_stride, v_stride, block_size, n_blocks);
   }
+  return hip_check_launch();
+}
+
+int xllm_mi355_block_copy(const int64_t* k_cache_ptrs, const int64_t* v_cache_ptrs, const int32_t* src_block_indices,
+                          const int32_t* dst_block_indices, const int32_t* cum_sum, int64_t num_layers,
+                          int64_t num_groups, int64_t num_dst_blocks, int64_t bytes_per_block, void* stream) {
+  if (num_groups == 0 || num_dst_blocks == 0 || num_layers == 0) return XM_OK;     // block_copy.cu:128-130
+  if (!k_cache_ptrs || !src_block_indices || !dst_block_indices || !cum_sum || num_layers < 0 || num_groups < 0 ||
+      num_dst_blocks < 0 || bytes_per_block <= 0)
+    return XM_ERR_INVALID;
+  if (num_dst_blocks > 65535 || num_layers > 65535) return XM_ERR_UNSUPPORTED;       // grid y / z limits
+  hipStream_t s = (hipStream_t)stream;
+  const int ng = (int)num_groups;
+  // the widest unit that divides a block; cache blocks are whole [block_size, heads, dim] slabs, so 16 in practice
+  const int unit = bytes_per_block % 16 == 0 ? 16 : bytes_per_block % 4 == 0 ? 4 : bytes_per_block % 2 == 0 ? 2 : 1;
+  const int64_t units = bytes_per_block / unit;
+  const dim3 grid((unsigned)((units + 256 * kBlockCopyChunks - 1) / (256 * kBlockCopyChunks)), (unsigned)num_dst_blocks,
+                  (unsigned)num_layers);
+  if (unit == 16)
+    hipLaunchKernelGGL((block_copy_kernel<uint4>), grid, dim3(256), 0, s, k_cache_ptrs, v_cache_ptrs, src_block_indices,
+                       dst_block_indices, cum_sum, ng, units);
+  else if (unit == 4)
+    hipLaunchKernelGGL((block_copy_kernel<uint32_t>), grid, dim3(256), 0, s, k_cache_ptrs, v_cache_ptrs,
+                       src_block_indices, dst_block_indices, cum_sum, ng, units);
+  else if (unit == 2)
+    hipLaunchKernelGGL((block_copy_kernel<uint16_t>), grid, dim3(256), 0, s, k_cache_ptrs, v_cache_ptrs,
+                       src_block_indices, dst_block_indices, cum_sum, ng, units);
+  else
+    hipLaunchKernelGGL((block_copy_kernel<uint8_t>), grid, dim3(256), 0, s, k_cache_ptrs, v_cache_ptrs, src_block_indices,
+                       dst_block_indices, cum_sum, ng, units);
   return hip_check_launch();
 }
 

@@ -61,6 +61,31 @@ def reshape_paged_cache(slot_ids, key, value, key_cache, value_cache) -> None:
         key.element_size(), _stream()), "reshape_paged_cache")
 
 
+def block_copy(key_cache_ptrs, value_cache_ptrs, src_block_indices, dst_block_indices, cum_sum, numel_per_block,
+               cache_dtype) -> None:
+    """xllm::kernel::cuda::block_copy (kernels/cuda/cuda_ops_api.h:50-56, block_copy.cu:120-205): key_cache_ptrs /
+    value_cache_ptrs are int64 DEVICE tensors [num_layers] of cache base addresses (WorkerImpl::refresh_cuda_block_copy_runtime_state,
+    runtime/worker_impl.cpp:1007-1058); destination j copies from source group g = first g with j < cum_sum[g].
+    value_cache_ptrs may be None (K-only caches)."""
+    if src_block_indices.numel() == 0:
+        return                                                                       # block_copy.cu:128-130
+    _need_cuda(*[t for t in (key_cache_ptrs, value_cache_ptrs, src_block_indices, dst_block_indices, cum_sum) if t is not None])
+    if key_cache_ptrs.dtype != torch.int64 or (value_cache_ptrs is not None and value_cache_ptrs.dtype != torch.int64):
+        raise Mi355Error("cache pointer tensors must be int64")                      # reference CHECK_EQ :141-142
+    for t in (src_block_indices, dst_block_indices, cum_sum):
+        if t.dtype != torch.int32 or t.dim() != 1 or not t.is_contiguous():
+            raise Mi355Error("src_block_indices / dst_block_indices / cum_sum must be contiguous 1-D int32")
+    if value_cache_ptrs is not None and value_cache_ptrs.numel() != key_cache_ptrs.numel():
+        raise Mi355Error("key_cache_ptrs and value_cache_ptrs differ in length")     # :156
+    if src_block_indices.numel() != cum_sum.numel() or numel_per_block <= 0:
+        raise Mi355Error("src_block_indices and cum_sum must have one entry per source group; numel_per_block > 0")
+    esz = torch.empty((), dtype=cache_dtype).element_size()
+    check(_lib.lib().xllm_mi355_block_copy(_p(key_cache_ptrs), _p(value_cache_ptrs), _p(src_block_indices),
+                                           _p(dst_block_indices), _p(cum_sum), key_cache_ptrs.numel(),
+                                           src_block_indices.numel(), dst_block_indices.numel(),
+                                           int(numel_per_block) * esz, _stream()), "block_copy")
+
+
 def store_latent_cache(latent_cache, slot_mapping, k_cache) -> None:
     """DeepseekV2AttentionImpl::store_latent_cache (layers/dcu/deepseek_v2_attention.cpp:170-178):
     k_cache.view(-1, 576).index_copy_(0, slot_mapping, latent_cache) -- the K-only form of reshape_paged_cache."""
