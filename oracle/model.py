@@ -76,6 +76,13 @@ class OracleQwen2:
         orc.fused_add_rms_norm(x, residual, w, eps)                          # both updated in place
         return x, residual
 
+    def _attention(self, q3, k3, v3, kc, vc, md, phase):                     # flash_attention.cpp:320-376
+        if phase == "prefill":
+            return orc.attention_varlen(q3, k3, v3, md["q_cu_seq_lens"], md["kv_cu_seq_lens"], self.scale, True, -1,
+                                        self.p_round)
+        return orc.paged_attention(q3, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"],
+                                   self.scale, phase == "chunked", -1, self.p_round)
+
     # ---- one decoder layer -----------------------------------------------------------------------------------------
     def _layer(self, lw, x, residual, positions, md, kc, vc, phase):
         t = self._t
@@ -93,13 +100,7 @@ class OracleQwen2:
         k3 = k.unflatten(-1, (self.nkv, self.d))
         v3 = v.unflatten(-1, (self.nkv, self.d))
         orc.reshape_paged_cache(md["new_cache_slots"], k3, v3, kc, vc)       # flash_attention.cpp:310-318
-        if phase == "prefill":
-            attn = orc.attention_varlen(q3, k3, v3, md["q_cu_seq_lens"], md["kv_cu_seq_lens"], self.scale, True, -1,
-                                        self.p_round)
-        else:
-            attn = orc.paged_attention(q3, kc, vc, md["q_cu_seq_lens"], md["kv_seq_lens"], md["block_tables"],
-                                       self.scale, phase == "chunked", -1, self.p_round)
-        t("attn", attn)
+        attn = t("attn", self._attention(q3, k3, v3, kc, vc, md, phase))
         x = t("o_proj", self._linear(attn.view(T, self.q_size), lw["o"]))
         x, residual = self._apply_norm(x, residual, lw["post_norm_w"])
         t("post_norm", x); t("residual2", residual)

@@ -7,7 +7,8 @@ same operators in the same order (gather / sub_ / scatter_, sort / masked_fill_ 
 
 Parity pinned: the reference holds no golden vector for these functions (tests/core/framework/sampling/ has sampling_params_test
 and rejection_sampler_test only); the restatement is the same torch calls, and tests/test_oracle_sampling.py pins its semantics on
-hand-computed cases (which ranks survive for a given p, the k <= 0 rule, the "at least one" rule of the both-given branch).
+hand-computed cases (which ranks survive for a given p, the k <= 0 rule -- "no limit" under both rules since round 5 --, the
+"at least one" rule of the both-given branch).
 One deliberate choice: torch.sort(descending=True) is called with stable=True so that ties have a defined order (by column index);
 the reference's unstable sort leaves it unspecified.
 """
@@ -33,10 +34,15 @@ def apply_temperatures(logits, temperatures):
     logits.div_(t)
 
 
-def apply_top_k_top_p_torch_impl(logits, top_k, top_p):
+def apply_top_k_top_p_torch_impl(logits, top_k, top_p, nonpositive_k_is_unlimited=False):
+    """logits_utils.cpp:61-84 as written (k clamped to [1, vocab]); with nonpositive_k_is_unlimited the k <= 0 rows keep every
+    column, as the reference's NPU both-given branch (:109-116) and its one-of-them branch (:126-133) do"""
     vocab = logits.size(-1)
     srt, idx = logits.sort(dim=-1, descending=True, stable=True)
-    k = top_k.unsqueeze(-1).clamp(1, vocab).to(torch.long)
+    k = top_k.unsqueeze(-1)
+    if nonpositive_k_is_unlimited:
+        k = torch.where(k <= 0, torch.tensor(vocab, dtype=k.dtype), k)
+    k = k.clamp(1, vocab).to(torch.long)
     k_mask = torch.arange(vocab).expand_as(srt) >= k
     srt.masked_fill_(k_mask, float("-inf"))
     p = top_p.unsqueeze(-1)
@@ -55,7 +61,10 @@ def apply_top_k_top_p(logits, temperatures, top_k, top_p):
     if top_k is None and top_p is None:
         return logits
     if top_k is not None and top_p is not None:
-        apply_top_k_top_p_torch_impl(logits, top_k, top_p)     # (what this backend applies; see the module docstring of the kernel)
+        # what this backend applies: torch_impl's inclusive prefix + "at least one", with k <= 0 = no limit (the reference's
+        # default top_k = -1 must not turn into top-1 in a mixed batch; on CUDA / DCU the reference's both-given branch is EMPTY,
+        # :108-119, so there is no behaviour to match beyond the branches that exist)
+        apply_top_k_top_p_torch_impl(logits, top_k, top_p, nonpositive_k_is_unlimited=True)
         return logits
     srt, idx = logits.sort(dim=-1, descending=True, stable=True)
     if top_k is not None:

@@ -272,13 +272,15 @@ def test_free_running_qwen2_7b_geometry_ragged_decode(mode):
     drift = [_rel(outs[1][0][b], ref[b]) for b in range(B)]
     _record(test="free_running_qwen2_7b_2layer_ragged_decode", mode=mode, hip_vs_oracle=errs,
             control_oracle_alt_order_vs_oracle=drift)
-    # 16-bit: a smooth drift, the HIP path within 2x the control. int8: re-quantisation makes the drift DISCRETE (a row is
-    # either bit-close, ~1e-4, or one quantisation step off, ~1e-2, in HIP and control alike), so rows are compared with
-    # the size of one int8 step through two layers instead
+    # 16-bit: a smooth drift, the HIP path within 2x the control. int8: the drift is DISCRETE (a row is either bit-close or one
+    # re-rolled int8 code and its cascade away) and this control -- re-ordered LINEARS, exact in int8 -- perturbs nothing that
+    # feeds a quantiser (round-4 review, weak #1): the int8 bar lives in test_free_running_int8_jumps_are_attributed_and_match_
+    # the_control below, on 64 rows against controls that perturb the attention's summation order; here only the absolute
+    # size of one jump is held
     if mode == "16bit":
         assert max(errs) <= 2.0 * max(drift), (errs, drift)
     else:
-        assert max(errs) <= 5e-2 and sorted(errs)[B // 2 - 1] <= 1e-3, errs
+        assert max(errs) <= 5e-2, errs
     for b in range(B):
         _check_token(hip[b], ref[b], max(max(drift), errs[b]), f"seq {b}")
     # the decode step wrote this step's K rows at the slots the host builder computed: layer 0 (identical inputs on both
@@ -287,6 +289,66 @@ def test_free_running_qwen2_7b_geometry_ragged_decode(mode):
     k_hip, k_ref = run.caches[0].k_cache.cpu(), kcs[0]
     assert (k_hip != k_ref).sum().item() <= 0.01 * B * 4 * 128
     assert ((k_hip.float() - k_ref.float()).abs() <= 2.0 ** -7 * k_ref.float().abs() + 1e-6).all()
+
+
+@pytest.mark.timeout(1500)
+def test_free_running_int8_jumps_are_attributed_and_match_the_control():
+    """round-4 review (weak #1, next #2): in a W8A8 model a free-running row is either bit-close to the oracle or a discrete
+    JUMP away (1e-3 .. 4e-2 in the logits). This test shows where the jumps come from and holds their size AND frequency to a
+    control that perturbs what actually feeds a quantiser -- the attention's fp32 summation order:
+
+      * 2 weight seeds x 32 sequences (two Qwen2-7B-geometry layers, one ragged decode step over random caches);
+      * controls = the oracle with its decode attention evaluated in other, equally valid, orders: keys split in 1 / 2 / 4 / 8
+        ranges merged in fp32, flash-decoding's online order over 16- / 64-key tiles, softmax in base e or base 2 -- and the
+        online order with P entering the PV product as hi + lo 16-bit parts (p to ~2^-17), the cast point of
+        attention_decode.hip:289-300 (the matrix core takes 16-bit operands);
+      * attribution, row by row (tests/_model_parity.py::attribute_rows): the first operator whose output differs from the
+        oracle's and the first per-token quantiser whose int8 codes differ.
+
+    Asserted: (a) the fused model is bit-equal to the reference operator order; (b) every HIP row is either clean (<= 3e-4: the
+    16-bit lm_head's summation order) or a jump whose FIRST difference is a handful of 1-ulp elements of an attention output and
+    whose first code difference is <= 4 codes of the o_proj operand moving by exactly 1 with the row's scale unchanged;
+    (c) size: HIP's largest jump <= 1.25 x the controls' largest; (d) frequency: HIP's jumps <= 1.5 x the hi + lo control's + 2
+    over the same 64 rows, and per differing attention element HIP jumps no more often than 1.5 x the pure-fp32 controls
+    (measured: 2.9 % against 4.9 %; HIP differs from the oracle on 0.17 % of the attention elements, the fp32 re-orderings on
+    0.03 %, the hi + lo control on 0.19 %)."""
+    import _model_parity as mp
+    tot = dict(hip_jumps=0, hilo_jumps=0, hip_diff=0, fp32_jumps=0, fp32_diff=0, rows=0)
+    hip_max = ctrl_max = 0.0
+    for seed in (23, 24):
+        r = mp.int8_jump_experiment(seed=seed)
+        B = len(r["lens"])
+        assert r["fused_equals_unfused"]                                                             # (a)
+        e, at = r["errors"]["hip"], r["attribution"]["hip"]
+        jumps = [i for i in range(B) if e[i] > mp.JUMP]
+        for i in range(B):                                                                           # (b)
+            if i in jumps:
+                fd, fc = at[i]["first_diff"], at[i]["first_code_diff"]
+                assert fd is not None and fd[1] == "attn" and fd[2] <= 0.01 * 3584 and fd[3] <= 1e-3, (seed, i, at[i])
+                assert fc is not None and fc[1] == "attn" and fc[2] <= 4 and fc[3] == 1 and not fc[4], (seed, i, at[i])
+            else:
+                assert e[i] <= 3e-4, (seed, i, e[i])
+        names = [c[0] for c in mp.CONTROLS]
+        fp32 = [n for n in names if "hilo" not in n]
+        hilo = [n for n in names if "hilo" in n]
+        count = lambda n: sum(1 for x in r["errors"][n] if x > mp.JUMP)
+        hip_max = max(hip_max, max(e))
+        ctrl_max = max([ctrl_max] + [max(r["errors"][n]) for n in names])
+        tot["rows"] += B
+        tot["hip_jumps"] += len(jumps)
+        tot["hilo_jumps"] += max(count(n) for n in hilo)
+        tot["hip_diff"] += r["attn0_diff_elements"]["hip"]
+        tot["fp32_jumps"] += sum(count(n) for n in fp32)
+        tot["fp32_diff"] += sum(r["attn0_diff_elements"][n] for n in fp32)
+        _record(test="free_running_int8_jump_attribution", seed=seed, lens=r["lens"], errors=r["errors"],
+                attn0_diff_elements=r["attn0_diff_elements"],
+                hip_attribution=[dict(row=i, err=e[i], **at[i]) for i in jumps],
+                control_jump_rows={n: [i for i in range(B) if r["errors"][n][i] > mp.JUMP] for n in names})
+    _record(test="free_running_int8_jump_summary", hip_max=hip_max, control_max=ctrl_max, **tot)
+    assert hip_max <= 1.25 * ctrl_max, (hip_max, ctrl_max)                                          # (c)
+    assert tot["hip_jumps"] <= 1.5 * tot["hilo_jumps"] + 2, tot                                      # (d)
+    assert tot["hip_diff"] <= 0.005 * tot["rows"] * 3584, tot
+    assert tot["fp32_diff"] > 0 and tot["hip_jumps"] / tot["hip_diff"] <= 1.5 * tot["fp32_jumps"] / tot["fp32_diff"], tot
 
 
 @pytest.mark.timeout(1500)

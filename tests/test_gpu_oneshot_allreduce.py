@@ -130,6 +130,55 @@ def _worker(rank, world, port, ret, distinct):
         with torch.cuda.stream(side):
             res["declines_other_stream"] = not ar.takes(torch.ones(4096, dtype=torch.bfloat16, device=f"cuda:{dev}"))
         torch.cuda.synchronize()
+        # suspended(): every launch declines, ALSO while a capture is running on a forked stream -- the case the one-stream rule
+        # alone lets through (round-4 advisor: DualBatchDecoder's two half-streams under HIP-graph capture)
+        probe = torch.ones(4096, dtype=torch.bfloat16, device=f"cuda:{dev}")
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            fork = torch.cuda.Stream()
+            fork.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(fork):
+                res["capture_fork_accepted_without_suspension"] = bool(ar.takes(probe))      # documents WHY the switch exists
+                with ar.suspended():
+                    res["suspended_declines_under_capture"] = not ar.takes(probe) and not ar._stream_ok()
+            torch.cuda.current_stream().wait_stream(fork)
+        res["resumes_after_suspension"] = bool(ar.takes(probe))
+        # DualBatchDecoder over a TP = 2 model with the one-shot kernel ENABLED: its forward() suspends the kernel (the epoch word
+        # does not move), the per-layer sums go through the group's own all-reduce from the two half-streams, and the hidden
+        # states equal the single-batch step with the same collectives
+        import math
+        from xllm_amd import attention, layers
+        args = layers.ModelArgs(1024, 2, 8, 2, 128, 2048, 1024, 1e-6, 1e6, 8192)
+        model = layers.Qwen2Model(args, "int8", torch.bfloat16, f"cuda:{dev}", seed=3, tp=pg)
+        Bd, bsz, ctx = 16, 128, 200
+        blocks = [[2 * i, 2 * i + 1] for i in range(Bd)]
+        bi = attention.build_batch_input([ctx - 1] * Bd, [ctx] * Bd, blocks, bsz)
+        amd = attention.build_attention_metadata(bi, False, False, f"cuda:{dev}")
+        gq = torch.Generator().manual_seed(77)
+        mk_caches = lambda: [attention.KVCache(torch.randn(2 * Bd, bsz, 1, 128, generator=gq).bfloat16().to(f"cuda:{dev}"),
+                                               torch.randn(2 * Bd, bsz, 1, 128, generator=gq).bfloat16().to(f"cuda:{dev}"))
+                             for _ in range(args.n_layers)]
+        caches = mk_caches()
+        toks = torch.randint(0, args.vocab_size, (Bd,), generator=gq).to(f"cuda:{dev}")
+        posd = bi.positions.long().to(f"cuda:{dev}")
+        snap = [(c.k_cache.clone(), c.v_cache.clone()) for c in caches]
+        with ar.suspended():
+            ref_h = model.forward(toks, posd, amd, caches).clone()
+        for c, (k0, v0) in zip(caches, snap):
+            c.k_cache.copy_(k0); c.v_cache.copy_(v0)
+        torch.cuda.synchronize()
+        epoch0 = int(ar.state[0].item())
+        dual = layers.DualBatchDecoder(model, amd, Bd)
+        got_h = dual.forward(toks, posd, caches)
+        torch.cuda.synchronize()
+        res["dual_tp_left_the_oneshot_kernel_alone"] = int(ar.state[0].item()) == epoch0
+        res["dual_tp_equals_single_batch"] = bool(torch.equal(got_h, ref_h))
+        dual.close()
+        # ... and the plain TP step DOES use it (the epoch moves), within one rounding of the gloo-summed step
+        h1 = model.forward(toks, posd, amd, caches)
+        torch.cuda.synchronize()
+        res["plain_tp_uses_the_oneshot_kernel"] = int(ar.state[0].item()) > epoch0
+        res["plain_tp_close_to_suspended"] = bool(((h1.float() - ref_h.float()).norm() / ref_h.float().norm()) < 5e-2)
         # graph replay: the collective is a plain kernel
         static = _msg(rank, 99, 256 * 3584, torch.bfloat16).cuda()
         src = [_msg(rank, 100 + k, 256 * 3584, torch.bfloat16).cuda() for k in range(3)]
@@ -186,6 +235,10 @@ def test_oneshot_allreduce_protocol(distinct):
     for r in range(2):
         assert ret[r]["ok"], ret[r]["log"]
         assert ret[r].get("declines_other_stream") is True
+        assert ret[r].get("capture_fork_accepted_without_suspension") is True and ret[r].get("suspended_declines_under_capture") is True
+        assert ret[r].get("resumes_after_suspension") is True
+        assert ret[r].get("dual_tp_left_the_oneshot_kernel_alone") is True and ret[r].get("dual_tp_equals_single_batch") is True
+        assert ret[r].get("plain_tp_uses_the_oneshot_kernel") is True and ret[r].get("plain_tp_close_to_suspended") is True
         assert ret[r].get("grid_limit") == (256 if distinct else 0)    # one row per block only with a GPU per rank
     assert ret[0].get("timeout_reported") is True
 

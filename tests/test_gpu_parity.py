@@ -634,7 +634,21 @@ def test_mlu_golden_vectors_through_hip():
     exp = torch.tensor([0.0005264282, 0.0008239746, 0.0005722046, 0.0006027222, 0.000831604, 0.0004405975,
                         0.001037598, 0.001083374, 0.000289917, 0.0007820129])
     got = out.flatten()[:10].float().cpu()
-    assert (got - exp).norm() / exp.norm() < 3e-2 and (got - exp).abs().max() <= 4e-5
+    # round-4 review, weak #2: held to <= 2 bf16 ulp per value like the prefill golden above (was: 3 % / 4e-5 absolute, which
+    # pinned nothing on values of 3e-4 .. 1e-3). The golden comes from an MLU kernel that rounds P to bf16 before PV (the oracle
+    # reproduces it to the last digit only in that mode, tests/test_oracle_golden.py::test_decode_golden); this kernel keeps P
+    # to ~2^-17 (hi + lo parts), so it sits where the oracle with fp32 P sits: 2.4e-3 (relative L2) from the golden, inside
+    # 2 ulp on every value -- and within 1e-3 / 2 ulp of THAT oracle on the whole output
+    G._assert_close_bf16(got, exp.tolist(), ulps=2)
+    e_gold = ((got - exp).norm() / exp.norm()).item()
+    kc_o, vc_o = G._caches()
+    ref = G._layer(hidden.cpu(), torch.full((B,), S), G._weights(), kc_o, vc_o, slots.cpu(), "decode", p_round=False,
+                   cu_q=torch.arange(B + 1, dtype=torch.int32), kv_lens=torch.full((B,), kv, dtype=torch.int32),
+                   block_table=table.cpu())
+    e_ref = ((ref.flatten()[:10].float() - exp).norm() / exp.norm()).item()
+    assert e_gold <= max(1.5 * e_ref, 3e-3), (e_gold, e_ref)
+    assert rel_l2(out.cpu(), ref) <= 2e-3
+    assert ((out.float().cpu() - ref.float()).abs() <= 2 * 2.0 ** -8 * ref.float().abs().amax(-1, keepdim=True)).all()
 
     # MixedSequenceLengthTest (:331-393): the reference's only vector for ragged q_cu_seq_lens -- 32 / 64 / 128 tokens in one
     # varlen prefill -- through the same HIP kernels, and equal to the oracle layer on EVERY output row (not only the ten values)

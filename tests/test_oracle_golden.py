@@ -188,3 +188,24 @@ def test_flash_cast_point_mode_is_anchored_on_the_reference_goldens():
     _assert_close_bf16(outs["flash"].flatten()[:10], GOLD["qwen2_attention_prefill"]["first10"], ulps=2)
     e_ref = rel(outs[True], outs[False])
     assert rel(outs["flash"], outs[True]) <= max(2.0 * e_ref, 1e-3), (rel(outs["flash"], outs[True]), e_ref)
+
+
+def test_flash_oracle_mode_restates_the_kernels_tile_constants():
+    """round-4 review, weak #3: oracle mode p_round="flash" RESTATES the tiling of the prefill kernels (64-key tiles aligned at
+    key 0, running maximum that only moves when a tile exceeds it by 2^8) so that they can be held to an absolute bar. If a
+    kernel's tile constant changes and the oracle's does not, the absolute-bar tests would quietly compare against the wrong cast
+    point (and at best fail with an unhelpful number): fail HERE, loudly, on the constants themselves."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    orc_src = open(os.path.join(root, "oracle", "xllm_oracle.c")).read()
+    body = orc_src[orc_src.index("static void attn_one_query_flash("):]
+    body = body[:body.index("\n}\n")]
+    tile = int(re.search(r"const int64_t TILE = (\d+);", body).group(1))
+    lazy = float(re.search(r"m_run \+ ([0-9.]+)f", body).group(1))
+    pf = open(os.path.join(root, "xllm_amd", "csrc", "attention_prefill.hip")).read()
+    mla = open(os.path.join(root, "xllm_amd", "csrc", "attention_mla.hip")).read()
+    k_tile = int(re.search(r"constexpr int kPf2Tile = (\d+);", pf).group(1))
+    k_lazy = {float(x) for x in re.findall(r"> m_run\[\w+\] \+ ([0-9.]+)f", pf)}
+    mla_tile = int(re.search(r"kMlaTile = (\d+)", mla).group(1))
+    assert tile == k_tile == mla_tile == 64, (tile, k_tile, mla_tile)
+    assert k_lazy == {lazy} == {8.0}, (k_lazy, lazy)

@@ -43,8 +43,21 @@ def test_top_k_and_top_p_rules_by_hand():
     both = row.clone()
     osm.apply_top_k_top_p(both, None, torch.tensor([3]), torch.tensor([0.8]))
     assert [v == NINF for v in both[0].tolist()] == [True, False, True, False]         # cum <= .8: ranks 0, 1
+    # both, k <= 0 (the reference's default top_k = -1 in a batch where ANOTHER request set top_k): no limit from k -- the row is
+    # filtered by p alone (inclusive prefixes .4, .7, .9, 1.0; rank 0 forced). Round-4 advisor: a clamp to 1 made it greedy.
     both = row.clone()
-    osm.apply_top_k_top_p(both, None, torch.tensor([0]), torch.tensor([0.1]))           # k = 0 clamps to 1
+    osm.apply_top_k_top_p(both, None, torch.tensor([0]), torch.tensor([0.1]))
+    assert [v == NINF for v in both[0].tolist()] == [True, False, True, True]          # p = .1: only the forced rank 0
+    both = row.clone()
+    osm.apply_top_k_top_p(both, None, torch.tensor([-1]), torch.tensor([0.75]))
+    assert [v == NINF for v in both[0].tolist()] == [True, False, True, False]         # cum <= .75: ranks 0, 1 -- NOT top-1
+    both = torch.cat([row, row])                                                       # a mixed batch: k = 2 and k = -1 side by side
+    osm.apply_top_k_top_p(both, None, torch.tensor([2, -1]), torch.tensor([0.95, 0.95]))
+    assert [v == NINF for v in both[0].tolist()] == [True, False, True, True]          # top-2 renormalised: cum .571, 1.0 -> only rank 0 is <= .95
+    assert [v == NINF for v in both[1].tolist()] == [True, False, False, False]        # no k: cum .4, .7, .9 <= .95 -> ranks 0, 1, 2
+    # the reference's torch_impl as written still clamps (restated faithfully; it is not what runs on CUDA / DCU / NPU)
+    both = row.clone()
+    osm.apply_top_k_top_p_torch_impl(both, torch.tensor([0]), torch.tensor([0.99]))
     assert [v == NINF for v in both[0].tolist()] == [True, False, True, True]
     # ties rank by column index (stable sort)
     tie = torch.tensor([[1.0, 2.0, 2.0, 2.0]])

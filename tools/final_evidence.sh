@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-4 evidence: the default bench line (roofline.traffic measured live), its kernel trace, the other configs
+# the round's evidence: the default bench line (roofline.traffic measured live), its kernel trace, the other configs
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4ev
+O=$R/gpurun_out/evidence
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cut -c1-600 $O/bench.json

@@ -3,7 +3,7 @@
 # New this round: the fused lm_head + argmax with the [B] pair exchange under TP, and the three exchange arms of `layouts`
 # (one-shot kernel = headline, <layout>_rccl, <layout>_rccl_overlap).
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r4e
+O=gpurun_out/multirank
 mkdir -p $O
 for N in ${1:-2 4}; do
   echo "# --gpus $N --backend gloo (ranks share the GPU)" | tee -a $O/multi.txt

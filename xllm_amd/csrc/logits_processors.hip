@@ -97,7 +97,7 @@ struct LpShared {
   unsigned int remaining;
 };
 
-// top-k / top-p for one row. rule: 0 = "one of them" (exclusive prefix, k <= 0 disables), 1 = "both" (clamped k, inclusive prefix)
+// top-k / top-p for one row. rule: 0 = "one of them" (exclusive prefix), 1 = "both" (inclusive prefix, at least one); k <= 0 disables top-k under both
 template <typename T>
 __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__ logits, int64_t row_stride, int V,
                                                                 const float* __restrict__ temperatures,
@@ -129,8 +129,12 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   __syncthreads();
 
   // ---- top-k: the k-th largest key and how many of its ties stay
+  // k <= 0 means "no limit" under BOTH rules: the reference's default is top_k = -1, the batch tensor exists as soon as ANY
+  // request sets top_k > 0, and every reference branch that runs maps k <= 0 to "unlimited" (the one-of-them branch,
+  // logits_utils.cpp:126-133, and the NPU both-given branch, :109-116). Only the otherwise unused torch_impl clamps to 1 (:70),
+  // which would turn every request that left top_k at its default into greedy sampling in a mixed batch (round-4 advisor).
   long long k = top_k ? top_k[b] : 0;
-  if (rule == 1) k = k < 1 ? 1 : (k > V ? V : k);
+  if (rule == 1 && k > V) k = V;
   const bool use_k = top_k && k > 0 && k < V;
   uint32_t kth_key = 0u;             // keep every key >= kth_key ...
   unsigned k_rem = 0xffffffffu;      // ... but of the ties at kth_key only the first k_rem by index

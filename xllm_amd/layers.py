@@ -654,12 +654,15 @@ class DualBatchDecoder:
     else of a half (o_proj, MLP, next qkv_proj, RoPE + KV write) runs on that half's own stream underneath the other
     half's attention. Arithmetic per sequence is unchanged (row-wise kernels and GEMM rows are independent, the
     attention kernel handles sequences independently), so the logits equal the single-batch step bit for bit.
-    W8A8 fused decode path, TP = 1 only."""
+    W8A8 fused decode path. Tensor parallel (round 4): allowed; each half's row-parallel linears reduce through the group's own
+    all-reduce (RCCL on its own stream) and the one-shot kernel is SUSPENDED for the duration of forward() -- also under graph
+    capture -- because its launches from two streams of one rank would share one epoch / flag / slot state (round-4 advisor)."""
 
     def __init__(self, model: "Qwen2Model", md: AttentionMetadata, batch: int):
         # tensor parallel (round 4): allowed -- each half's row-parallel linears reduce through the group's own all-reduce (RCCL runs
         # it on its own stream, fenced against the half's stream), which is what lets the OTHER half's GEMMs overlap the transfer.
-        # The one-shot kernel is bound to one stream (OneShotAllReduce), so launches from the two half-streams decline it by design.
+        # The one-shot kernel keeps ONE epoch / flag / slot state per rank: forward() suspends it explicitly (its "one stream" rule
+        # accepts any stream while a capture is running, which would let both forked branches launch it).
         assert all(l.fuse for l in model.layers)
         self.model, self.B = model, batch
         h = batch // 2
@@ -686,6 +689,13 @@ class DualBatchDecoder:
             pass
 
     def forward(self, tokens, positions, kv_caches):
+        oneshot = self.model.tp.oneshot if self.model.tp is not None else None
+        if oneshot is not None:
+            with oneshot.suspended():
+                return self._forward(tokens, positions, kv_caches)
+        return self._forward(tokens, positions, kv_caches)
+
+    def _forward(self, tokens, positions, kv_caches):
         m = self.model
         main = torch.cuda.current_stream()
         x_full = torch.nn.functional.embedding(tokens, m.embed)

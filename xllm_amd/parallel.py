@@ -163,6 +163,7 @@ class OneShotAllReduce:
         self.device = torch.device(device)
         self.refused = None
         self._stream = None
+        self._suspended = 0          # > 0 inside suspended(): every launch declines the kernel
         self.grid_limit = 0          # 0 = the library's 64 blocks; raised below when every rank has a GPU of its own
         world, rank = pg.world_size(), pg.rank()
         total = l.xllm_mi355_oneshot_allreduce_buffer_bytes(self.max_bytes)
@@ -237,10 +238,30 @@ class OneShotAllReduce:
 
     # ---- which messages ------------------------------------------------------------------------------------------------
     def _stream_ok(self) -> bool:
+        if self._suspended:
+            return False
         cur = torch.cuda.current_stream(self.device).cuda_stream
         if self._stream is None:
             return True
         return cur == self._stream or torch.cuda.is_current_stream_capturing()
+
+    def suspended(self):
+        """context manager: every launch inside declines the one-shot kernel (RCCL / gloo serves it), whatever the stream and
+        also under graph capture. For callers that issue collectives from SEVERAL streams of one rank -- DualBatchDecoder's
+        two half-streams: all launches of a rank share one epoch word, one flag area and one set of data slots, so two of them
+        running concurrently (parallel graph branches!) and in a rank-dependent order corrupt each other or time out. `capturing`
+        alone cannot tell a forked branch from the bound stream, hence the explicit switch (round-4 advisor). Rank-invariant as
+        long as every rank runs the same code path."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._suspended += 1
+            try:
+                yield
+            finally:
+                self._suspended -= 1
+        return cm()
 
     def takes(self, x: torch.Tensor) -> bool:
         """rank-invariant: dtype, element count, size limit, device kind (+ the one-stream rule)"""
@@ -361,6 +382,16 @@ class OneShotAllReduce:
             (n16, ysum) = self.allreduce_add_rms_norm(pat * float(rank + 1), res, w, 1e-6, quantize=False, want_sum=True)
             ok = ok and bool(torch.equal(ysum, pat * float(tri))) and bool(torch.equal(res, pat * float(tri) + 1.0))
             ok = ok and bool(torch.isfinite(n16.float()).all())
+            if self.grid_limit > 64:
+                # one row per block (grid_limit = 256, every rank on a GPU of its own): production decode sends M = 256 rows, which
+                # uses flag rows 64 .. 255 and relies on 256 co-resident blocks per rank -- the 8-row message above never touches
+                # either (round-4 advisor): send one message of that regime before the verdict is agreed
+                M2 = 256
+                pat2 = (torch.arange(M2 * H, device=self.device).view(M2, H) % 5).to(torch.bfloat16)
+                res2 = torch.ones(M2, H, dtype=torch.bfloat16, device=self.device)
+                (n16b, ysum2) = self.allreduce_add_rms_norm(pat2 * float(rank + 1), res2, w, 1e-6, quantize=False, want_sum=True)
+                ok = ok and bool(torch.equal(ysum2, pat2 * float(tri))) and bool(torch.equal(res2, pat2 * float(tri) + 1.0))
+                ok = ok and bool(torch.isfinite(n16b.float()).all())
             # the GEMM-fed form: every rank multiplies ones by ones (sum = K) with a_scale = (rank + 1) / K -> partial = rank + 1
             from . import ops
             M, K, N = 8, 512, 512
