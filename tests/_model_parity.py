@@ -196,7 +196,7 @@ def attribute_rows(per_layer_a, per_layer_b, int8: bool):
     return rows
 
 
-JUMP = 1e-3      # a row whose free-running logits are further than this from the oracle's has re-rolled int8 codes somewhere
+JUMP = 5e-4      # a row whose free-running logits are further than this from the oracle's has re-rolled int8 codes somewhere
 CONTROLS = [("split1_exp2", 1, True, False), ("split2_exp2", 2, True, False), ("split4_exp2", 4, True, False),
             ("split8_exp2", 8, True, False), ("split2", 2, False, False), ("split4", 4, False, False),
             ("online16_exp2", -16, True, False), ("online64_exp2", -64, True, False), ("online64", -64, False, False),

@@ -217,8 +217,9 @@ def _worker(rank, world, port, ret, distinct):
         dist.barrier()
         ar.close()
     except Exception as e:   # noqa: BLE001
+        import traceback
         res["ok"] = False
-        res["log"].append(repr(e))
+        res["log"].append(repr(e) + "\n" + traceback.format_exc()[-1500:])
     ret[rank] = res
     dist.destroy_process_group()
 

@@ -257,7 +257,7 @@ class Qwen2DecoderLayer:
                                                 md.kv_seq_lens, md.block_table, md.max_seq_len, self.attn.scale,
                                                 self.attn.window_left)
         if fused is not None:
-            return fused
+            return fused[0], fused[1]      # (the third element is the 16-bit output; QuantLinear.forward unpacks a pair)
         attn = ops.paged_attention(q.unflatten(-1, (self.nq, self.d)), kv_cache.k_cache, kv_cache.v_cache, None,
                                    md.kv_seq_lens, md.block_table, 1, md.max_seq_len, self.attn.scale, False,
                                    self.attn.window_left)
