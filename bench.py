@@ -541,27 +541,84 @@ def main():
     model, md, n_blocks, kv_caches, tokens, positions, B = (w["model"], w["md"], w["n_blocks"], w["kv_caches"], w["tokens"],
                                                              w["positions"], w["B"])
     tp_pg, tp_size, dp_size, nkv_l = w["tp_pg"], w["tp_size"], w["dp_size"], w["nkv_l"]
-    # Tensor parallel over the one-shot kernel: a launch that gave up waiting for a peer (status word, checked after the timed
-    # region) voids the measurement. The verdict is agreed over ALL ranks, and on a failure every rank drops the kernel and the
-    # step is captured and timed again on RCCL -- the line still comes out, and `allreduce` / `allreduce_note` say what ran.
-    r, err = None, None
-    try:
-        r = time_decode(w, a.steps)
-        if os.environ.get("XLLM_MI355_BENCH_INJECT_ONESHOT_FAILURE") == "1" and w["tp_pg"] is not None and w["tp_pg"].oneshot is not None:
-            raise RuntimeError("injected one-shot failure (test of the fallback)")
-    except Exception as e:  # noqa: BLE001
-        if world == 1 or w["tp_pg"] is None or w["tp_pg"].oneshot is None:
-            raise
-        err = repr(e)
+    # ---- the headline timing, made hard to lose (round-4 review, next #5): a multi-GPU lease is rare, so
+    #   * every attempt is guarded and its verdict AGREED over the ranks (a failure on any rank counts for all, so every rank takes
+    #     the same next branch and issues the same collectives);
+    #   * tensor parallel: the conservative arm `north_star` names -- the group's own all-reduce (RCCL over xGMI) in stream between
+    #     piecewise graphs -- is timed FIRST; only then the one-shot kernel (self-tested at set-up) gets its run. The headline is the
+    #     one-shot run when it came out clean on every rank (bounded waits, status word checked after the timed region), the RCCL
+    #     run otherwise; both are reported in `layouts`;
+    #   * an attempt whose graph capture fails is repeated with eager launches before anything is given up;
+    #   * if nothing could be timed, rank 0 still prints ONE valid JSON line (value null, the errors in `config.attempts`).
+    attempts = []
+
+    def attempt(label, fn):
+        res, err = None, None
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+            print(f"[bench] rank {rank}: attempt '{label}' failed: {err}", file=sys.stderr)
+        failed = err is not None
+        if world > 1:
+            flag = torch.tensor([1.0 if failed else 0.0], device=dev if a.backend == "nccl" else "cpu")
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                failed = float(flag.item()) > 0
+            except Exception as e:  # noqa: BLE001
+                failed, err = True, (err or "") + f" | agreement all-reduce failed: {e!r}"
+        attempts.append({"arm": label, "ok": False, "error": err or "failed on another rank"} if failed else {"arm": label, "ok": True})
+        return None if failed else res
+
+    def timed(label, **kw):
+        got = attempt(label, lambda: time_decode(w, a.steps, **kw))
+        if got is None and not a.no_graph:
+            a.no_graph = True            # eager launches: no capture to fail
+            try:
+                got = attempt(label + " (eager, no graph)", lambda: time_decode(w, a.steps, **kw))
+            finally:
+                a.no_graph = False
+        return got
+
+    rccl_ranks_seen = None
+    if world > 1:      # every rank adds a one through the group the step will use: the line says how many ranks RCCL / gloo saw
+        def _count():
+            ones = torch.ones(1, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            return int(ones.item())
+        rccl_ranks_seen = attempt("world all-reduce of ones", _count)
+    r, r_rccl, r_oneshot = None, None, None
     if world > 1 and w["tp_pg"] is not None and w["tp_size"] > 1:
-        flag = torch.tensor([1.0 if err else 0.0], device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if float(flag.item()) > 0 and w["tp_pg"].oneshot is not None:
-            w["tp_pg"].oneshot_note = f"dropped after the first timed run failed on some rank ({err or 'another rank'}); RCCL instead"
-            if rank == 0:
-                print(f"[bench] one-shot all-reduce {w['tp_pg'].oneshot_note}", file=sys.stderr)
-            w["tp_pg"].oneshot = None
-            r = time_decode(w, a.steps)
+        saved_oneshot = w["tp_pg"].oneshot
+        w["tp_pg"].oneshot = None
+        r_rccl = timed(f"{layout}_rccl")
+        w["tp_pg"].oneshot = saved_oneshot
+        if saved_oneshot is not None:
+            def _oneshot_run():
+                got = time_decode(w, a.steps)
+                if os.environ.get("XLLM_MI355_BENCH_INJECT_ONESHOT_FAILURE") == "1":
+                    raise RuntimeError("injected one-shot failure (test of the fallback)")
+                return got
+            r_oneshot = attempt(f"{layout}_oneshot", _oneshot_run)
+            if r_oneshot is None:
+                w["tp_pg"].oneshot_note = "dropped: its timed run failed on some rank (see config.attempts); RCCL is the headline"
+                if rank == 0:
+                    print(f"[bench] one-shot all-reduce {w['tp_pg'].oneshot_note}", file=sys.stderr)
+                w["tp_pg"].oneshot = None
+        r = r_oneshot if r_oneshot is not None else r_rccl
+    else:
+        r = timed("headline")
+    if r is None:
+        if rank == 0:
+            print(json.dumps({"metric": "decode tokens/s, Qwen2-7B int8 bs=256 ctx=4096", "value": None, "unit": "tokens/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                              "scaling": "strong", "vs_baseline": None, "dtype": "int8" if mode == "int8" else "bf16",
+                              "data": "synthetic", "config": {"workload": f"{model_name} decode step", "layout": layout,
+                                                              "attempts": attempts, "rccl_ranks_seen": rccl_ranks_seen},
+                              "error": "no arm of the decode step could be timed"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(1)
     ms_per_step, tok_s, graph, piecewise, exposed_comm_ms, dual, step = (r["ms_per_step"], r["tok_s"], r["graph"], r["piecewise"],
                                                                         r["exposed_comm_ms"], r["dual"], r["step"])
     # exchange accounting (reference: 2 all-reduces per layer + the logits all-gather, linear.cpp:1518-1520, 712-714)
@@ -608,34 +665,33 @@ def main():
         # executor (the overlap north_star describes). Each arm is optional: a failure is recorded, never fatal. Every rank runs
         # the same code, so the collectives of an arm are issued in the same order everywhere.
         saved_oneshot = tp_pg.oneshot if tp_pg is not None else None
-        for arm, overlap in ((layout + "_rccl", False), (layout + "_rccl_overlap", True)):
-            if saved_oneshot is None and not overlap:
-                layouts[arm] = {"same_as": layout}          # the headline already ran on the group's own all-reduce
-                continue
-            try:
-                tp_pg.oneshot = None
-                ra = time_decode(w, a.steps, overlap_arm=overlap)
-                layouts[arm] = {"ms_per_step": round(ra["ms_per_step"], 4), "tokens_per_s": round(ra["tok_s"], 2),
-                                "collectives_per_step": collectives_per_step, "allreduce": tp_pg.allreduce_kind(),
-                                "exposed_comm_ms": ra["exposed_comm_ms"], "micro_batches": 2 if overlap else 1,
-                                "hip_graph": ("piecewise" if ra["piecewise"] else bool(ra["graph"])) if ra["graph"] is not None else False}
+        fmt = lambda ra, overlap: {"ms_per_step": round(ra["ms_per_step"], 4), "tokens_per_s": round(ra["tok_s"], 2),
+                                   "collectives_per_step": collectives_per_step, "allreduce": "rccl" if a.backend == "nccl" else a.backend,
+                                   "exposed_comm_ms": ra["exposed_comm_ms"], "micro_batches": 2 if overlap else 1,
+                                   "hip_graph": ("piecewise" if ra["piecewise"] else bool(ra["graph"])) if ra["graph"] is not None else False}
+        # <layout>_rccl was timed FIRST (above); when the one-shot run did not make the headline, the headline IS that run
+        layouts[layout + "_rccl"] = ({"same_as": layout} if r is r_rccl else fmt(r_rccl, False)) if r_rccl is not None else \
+            {"error": "see config.attempts"}
+        arm = layout + "_rccl_overlap"
+        try:
+            tp_pg.oneshot = None
+            ra = attempt(arm, lambda: time_decode(w, a.steps, overlap_arm=True))
+            if ra is None:
+                layouts[arm] = {"error": "see config.attempts"}
+            else:
+                layouts[arm] = fmt(ra, True)
                 if ra.get("dual") is not None:
                     ra["dual"].close()
-                del ra
-            except Exception as e:  # noqa: BLE001
-                layouts[arm] = {"error": repr(e)}
-            finally:
-                tp_pg.oneshot = saved_oneshot
+            del ra
+        finally:
+            tp_pg.oneshot = saved_oneshot
         torch.cuda.empty_cache()
-        try:
+        def _dp():
             w2 = build(1)
             r2 = time_decode(w2, a.steps)
-            layouts["dp"] = {"ms_per_step": round(r2["ms_per_step"], 4), "tokens_per_s": round(r2["tok_s"], 2),
-                             "collectives_per_step": 0, "allreduce": None, "exposed_comm_ms": 0.0,
-                             "per_gpu_batch": w2["B"]}
-            del w2, r2
-        except Exception as e:  # noqa: BLE001
-            layouts["dp"] = {"error": repr(e)}
+            return {"ms_per_step": round(r2["ms_per_step"], 4), "tokens_per_s": round(r2["tok_s"], 2), "collectives_per_step": 0,
+                    "allreduce": None, "exposed_comm_ms": 0.0, "per_gpu_batch": w2["B"]}
+        layouts["dp"] = attempt("dp", _dp) or {"error": "see config.attempts"}
         torch.cuda.empty_cache()
 
     prefill = None
@@ -675,6 +731,7 @@ def main():
                        "allreduce_grid_limit": (getattr(getattr(tp_pg, "oneshot", None), "grid_limit", None)
                                                 if (tp_pg is not None and tp_size > 1 and world > 1) else None),
                        "eager_collectives_per_step": r["eager_collectives"] if tp_size > 1 else 0,
+                       "rccl_ranks_seen": rccl_ranks_seen, "attempts": attempts,
                        "exposed_comm_ms": exposed_comm_ms,
                        "quant_fusion": not a.no_fuse, "micro_batches": 2 if dual is not None else 1,
                        "hip_graph": ("piecewise" if piecewise else True) if graph is not None else False},
@@ -738,7 +795,7 @@ def gemm_leg(dev, live_pmc=True):
             ws = [(torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.float8_e4m3fn) for _ in range(copies)]
             wps = [ops.pack_weight_fp8(w) for w in ws]
         w_s = torch.rand(N, device=dev, generator=g) * 0.02 + 0.01
-        for M in (8192, 128):
+        for M in (8192, 256, 128):       # 256 = the headline's decode batch (round-4 review, weak #5: the shape the step runs was absent)
             if kind == "int8":
                 a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g)
                 a_s = torch.rand(M, device=dev, generator=g) * 0.01
@@ -775,6 +832,64 @@ def gemm_leg(dev, live_pmc=True):
                                     "frac_of_hbm": round((N * K + M * K + 2 * M * N) / us / 1e3 / HBM_PEAK_GBS, 4)}
         del ws, wps
     torch.cuda.empty_cache()
+    out["decode_layer_M256"] = decode_layer_gemms(dev, 256)
+    return out
+
+
+def decode_layer_gemms(dev, M):
+    """the four W8A8 GEMMs of ONE Qwen2-7B decoder layer at the headline's decode batch, in the fused forms the step launches
+    (qkv -> slabs for the RoPE + KV-write pass, o / down -> slabs for the add + norm pass, gate_up with SiLU.mul in its epilogue +
+    the quantising pass), each timed by itself over a graph of 50 launches on rotating weight copies; `floor_us` = max(weight
+    stream at 8 TB/s, int8 MFMA at 5 POP/s). The layer's sum is what the review's "<= 75 us per layer" refers to."""
+    from xllm_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    H, I, QKV = 3584, 18944, 4608
+    copies = 6
+    out, total = {}, 0.0
+    a_scale = torch.rand(M, device=dev, generator=g) * 0.01 + 0.001
+
+    def bench(fn, n=50, reps=10):
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            fn(0)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for i in range(n):
+                    fn(i)
+            for _ in range(reps):
+                gr.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                gr.replay()
+            e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * n)
+
+    for name, N, K in (("qkv", QKV, H), ("o", H, H), ("gate_up", 2 * I, H), ("down", H, I)):
+        ws = [torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g) for _ in range(copies)]
+        wps = [ops.pack_weight_i8(w) for w in ws]
+        w_s = torch.rand(N, device=dev, generator=g) * 0.02 + 0.01
+        a8 = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g)
+        if name == "gate_up":
+            fn = lambda i: ops.scaled_matmul_silu_mul_quant(a8, ws[i % copies], a_scale, w_s, torch.bfloat16, None, b_packed=wps[i % copies])
+            what = "scaled_matmul_gate_up_act + quantize_with_row_amax (two launches)"
+        else:
+            fn = lambda i: ops.scaled_matmul(a8, ws[i % copies], a_scale, w_s, torch.bfloat16, b_packed=wps[i % copies])
+            what = "scaled_matmul on packed weights (GEMM + K-slice epilogue when the plan slices)"
+        us = bench(fn)
+        byts = N * K + M * K + 2 * M * (N // 2 if name == "gate_up" else N)
+        floor = max(byts / HBM_PEAK_GBS / 1e3, 2.0 * M * N * K / 5000.0 / 1e6)
+        out[name] = {"us": round(us, 1), "what": what, "gbs": round(byts / us / 1e3, 1), "frac_of_hbm": round(byts / us / 1e3 / HBM_PEAK_GBS, 4),
+                     "tops": round(2.0 * M * N * K / us / 1e6, 1), "floor_us": round(floor, 1)}
+        total += us
+        del ws, wps
+        torch.cuda.empty_cache()
+    out["sum_us"] = round(total, 1)
     return out
 
 def via_shim_leg(model, margs, md, kv_caches, tokens, positions, steps, warmup):

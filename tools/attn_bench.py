@@ -30,7 +30,11 @@ for name, B, nq, nkv, S in cases:
     kv_lens = torch.full((B,), S, dtype=torch.int32, device=dev)
     q = torch.randn(B, nq, d, device=dev).bfloat16()
     if os.environ.get("ATTN_INT8") == "1":          # the bench path: epilogue emits o_proj's int8 operand
-        fn = lambda i: ops.paged_decode_attention_int8(q, caches[i % NC][0], caches[i % NC][1], kv_lens, table, S, d ** -0.5)
+        def fn(i):   # what the layer runs: the fused epilogue, or -- when the plan declines it -- attention + scaled_quantize
+            got = ops.paged_decode_attention_int8(q, caches[i % NC][0], caches[i % NC][1], kv_lens, table, S, d ** -0.5)
+            if got is None:
+                got = ops.scaled_quantize(ops.paged_attention(q, caches[i % NC][0], caches[i % NC][1], None, kv_lens, table, 1, S, d ** -0.5))
+            return got
     else:
         fn = lambda i: ops.paged_attention(q, caches[i % NC][0], caches[i % NC][1], None, kv_lens, table, 1, S, d ** -0.5)
     for i in range(3):
