@@ -135,10 +135,10 @@ def cfg4_slice(a, dev):
                                "random-init weights", "global_batch": B, "ctx": ctx, "per_gpu_batch": B,
                    "parallelism": "rank 0 of tp8 (shard shapes, no exchange timed)", "collectives_per_step": 2,
                    "hip_graph": True,
-                   # disclosed (round-3 review, weak #6): the two absorbed-weight batch GEMMs q_nope x w_kc and attn x w_vc run on
-                   # torch.bmm (= rocBLAS), exactly as in the reference (deepseek_v2_attention.cpp:180-187, 309-311); their time is
-                   # inside ms_per_step but they are vendor-library work, not this backend's kernels
-                   "vendor_library_ops": ["torch.bmm (w_kc absorption, w_vc projection)", "torch.cat / embedding glue"]},
+                   # round 5: the two absorbed-weight batch GEMMs (q_nope x w_kc, attn x w_vc; torch::bmm = rocBLAS in the reference,
+                   # deepseek_v2_attention.cpp:180-187, 310-311) run on this backend's per-head GEMM (xllm_mi355_bmm_heads), in place
+                   # on the token-major tensors; what is left of the vendor library on the measured path is copy / embedding glue
+                   "vendor_library_ops": ["torch copy / embedding glue"]},
         "roofline": {"bound": "hbm", "kernel": "mla_decode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
                      "avg_launch_ms": round(attn_ms, 4), "launches_timed": len(ms)},

@@ -574,6 +574,16 @@ XM_API int xllm_mi355_moe_combine_sorted_local(void* out, const void* gemm2_sort
                                                const float* weights, const int32_t* local_expert_sizes,
                                                int64_t n_local_experts, int64_t n_tokens, int64_t topk, int64_t hidden,
                                                int dtype, void* stream);
+/* Per-head batched GEMM of MLA's weight absorption (round 5): out[t, h, n] = r16(sum_k x[t, h, k] * w[h, n, k]), fp32 accumulation.
+ * Replaces the two torch::bmm calls (rocBLAS) + transposes of DeepseekV2AttentionImpl (layers/dcu/deepseek_v2_attention.cpp:
+ * 310-311: q_nope x W_kc, K = 128, N = 512; :180-187 project_output: attn x W_vc, K = 512, N = 128). x and out are the reference's
+ * token-major tensors, addressed through their (token, head) strides in ELEMENTS (x may be a slice of the packed q tensor); w holds
+ * each head's matrix with K contiguous per output column, (head, column) strides in elements -- for W_vc that is kv_b_proj's own
+ * weight slice [h, v, kv_lora] before the reference transposes it for bmm (:336-338), W_kc is transposed once at load time.
+ * K % 32 == 0; strides of x and w multiples of 8 elements, of out multiples of 4; XM_ERR_UNSUPPORTED otherwise. bf16 / f16. */
+XM_API int xllm_mi355_bmm_heads(const void* x, int64_t x_stride_t, int64_t x_stride_h, const void* w, int64_t w_stride_h,
+                                int64_t w_stride_n, void* out, int64_t out_stride_t, int64_t out_stride_h, int64_t n_tokens,
+                                int64_t n_heads, int64_t N, int64_t K, int dtype, void* stream);
 /* kernel::group_gemm (ops_api.h:57) -> dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74):
  * rows of `a` sorted by expert; out[off_e:off_e+M_e] = a[...] @ w[e]^T, w [E,N,K]; token_count is a
  * DEVICE int32 [E] (no host read). max_rows = a's row count. */

@@ -257,6 +257,13 @@ def matmul(a, w, bias=None):
     return out
 
 
+def bmm_heads(x, w_nk):
+    """torch::bmm(x.transpose(0, 1), w).transpose(0, 1) of DeepseekV2AttentionImpl (layers/dcu/deepseek_v2_attention.cpp:180-187,
+    310-311) with w given as [h, N, K] (K contiguous): per head F::linear, fp32 sequential sums, one rounding (oracle matmul)."""
+    T, H, K = x.shape
+    return torch.stack([matmul(x[:, h].contiguous(), w_nk[h].contiguous(), None) for h in range(H)], 1)
+
+
 def static_scaled_fp8_quant(x, scale):
     out = torch.empty(x.shape, dtype=torch.uint8)
     x_c = x.contiguous()  # keep the (possibly new) tensor alive across the call

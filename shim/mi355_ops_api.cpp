@@ -89,6 +89,19 @@ void reshape_paged_cache(torch::Tensor slot_ids, torch::Tensor keys, torch::Tens
         "reshape_paged_cache");
 }
 
+torch::Tensor bmm_heads(const torch::Tensor& x, const torch::Tensor& w_nk, std::optional<torch::Tensor> out) {
+  TORCH_CHECK(x.dim() == 3 && w_nk.dim() == 3 && x.size(1) == w_nk.size(0) && x.size(2) == w_nk.size(2),
+              "bmm_heads: x [tokens, heads, K], w [heads, N, K]");
+  TORCH_CHECK(x.stride(2) == 1 && w_nk.stride(2) == 1 && x.scalar_type() == w_nk.scalar_type());
+  DeviceGuard guard(x.device());
+  torch::Tensor o = out.has_value() ? *out : torch::empty({x.size(0), x.size(1), w_nk.size(1)}, x.options());
+  TORCH_CHECK(o.stride(2) == 1);
+  check(xllm_mi355_bmm_heads(p(x), x.stride(0), x.stride(1), p(w_nk), w_nk.stride(0), w_nk.stride(1), p(o), o.stride(0),
+                             o.stride(1), x.size(0), x.size(1), w_nk.size(1), x.size(2), dt(x), cur_stream()),
+        "bmm_heads");
+  return o;
+}
+
 void block_copy(torch::Tensor key_cache_ptrs, torch::Tensor value_cache_ptrs, torch::Tensor src_block_indices,
                 torch::Tensor dst_block_indices, torch::Tensor cum_sum, int64_t numel_per_block,
                 torch::ScalarType cache_dtype) {

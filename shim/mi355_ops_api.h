@@ -18,6 +18,12 @@
 
 namespace xllm::kernel::mi355 {
 
+// MLA weight absorption (round 5): what DeepseekV2AttentionImpl computes with torch::bmm(x.transpose(0, 1), w).transpose(0, 1)
+// (layers/dcu/deepseek_v2_attention.cpp:180-187 project_output, :310-311 q_nope x W_kc), on this backend's kernel and without the
+// transposes: x [tokens, heads, K] (any token / head strides), w_nk [heads, N, K] (K contiguous per output column: kv_b_proj's own
+// slice for W_vc -- skip the transpose of :336-338 --, W_kc transposed once at load time) -> [tokens, heads, N]
+torch::Tensor bmm_heads(const torch::Tensor& x, const torch::Tensor& w_nk, std::optional<torch::Tensor> out = std::nullopt);
+
 // kernels/cuda/cuda_ops_api.h:50-56 (block_copy.cu:120-205): whole-block KV copies for beam-search / prefix forks, called by
 // WorkerImpl::execute_cuda_block_copy_kernel (runtime/worker_impl.cpp:1071-1082) under USE_CUDA || USE_DCU (|| USE_MI355)
 void block_copy(torch::Tensor key_cache_ptrs, torch::Tensor value_cache_ptrs, torch::Tensor src_block_indices,

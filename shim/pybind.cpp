@@ -13,6 +13,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("act_and_mul", &k::act_and_mul);
   m.def("reshape_paged_cache", &k::reshape_paged_cache);
   m.def("block_copy", &k::block_copy);
+  m.def("bmm_heads", [](const torch::Tensor& x, const torch::Tensor& w) { return k::bmm_heads(x, w); });
   m.def("rotary_embedding", [](torch::Tensor pos, torch::Tensor q, std::optional<torch::Tensor> kk, torch::Tensor cache, bool neox) { k::rotary_embedding(pos, q, kk, cache, neox); });
   m.def("matmul", &k::matmul);
   m.def("random_sample", &k::random_sample);

@@ -90,6 +90,49 @@ def test_library_loaded_is_hip_path():
     assert _lib.lib().xllm_mi355_build_digest().decode() == sd.lib_digest(), "libxllm_mi355.so was not built from these sources"
 
 
+# ------------------------------------------------------------------------------------------- MLA weight absorption
+@pytest.mark.parametrize("T,H,K,N,dtype,strided", [(128, 16, 128, 512, torch.bfloat16, True),    # cfg4 rank: q_nope x W_kc
+                                                    (128, 16, 512, 128, torch.bfloat16, False),   # cfg4 rank: attn x W_vc (project_output)
+                                                    (77, 3, 64, 40, torch.float16, True),         # ragged tokens, columns not a tile multiple
+                                                    (1, 128, 128, 512, torch.bfloat16, False),    # one token, every head of the model
+                                                    (300, 2, 512, 128, torch.bfloat16, True)])
+def test_bmm_heads_matches_the_oracle(T, H, K, N, dtype, strided):
+    """torch::bmm(x.transpose(0, 1), w).transpose(0, 1) of DeepseekV2AttentionImpl (deepseek_v2_attention.cpp:180-187, 310-311) on
+    this backend's per-head GEMM: against the oracle's F::linear per head (fp32 sequential sums, one rounding). x is a slice of a
+    wider packed tensor and w a strided view over heads when `strided` (what the layer passes: q[..., :nope], kv_b_proj's slice)."""
+    g = torch.Generator().manual_seed(T * 131 + N)
+    xw = torch.randn(T, H, K + 64, generator=g).to(dtype)
+    x = xw[..., :K] if strided else xw[..., :K].contiguous()
+    ww = (torch.randn(H, N + 16, K, generator=g) / math.sqrt(K)).to(dtype)
+    w = ww[:, 8:8 + N] if strided else ww[:, 8:8 + N].contiguous()
+    ref = orc.bmm_heads(x, w)
+    xd, wd = xw.to(DEV)[..., :K], ww.to(DEV)[:, 8:8 + N]
+    if not strided:
+        xd, wd = xd.contiguous(), wd.contiguous()
+    got = ops.bmm_heads(xd, wd)
+    assert got.shape == (T, H, N)
+    assert_ulp_close(got, ref, dtype, ulps=1.0, min_exact=0.98)
+    # into a strided output (the layer writes the first kv_lora columns of the attention kernel's [T, h, 576] input)
+    buf = torch.full((T, H, N + 64), 7.0, dtype=dtype, device=DEV)
+    ops.bmm_heads(xd, wd, out=buf[..., :N])
+    assert torch.equal(buf[..., :N], got) and bool((buf[..., N:] == 7.0).all())
+    # the vendor-library form it replaces agrees to the last bit or so (same products, another summation order)
+    vend = torch.bmm(xd.transpose(0, 1), wd.transpose(1, 2)).transpose(0, 1)
+    assert_ulp_close(got, vend.cpu(), dtype, ulps=2.0, min_exact=0.9)
+
+
+def test_bmm_heads_declines_what_it_cannot_address():
+    from xllm_amd._lib import Mi355Error
+    x = torch.randn(8, 2, 48, device=DEV).bfloat16()          # K % 32 != 0
+    w = torch.randn(2, 16, 48, device=DEV).bfloat16()
+    with pytest.raises(Mi355Error):
+        ops.bmm_heads(x, w)
+    x = torch.randn(8, 2, 68, device=DEV).bfloat16()[..., 4:]  # rows start off a 16-byte boundary
+    w = torch.randn(2, 16, 64, device=DEV).bfloat16()
+    with pytest.raises(Mi355Error):
+        ops.bmm_heads(x, w)
+
+
 # ------------------------------------------------------------------------------------------- KV block copy
 @pytest.mark.parametrize("shape,dtype,with_v", [((128, 4, 128), torch.bfloat16, True),     # Qwen2-7B page: 128 KiB per block
                                                 ((16, 2, 64), torch.float16, True),

@@ -28,7 +28,7 @@ def test_shim_builds_and_exposes_reference_operator_names():
                  "scaled_quantize", "scaled_matmul", "fp8_scaled_quantize", "paged_attention", "attention_forward",
                  "random_sample", "rejection_sample", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
                  "moe_combine_result", "moe_combine_result_sorted", "group_gemm", "group_gemm_gather", "group_gemm_w8a8", "mla_decode",
-                 "flash_mla_dense_decode", "flash_mla_prefill_paged", "flash_mla_store_latent_cache", "block_copy",
+                 "flash_mla_dense_decode", "flash_mla_prefill_paged", "flash_mla_store_latent_cache", "block_copy", "bmm_heads",
                  "attention_prefill_forward", "piecewise_replay"):
         assert hasattr(m, name)
     from xllm_amd import _lib
@@ -40,7 +40,7 @@ def test_shim_builds_and_exposes_reference_operator_names():
                 "scaled_matmul", "group_gemm", "build_block_table_from_paged_kv", "random_sample", "rejection_sample",
                 "update_llm_decode_metadata", "moe_fused_topk", "moe_grouped_topk", "moe_active_topk", "moe_gen_idx",
                 "moe_combine_result", "group_gemm_gather", "mla_decode", "dense_decode", "prefill_paged", "store_latent_cache",
-                "block_copy"):
+                "block_copy", "bmm_heads"):
         assert sym + "(" in hdr, sym
 
 
@@ -424,3 +424,21 @@ def test_shim_attention_prefill_piecewise_capture_and_replay():
     m.piecewise_replay(cu.clone().to(dev), cu.clone().to(dev), max(lens), T)
     torch.cuda.synchronize()
     assert torch.equal(out_c, out_e)
+
+
+@pytest.mark.gpu
+def test_shim_bmm_heads_equals_the_ctypes_path():
+    """xllm::kernel::mi355::bmm_heads as the patched DeepseekV2AttentionImpl calls it (project_output / q_nope absorption)"""
+    from xllm_amd import ops
+    m = _shim()
+    g = torch.Generator().manual_seed(31)
+    q = torch.randn(64, 16, 192, generator=g).bfloat16().cuda()
+    kv_b = (torch.randn(16, 256, 512, generator=g) / 16).bfloat16().cuda()
+    w_kc_nk = kv_b[:, :128].transpose(1, 2).contiguous()      # load_state_dict under USE_MI355
+    w_vc_nk = kv_b[:, 128:]                                   # kv_b_proj's own slice, a view
+    a = m.bmm_heads(q[..., :128], w_kc_nk)
+    assert torch.equal(a, ops.bmm_heads(q[..., :128], w_kc_nk)) and a.shape == (64, 16, 512)
+    b = m.bmm_heads(a, w_vc_nk)
+    assert torch.equal(b, ops.bmm_heads(a, w_vc_nk)) and b.shape == (64, 16, 128)
+    with pytest.raises(RuntimeError):
+        m.bmm_heads(q[..., :128], w_vc_nk)                     # K mismatch: the reference's TORCH_CHECK inside bmm

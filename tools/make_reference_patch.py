@@ -151,6 +151,29 @@ def edit_deepseek_v2_attention(src: str) -> str:
                          '#include "kernels/mi355/mi355_ops_api.h"\n'
                          'namespace xllm::kernel {\nnamespace dcu = mi355;\n}  // namespace xllm::kernel\n'
                          '#else\n' + a + '#endif\n', 1)
+    # (3) the two weight-absorption products leave rocBLAS: kernel::mi355::bmm_heads reads the token-major tensors in place and takes
+    #     every head's matrix K-contiguous per output column ([h, N, K]): w_vc_ stays the slice of kv_b_proj's weight (no transpose at
+    #     load), w_kc_ is transposed once at load instead
+    c = ('  torch::Tensor attn_bmm =\n      torch::bmm(attn_latent.transpose(0, 1), w_vc_);  // [tp_heads, tokens, v]\n'
+         '  attn_bmm = attn_bmm.transpose(0, 1);                 // [tokens, tp_heads, v]\n')
+    assert c in src
+    src = src.replace(c, '#if defined(USE_MI355)\n'
+                         '  // w_vc_ is [tp_heads, v, kv_lora] here (see load_state_dict): one launch, no transposes\n'
+                         '  torch::Tensor attn_bmm = kernel::mi355::bmm_heads(attn_latent, w_vc_);  // [tokens, tp_heads, v]\n'
+                         '#else\n' + c + '#endif\n', 1)
+    d = ('  torch::Tensor q_nope_absorbed =\n      torch::bmm(q_nope.transpose(0, 1), w_kc_).transpose(0, 1);\n')
+    assert d in src
+    src = src.replace(d, '#if defined(USE_MI355)\n'
+                         '  // w_kc_ is [tp_heads, kv_lora, qk_nope] here (see load_state_dict)\n'
+                         '  torch::Tensor q_nope_absorbed = kernel::mi355::bmm_heads(q_nope, w_kc_);\n'
+                         '#else\n' + d + '#endif\n', 1)
+    e = ('    w_vc_ = w_vc_.transpose(1, 2)\n                .contiguous();  // [H, v_head, kv_lora] -> [H, kv_lora, v_head]\n')
+    assert e in src
+    src = src.replace(e, '#if defined(USE_MI355)\n'
+                         '    // kernel::mi355::bmm_heads takes [H, N, K]: W_vc as it lies in kv_b_proj ([H, v_head, kv_lora], a view), W_kc\n'
+                         '    // transposed once: [H, qk_nope, kv_lora] -> [H, kv_lora, qk_nope]\n'
+                         '    w_kc_ = w_kc_.transpose(1, 2).contiguous();\n'
+                         '#else\n' + e + '#endif\n', 1)
     b = '  if (is_prefill) {\n    return prefill_sdpa(q_nope_absorbed, q_pe, latent_normed, attn_metadata);\n  }\n'
     assert b in src
     src = src.replace(b, '  if (is_prefill) {\n'

@@ -50,6 +50,7 @@ _SIGS = {
     "xllm_mi355_abi_version": ([], ci),
     "xllm_mi355_build_digest": ([], C.c_char_p),
     "xllm_mi355_block_copy": ([vp, vp, vp, vp, vp, i64, i64, i64, i64, vp], ci),
+    "xllm_mi355_bmm_heads": ([vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_gemm_plan_hint": ([ci, ci, ci], None),
     "xllm_mi355_scaled_matmul_rope_cache_packed": ([vp, vp, vp, vp, vp, vp, i64, i64, i64, ci, vp, vp, vp, vp, vp, i64, i64, i64,
                                                     i64, i64, i64, ci, vp, sz, vp], ci),

@@ -390,4 +390,97 @@ template int launch_gemm_wsb_grouped<bf16_t>(const void*, const void*, const int
 template int launch_gemm_wsb_grouped<f16_t>(const void*, const void*, const int32_t*, void*, int64_t, int64_t, int64_t,
                                             int64_t, const int32_t*, int64_t, hipStream_t);
 
+// ------------------------------------------------------------------------------------------------ per-head batched GEMM
+// out[t, h, n] = r16( sum_k x[t, h, k] * w[h, n, k] ): the two weight-absorption products of MLA attention,
+//   q_nope . W_kc  (DeepseekV2AttentionImpl::forward, layers/dcu/deepseek_v2_attention.cpp:310-311: K = qk_nope 128, N = kv_lora 512)
+//   attn   . W_vc  (project_output, :180-187:                                              K = kv_lora 512, N = v_head 128)
+// which the reference runs as torch::bmm over transposed views (rocBLAS) plus two transposes. Here the token-major tensors are
+// read and written in place through their (token, head) strides -- no transpose, no copy -- and the weights are taken K-contiguous
+// per output column ([h, N, K]: for W_vc that IS kv_b_proj's weight slice before the reference transposes it for bmm, :336-338;
+// W_kc is transposed once at load time). A few hundred MFLOP and a few MB per call: the structure of the weight-stream kernel above
+// without K slices or an LDS stage -- wave = 16 tokens x 64 columns of one head, both operands straight from L2 into MFMA operand
+// order (lane (r = l & 15, kq = l >> 4) loads the 16 bytes [32 s + 8 kq, +8) of row r), W as the MFMA row operand so that a
+// lane of the accumulator holds 4 consecutive n of one token and the result leaves as 8-byte stores. fp32 accumulation, k ascending.
+template <typename T>
+__global__ __launch_bounds__(256) void bmm_heads_kernel(const T* __restrict__ x, int64_t x_st, int64_t x_sh,
+                                                        const T* __restrict__ w, int64_t w_sh, int64_t w_sn,
+                                                        T* __restrict__ out, int64_t o_st, int64_t o_sh, int Tn, int N, int K) {
+  const int h = blockIdx.z, n0 = blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int t = blockIdx.x * 64 + wave * 16 + r;
+  const bool t_ok = t < Tn;
+  const T* const xrow = x + (int64_t)(t_ok ? t : 0) * x_st + (int64_t)h * x_sh + kq * 8;
+  const T* wrow[4];
+  bool n_ok[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = n0 + nb * 16 + r;
+    n_ok[nb] = n < N;
+    wrow[nb] = w + (int64_t)h * w_sh + (int64_t)(n_ok[nb] ? n : 0) * w_sn + kq * 8;
+  }
+  wsb_f32x4 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) acc[nb] = wsb_f32x4{0.f, 0.f, 0.f, 0.f};
+  const wsb_u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int k = 0; k < K; k += 32) {
+    const wsb_u32x4 xv = t_ok ? *reinterpret_cast<const wsb_u32x4*>(xrow + k) : zero;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const wsb_u32x4 wv = n_ok[nb] ? *reinterpret_cast<const wsb_u32x4*>(wrow[nb] + k) : zero;
+      acc[nb] = WsbTraits<T>::mfma(wv, xv, acc[nb]);     // D[n][m]: lane & 15 = token, registers = 4 consecutive n
+    }
+  }
+  if (!t_ok) return;
+  T* const orow = out + (int64_t)t * o_st + (int64_t)h * o_sh;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = n0 + nb * 16 + 4 * kq;
+    if (n + 3 < N) {
+      uint16_t hb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const T v16 = from_f32<T>(acc[nb][e]);     // RNE, like every 16-bit store of this file
+        __builtin_memcpy(&hb[e], &v16, 2);
+      }
+      *reinterpret_cast<uint2*>(orow + n) = make_uint2((unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) orow[n + e] = from_f32<T>(acc[nb][e]);
+    }
+  }
+}
+
+template <typename T>
+int launch_bmm_heads(const void* x, int64_t x_st, int64_t x_sh, const void* w, int64_t w_sh, int64_t w_sn, void* out, int64_t o_st,
+                     int64_t o_sh, int64_t Tn, int64_t H, int64_t N, int64_t K, hipStream_t s) {
+  const dim3 grid((unsigned)((Tn + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)H);
+  hipLaunchKernelGGL((bmm_heads_kernel<T>), grid, dim3(256), 0, s, (const T*)x, x_st, x_sh, (const T*)w, w_sh, w_sn, (T*)out, o_st,
+                     o_sh, (int)Tn, (int)N, (int)K);
+  return hip_check_launch();
+}
+
 }  // namespace xm
+
+extern "C" {
+int xllm_mi355_bmm_heads(const void* x, int64_t x_stride_t, int64_t x_stride_h, const void* w, int64_t w_stride_h,
+                         int64_t w_stride_n, void* out, int64_t out_stride_t, int64_t out_stride_h, int64_t n_tokens,
+                         int64_t n_heads, int64_t N, int64_t K, int dtype, void* stream) {
+  using namespace xm;
+  if (!x || !w || !out || n_tokens < 0 || n_heads <= 0 || N <= 0 || K <= 0) return XM_ERR_INVALID;
+  if (n_tokens == 0) return XM_OK;
+  // 16-byte operand loads, 8-byte stores: every row of every operand starts on such a boundary
+  if (K % 32 || x_stride_t % 8 || x_stride_h % 8 || w_stride_h % 8 || w_stride_n % 8 || out_stride_t % 4 || out_stride_h % 4 ||
+      ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8) || n_heads > 65535 || (N + 63) / 64 > 65535 ||
+      n_tokens >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31))
+    return XM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == XM_BF16)
+    return launch_bmm_heads<bf16_t>(x, x_stride_t, x_stride_h, w, w_stride_h, w_stride_n, out, out_stride_t, out_stride_h, n_tokens,
+                                    n_heads, N, K, s);
+  if (dtype == XM_F16)
+    return launch_bmm_heads<f16_t>(x, x_stride_t, x_stride_h, w, w_stride_h, w_stride_n, out, out_stride_t, out_stride_h, n_tokens,
+                                   n_heads, N, K, s);
+  return XM_ERR_UNSUPPORTED;
+}
+}

@@ -456,6 +456,10 @@ class DeepseekV2Attention:
         kv_b = rnd(self.h * (nope + v_dim), kv_lora).unflatten(0, (self.h, nope + v_dim))
         self.w_kc = kv_b[:, :nope].contiguous()                       # [h, nope, kv_lora]
         self.w_vc = kv_b[:, nope:].transpose(1, 2).contiguous()       # [h, kv_lora, v]  (load_state_dict :335-339)
+        # what ops.bmm_heads reads (round 5): every head's matrix K-contiguous per output column, [h, N, K]. For W_vc that is the
+        # slice of kv_b_proj's weight itself (a VIEW, before the reference transposes it for torch::bmm); W_kc is transposed once here
+        self.w_kc_nk = self.w_kc.transpose(1, 2).contiguous()         # [h, kv_lora, nope]
+        self.w_vc_nk = kv_b[:, nope:]                                 # [h, v, kv_lora] (strided over h)
         self.o_w = rnd(hidden, self.h * v_dim)
         if quant != "16bit":
             assert q_lora > 0 and quant == "fp8"
@@ -487,18 +491,20 @@ class DeepseekV2Attention:
         else:
             q = ops.matmul(hidden_states, self.q_w)
         q = q.view(T, self.h, self.nope + self.rope)
-        q_nope = q[..., :self.nope].contiguous()
         q_pe = to_deepseek_rope_layout(q[..., self.nope:].contiguous())
         ops.rotary_embedding(positions, q_pe, None, self.cos_sin, True, head_size=self.rope)
-        q_abs = torch.bmm(q_nope.transpose(0, 1), self.w_kc).transpose(0, 1)                      # [T, h, kv_lora]
-        q_in = torch.cat([q_abs, q_pe], -1).contiguous()
+        # q_nope x W_kc (:310-311: torch::bmm over transposed views = rocBLAS in the reference): one launch of this backend's per-head
+        # GEMM, reading the q_nope slice of the packed q tensor in place and writing the first kv_lora columns of the kernel's input
+        q_in = torch.empty(T, self.h, self.kv_lora + self.rope, dtype=q.dtype, device=q.device)
+        ops.bmm_heads(q[..., :self.nope], self.w_kc_nk, out=q_in[..., :self.kv_lora])             # [T, h, kv_lora]
+        q_in[..., self.kv_lora:] = q_pe
         if md.is_prefill or md.is_chunked_prefill:
             attn = ops.mla_prefill(q_in, kv_cache.get_k_cache(), md.q_cu_seq_lens, md.kv_seq_lens, md.block_table,
                                    self.kv_lora, self.scale, md.max_seq_len, True)
         else:
             attn = ops.mla_decode(q_in, kv_cache.get_k_cache(), md.kv_seq_lens, md.block_table, self.kv_lora, self.scale,
                                   md.max_seq_len)
-        out = torch.bmm(attn.transpose(0, 1), self.w_vc).transpose(0, 1).flatten(1, 2)            # project_output :180-187
+        out = ops.bmm_heads(attn.view(T, self.h, self.kv_lora), self.w_vc_nk).flatten(1, 2)       # project_output :180-187
         if self.quant != "16bit":
             return self.o_lin.forward(out)
         return ops.matmul(out, self.o_w)   # partial sums under TP: the decoder layer reduces

@@ -845,6 +845,25 @@ def moe_combine_sorted(gemm2_sorted, src_dst, weights, n_tokens: int, topk: int,
     return out
 
 
+def bmm_heads(x, w_nk, out=None) -> torch.Tensor:
+    """MLA weight absorption without rocBLAS (round 5): out[t, h, n] = sum_k x[t, h, k] * w_nk[h, n, k] -- torch::bmm(x.transpose(0, 1),
+    w).transpose(0, 1) of DeepseekV2AttentionImpl (layers/dcu/deepseek_v2_attention.cpp:180-187, 310-311) with the head's matrix
+    stored K-contiguous ([h, N, K]: kv_b_proj's own slice for W_vc; W_kc transposed once at load). x [T, h, K] and out [T, h, N] may
+    be strided views (x: a slice of the packed q tensor); no transpose, no copy. Raises when the shape is outside the kernel."""
+    _need_cuda(x, w_nk)
+    T, H, K = x.shape
+    N = w_nk.size(1)
+    if w_nk.size(0) != H or w_nk.size(2) != K or x.stride(2) != 1 or w_nk.stride(2) != 1 or x.dtype != w_nk.dtype:
+        raise Mi355Error("bmm_heads: x [T, h, K] and w [h, N, K] with K contiguous and one dtype")
+    if out is None:
+        out = torch.empty(T, H, N, dtype=x.dtype, device=x.device)
+    if out.stride(2) != 1:
+        raise Mi355Error("bmm_heads: out must be contiguous over N")
+    check(_lib.lib().xllm_mi355_bmm_heads(_p(x), x.stride(0), x.stride(1), _p(w_nk), w_nk.stride(0), w_nk.stride(1), _p(out),
+                                          out.stride(0), out.stride(1), T, H, N, K, _dt(x), _stream()), "bmm_heads")
+    return out
+
+
 def group_gemm(input, weight, token_count, output=None):
     """dcu::group_gemm(input [total, K], weight [E, N, K], token_count [E] int32 (device), out?) (dcu_ops_api.h:48-51)"""
     _need_cuda(input, weight, token_count)
