@@ -91,10 +91,14 @@ struct WsDma {
                               // tile), the default policy when the m tiles of a column range share them through their XCD's L2
                               // (wave-uniform: a scalar branch; round 3, M = 256 on 128-row tiles: qkv 19.4 -> 17.2, o 19.7 -> 17.9 us)
 };
-template <int NDA, int NDW>
+// WNT: the weight stream's cache policy as a compile-time constant (1 = nt, 0 = default) or -1 = the run-time flag d.w_nt. The
+// staggered eight-wave kernel passes a constant: with the run-time flag every DMA issue of its matrix phase sat behind a scalar
+// branch (14 s_cbranch per K tile, each taken branch an instruction-fetch bubble between MFMAs; probe at the end of round 4:
+// gate_up + SiLU.mul at M = 256 52.0 -> 49.7-50.6 us, profiles/r04_next_round_probes.txt)
+template <int NDA, int NDW, int WNT = -1>
 __device__ __forceinline__ void ws_dma_piece(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int j) {
   if (j < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_a, d.dst_a + j * WS_FRAG, 16, voff_a[j], d.so_a, 0, 0);
-  else if (d.w_nt)
+  else if (WNT == 1 || (WNT < 0 && d.w_nt))
     __builtin_amdgcn_raw_ptr_buffer_load_lds(d.rsrc_w, (j - NDA) < d.nvalid_w ? d.dst_w + (j - NDA) * WS_FRAG : d.dump, 16,
                                              voff_w[j - NDA], d.so_w, 0, WS_W_AUX);
   else
@@ -112,11 +116,11 @@ __device__ __forceinline__ void ws_dma_slot(const WsDma& d, const int (&voff_a)[
 
 // pieces [LO, HI) of the tile, the part due after MFMA group `slot` of `nslots` (staggered kernel: a tile's pieces are split
 // between a read phase and a matrix phase)
-template <int NDA, int NDW, int LO, int HI>
+template <int NDA, int NDW, int LO, int HI, int WNT = -1>
 __device__ __forceinline__ void ws_dma_range(const WsDma& d, const int (&voff_a)[8], const int (&voff_w)[8], int slot, int nslots) {
   const int lo = LO + slot * (HI - LO) / nslots, hi = LO + (slot + 1) * (HI - LO) / nslots;
 #pragma unroll
-  for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW>(d, voff_a, voff_w, j);
+  for (int j = lo; j < hi; ++j) ws_dma_piece<NDA, NDW, WNT>(d, voff_a, voff_w, j);
 }
 
 // k step 1 of a tile, group by group (compile-time recursion: the wait counts are immediates)
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void gemm_ws_kernel(const uint8_t* __r
 #ifdef WS8_TIMING
 __device__ long long ws8_dbg[64];
 #endif
-template <int KIND, int NG, int DW, int NRD>
+template <int KIND, int NG, int DW, int NRD, int WNT>
 __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wp,
                                                           int M, int N, int64_t K, int m_tiles, int n_tiles,
                                                           int kt_per_slice, int n_slices, GemmEpi epi,
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
     slice = rest / n_tiles;
   }
   const int KT = (int)(K / WS_BK);
-  const int w_nt = epi.w_policy ? epi.w_policy == 1 : m_tiles == 1;   // (WsDma::w_nt)
+  constexpr int w_nt = WNT;   // (the launcher turns epi.w_policy / the tile count into the template argument)
   const int kt0 = slice * kt_per_slice;
   int kt1 = kt0 + kt_per_slice;
   kt1 = kt1 > KT ? KT : kt1;
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
   }
   if (grp) {
     WS8_DESC(dp, DW)
-    ws_dma_range<NDA, NDW, 0, NRD>(dp, voff_a, voff_w, 0, 1);   // group 1 is one half-tile of requests ahead
+    ws_dma_range<NDA, NDW, 0, NRD, WNT>(dp, voff_a, voff_w, 0, 1);   // group 1 is one half-tile of requests ahead
     // tiles 0 and 1 have landed: DW - 2 whole tiles + the NRD pieces stay in flight
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DW - 2) * ND + NRD) : "memory");
     __builtin_amdgcn_s_setprio(1);  // the younger half loses every arbitration otherwise (MI355X_MICROARCH.md)
@@ -920,10 +924,10 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
     {  // this phase's share of tile t + DW: group 0 opens the tile, group 1 completes it (and then waits for tile t + 1)
       WS8_DESC(dr, t + DW)
       if (grp) {
-        ws_dma_range<NDA, NDW, NRD, ND>(dr, voff_a, voff_w, 0, 1);
+        ws_dma_range<NDA, NDW, NRD, ND, WNT>(dr, voff_a, voff_w, 0, 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMCNT) : "memory");
       } else {
-        ws_dma_range<NDA, NDW, 0, NRD>(dr, voff_a, voff_w, 0, 1);
+        ws_dma_range<NDA, NDW, 0, NRD, WNT>(dr, voff_a, voff_w, 0, 1);
       }
     }
     // retired before the barrier: the other group (or this one) re-stages the slot in the next phase
@@ -943,24 +947,24 @@ __global__ __launch_bounds__(512, 1) void gemm_ws8s_kernel(const uint8_t* __rest
       if constexpr (KIND == kI8) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], w0[ng], a0[mb]);
-        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, 2 * NG);
-        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, 2 * NG);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD, WNT>(d, voff_a, voff_w, ng, 2 * NG);
+        else ws_dma_range<NDA, NDW, NRD, ND, WNT>(d, voff_a, voff_w, ng, 2 * NG);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) WS_MFMA(acc[mb][ng], w1[ng], a1[mb]);
-        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, NG + ng, 2 * NG);
-        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, NG + ng, 2 * NG);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD, WNT>(d, voff_a, voff_w, NG + ng, 2 * NG);
+        else ws_dma_range<NDA, NDW, NRD, ND, WNT>(d, voff_a, voff_w, NG + ng, 2 * NG);
       } else if constexpr (KIND == kFP8) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_fp8(w0[ng], w1[ng], a0[mb], a1[mb], acc[mb][ng]);
-        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, NG);
-        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, NG);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD, WNT>(d, voff_a, voff_w, ng, NG);
+        else ws_dma_range<NDA, NDW, NRD, ND, WNT>(d, voff_a, voff_w, ng, NG);
       } else {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(w0[ng], a0[mb], acc[mb][ng]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb][ng] = ws_mma_h16<KIND>(w1[ng], a1[mb], acc[mb][ng]);
-        if (grp) ws_dma_range<NDA, NDW, 0, NRD>(d, voff_a, voff_w, ng, NG);
-        else ws_dma_range<NDA, NDW, NRD, ND>(d, voff_a, voff_w, ng, NG);
+        if (grp) ws_dma_range<NDA, NDW, 0, NRD, WNT>(d, voff_a, voff_w, ng, NG);
+        else ws_dma_range<NDA, NDW, NRD, ND, WNT>(d, voff_a, voff_w, ng, NG);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1089,8 +1093,13 @@ int ws_launch_cfg(const void* A, const void* Wp, int64_t M, int64_t N, int64_t K
 #endif
     constexpr int ND8 = (2 * WN * NG + 7) / 8 + 4;  // pieces per wave and tile (weights + 4 activation pieces)
     // (a first version issued every request from the matrix phase, NRD = 0: 46.0 vs 45.4 us for gate_up at M = 256 -- removed)
-    hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
-                       (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+    const bool w_nt = epi.w_policy ? epi.w_policy == 1 : m_tiles == 1;   // (WsDma::w_nt, decided here since round 5)
+    if (w_nt)
+      hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2, 1>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
+    else
+      hipLaunchKernelGGL((gemm_ws8s_kernel<KIND, NG, DW, ND8 / 2, 0>), dim3(grid), dim3(512), 0, s, (const uint8_t*)A,
+                         (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs);
   } else {
     hipLaunchKernelGGL((gemm_ws_kernel<KIND, NWV, WM, WN, MB, NG, DW>), dim3(grid), dim3(NWV * 64), 0, s, (const uint8_t*)A,
                        (const uint8_t*)Wp, (int)M, (int)N, K, m_tiles, n_tiles, per, slices, epi, slabs, f_kstagger);
