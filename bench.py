@@ -83,6 +83,8 @@ def parse():
                         "beside the headline")
     p.add_argument("--no-pmc", action="store_true",
                    help="skip the live rocprofv3 --pmc passes behind roofline.traffic (then the committed record is quoted)")
+    p.add_argument("--no-per-rank", action="store_true",
+                   help="N = 1: skip the per_rank_emulated block (one rank's step at the TP4 x DP2 and DP8 shard shapes, no exchange)")
     p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
@@ -635,6 +637,48 @@ def main():
     record["on"] = False
 
     attn_ms = sum(e0.elapsed_time(e1) for e0, e1 in attn_events) / max(len(attn_events), 1)
+
+    def attention_path_in_graph():
+        """the attention launches of the step by themselves -- every layer's call on its own KV cache, exactly what the layer issues
+        (the fused int8 epilogue, or attention + split-KV merge + scaled_quantize when the plan declines it) -- captured into ONE
+        graph and replayed: microseconds per layer without the host's launch gaps. For the 336-us launches of the headline the
+        eager HIP events above agree with it; for the short launches of the per-rank shapes (50-60 us) the eager figure is an
+        upper bound (the host cannot enqueue fast enough) and this is the kernel-side number."""
+        L0 = model.layers[0]
+        qa = torch.randn(B, L0.nq * L0.d, device=dev, dtype=dtype)
+
+        def run():
+            for layer, kvc in zip(model.layers, kv_caches):
+                if mode == "int8" and not a.no_fuse:
+                    layer.attention_kernel(qa, md, kvc)
+                else:
+                    ops.paged_attention(qa.unflatten(-1, (L0.nq, L0.d)), kvc.k_cache, kvc.v_cache, None, md.kv_seq_lens, md.block_table,
+                                        1, md.max_seq_len, L0.attn.scale, False, L0.attn.window_left)
+        try:
+            record["on"] = False
+            run()
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                run()
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    run()
+                for _ in range(2):
+                    gr.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    gr.replay()
+                e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / (5 * len(model.layers))
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] attention-in-graph timing failed: {e!r}", file=sys.stderr)
+            return None
+
+    attn_graph_ms = attention_path_in_graph() if world == 1 else None
     nq_l = model.layers[0].nq
     d = margs.head_dim
     # algorithmic bytes per launch (SURVEY 8d): K+V of every cached token once + Q in + O out
@@ -703,6 +747,10 @@ def main():
     if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_gemm:
         gemm_info = gemm_leg(dev, live_pmc=not a.no_pmc)
 
+    per_rank = None
+    if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_per_rank and a.emulate_tp <= 1 and a.emulate_dp <= 1:
+        per_rank = per_rank_emulated()
+
     shim_info = None
     if a.via_shim and world == 1 and tp_size == 1 and mode == "int8":
         shim_info = via_shim_leg(model, margs, md, kv_caches, tokens, positions, a.steps, a.warmup)
@@ -740,7 +788,9 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": attn_bytes, "avg_launch_ms": round(attn_ms, 4),
-                         "launches_timed": len(attn_events)},
+                         "launches_timed": len(attn_events),
+                         "attention_path_ms_in_graph": None if attn_graph_ms is None else round(attn_graph_ms, 4),
+                         "attention_path_frac_in_graph": None if not attn_graph_ms else round(attn_bytes / (attn_graph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         if layouts is not None:
             out["layouts"] = layouts
@@ -752,6 +802,8 @@ def main():
             out["via_shim"] = shim_info
         if gemm_info is not None:
             out["gemm"] = gemm_info
+        if per_rank is not None:
+            out["per_rank_emulated"] = per_rank
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
             if a.config == "cfg3":
@@ -761,6 +813,31 @@ def main():
         dist.destroy_process_group()
 
 
+
+
+def per_rank_emulated():
+    """what ONE rank of the 8-GPU layouts computes per step, measured on this GPU with the shard shapes and NO exchange
+    (children of this process: `bench.py --emulate-tp 4 --emulate-dp 2` = a rank of TP4 x DP2, B = 128, 7 q heads + 1 kv head,
+    a quarter of every weight; `--emulate-dp 8` = a DP replica, B = 32, the whole model). The driver measures the real scaling;
+    these bound it from above: N-GPU speed-up <= step(1 GPU) / step(rank)."""
+    import subprocess
+    out = {}
+    for name, flags in (("tp4dp2_rank", ["--emulate-tp", "4", "--emulate-dp", "2"]), ("dp8_replica", ["--emulate-dp", "8"])):
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--no-cpu-baseline", "--no-prefill", "--no-gemm", "--no-engine",
+                                                                      "--no-pmc", "--no-per-rank", "--steps", "20", "--warmup", "3"]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            r = d["roofline"]
+            out[name] = {"ms_per_step": d["ms_per_step"], "per_rank_batch": d["config"]["per_gpu_batch"],
+                         "attention_us_eager_events": round(r["avg_launch_ms"] * 1e3, 1), "attention_frac_eager_events": r["frac"],
+                         "attention_path_us_in_graph": None if r.get("attention_path_ms_in_graph") is None else round(r["attention_path_ms_in_graph"] * 1e3, 1),
+                         "attention_path_frac_in_graph": r.get("attention_path_frac_in_graph"),
+                         "attention_bytes_per_launch": r["bytes_per_launch"], "command": "bench.py " + " ".join(flags)}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def gemm_leg(dev, live_pmc=True):
