@@ -2457,6 +2457,32 @@ def _mask_mismatch_is_a_boundary_case(ref_row_sorted_probs, p, rank_a, rank_b, e
     return bool(((pref[lo:hi + 1] - p).abs() <= 2e-5).any())
 
 
+def test_apply_top_k_top_p_degenerate_rows_and_default_k():
+    """round-4 advisor: (a) a batch in which ONE request sets top_k carries the others' default top_k = -1: under the both-given
+    rule those rows are filtered by p alone (not reduced to top-1); (b) a row without a finite maximum (all -inf) and NaN logits in
+    an otherwise finite row do not poison the selection: the all -inf row comes back unchanged, NaN columns carry no mass."""
+    from oracle import sampling as osm
+    g = torch.Generator().manual_seed(4)
+    V = 4096
+    base = torch.randn(4, V, generator=g) * 3
+    top_k = torch.tensor([50, -1, 0, 7], dtype=torch.int64)
+    top_p = torch.tensor([0.9, 0.9, 0.5, 1.0])
+    ref = osm.apply_top_k_top_p(base.clone(), None, top_k, top_p)
+    got = ops.apply_top_k_top_p(base.clone().to(DEV), None, top_k.to(DEV), top_p.to(DEV)).cpu()
+    for b in range(4):       # the same survivors as the sorting reference (one more or less exactly at the cumulative-p boundary)
+        kg, kr = ~torch.isinf(got[b]), ~torch.isinf(ref[b])
+        assert abs(int(kg.sum()) - int(kr.sum())) <= 1 and int((kg ^ kr).sum()) <= 1, (b, int(kg.sum()), int(kr.sum()))
+        assert torch.equal(got[b][kg & kr], ref[b][kg & kr])
+    assert int((~torch.isinf(got[1])).sum()) > 50 and int((~torch.isinf(got[2])).sum()) > 1      # k <= 0: NOT greedy
+    bad = base.clone()
+    bad[1] = float("-inf")
+    bad[3, 5] = float("nan")
+    out = ops.apply_top_k_top_p(bad.clone().to(DEV), None, top_k.to(DEV), top_p.to(DEV)).cpu()
+    assert torch.isinf(out[1]).all() and (out[1] < 0).all()                                         # untouched
+    keep3 = ~torch.isinf(out[3])
+    assert int(keep3.sum()) <= 8 and torch.equal(out[0], got[0])                                    # k = 7 (+ the NaN column at most)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("V", [1000, 152064])
 def test_apply_top_k_top_p_matches_the_sorting_reference(V, dtype):

@@ -82,8 +82,10 @@ __device__ __forceinline__ float lp_unkey(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 // probability mass of a logit in 2^-40 fixed point (x <= row max: the mass is in (0, 1])
+// (a NaN logit has no mass: the float -> integer conversion of a NaN is undefined behaviour)
 __device__ __forceinline__ unsigned long long lp_mass(float x, float mx) {
-  return (unsigned long long)(__expf(x - mx) * 1099511627776.0f);
+  const float e = __expf(x - mx) * 1099511627776.0f;
+  return e == e ? (unsigned long long)e : 0ull;
 }
 
 struct LpShared {
@@ -133,9 +135,12 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   // request sets top_k > 0, and every reference branch that runs maps k <= 0 to "unlimited" (the one-of-them branch,
   // logits_utils.cpp:126-133, and the NPU both-given branch, :109-116). Only the otherwise unused torch_impl clamps to 1 (:70),
   // which would turn every request that left top_k at its default into greedy sampling in a mixed batch (round-4 advisor).
+  // a row without a finite maximum (all -inf, all NaN) has no ranking and no probability mass (x - mx is NaN): it is left
+  // unfiltered -- only the temperature is applied -- instead of running the selections on garbage (round-4 advisor)
+  const bool degenerate = !(mx > -__builtin_inff());
   long long k = top_k ? top_k[b] : 0;
   if (rule == 1 && k > V) k = V;
-  const bool use_k = top_k && k > 0 && k < V;
+  const bool use_k = top_k && k > 0 && k < V && !degenerate;
   uint32_t kth_key = 0u;             // keep every key >= kth_key ...
   unsigned k_rem = 0xffffffffu;      // ... but of the ties at kth_key only the first k_rem by index
   if (use_k) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   // ---- top-p: the key K* at which the cumulative probability of the sorted, top-k-masked row crosses p
   uint32_t p_key = 0u;               // keep every key > p_key, and of the ties at p_key the first p_keep (by index)
   unsigned p_keep = 0xffffffffu;
-  if (top_p) {
+  if (top_p && !degenerate) {
     const float p = top_p[b];
     // Z = sum of the kept masses (the ties at kth_key count k_rem times)
     unsigned long long z = 0ull;
