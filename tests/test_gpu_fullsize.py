@@ -99,6 +99,39 @@ def test_kv_write_full_size_round_trip():
     assert int(kc.view(-1, NKV * D)[untouched].abs().sum()) == 0
 
 
+def test_block_copy_full_size_fan_out_over_all_layers():
+    """cuda::block_copy at the headline geometry (28 layers, 128-KiB cache blocks of 128 tokens x 4 kv heads x 128): a beam-search
+    fork of 64 sources into 4 destinations each over every layer in ONE launch. Size-independent properties: every destination
+    block equals its source bit for bit, sources and bystanders are untouched (int64 checksums of the whole caches), and copying
+    the same plan twice changes nothing (idempotence)."""
+    g = torch.Generator().manual_seed(55)
+    L, nb, fan, nsrc = 28, 600, 4, 64
+    gd = torch.Generator(device=DEV).manual_seed(56)
+    mk = lambda: torch.randint(-30000, 30000, (nb, BS, NKV, D), dtype=torch.int16, device=DEV, generator=gd).view(torch.bfloat16)
+    k, v = [mk() for _ in range(L)], [mk() for _ in range(L)]
+    perm = torch.randperm(nb, generator=g)
+    src = perm[:nsrc].to(torch.int32)
+    dst = perm[nsrc:nsrc + nsrc * fan].to(torch.int32)
+    cs = (torch.arange(1, nsrc + 1) * fan).to(torch.int32)
+    before = [(t.view(torch.int16).long().sum(dim=(1, 2, 3)), u.view(torch.int16).long().sum(dim=(1, 2, 3))) for t, u in zip(k, v)]
+    kp = torch.tensor([t.data_ptr() for t in k], dtype=torch.int64, device=DEV)
+    vp = torch.tensor([t.data_ptr() for t in v], dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        ops.block_copy(kp, vp, src.to(DEV), dst.to(DEV), cs.to(DEV), k[0][0].numel(), torch.bfloat16)
+    torch.cuda.synchronize()
+    owner = src.long().repeat_interleave(fan)                       # destination j copies source j // fan
+    dl = dst.long()
+    for l in (0, 13, 27):
+        assert torch.equal(k[l][dl.to(DEV)].view(torch.int16), k[l][owner.to(DEV)].view(torch.int16))
+        assert torch.equal(v[l][dl.to(DEV)].view(torch.int16), v[l][owner.to(DEV)].view(torch.int16))
+    keep = torch.ones(nb, dtype=torch.bool)
+    keep[dl] = False
+    for l in range(L):
+        ck, cv = k[l].view(torch.int16).long().sum(dim=(1, 2, 3)), v[l].view(torch.int16).long().sum(dim=(1, 2, 3))
+        assert torch.equal(ck[keep.to(DEV)], before[l][0][keep.to(DEV)]) and torch.equal(cv[keep.to(DEV)], before[l][1][keep.to(DEV)])
+        assert torch.equal(ck[dl.to(DEV)], before[l][0][owner.to(DEV)]) and torch.equal(cv[dl.to(DEV)], before[l][1][owner.to(DEV)])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 2 * I, H), (256, H, I), (8192, 2 * I, H), (8192, H, I), (8192, 4608, H)])
 def test_int8_gemm_full_size_checksums(M, N, K):
     """exact int32 accumulators at the full Qwen2-7B shapes: column / row checksums over the WHOLE output (int64,
