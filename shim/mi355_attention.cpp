@@ -1,11 +1,21 @@
+// inside the xLLM tree this file is xllm/core/layers/mi355/attention.cpp next to attention.h (= mi355_attention.h, INTEGRATION.md
+// section 3); in this repository the header keeps its own name
+#if __has_include("layers/mi355/attention.h")
+#include "layers/mi355/attention.h"
+#else
 #include "mi355_attention.h"
+#endif
 
 #include <type_traits>
 
 // the reference's host code for piecewise HIP-graph capture (kernels/dcu/attention_runner.{h,cpp}, compiled into a USE_MI355
 // build unchanged); outside the xLLM tree shim/stub/kernels/dcu/ stands in
 #include "kernels/dcu/attention_runner.h"
+#if __has_include("kernels/mi355/mi355_ops_api.h")
+#include "kernels/mi355/mi355_ops_api.h"
+#else
 #include "mi355_ops_api.h"
+#endif
 
 namespace xllm {
 namespace layer {
