@@ -95,7 +95,8 @@ def parse():
     return p.parse_args()
 
 
-def live_pmc_traffic(B, ctx, nq, nkv, launches=4, timeout_s=240):
+def live_pmc_traffic(B, ctx, nq, nkv, launches=4, timeout_s=240, probe_name="attn_pmc_probe.py", kernel_like="%paged_decode_kernel%",
+                     probe_args=None):
     """roofline.traffic measured in this run: rocprofv3 --kernel-trace --pmc <counter> (one counter per pass) around
     tools/attn_pmc_probe.py, per-dispatch sums of the paged_decode kernel read back from the rocpd database. gfx950 correction of
     MI355X_MICROARCH.md's HBM section: FETCH_SIZE (KiB) reports half the bytes of a wide coalesced streaming read -> doubled;
@@ -108,29 +109,29 @@ def live_pmc_traffic(B, ctx, nq, nkv, launches=4, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, None
-    probe = os.path.join(ROOT, "tools", "attn_pmc_probe.py")
+    probe = os.path.join(ROOT, "tools", probe_name)
+    pargs = [str(x) for x in (probe_args if probe_args is not None else (B, ctx, nq, nkv, launches))]
     got = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             tmp = tempfile.mkdtemp(prefix="xm_pmc_", dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp")
             try:
-                subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "--", sys.executable, probe, str(B), str(ctx),
-                                str(nq), str(nkv), str(launches)], cwd="/tmp", env=env, timeout=timeout_s, check=True,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "--", sys.executable, probe] + pargs,
+                               cwd="/tmp", env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
                 if not dbs:
                     return None, None
                 cur = sqlite3.connect(dbs[0]).cursor()
                 row = cur.execute("select sum(value), count(*) from counters_collection where counter_name = ? and "
-                                  "kernel_name like '%paged_decode_kernel%'", (counter,)).fetchone()
+                                  "kernel_name like ?", (counter, kernel_like)).fetchone()
                 if not row or not row[1]:
                     return None, None
                 got[counter] = float(row[0]) / float(row[1])          # KiB per dispatch
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         traffic = int(2.0 * got["FETCH_SIZE"] * 1024 + got["WRITE_SIZE"] * 1024)
-        return traffic, (f"rocprofv3 --pmc in this run (tools/attn_pmc_probe.py, {launches} launches per counter pass): FETCH_SIZE "
+        return traffic, (f"rocprofv3 --pmc in this run (tools/{probe_name}, {launches} launches per counter pass): FETCH_SIZE "
                          f"{got['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction) + WRITE_SIZE {got['WRITE_SIZE']:.0f} KiB per dispatch")
     except Exception as e:  # noqa: BLE001
         print(f"[bench] live PMC pass failed ({e!r}); quoting the committed record instead", file=sys.stderr)
@@ -685,7 +686,7 @@ def main():
     attn_bytes = B * (ctx * nkv_l * d * 2 * 2 + 2 * nq_l * d * 2)
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9 if attn_ms > 0 else 0.0
     traffic, traffic_source = None, None
-    if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_pmc:
+    if world == 1 and tp_size == 1 and a.config in ("cfg3", "cfg2") and not a.no_pmc:
         # HBM bytes per launch of the dominant kernel from the PMC counters, collected IN THIS RUN (round-3 review, weak #12): two
         # rocprofv3 passes (one counter each, as MI355X_MICROARCH.md prescribes) over tools/attn_pmc_probe.py = the same kernel at
         # the same shape in a child process

@@ -126,6 +126,13 @@ def cfg4_slice(a, dev):
         return e0.elapsed_time(e1) / (2 * n)
 
     qb_ms, o_ms = graph_time(attn.q_b_lin), graph_time(attn.o_lin)
+    # HBM bytes of the dominant kernel from the PMC counters, in this run (two rocprofv3 --pmc passes over tools/mla_pmc_probe.py: the
+    # same kernel at the same shape in a child process; the guide's gfx950 correction is applied by bench.live_pmc_traffic)
+    traffic, traffic_source = None, None
+    if not getattr(a, "no_pmc", False):
+        import bench as _bench
+        traffic, traffic_source = _bench.live_pmc_traffic(B, ctx, h_l, 1, probe_name="mla_pmc_probe.py", kernel_like="%mla_decode%",
+                                                          probe_args=(B, ctx, h_l, 4))
     qb_bytes, o_bytes = h_l * (nope + rope) * q_lora, H * h_l * v_dim
     return {
         "metric": "decode tokens/s through one DeepSeek-V3 layer of one TP=8 rank (cfg4-slice)",
@@ -140,8 +147,8 @@ def cfg4_slice(a, dev):
                    # on the token-major tensors; what is left of the vendor library on the measured path is copy / embedding glue
                    "vendor_library_ops": ["torch copy / embedding glue"]},
         "roofline": {"bound": "hbm", "kernel": "mla_decode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
-                     "avg_launch_ms": round(attn_ms, 4), "launches_timed": len(ms)},
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "bytes_per_launch": nbytes, "avg_launch_ms": round(attn_ms, 4), "launches_timed": len(ms)},
         "fp8_linears": {"q_b_proj": {"M": B, "N": h_l * (nope + rope), "K": q_lora, "us": round(qb_ms * 1e3, 2),
                                       "weight_gbs": round(qb_bytes / (qb_ms * 1e-3) / 1e9, 1),
                                       "us_eager_events": round(qb_eager_ms * 1e3, 2)},

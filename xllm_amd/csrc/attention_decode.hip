@@ -160,8 +160,13 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
   };
   // every load is unconditional (tiles past the range re-load the last tile, tokens past kv_len the last token):
   // a branch around a load would make hipcc fall back to s_waitcnt vmcnt(0) and collapse the prefetch depth
+  // The prefetch of the iteration that computes the wave's LAST tile asks for tile my_hi: nobody consumes it. It used to re-load
+  // the whole last tile (16 KiB per wave: 0.8 % of the launch's bytes at cfg3, 6 % on a 16-tile range -- and with non-temporal
+  // loads those lines are often gone from the L2 again, so they came from HBM: PMC traffic 1.007 x / 1.047 x algorithmic); now
+  // every lane of such a request reads the FIRST row of that tile (one 2D-byte row, two cache lines). Still unconditional.
   auto issue_loads = [&](int tile, int page, x8 (&kr)[2][KK], u32x4 (&vr)[NV]) {
-    tile = tile < my_hi ? tile : my_hi - 1;
+    const bool past = tile >= my_hi;            // wave-uniform
+    tile = past ? my_hi - 1 : tile;
     const int t0 = tile * kTile;
     if constexpr (KROWS) {
       // K like V: an instruction fetches WHOLE head rows (64 / CH token rows x 2 D bytes) and compute_tile() re-lays the tile
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
       // the direct operand-layout fetch below ties or wins by 0.6 %, so the plan picks per launch.
 #pragma unroll
       for (int j = 0; j < 2 * KK; ++j) {
-        int tok = t0 + j * TPI + lane / CH;
+        int tok = past ? t0 : t0 + j * TPI + lane / CH;
         tok = tok < kv_len ? tok : kv_len - 1;
         int64_t rowi;
         if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
       // 16 token rows per instruction)
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        int tok = t0 + blk * 16 + p16;
+        int tok = past ? t0 : t0 + blk * 16 + p16;
         tok = tok < kv_len ? tok : kv_len - 1;
         int64_t rowi;
         if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, DEEP ? 1 : 2) void paged_decode_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int tok = t0 + i * TPI + lane / CH;
+      int tok = past ? t0 : t0 + i * TPI + lane / CH;
       tok = tok < kv_len ? tok : kv_len - 1;
       int64_t rowi;
       if constexpr (UNIFORM) rowi = (int64_t)page * block_size + (tok % block_size);
