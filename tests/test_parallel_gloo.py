@@ -278,3 +278,41 @@ def _argmax_merge(rank, world):
 def test_sharded_greedy_argmax_pairs_merge_like_argmax_of_the_gathered_logits():
     for got, want in _run(_argmax_merge):
         assert got == want
+
+
+def _tp4dp2(rank, world):
+    """the N = 8 headline layout of bench.py (TP = 4 inside two replicas): group membership, in-group collectives, the agreed
+    attempt verdict over the WORLD group while the TP sub-groups exist, and the sharded greedy-argmax merge inside a TP group"""
+    from xllm_amd import parallel
+    pg, dp_rank = parallel.make_tp_dp_groups(world, rank, 4)
+    x = torch.full((5,), float(rank + 1))
+    parallel.reduce(x, pg)                                    # sum over the 4 ranks of THIS replica only
+    y = parallel.gather(torch.full((1, 2), float(rank)), pg)
+    # bench.py's attempt(): a failure on ANY rank of ANY replica is seen by all (MAX over the world group)
+    flag = torch.tensor([1.0 if rank == 6 else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    # sharded lm_head argmax: every rank holds (max value, GLOBAL column) of its vocabulary shard; ties go to the lowest column
+    V = 40
+    g = torch.Generator().manual_seed(100 + dp_rank)
+    logits = torch.randn(3, V, generator=g)
+    logits[1, 7] = logits[1, 33] = 9.0                        # a tie across shards (columns 7 -> rank 0, 33 -> rank 3 of the group)
+    sh = V // 4
+    mine = logits[:, pg.rank() * sh:(pg.rank() + 1) * sh]
+    val, idx = mine.max(dim=1)
+    merged = parallel.argmax_merge(val, idx + pg.rank() * sh, pg)
+    return x.tolist(), y.tolist(), float(flag), float(ones), merged.tolist(), logits.argmax(1).tolist(), pg.rank(), dp_rank
+
+
+def test_tp4dp2_layout_on_eight_ranks():
+    """bench.py --gpus 8 runs TP = 4 inside two replicas (qwen2_attention.cpp:54: 28 heads do not divide over 8 ranks); no 8-GPU node
+    was ever available, so the layout's group logic is exercised here with eight gloo ranks on the CPU"""
+    out = _run(_tp4dp2, world=8)
+    for rank, (x, y, flag, ones, merged, want, tp_rank, dp_rank) in enumerate(out):
+        lo = 4 * (rank // 4)
+        assert tp_rank == rank % 4 and dp_rank == rank // 4
+        assert x == [float(sum(r + 1 for r in range(lo, lo + 4)))] * 5            # reduced inside the replica's TP group only
+        assert y == [[float(r) for r in range(lo, lo + 4) for _ in range(2)]]      # gathered along the last dim, rank order
+        assert flag == 1.0 and ones == 8.0                                         # world-wide agreement / rccl_ranks_seen
+        assert merged == want and merged[1] == 7                                   # == argmax of the gathered logits, ties included
