@@ -81,7 +81,13 @@ __device__ __forceinline__ uint32_t lp_key(float x) {
 __device__ __forceinline__ float lp_unkey(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
-// probability mass of a logit in 2^-40 fixed point (x <= row max: the mass is in (0, 1])
+// probability mass of a logit in 2^-40 fixed point (x <= row max: the mass is in (0, 1]). The mass is ALWAYS fp32 exp(x - max):
+// for fp32 logits (what the engine passes, engine.py: logits(hidden).float()) this is the reference's softmax -> fp32 cumsum; for
+// 16-bit logits the reference's one-of-them branch runs softmax in the logits dtype first (logits_utils.cpp:145), i.e. rounds each
+// probability to 16 bit before the fp32 cumsum, so its cut-off rank can differ from this kernel's by the ranks whose cumulative
+// mass lies within that rounding of p. Parity with the sorting reference is therefore asserted for fp32 logits (exact up to
+// boundary cases) and for 16-bit logits only up to such boundary ranks (tests/test_gpu_parity.py::
+// test_apply_top_k_top_p_matches_the_sorting_reference).
 // (a NaN logit has no mass: the float -> integer conversion of a NaN is undefined behaviour)
 __device__ __forceinline__ unsigned long long lp_mass(float x, float mx) {
   const float e = __expf(x - mx) * 1099511627776.0f;
