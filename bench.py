@@ -85,6 +85,9 @@ def parse():
                    help="skip the live rocprofv3 --pmc passes behind roofline.traffic (then the committed record is quoted)")
     p.add_argument("--no-per-rank", action="store_true",
                    help="N = 1: skip the per_rank_emulated block (one rank's step at the TP4 x DP2 and DP8 shard shapes, no exchange)")
+    p.add_argument("--no-allocator-pages", action="store_true",
+                   help="N = 1: skip the allocator_order_pages leg (the same step with the block table a fresh BlockManagerImpl pool "
+                        "would hand out instead of the headline's random placement)")
     p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
@@ -180,12 +183,20 @@ def live_mfma_busy(kind, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def build_metadata(B, ctx, block_size, device, seed):
-    """BatchInputBuilder-shaped decode metadata (framework/batch/batch_input_builder.cpp:739-830, 904-938)."""
+def build_metadata(B, ctx, block_size, device, seed, placement="random"):
+    """BatchInputBuilder-shaped decode metadata (framework/batch/batch_input_builder.cpp:739-830, 904-938).
+    placement of a sequence's pages in the pool: "random" = a random permutation of the pool (a long-running server whose free
+    list has been recycled; the headline, and the pessimistic case for the KV walk); "allocator" = what the reference's
+    BlockManagerImpl hands a batch of whole prompts from a FRESH pool (framework/block/block_manager_impl.cpp:56-61: the free
+    list is filled with descending ids and popped from the back, block 0 is the padding block; :66-80 allocate(n) pops n ids in a
+    row): sequence i owns the ascending ids 1 + i * pages ... (i + 1) * pages."""
     pages = (ctx + block_size - 1) // block_size
     n_blocks = int(B * pages * 1.1) + 1
     g = torch.Generator().manual_seed(seed)
-    perm = torch.randperm(n_blocks, generator=g)[: B * pages].to(torch.int32).view(B, pages)
+    if placement == "allocator":
+        perm = (1 + torch.arange(B * pages, dtype=torch.int32)).view(B, pages)
+    else:
+        perm = torch.randperm(n_blocks, generator=g)[: B * pages].to(torch.int32).view(B, pages)
     # the product's own host-side builder (C++ behind the C ABI): one new token per sequence, ctx - 1 already cached
     from xllm_amd import attention
     bi = attention.build_batch_input([ctx - 1] * B, [ctx] * B, perm.tolist(), block_size)
@@ -752,6 +763,18 @@ def main():
     if world == 1 and tp_size == 1 and a.config == "cfg3" and not a.no_per_rank and a.emulate_tp <= 1 and a.emulate_dp <= 1:
         per_rank = per_rank_emulated()
 
+    alloc_pages = None
+    if world == 1 and tp_size == 1 and dual is None and not a.no_allocator_pages and a.emulate_tp <= 1 and a.emulate_dp <= 1:
+        def _alloc_pages():
+            w2 = dict(w)
+            w2["md"], nb2 = build_metadata(B, ctx, block_size, dev, seed=0, placement="allocator")
+            assert nb2 == n_blocks
+            r2 = time_decode(w2, a.steps)
+            return {"ms_per_step": round(r2["ms_per_step"], 4), "tokens_per_s": round(r2["tok_s"], 2),
+                    "what": "the SAME step and KV pool with the block table of a fresh BlockManagerImpl pool (block_manager_impl.cpp:56-80: "
+                            "each sequence's pages are consecutive ascending ids) instead of the headline's random placement; not the headline"}
+        alloc_pages = attempt("allocator-order pages", _alloc_pages)
+
     shim_info = None
     if a.via_shim and world == 1 and tp_size == 1 and mode == "int8":
         shim_info = via_shim_leg(model, margs, md, kv_caches, tokens, positions, a.steps, a.warmup)
@@ -773,6 +796,7 @@ def main():
                                    f"global_batch={gbatch} ctx={ctx}, paged KV block={block_size} bf16, "
                                    f"{margs.n_layers} layers + lm_head + argmax, random-init weights",
                        "global_batch": gbatch, "ctx": ctx, "per_gpu_batch": B,
+                       "block_table": "random placement of every sequence's pages in a pool of 1.1 x the pages in use",
                        "parallelism": (f"dp{dp_size}" if tp_size == 1 and dp_size > 1 else
                                        f"tp{tp_size}" + (f"xdp{dp_size}" if dp_size > 1 else "")),
                        "layout": layout if world > 1 else "single", "collectives_per_step": collectives_per_step,
@@ -805,6 +829,8 @@ def main():
             out["gemm"] = gemm_info
         if per_rank is not None:
             out["per_rank_emulated"] = per_rank
+        if alloc_pages is not None:
+            out["allocator_order_pages"] = alloc_pages
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(margs, mode, ctx, block_size)
             if a.config == "cfg3":
