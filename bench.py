@@ -448,6 +448,8 @@ def main():
             B = gbatch // a.emulate_dp
         if a.emulate_tp > 1 and world == 1:
             class _StubPG(parallel.ProcessGroup):  # shard shapes of TP=k, no exchange: per-rank compute only
+                exchange_stubbed = True   # row-parallel GEMM -> ONE slab consumer (add + norm + quant), as the one-shot kernel does
+
                 def allreduce(self, x):
                     return None
 

@@ -524,6 +524,17 @@ XM_API int xllm_mi355_random_sample(const float* probs, int32_t* out, int64_t ba
                                     const float* uniform, uint64_t philox_seed, uint64_t philox_offset,
                                     void* stream);
 XM_API int xllm_mi355_philox_uniform(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* Sampler::forward's tail in ONE launch (framework/sampling/sampler.cpp:118-137: probs = softmax(sample_logits, -1, fp32);
+ * samples = random_sample(probs) | greedy_sample(probs) | where(do_sample, random, greedy)): logits [batch, vocab] (XM_F32 /
+ * XM_BF16 / XM_F16, row pitch `row_stride` elements; already temperature-scaled and top-k / top-p masked, e.g. by
+ * xllm_mi355_apply_top_k_top_p) -> out[batch] int32.  The [batch, vocab] fp32 probabilities are never materialised.
+ * Rows with do_sample[b] == 0 (do_sample may be null = sample every row) take the FIRST column of the row maximum
+ * (= argmax of the probabilities).  u and the tie / fallback rules: as xllm_mi355_random_sample; prefix sums run over
+ * exp(x - max) in fp32 against u * sum, so the index can differ from softmax -> random_sample only when u lies within fp32
+ * rounding of a CDF step.  -inf and NaN logits carry no mass; a row without a finite maximum returns 0 (+inf: its first column). */
+XM_API int xllm_mi355_softmax_random_sample(const void* logits, int32_t* out, int64_t batch, int64_t vocab, int64_t row_stride,
+                                            int dtype, const float* uniform, uint64_t philox_seed, uint64_t philox_offset,
+                                            const uint8_t* do_sample, void* stream);
 /* The greedy branch of the sampler: Sampler::greedy_sample = argmax over the last dim (framework/sampling/sampler.cpp:160-168).
  * logits [batch, vocab] (XM_F32 / XM_BF16 / XM_F16) -> out[batch] int64 = the FIRST index of each row's maximum; a NaN counts
  * as larger than every number (torch.argmax). One workgroup per row, one pass, 16-byte loads. */

@@ -1515,6 +1515,88 @@ def test_random_sample(B, V):
     assert torch.equal(got_rng, got_u)
 
 
+@pytest.mark.parametrize("B,V,dtype", [(64, 152064, torch.bfloat16), (16, 152064, torch.float32), (33, 1003, torch.float16),
+                                       (5, 8192, torch.bfloat16), (7, 8200, torch.float32)])
+def test_softmax_random_sample_equals_softmax_then_random_sample(B, V, dtype):
+    """xllm_mi355_softmax_random_sample (round 6) = torch.softmax(logits, -1, fp32) -> random_sample (sampler.cpp:118-137) without
+    the [B, V] probabilities: the token equals the oracle's (fp64 CDF of the fp32 softmax) except where u sits within fp32 rounding
+    of a CDF step; masked (-inf) and NaN columns are never drawn; rows without mass give 0; do_sample = False rows take the first
+    column of the maximum (= argmax of the probabilities)."""
+    g = torch.Generator().manual_seed(B * 7 + V)
+    logits = (torch.randn(B, V, generator=g) * 3).to(dtype)
+    kth = logits.float().topk(min(50, V), -1).values[:, -1:]
+    logits[logits.float() < kth] = float("-inf")            # top-k style masking: most columns carry no mass
+    logits[1] = float("-inf")                               # nothing valid -> 0
+    logits[3, 5] = float("nan")                             # a NaN column has no mass and is not the maximum
+    u = torch.rand(B, generator=g)
+    u[2] = 1.0                                              # beyond the total -> last column with mass
+    do = torch.ones(B, dtype=torch.bool)
+    do[4] = False
+    clean = torch.where(torch.isnan(logits.float()), torch.tensor(float("-inf")), logits.float())
+    probs = torch.softmax(clean, -1)
+    probs[1] = 0.0                                          # (softmax of an all -inf row is NaN: no p > 0, random_sample answers 0)
+    ref = orc.random_sample(probs, u)
+    got = ops.softmax_random_sample(logits.to(DEV), uniform=u.to(DEV), do_sample=do.to(DEV)).cpu()
+    assert got[1] == 0
+    assert got[4] == int(torch.argmax(clean[4]))            # first column of the maximum
+    last_valid = int((probs[2] > 0).nonzero().max())
+    assert got[2] == last_valid or probs[2].double().sum() > 1.0 - 1e-6
+    cdf = torch.cumsum(probs.double(), -1)
+    rows = [b for b in range(B) if b not in (1, 4)]
+    same = sum(int(got[b] == ref[b]) for b in rows)
+    assert same >= 0.9 * len(rows)
+    for b in rows:
+        i = int(got[b])
+        assert probs[b, i] > 0, (b, i)                      # never a masked / NaN column
+        if got[b] != ref[b]:                                # any difference sits on an fp32-rounding tie of the CDF
+            assert cdf[b, i] > u[b] - 1e-4 and (i == 0 or cdf[b, i - 1] <= u[b] + 1e-4), (b, i)
+    # every row sampled when do_sample is absent; the Philox path equals the explicit-uniform path on the same numbers
+    seed, off = 99, 12
+    a = ops.softmax_random_sample(logits.to(DEV), seed=seed, offset=off)
+    b_ = ops.softmax_random_sample(logits.to(DEV), uniform=ops.philox_uniform(B, seed, off))
+    assert torch.equal(a, b_)
+    # a strided view (row pitch > V) reads the same rows
+    wide = torch.full((B, V + 24), 7.0, dtype=dtype, device=DEV)
+    wide[:, :V] = logits.to(DEV)
+    assert torch.equal(ops.softmax_random_sample(wide[:, :V], uniform=u.to(DEV), do_sample=do.to(DEV)).cpu(), got)
+
+
+def test_sample_top_k_top_p_is_the_unfused_sampler_sequence():
+    """ops.sample_top_k_top_p (two launches, no [B, V] temporary) against the operator sequence it replaces -- apply_top_k_top_p,
+    torch.softmax(fp32), random_sample -- on 16-bit logits at the model's vocabulary: processed logits bit-equal, tokens equal
+    except on fp32 CDF ties, and every token is a survivor of the oracle's masking (oracle/sampling.py)."""
+    osm = _osm()
+    g = torch.Generator().manual_seed(21)
+    B, V = 24, 152064
+    logits = (torch.randn(B, V, generator=g) * 3).bfloat16()
+    temps = torch.rand(B, generator=g) + 0.5
+    top_k = torch.randint(1, 200, (B,), generator=g)
+    top_k[0] = -1                                           # no limit
+    top_p = torch.rand(B, generator=g) * 0.5 + 0.5
+    u = torch.rand(B, generator=g)
+    for k, p in ((top_k, None), (None, top_p), (top_k, top_p), (None, None)):
+        K, P = (None if k is None else k.to(DEV)), (None if p is None else p.to(DEV))
+        fused_logits = logits.clone().to(DEV)
+        tok = ops.sample_top_k_top_p(fused_logits, temps.to(DEV), K, P, uniform=u.to(DEV)).cpu()
+        unf = logits.clone().to(DEV)
+        ops.apply_top_k_top_p(unf, temps.to(DEV), K, P)
+        assert torch.equal(unf, fused_logits)
+        probs = torch.softmax(unf, -1, dtype=torch.float32)
+        tok_unf = ops.random_sample(probs, uniform=u.to(DEV)).cpu()
+        cdf = torch.cumsum(probs.double().cpu(), -1)
+        for b in range(B):
+            i = int(tok[b])
+            assert bool(torch.isfinite(unf[b, i].float())), (b, i)
+            if tok[b] != tok_unf[b]:
+                assert cdf[b, i] > u[b] - 1e-4 and (i == 0 or cdf[b, i - 1] <= u[b] + 1e-4), (b, i)
+        assert (tok == tok_unf).float().mean() >= 0.9
+        if k is not None and p is None:     # the oracle's masking (fp32 restatement on the temperature-scaled 16-bit values)
+            base = logits.clone()
+            osm.apply_temperatures(base, temps.clone())
+            ref = osm.apply_top_k_top_p(base.float(), None, k, None)
+            assert bool(torch.isfinite(ref.gather(1, tok.long().view(-1, 1))).all())
+
+
 def test_random_sample_on_segment_boundaries_stays_next_to_the_crossing():
     """u placed within an ulp of the running sum at the kernel's segment boundaries (multiples of 1024): whichever way the
     two summation orders round, the sampled index has to sit on the crossing of the exact CDF, never far away."""
@@ -1813,7 +1895,9 @@ def test_decode_engine_steps_equal_a_hand_driven_loop(temperature):
         if temperature <= 0:
             cur = torch.argmax(logits, -1).to(torch.int32).cpu()
         else:
-            cur = ops.random_sample(torch.softmax(logits.float() / temperature, -1),
+            # the reference's order on the lm_head's own 16-bit logits: div_ in the logits dtype (logits_utils.cpp:54-64), softmax
+            # in fp32 (sampler.cpp:118-119), random_sample -- here as the unfused operators, the engine runs the fused launch
+            cur = ops.random_sample(torch.softmax(logits.clone().div_(temperature), -1, dtype=torch.float32),
                                     uniform=ops.philox_uniform(B, 3, s, device=DEV)).cpu()
         ref.append(cur)
         lens = [n + 1 for n in lens]

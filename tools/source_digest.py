@@ -8,7 +8,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATTERNS = ["xllm_amd/csrc/*.hip", "xllm_amd/csrc/*.h", "xllm_amd/csrc/Makefile", "xllm_amd/*.py", "include/*.h", "shim/*.cpp", "shim/*.h",
-            "shim/build_shim.py", "shim/stub/**/*.h", "oracle/*.py", "oracle/*.c", "oracle/Makefile", "tests/*.py", "tests/golden/*",
+            "shim/build_shim.py", "shim/stub/**/*.h", "shim/stub/**/*.cpp", "oracle/*.py", "oracle/*.c", "oracle/Makefile", "tests/*.py", "tests/golden/*",
             "__graft_entry__.py"]
 
 

@@ -121,6 +121,7 @@ _OPTIONAL = {
                                 vp], ci),
     "xllm_mi355_random_sample": ([vp, vp, i64, i64, vp, u64, u64, vp], ci),
     "xllm_mi355_philox_uniform": ([vp, i64, u64, u64, vp], ci),
+    "xllm_mi355_softmax_random_sample": ([vp, vp, i64, i64, i64, ci, vp, u64, u64, vp, vp], ci),
     "xllm_mi355_rejection_sample": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp], ci),
     "xllm_mi355_greedy_argmax": ([vp, vp, i64, i64, ci, vp], ci),
     "xllm_mi355_apply_penalties_workspace_bytes": ([i64, i64], sz),

@@ -729,6 +729,7 @@ __global__ __launch_bounds__(1024) void group_plan_kernel(const int32_t* __restr
     __syncthreads();
   }
   const int used = tiles_incl[1023];
+  if (e == 0) table[4 * slots] = used < slots ? used : slots;   // live slots (round 6): the 8-phase kernels balance them over the XCDs
   for (int t = used + e; t < slots; t += 1024) reinterpret_cast<int4*>(table)[t] = make_int4(-1, 0, 0, 0);
   if (e < E) {
     const int nt = (c + bm - 1) / bm, t0 = tiles_incl[e] - nt, off = rows_incl[e] - c;
@@ -1005,7 +1006,7 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   size_t scratch_bytes = 0;
   xm_moe_scratch(stream, &scratch, &scratch_bytes);
   const int64_t slots = (max_rows + 255) / 256 + n_experts;
-  const size_t table_bytes = (size_t)slots * 16;
+  const size_t table_bytes = (size_t)(slots + 1) * 16;   // + the live-slot count behind the last slot
   // 256-row tiles pay once the experts hold rows of their own: below ~64 rows per expert the launch streams weights only
   if (p8_mode && scratch && scratch_bytes >= table_bytes + 64 && n_experts <= 1024 && max_rows >= 256 * 4 &&
       max_rows >= 64 * n_experts) {
@@ -1051,7 +1052,7 @@ int xllm_mi355_group_gemm_w8a8(const int8_t* a, int64_t a_rows, const float* a_s
   size_t scratch_bytes = 0;
   xm_moe_scratch(stream, &scratch, &scratch_bytes);
   const int64_t slots = (max_rows + 255) / 256 + n_experts;
-  const size_t table_bytes = (size_t)slots * 16;
+  const size_t table_bytes = (size_t)(slots + 1) * 16;   // + the live-slot count behind the last slot
   if (!scratch || scratch_bytes < table_bytes + 64) return XM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));

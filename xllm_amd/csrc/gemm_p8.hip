@@ -217,7 +217,21 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
   // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
   int mt, nt;
-  {
+  if (epi.group_tiles) {
+    // grouped (MoE) mode, round 6: the table's live m-tile slots are COMPACT at its front (experts in order, group_plan_kernel)
+    // and how many there are is known on the device only (the plan kernel leaves the count behind the last slot). The
+    // super-block walk below put them on whichever XCDs the first super-blocks belong to (cfg5: 32-40 live m tiles of 48 slots =
+    // two rounds of workgroups on XCDs 0 and 1, none on XCDs 4 and 5). Here the live (m slot, n tile) units, n tile fastest, are
+    // cut into eight equal contiguous ranges, one per XCD (block b runs on XCD b % 8): every XCD gets the same number of
+    // workgroups whatever the routing, the n tiles of an m slot -- one gathered activation panel -- and an expert's m slots --
+    // one weight panel -- stay neighbours on one XCD, and the surplus blocks of the worst-case grid exit at once.
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int live = __builtin_amdgcn_readfirstlane(epi.group_tiles[4 * m_tiles]) * n_tiles;
+    const int lo = (int)((int64_t)xcd * live / 8), hi = (int)((int64_t)(xcd + 1) * live / 8);
+    if (lo + j >= hi) return;
+    mt = (lo + j) / n_tiles;
+    nt = (lo + j) % n_tiles;
+  } else {
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int sb = j >> 5, within = j & 31;
@@ -459,7 +473,9 @@ int launch_gemm_p8(const void* A, const void* W, int64_t M, int64_t N, int64_t K
   splits = (ktiles + per - 1) / per;
   const int lm = m_tiles >= 8 ? 3 : (m_tiles >= 4 ? 2 : (m_tiles >= 2 ? 1 : 0));
   const int n_sb = ((m_tiles + (1 << lm) - 1) >> lm) * ((n_tiles + (1 << (5 - lm)) - 1) >> (5 - lm));
-  const dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  dim3 grid((unsigned)(((n_sb + 7) / 8) * 8 * 32), 1, (unsigned)splits);
+  if (epi.group_tiles)   // eight equal ranges of the live (m slot, n tile) units, sized for the worst case (see the kernels)
+    grid.x = (unsigned)(((m_tiles * n_tiles + 7) / 8) * 8);
   if constexpr (KIND == kI8) {
     // int8 lives in the 16x16x64 specialisation (gemm_p8i.hip): the only 8-phase kernel with the gate_up epilogue, the grouped
     // mode and split-K. (The 32x32x32 int8 arm of this file lost its round-1 A/B and left the library in round 4.)

@@ -159,6 +159,170 @@ __global__ __launch_bounds__(kRsThreads) void random_sample_kernel(const float* 
   }
 }
 
+// ---- softmax + random_sample in one launch (round 6) -----------------------------------------------------------------
+// Sampler::forward's tail (framework/sampling/sampler.cpp:118-137): probs = softmax(sample_logits, -1, fp32); samples =
+// random_sample(probs) | greedy_sample(probs) | where(do_sample, random, greedy). The unfused form materialises [B, V] fp32
+// probabilities (and, in this repository's engine until round 5, an fp32 copy of the logits in front of it): 156 MB written and
+// read back per decode step at B = 256. Here one workgroup per row reads the (already temperature-scaled, top-k / top-p masked)
+// logits of ANY dtype three times from L2 / Infinity Cache -- row maximum; e = exp(x - max) with one partial sum per (4096-element
+// segment, wave) in LDS and the row total Z; the crossing segment again for the in-segment scan -- and writes one token id.
+// Arithmetic: p_i = e_i / Z is never rounded on its own; the prefix sums run over e_i (fp32, the association of
+// random_sample_kernel) and are compared against u * Z. Against softmax -> random_sample the selected index can differ only
+// when u lies within fp32 rounding of a CDF step (the caveat random_sample already carries; tests bound it with an fp64 CDF).
+// -inf logits (masked columns) and NaN carry no mass; a row without a finite maximum yields index 0 (the reference's probs are
+// NaN there and no index has p > 0). Greedy rows (do_sample[b] == 0): the FIRST column holding the row maximum = argmax(probs).
+template <typename T>
+__global__ __launch_bounds__(kRsThreads) void softmax_random_sample_kernel(const T* __restrict__ logits, int64_t row_stride,
+                                                                          int32_t* __restrict__ out, int d,
+                                                                          const float* __restrict__ uniform, uint64_t seed,
+                                                                          uint64_t offset, const uint8_t* __restrict__ do_sample) {
+  constexpr int VEC = 16 / sizeof(T);          // elements per 16-byte load
+  constexpr int SEG = kRsThreads * VEC;        // elements per segment
+  constexpr int MAXSEG = kRsSeg * kRsMaxSeg / SEG < 1 ? 1 : kRsSeg * kRsMaxSeg / SEG;
+  __shared__ float part[kRsMaxSeg][kRsWaves];
+  __shared__ float wave_red[kRsWaves];
+  __shared__ int wave_idx[kRsWaves];
+  __shared__ float wave_tot[kRsWaves];
+  __shared__ int s_seg, s_sampled, s_seg_last, s_last;
+  __shared__ float s_prefix, s_target;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const T* p = logits + row * row_stride;
+  const bool vec = (d % VEC == 0) && (((uintptr_t)p) % 16 == 0);
+  const int nseg = (d + SEG - 1) / SEG;
+  (void)MAXSEG;
+
+  auto loadv = [&](int base, float (&v)[VEC]) {   // NaN and out-of-range columns read as -inf: no mass, never the maximum
+    if (vec && base + VEC - 1 < d) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(p + base);
+      T e[VEC];
+      __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = to_f32<T>(e[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = base + j < d ? to_f32<T>(p[base + j]) : -__builtin_inff();
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = v[j] == v[j] ? v[j] : -__builtin_inff();
+  };
+
+  // ---- pass 1: row maximum and its first column
+  float mx = -__builtin_inff();
+  int mi = 0x7fffffff;
+  for (int s = 0; s < nseg; ++s) {
+    const int base = s * SEG + tid * VEC;
+    float v[VEC];
+    loadv(base, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (v[j] > mx) { mx = v[j]; mi = base + j; }    // strictly greater: the first column of a thread's maximum
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(mi, o);
+    if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+  }
+  if (lane == 0) { wave_red[wave] = mx; wave_idx[wave] = mi; }
+  __syncthreads();
+  mx = wave_red[0];
+  mi = wave_idx[0];
+  for (int w = 1; w < kRsWaves; ++w)
+    if (wave_red[w] > mx || (wave_red[w] == mx && wave_idx[w] < mi)) { mx = wave_red[w]; mi = wave_idx[w]; }
+  __syncthreads();
+  const bool finite_max = mx > -__builtin_inff() && mx < __builtin_inff();
+  if (!finite_max || (do_sample && !do_sample[row])) {
+    // greedy row: argmax(probs) = the first column of the maximum; a row with no finite maximum has no probability mass at all
+    // (softmax gives NaN): index 0 like random_sample's "no p > 0" answer -- except a +inf maximum, whose first column wins
+    if (tid == 0) out[row] = (mx == __builtin_inff() || (finite_max && mi != 0x7fffffff)) ? mi : 0;
+    return;
+  }
+  const float u = uniform ? uniform[row] : philox_first_uniform(seed, (uint64_t)row, offset);
+
+  // ---- pass 2: e = exp(x - max); one partial sum per (segment, wave); last column with mass
+  int last_valid = -1;
+  for (int s = 0; s < nseg; ++s) {
+    const int base = s * SEG + tid * VEC;
+    float v[VEC];
+    loadv(base, v);
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float e = expf(v[j] - mx);     // exp(-inf) = 0: masked columns carry no mass
+      if (e > 0.0f) last_valid = base + j;
+      sum += e;
+    }
+    const float ws = rs_wave_sum(sum);
+    if (lane == 0) part[s][wave] = ws;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(last_valid, o); last_valid = t > last_valid ? t : last_valid; }
+  if (lane == 0) wave_idx[wave] = last_valid;
+  __syncthreads();
+  if (tid == 0) {
+    float z = 0.0f;
+    for (int s = 0; s < nseg; ++s) {
+      float tot = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kRsWaves; ++w) tot += part[s][w];
+      z += tot;
+    }
+    const float target = u * z;            // prefix(e) > u * Z  <=>  prefix(e / Z) > u up to rounding
+    float agg = 0.0f;
+    int seg = -1;
+    for (int s = 0; s < nseg; ++s) {
+      float tot = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kRsWaves; ++w) tot += part[s][w];
+      if (agg + tot > target) { seg = s; break; }
+      agg += tot;
+    }
+    int lv = -1;
+    for (int w = 0; w < kRsWaves; ++w) lv = wave_idx[w] > lv ? wave_idx[w] : lv;
+    s_seg = seg;
+    s_prefix = agg;
+    s_target = target;
+    s_last = lv;
+    s_sampled = d;
+    s_seg_last = -1;
+  }
+  __syncthreads();
+  const int seg = s_seg;
+  if (seg >= 0) {
+    const float target = s_target;
+    const int base = seg * SEG + tid * VEC;
+    float v[VEC], c[VEC];
+    loadv(base, v);
+    float run = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { v[j] = expf(v[j] - mx); run += v[j]; c[j] = run; }
+    float incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    float pre = s_prefix;
+    for (int w = 0; w < wave; ++w) pre += wave_tot[w];
+    pre += incl - run;
+    int cand = d, seg_last = -1;
+#pragma unroll
+    for (int j = VEC - 1; j >= 0; --j)
+      if (v[j] > 0.0f && pre + c[j] > target) cand = base + j;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      if (v[j] > 0.0f) seg_last = base + j;
+    if (cand < d) atomicMin(&s_sampled, cand);
+    if (seg_last >= 0) atomicMax(&s_seg_last, seg_last);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int r = s_sampled;
+    if (r >= d) r = s_seg_last >= 0 ? s_seg_last : (s_last >= 0 ? s_last : 0);
+    out[row] = r;
+  }
+}
+
 // ---- rejection_sample ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rejection_sample_kernel(
     const int32_t* __restrict__ draft_token_ids, const int32_t* __restrict__ num_draft_tokens,
@@ -291,6 +455,25 @@ int xllm_mi355_random_sample(const float* probs, int32_t* out, int64_t batch, in
   else
     hipLaunchKernelGGL((random_sample_kernel<false>), dim3((unsigned)batch), dim3(kRsThreads), 0, (hipStream_t)stream,
                        probs, out, (int)vocab, uniform, philox_seed, philox_offset);
+  return hip_check_launch();
+}
+
+int xllm_mi355_softmax_random_sample(const void* logits, int32_t* out, int64_t batch, int64_t vocab, int64_t row_stride, int dtype,
+                                     const float* uniform, uint64_t philox_seed, uint64_t philox_offset, const uint8_t* do_sample,
+                                     void* stream) {
+  if (!logits || !out || batch < 0 || vocab <= 0 || row_stride < vocab) return XM_ERR_INVALID;
+  if (batch == 0) return XM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t seg = (int64_t)kRsThreads * (dtype == XM_F32 ? 4 : 8);
+  if ((vocab + seg - 1) / seg > kRsMaxSeg) return XM_ERR_UNSUPPORTED;
+#define XM_SRS(T)                                                                                                         \
+  hipLaunchKernelGGL((softmax_random_sample_kernel<T>), dim3((unsigned)batch), dim3(kRsThreads), 0, s, (const T*)logits,  \
+                     row_stride, out, (int)vocab, uniform, philox_seed, philox_offset, do_sample)
+  if (dtype == XM_F32) XM_SRS(float);
+  else if (dtype == XM_BF16) XM_SRS(bf16_t);
+  else if (dtype == XM_F16) XM_SRS(f16_t);
+  else return XM_ERR_UNSUPPORTED;
+#undef XM_SRS
   return hip_check_launch();
 }
 

@@ -14,7 +14,7 @@ and stop-condition handling of the reference are out of scope): every step
   4. replays ONE captured HIP graph: embedding -> L decoder layers (KV write included) -> lm_head -> sampler,
   5. reads the sampled tokens back (the only host sync of the step).
 Sampling: greedy argmax, or temperature (+ top-k / top-p: ops.apply_top_k_top_p, the logits processors of
-framework/sampling/logits_utils.cpp as kernels) sampling through ops.random_sample with the step's uniforms drawn OUTSIDE the
+framework/sampling/logits_utils.cpp as kernels) sampling through ops.softmax_random_sample with the step's uniforms drawn OUTSIDE the
 graph (ops.philox_uniform with offset = step), so a replay never repeats random numbers.
 """
 from __future__ import annotations
@@ -82,12 +82,11 @@ class DecodeEngine:
         hidden = self.model.forward(self._tokens64, self._pos64, self.md, self.kv_caches)
         if self.temperature <= 0.0:
             return self.model.greedy_tokens(hidden).to(torch.int32)   # lm_head + argmax in one pass, no [B, V] logits
-        # Sampler::forward's random path (sampler.cpp:100-125): temperatures -> top-k -> top-p (apply_top_k_top_p, one sort-free
-        # kernel) -> softmax in fp32 -> random_sample
-        logits = self.model.logits(hidden).float()
-        ops.apply_top_k_top_p(logits, self._temps, self._top_k, self._top_p)
-        probs = torch.softmax(logits, dim=-1)
-        return ops.random_sample(probs, uniform=self._uniform)
+        # Sampler::forward's random path (sampler.cpp:100-137): temperatures -> top-k -> top-p (apply_top_k_top_p, one sort-free
+        # kernel, in place on the lm_head's own 16-bit logits as in the reference) -> softmax in fp32 + random_sample in ONE launch
+        # (ops.softmax_random_sample, round 6): no fp32 copy of the logits, no [B, V] probabilities, no vendor operator
+        logits = self.model.logits(hidden)
+        return ops.sample_top_k_top_p(logits, self._temps, self._top_k, self._top_p, uniform=self._uniform)
 
     @property
     def seq_lens(self) -> List[int]:

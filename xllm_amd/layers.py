@@ -190,7 +190,10 @@ class Qwen2DecoderLayer:
     def _fused_linear_norm(self, lin: "QuantLinear", pre_quant, residual, norm_w, quantize=True):
         """N1 across the GEMM boundary: row-parallel W8A8 linear + residual add + RMSNorm (+ int8 quant) in two launches
         (ops.scaled_matmul_add_rms_norm). Only without a TP all-reduce in between; None = not applicable."""
-        if not self.fuse or lin.pg is not None or lin.mode != "int8" or residual is None or norm_w is None:
+        # (a group whose exchange is stubbed -- bench.py --emulate-tp: one rank's compute, no peers -- takes this path too: it is
+        # the one-shot kernel of _tp_linear_norm minus the peer reads, GEMM -> ONE consumer of the int32 slabs)
+        exchanged = lin.pg is not None and lin.pg.world_size() > 1 and not getattr(lin.pg, "exchange_stubbed", False)
+        if not self.fuse or exchanged or lin.mode != "int8" or residual is None or norm_w is None:
             return None
         return ops.scaled_matmul_add_rms_norm(pre_quant[0], lin.weight, pre_quant[1], lin.w_scale, residual, norm_w,
                                               self.args.rms_norm_eps, lin.bias, quantize=quantize, b_packed=lin.weight_packed)

@@ -901,7 +901,7 @@ def group_gemm_w8a8(a, a_scale, weight, w_scale, token_count, output_dtype=torch
     _need_cuda(a, a_scale, weight, w_scale, token_count)
     E, N, K = weight.shape
     rows = row_index.numel() if row_index is not None else a.size(0)
-    need = 16 * (rows // 256 + E) + 64
+    need = 16 * (rows // 256 + E + 2) + 64
     ws = _moe_ws.get(a.device)
     if ws is not None and ws.numel() < need:
         _retired_ws.append(ws)
@@ -1036,6 +1036,32 @@ def random_sample(probs, uniform=None, seed: int = 0, offset: int = 0):
     check(_lib.lib().xllm_mi355_random_sample(_p(flat), _p(out), flat.size(0), flat.size(1), _p(uniform), seed, offset,
                                               _stream()), "random_sample")
     return out.view(probs.shape[:-1])
+
+
+def softmax_random_sample(logits, uniform=None, seed: int = 0, offset: int = 0, do_sample=None):
+    """Sampler::forward's tail (sampler.cpp:118-137) in one launch: softmax(logits, -1, fp32) -> random_sample (rows with
+    do_sample False: greedy = the first column of the maximum) WITHOUT materialising the [B, V] probabilities
+    (xllm_mi355_softmax_random_sample). logits [B, V] fp32 / bf16 / f16, already temperature-scaled and top-k / top-p masked;
+    returns int32 [B]"""
+    B, V, stride = _logits_2d(logits)
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    ds = None
+    if do_sample is not None:
+        _need_cuda(do_sample)
+        ds = do_sample.to(torch.uint8).contiguous()
+    u = None if uniform is None else uniform.to(torch.float32).contiguous()
+    check(_lib.lib().xllm_mi355_softmax_random_sample(_p(logits), _p(out), B, V, stride, _dt(logits), _p(u), seed, offset, _p(ds),
+                                                      _stream()), "softmax_random_sample")
+    return out
+
+
+def sample_top_k_top_p(logits, temperatures=None, top_k=None, top_p=None, uniform=None, seed: int = 0, offset: int = 0,
+                       do_sample=None):
+    """Sampler::forward's random path (sampler.cpp:100-137) as TWO launches and no [B, V] temporary: apply_top_k_top_p in place
+    on the logits in THEIR OWN dtype (what the reference does: the sampler sees the lm_head's 16-bit logits), then
+    softmax_random_sample. Returns int32 [B]; `logits` holds the processed logits afterwards, as in the reference."""
+    apply_top_k_top_p(logits, temperatures, top_k, top_p)
+    return softmax_random_sample(logits, uniform, seed, offset, do_sample)
 
 
 def _logits_2d(logits):
