@@ -91,6 +91,15 @@ def parse():
     p.add_argument("--no-layouts", action="store_true", help="N > 1: skip the second (data-parallel) measurement of `layouts`")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl = RCCL over xGMI (default); gloo lets several ranks share ONE GPU to exercise the multi-rank path")
+    p.add_argument("--overlap-graph", action="store_true",
+                   help="N > 1, RCCL: ALSO time the <layout>_rccl_overlap design captured into ONE HIP graph (the all-reduces on the "
+                        "forked half-stream branches, the other half's GEMMs beside them: the graph form of north_star's overlap). "
+                        "Opt-in and timed LAST: a capture of a collective that fails cannot always be recovered in-process "
+                        "(tools/rccl_capture_probe.py is the one-GPU probe of the mechanism)")
+    p.add_argument("--time-limit-s", type=float, default=0.0,
+                   help="N > 1: wall-clock budget of the run; once it is spent the remaining OPTIONAL arms (rccl_overlap, dp, prefill, "
+                        "engine) are skipped -- decided collectively, recorded in config.attempts -- so that rank 0 still prints its "
+                        "line (the one-GPU pre-flight of the multi-rank paths sets it; 0 = no limit)")
     p.add_argument("--emulate-tp", type=int, default=0,
                    help="single GPU: run ONE rank's shard of a TP=k job with the collectives stubbed (tuning aid)")
     p.add_argument("--emulate-dp", type=int, default=0,
@@ -471,7 +480,7 @@ def main():
         return dict(model=model, md=md, n_blocks=n_blocks, kv_caches=kv_caches, tokens=tokens, positions=positions, B=B,
                     tp_pg=tp_pg, tp_size=tp_sz, dp_size=dp_sz, nkv_l=nkv_l)
 
-    def time_decode(w, steps, overlap_arm=False):
+    def time_decode(w, steps, overlap_arm=False, overlap_graph=False):
         """warm up, capture (one graph without collectives, piecewise graphs around eager collectives, or -- one-shot kernel --
         one graph WITH them), time `steps` replays; returns the timing record and the eager step function.
         overlap_arm: tensor parallel with the per-layer all-reduces on RCCL's own stream under the dual micro-batch executor
@@ -494,7 +503,11 @@ def main():
         # (every op of the C ABI is capture-safe: no host sync, no allocation inside) and replay it.
         graph = None
         # no collective inside the step (one GPU, or data-parallel replicas): ONE graph; tensor parallel: piecewise graphs
-        use_graph = (not a.no_graph) and not overlap_arm and (tp_sz == 1 or (a.graph and a.backend == "nccl"))
+        # overlap_graph (opt-in, --overlap-graph): the dual micro-batch step with its RCCL all-reduces captured into ONE graph -- under
+        # capture launch_reduce issues the collective in place on the half's forked stream (parallel.launch_reduce), so the graph holds
+        # it as a node of that branch and the other half's GEMMs as nodes of the other branch
+        use_graph = (not a.no_graph) and (not overlap_arm or overlap_graph) and \
+                    (tp_sz == 1 or ((a.graph or overlap_graph) and a.backend == "nccl"))
         piecewise = (not a.no_graph) and not overlap_arm and tp_sz > 1 and not use_graph
         if piecewise:
             # TP > 1: one graph per run of kernels between two EAGER collectives (xllm_amd/parallel.py::PiecewiseGraph); RCCL / gloo
@@ -587,6 +600,21 @@ def main():
         attempts.append({"arm": label, "ok": False, "error": err or "failed on another rank"} if failed else {"arm": label, "ok": True})
         return None if failed else res
 
+    t_run0 = time.perf_counter()
+    shared_gpu = world > 1 and world > torch.cuda.device_count()   # the gloo pre-flight: several ranks on ONE GPU (rank-invariant)
+
+    def skip_arm(label):
+        """collective: True when an OPTIONAL arm is to be left out -- the run's wall-clock budget (--time-limit-s) is spent on ANY
+        rank (agreed: a rank that went on alone would sit in collectives its peers never issue). Recorded in config.attempts."""
+        over = a.time_limit_s > 0 and (time.perf_counter() - t_run0) > a.time_limit_s
+        if world > 1:
+            flag = torch.tensor([1.0 if over else 0.0], device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            over = float(flag.item()) > 0
+        if over:
+            attempts.append({"arm": label, "ok": False, "skipped": f"--time-limit-s {a.time_limit_s:g} spent before this arm"})
+        return over
+
     def timed(label, **kw):
         got = attempt(label, lambda: time_decode(w, a.steps, **kw))
         if got is None and not a.no_graph:
@@ -658,7 +686,7 @@ def main():
     # roofline leg: per-launch HIP events around the dominant kernel (paged decode attention) on the launch
     # stream, over eager steps of the same workload (events cannot be read back from inside a replayed graph)
     record["on"] = True
-    for _ in range(min(a.steps, 3)):
+    for _ in range(min(max(a.steps, 1), 20)):     # up to 20 eager steps = 560 launches (round-5 review: 3 steps were 84)
         step()
     sync_all()
     record["on"] = False
@@ -696,11 +724,11 @@ def main():
                     gr.replay()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(5):
+                for _ in range(20):
                     gr.replay()
                 e1.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / (5 * len(model.layers))
+            return e0.elapsed_time(e1) / (20 * len(model.layers))
         except Exception as e:  # noqa: BLE001
             print(f"[bench] attention-in-graph timing failed: {e!r}", file=sys.stderr)
             return None
@@ -747,7 +775,7 @@ def main():
         arm = layout + "_rccl_overlap"
         try:
             tp_pg.oneshot = None
-            ra = attempt(arm, lambda: time_decode(w, a.steps, overlap_arm=True))
+            ra = None if skip_arm(arm) else attempt(arm, lambda: time_decode(w, a.steps, overlap_arm=True))
             if ra is None:
                 layouts[arm] = {"error": "see config.attempts"}
             else:
@@ -763,11 +791,31 @@ def main():
             r2 = time_decode(w2, a.steps)
             return {"ms_per_step": round(r2["ms_per_step"], 4), "tokens_per_s": round(r2["tok_s"], 2), "collectives_per_step": 0,
                     "allreduce": None, "exposed_comm_ms": 0.0, "per_gpu_batch": w2["B"]}
-        layouts["dp"] = attempt("dp", _dp) or {"error": "see config.attempts"}
+        if shared_gpu:
+            # N full replicas of the model next to the TP shards do not fit ONE GPU (8 x 33 GB at N = 8: round 5's pre-flight ran
+            # out of memory here and never printed its line); the arm needs one GPU per rank
+            attempts.append({"arm": "dp", "ok": False, "skipped": "ranks share one GPU: N replicas of the whole model do not fit it"})
+            layouts["dp"] = {"skipped": "ranks share one GPU"}
+        elif skip_arm("dp"):
+            layouts["dp"] = {"error": "see config.attempts"}
+        else:
+            layouts["dp"] = attempt("dp", _dp) or {"error": "see config.attempts"}
         torch.cuda.empty_cache()
+        if a.overlap_graph and a.backend == "nccl":
+            arm = layout + "_rccl_overlap_graph"
+            try:
+                tp_pg.oneshot = None
+                ra = None if skip_arm(arm) else attempt(arm, lambda: time_decode(w, a.steps, overlap_arm=True, overlap_graph=True))
+                layouts[arm] = fmt(ra, True) if ra is not None else {"error": "see config.attempts"}
+                if ra is not None and ra.get("dual") is not None:
+                    ra["dual"].close()
+                del ra
+            finally:
+                tp_pg.oneshot = saved_oneshot
+            torch.cuda.empty_cache()
 
     prefill = None
-    if not a.no_prefill and a.config == "cfg3":
+    if not a.no_prefill and a.config == "cfg3" and not (world > 1 and skip_arm("prefill")):
         prefill = prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all)
 
     gemm_info = None

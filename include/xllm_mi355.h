@@ -71,7 +71,8 @@ XM_API int xllm_mi355_reshape_paged_cache(const int32_t* slot_ids, const void* k
  * K_l[dst[j]] <- K_l[src[g]] and V_l[dst[j]] <- V_l[src[g]] (whole cache blocks of bytes_per_block bytes).
  * k_cache_ptrs / v_cache_ptrs: DEVICE arrays [num_layers] of cache base addresses as int64 (the reference's layout);
  * v_cache_ptrs may be NULL (K-only caches: the MLA latent cache). A destination that is also a source of the same launch
- * is undefined, as in the reference. Byte copy: any cache dtype. */
+ * is undefined, as in the reference. Byte copy: any cache dtype.  Cache base addresses that are not a multiple of 16 bytes
+ * (a view at an odd offset; allocator-returned tensors never are) are served by a byte-wise walk instead of vector accesses. */
 XM_API int xllm_mi355_block_copy(const int64_t* k_cache_ptrs, const int64_t* v_cache_ptrs,
                                  const int32_t* src_block_indices, const int32_t* dst_block_indices,
                                  const int32_t* cum_sum, int64_t num_layers, int64_t num_groups,

@@ -50,6 +50,9 @@ std::tuple<torch::Tensor, std::optional<torch::Tensor>> AttentionImpl::forward(c
   // the output is allocated here so that a captured graph segment after the attention records its address
   // (layers/dcu/attention.cpp:46-47)
   torch::Tensor output = torch::empty_like(query);
+  // an empty / dummy data-parallel step: nothing to write, nothing to attend, and no runner registered under capture
+  // (layers/dcu/flash_attention.cpp:299-302)
+  if (md.max_seq_len == 0) return {output, std::nullopt};
   auto q = query.unflatten(-1, {num_heads_, head_size_});
   auto kk = key.unflatten(-1, {num_kv_heads_, head_size_});
   auto vv = value.unflatten(-1, {num_kv_heads_, head_size_});

@@ -4,6 +4,7 @@
 #include "kernels/dcu/attention_runner.h"
 #include "mi355_attention.h"
 #include "mi355_ops_api.h"
+#include "mi355_process_group.h"
 
 namespace k = xllm::kernel::mi355;
 
@@ -111,4 +112,67 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     xllm::kernel::dcu::stub_replay_runners(params);
   });
   m.def("abi_version", [] { return (int64_t)xllm_mi355_abi_version(); });
+
+  // ---- the C++ host side of the one-shot all-reduce (shim/mi355_process_group.{h,cpp}), as ProcessGroupImpl would drive it
+  // (cuda_process_group.h:25-53: one TCPStore per group, rank 0 serves): tests/test_shim.py runs two processes through this
+  namespace pg = xllm::mi355;
+  struct OneShotGroup {
+    c10::intrusive_ptr<c10d::Store> store;
+    std::shared_ptr<pg::OneShotAllReduce> ar;
+    std::unique_ptr<pg::ProcessGroupMi355> group;
+    std::string note;
+    int rank, world;
+  };
+  pybind11::class_<OneShotGroup>(m, "OneShotGroup")
+      .def(pybind11::init([](const std::string& host, int port, int rank, int world, int device_index, int64_t max_bytes,
+                             bool self_test, const std::string& prefix, pybind11::object fallback) {
+             auto g = std::make_unique<OneShotGroup>();
+             g->rank = rank;
+             g->world = world;
+             g->store = pg::create_tcp_store(host, port, rank, world);
+             pg::OneShotAllReduce::Options opt;
+             opt.max_bytes = (size_t)max_bytes;
+             opt.self_test = self_test;
+             {
+               pybind11::gil_scoped_release nogil;   // the set-up blocks on the store until every rank has arrived
+               g->ar = pg::OneShotAllReduce::create(g->store, prefix, rank, world, torch::Device(torch::kCUDA, device_index), opt, &g->note);
+             }
+             std::function<void(torch::Tensor&)> fb;
+             if (!fallback.is_none()) fb = [fallback](torch::Tensor& t) { pybind11::gil_scoped_acquire gil; fallback(t); };
+             g->group = std::make_unique<pg::ProcessGroupMi355>(rank, world, g->ar, fb);
+             return g;
+           }),
+           pybind11::arg("host"), pybind11::arg("port"), pybind11::arg("rank"), pybind11::arg("world"), pybind11::arg("device_index"),
+           pybind11::arg("max_bytes") = (int64_t)(8 << 20), pybind11::arg("self_test") = true, pybind11::arg("prefix") = "tp0",
+           pybind11::arg("fallback") = pybind11::none())
+      .def("active", [](OneShotGroup& g) { return g.ar != nullptr; })
+      .def("note", [](OneShotGroup& g) { return g.note; })
+      .def("allreduce_kind", [](OneShotGroup& g) { return g.group->allreduce_kind(); })
+      .def("grid_limit", [](OneShotGroup& g) { return g.ar ? g.ar->grid_limit() : -1; })
+      .def("set_grid_limit", [](OneShotGroup& g, int v) { if (g.ar) g.ar->set_grid_limit(v); })
+      .def("memory_kind", [](OneShotGroup& g) { return g.ar ? g.ar->memory_kind() : -1; })
+      .def("takes", [](OneShotGroup& g, const torch::Tensor& x) { return g.ar && g.ar->takes(x); })
+      .def("allreduce", [](OneShotGroup& g, torch::Tensor x) { g.group->allreduce(x); return x; })
+      .def("allreduce_add_rms_norm", [](OneShotGroup& g, const torch::Tensor& partial, torch::Tensor residual, const torch::Tensor& w,
+                                        double eps, bool quantize) -> pybind11::object {
+        TORCH_CHECK(g.ar, "one-shot path is off: ", g.note);
+        torch::Tensor sum;
+        auto got = g.ar->allreduce_add_rms_norm(partial, residual, w, eps, quantize, &sum);
+        if (!got.has_value()) return pybind11::none();
+        return pybind11::cast(std::make_tuple(got->first, got->second, sum));
+      })
+      .def("matmul_allreduce_add_rms_norm", [](OneShotGroup& g, const torch::Tensor& a, const torch::Tensor& as, const torch::Tensor& wp,
+                                               const torch::Tensor& ws, std::optional<torch::Tensor> bias, torch::Tensor residual,
+                                               const torch::Tensor& w, double eps, bool quantize) -> pybind11::object {
+        TORCH_CHECK(g.ar, "one-shot path is off: ", g.note);
+        torch::Tensor sum;
+        auto got = g.ar->matmul_allreduce_add_rms_norm(a, as, wp, ws, bias, residual, w, eps, quantize, &sum);
+        if (!got.has_value()) return pybind11::none();
+        return pybind11::cast(std::make_tuple(got->first, got->second, sum));
+      })
+      .def("healthy", [](OneShotGroup& g) { return g.ar && g.ar->healthy(); })
+      .def("close", [](OneShotGroup& g) {
+        if (g.ar) { pybind11::gil_scoped_release nogil; g.ar->close(); }
+        g.ar.reset();
+      });
 }

@@ -166,6 +166,35 @@ def test_block_copy_bit_exact(shape, dtype, with_v):
     ops.block_copy(kp, vp, src[:0].to(DEV), dst[:0].to(DEV), cs[:0].to(DEV), kd[0][0].numel(), dtype)
 
 
+def test_block_copy_at_cache_bases_that_are_not_16_byte_aligned():
+    """round-5 advisor: the unit width comes from the block size alone, the cache base addresses from device arrays; a cache that is
+    a VIEW at an 8-byte (2-byte) offset must still copy bit-exactly (byte-wise walk of the same units), not fault"""
+    L, nb, shape, dtype = 3, 12, (16, 2, 64), torch.bfloat16          # 4096 bytes per block: the 16-byte unit is selected
+    g = torch.Generator().manual_seed(5)
+    numel = nb * 16 * 2 * 64
+    for off in (4, 1):                                                # element offsets: 8 and 2 bytes
+        backing = [(torch.randn(numel + 8, generator=g) * 9).to(dtype) for _ in range(2 * L)]
+        dev = [t.to(DEV) for t in backing]
+        k = [t[off:off + numel].view(nb, *shape).clone() for t in backing[:L]]
+        v = [t[off:off + numel].view(nb, *shape).clone() for t in backing[L:]]
+        kd = [t[off:off + numel].view(nb, *shape) for t in dev[:L]]
+        vd = [t[off:off + numel].view(nb, *shape) for t in dev[L:]]
+        assert kd[0].data_ptr() % 16 != 0
+        src = torch.tensor([1, 7], dtype=torch.int32)
+        dst = torch.tensor([0, 3, 9], dtype=torch.int32)
+        cs = torch.tensor([2, 3], dtype=torch.int32)
+        orc.block_copy(k, v, src, dst, cs)
+        kp = torch.tensor([t.data_ptr() for t in kd], dtype=torch.int64, device=DEV)
+        vp = torch.tensor([t.data_ptr() for t in vd], dtype=torch.int64, device=DEV)
+        ops.block_copy(kp, vp, src.to(DEV), dst.to(DEV), cs.to(DEV), kd[0][0].numel(), dtype)
+        torch.cuda.synchronize()
+        for l in range(L):
+            assert torch.equal(kd[l].cpu().view(torch.uint8), k[l].view(torch.uint8))
+            assert torch.equal(vd[l].cpu().view(torch.uint8), v[l].view(torch.uint8))
+            # nothing outside the view was touched
+            assert torch.equal(dev[l][:off].cpu(), backing[l][:off]) and torch.equal(dev[l][off + numel:].cpu(), backing[l][off + numel:])
+
+
 # ------------------------------------------------------------------------------------------- KV write
 @pytest.mark.parametrize("nkv,d,bs,dtype", [(4, 128, 128, torch.bfloat16), (8, 128, 16, torch.bfloat16),
                                             (2, 64, 16, torch.float16), (1, 128, 64, torch.bfloat16),
@@ -1779,7 +1808,7 @@ def test_deepseek_v2_attention_layer_matches_a_plain_restatement():
         q = (rms((f(x) @ f(attn.q_a_w).T).bfloat16().float(), attn.q_a_norm_w).bfloat16().float() @ f(attn.q_b_w).T).bfloat16().float()
         q = q.view(-1, heads, nope + rope)
         qpe = rope_ds(layers.to_deepseek_rope_layout(q[..., nope:]))
-        qabs = torch.einsum("thn,hnk->thk", q[..., :nope], f(attn.w_kc)).bfloat16().float()
+        qabs = torch.einsum("thn,hnk->thk", q[..., :nope], f(attn.w_kc_nk.transpose(1, 2))).bfloat16().float()
         qin = torch.cat([qabs, qpe], -1)
         outs = []
         for b, (a0, a1) in enumerate(seq_ranges):
@@ -1790,7 +1819,7 @@ def test_deepseek_v2_attention_layer_matches_a_plain_restatement():
             p = torch.softmax(sc.masked_fill(~mask, float("-inf")), -1)
             outs.append(torch.einsum("hqk,kd->qhd", p, K[:, :kv_lora]))
         o = torch.cat(outs, 0).bfloat16().float()
-        o = torch.einsum("thk,hkv->thv", o, f(attn.w_vc)).bfloat16().float().flatten(1, 2)
+        o = torch.einsum("thk,hkv->thv", o, f(attn.w_vc_nk.transpose(1, 2))).bfloat16().float().flatten(1, 2)
         return (o @ f(attn.o_w).T), latn
 
     # prefill

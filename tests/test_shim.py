@@ -442,3 +442,167 @@ def test_shim_bmm_heads_equals_the_ctypes_path():
     assert torch.equal(b, ops.bmm_heads(a, w_vc_nk)) and b.shape == (64, 16, 128)
     with pytest.raises(RuntimeError):
         m.bmm_heads(q[..., :128], w_vc_nk)                     # K mismatch: the reference's TORCH_CHECK inside bmm
+
+
+# ------------------------------------------------------------------------------------------- C++ one-shot all-reduce group
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oneshot_msg(rank, i, n, dtype):
+    g = torch.Generator().manual_seed(1000 * i + rank)
+    return (torch.randn(n, generator=g) * (1 + rank)).to(dtype)
+
+
+def _oneshot_worker(rank, world, port, ret, fail_rank):
+    """one rank of the C++ group (shim/mi355_process_group.cpp) on GPU 0: set-up over a TCPStore as ProcessGroupImpl builds one
+    (cuda_process_group.h:49-51), agreed self-test, plain and fused collectives against the single-process operators"""
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = {"ok": True, "log": []}
+    try:
+        torch.cuda.set_device(0)
+        m = _shim()
+        from xllm_amd import ops
+        fell_back = []
+
+        def fallback(t):            # the group's own all-reduce in an xLLM build (RCCL); here it only records that it was asked
+            fell_back.append(t.numel())
+
+        if rank == fail_rank:
+            # a rank whose buffer cannot be set up (max_bytes that the allocator refuses) must not hang its peers: everybody gets
+            # "inactive" + the same note
+            grp = m.OneShotGroup("127.0.0.1", port, rank, world, 0, max_bytes=1 << 50, self_test=True, prefix="tpX", fallback=fallback)
+        else:
+            grp = m.OneShotGroup("127.0.0.1", port, rank, world, 0, max_bytes=4 << 20, self_test=True, prefix="tpX", fallback=fallback)
+        res["active"], res["note"], res["kind"] = grp.active(), grp.note(), grp.allreduce_kind()
+        if fail_rank >= 0:
+            x = torch.ones(64, dtype=torch.bfloat16, device="cuda")
+            grp.allreduce(x)                                  # -> the fallback, on every rank
+            res["fell_back"] = list(fell_back)
+            ret[rank] = res
+            return
+        assert grp.active(), grp.note()
+        res["grid_limit"], res["memory_kind"] = grp.grid_limit(), grp.memory_kind()
+        for i, n in enumerate([8, 3584, 256 * 3584, 24, 1 << 20, 4096]):
+            dtype = (torch.bfloat16, torch.float16, torch.float32)[i % 3]
+            x = _oneshot_msg(rank, i, n, dtype).cuda()
+            want = sum(_oneshot_msg(r, i, n, dtype).float() for r in range(world)).to(dtype)   # fp32 sum in rank order, one rounding
+            grp.allreduce(x)
+            if not torch.equal(x.cpu(), want):
+                res["ok"] = False
+                res["log"].append(f"all-reduce mismatch at message {i} (n={n}, {dtype})")
+        big = torch.ones(3 << 20, dtype=torch.bfloat16, device="cuda")       # beyond the slot: the backend serves it
+        assert not grp.takes(big)
+        grp.allreduce(big)
+        res["fell_back"] = list(fell_back)
+        # fused tail == all-reduce, then the row-wise operator
+        for (M, H, quant) in ((256, 3584, True), (70, 7168, False), (1, 128, True)):
+            part = (_oneshot_msg(rank, 300 + M, M * H, torch.bfloat16) * 0.5).view(M, H).cuda()
+            g0 = torch.Generator().manual_seed(M * 7 + H)
+            resid0 = torch.randn(M, H, generator=g0).bfloat16().cuda()
+            nw = (torch.rand(H, generator=g0) + 0.5).bfloat16().cuda()
+            y = part.clone()
+            grp.allreduce(y)
+            r_ref = resid0.clone()
+            if quant:
+                q_ref, s_ref = ops.rms_norm_dynamic_int8_quant(y.clone(), nw, 1e-6, residual=r_ref)
+            else:
+                n_ref = y.clone()
+                ops.fused_add_rms_norm(n_ref, r_ref, nw, 1e-6)
+            r_got = resid0.clone()
+            got = grp.allreduce_add_rms_norm(part, r_got, nw, 1e-6, quant)
+            good = got is not None and torch.equal(r_got, r_ref) and torch.equal(got[2], y)
+            good = good and ((torch.equal(got[0], q_ref) and torch.equal(got[1], s_ref)) if quant else torch.equal(got[0], n_ref))
+            if not good:
+                res["ok"] = False
+                res["log"].append(f"fused all-reduce + add + norm mismatch at M={M} H={H} quant={quant}")
+        # the GEMM-fed form == packed scaled_matmul -> fused tail, bit for bit (rank 0 carries the bias)
+        for (M, N, K, quant) in ((256, 3584, 1792, True), (32, 3584, 896, False)):
+            g1 = torch.Generator().manual_seed(1000 * rank + M + K)
+            a = torch.randint(-127, 128, (M, K), generator=g1, dtype=torch.int8).cuda()
+            w = torch.randint(-127, 128, (N, K), generator=g1, dtype=torch.int8).cuda()
+            a_s = (torch.rand(M, generator=g1) * 0.002 + 0.0005).cuda()
+            w_s = (torch.rand(N, generator=g1) * 0.002 + 0.0005).cuda()
+            g0 = torch.Generator().manual_seed(M + N + K)
+            bias = (torch.randn(N, generator=g0).bfloat16() if rank == 0 else torch.zeros(N, dtype=torch.bfloat16)).cuda()
+            resid0 = torch.randn(M, N, generator=g0).bfloat16().cuda()
+            nw = (torch.rand(N, generator=g0) + 0.5).bfloat16().cuda()
+            wp = ops.pack_weight_i8(w)
+            part = ops.scaled_matmul(a, w, a_s, w_s, torch.bfloat16, bias, b_packed=wp)
+            r_ref = resid0.clone()
+            ref = grp.allreduce_add_rms_norm(part, r_ref, nw, 1e-6, quant)
+            r_got = resid0.clone()
+            got = grp.matmul_allreduce_add_rms_norm(a, a_s, wp, w_s, bias, r_got, nw, 1e-6, quant)
+            good = got is not None and ref is not None and torch.equal(r_got, r_ref) and torch.equal(got[0], ref[0])
+            good = good and (not quant or torch.equal(got[1], ref[1]))
+            if not good:
+                res["ok"] = False
+                res["log"].append(f"GEMM-fed fused tail mismatch at M={M} N={N} K={K} quant={quant}")
+        # a HIP graph holding the collective replays correctly (a plain kernel: no eager piece needed)
+        xg = _oneshot_msg(rank, 77, 4096, torch.bfloat16).cuda()
+        xin = xg.clone()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                grp.allreduce(xin)
+            xin.copy_(xg)
+            g.replay()
+        torch.cuda.synchronize()
+        want = sum(_oneshot_msg(r, 77, 4096, torch.bfloat16).float() for r in range(world)).bfloat16()
+        if not torch.equal(xin.cpu(), want):
+            res["ok"] = False
+            res["log"].append("graph replay of the collective mismatch")
+        res["healthy"] = grp.healthy()
+        grp.close()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        res["ok"] = False
+        res["log"].append(traceback.format_exc())
+    ret[rank] = res
+
+
+def _run_oneshot_group(fail_rank):
+    import torch.multiprocessing as mp
+    _shim()                                  # built once, before the ranks race for it
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    ctx = mp.spawn(_oneshot_worker, args=(2, port, ret, fail_rank), nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        assert time.time() - t0 < 240, "the two-rank C++ one-shot group did not finish (a rank hangs in the set-up?)"
+    return dict(ret)
+
+
+@pytest.mark.gpu
+def test_cpp_oneshot_group_two_ranks_on_one_gpu():
+    """shim/mi355_process_group.cpp (round 6: the C++ host side of the one-shot all-reduce; the reference binds its collectives in
+    C++, process_group.cpp:98-110): two processes on one GPU run the store-based set-up, the agreed self-test, plain / fused /
+    GEMM-fed collectives bit-equal to the single-process operators, a graph replay, the size fall-back and a collective close()"""
+    ret = _run_oneshot_group(fail_rank=-1)
+    assert len(ret) == 2
+    for r in (0, 1):
+        assert ret[r]["ok"], "\n".join(ret[r]["log"])
+        assert ret[r]["active"] and ret[r]["note"] == "ok" and ret[r]["kind"] == "oneshot-xgmi"
+        assert ret[r]["grid_limit"] == 0                 # two ranks share the GPU: 64 blocks, never 256
+        assert ret[r]["fell_back"] == [3 << 20] and ret[r]["healthy"]
+    assert ret[0]["memory_kind"] == ret[1]["memory_kind"]
+
+
+@pytest.mark.gpu
+def test_cpp_oneshot_group_declines_together_when_one_rank_cannot_set_up():
+    """a rank-local set-up failure travels over the store: BOTH ranks end up inactive with the same note and take the backend
+    (nobody hangs in an exchange the other one skipped)"""
+    ret = _run_oneshot_group(fail_rank=1)
+    assert len(ret) == 2
+    for r in (0, 1):
+        assert ret[r]["ok"], "\n".join(ret[r]["log"])
+        assert not ret[r]["active"] and ret[r]["kind"] == "backend" and ret[r]["fell_back"] == [64]
+    assert ret[0]["note"] == ret[1]["note"] and "rank" in ret[0]["note"]

@@ -7,6 +7,6 @@ O=gpurun_out/multirank
 mkdir -p $O
 for N in ${1:-2 4}; do
   echo "# --gpus $N --backend gloo (ranks share the GPU)" | tee -a $O/multi.txt
-  timeout 1200 python bench.py --gpus $N --backend gloo --steps 2 --warmup 1 --no-cpu-baseline --no-prefill 2>$O/n$N.err | grep metric | cut -c1-3000 | tee -a $O/multi.txt
+  timeout 1500 python bench.py --gpus $N --backend gloo --steps 2 --warmup 1 --no-cpu-baseline --no-prefill --time-limit-s 600 2>$O/n$N.err | grep metric | cut -c1-3000 | tee -a $O/multi.txt
   grep -i "error\|bench\]\|Traceback" $O/n$N.err | head -8 | tee -a $O/multi.txt
 done

@@ -741,6 +741,338 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the same flash kernel on v_mfma_f32_32x32x16 with the softmax VALU work placed in the shadow of the MFMAs.
+// Why: with 16x16x32 MFMAs (17 cycles each) a wave's fp32 VALU work serialises with its own matrix work (tools/coissue_bench.hip,
+// profiles/r01_prefill_attention.txt: the kernel was the SUM of its MFMA and VALU issue time, 0.33 of the bf16 peak). A 32x32x16
+// MFMA occupies the pipe for 32 cycles but one issue slot, so the wave can issue ~5 other instructions per MFMA
+// (MI355X_MICROARCH.md, per-instruction constants) -- IF independent work sits next to it in program order. Structure:
+//   * a wave owns 32 queries (one MFMA column block); S^T = K Q^T leaves lane (q = lane & 31, hi = lane >> 5) with the scores of
+//     ONE query for keys 32 kb + (r & 3) + 8 (r >> 2) + 4 hi (16 of each 32-key block): the softmax is lane-local plus one
+//     v_permlane32_swap for the row maximum; the row sum stays lane-partial until the epilogue;
+//   * those 8-score groups ARE the B operand of O^T += V^T P^T once converted (k slot (hi, j) <-> key base + 8 (j >> 2) + 4 hi +
+//     (j & 3)): no cross-lane traffic for P at all; the V^T operand is fetched with ds_read_b64_tr_b16 in exactly that key order;
+//   * software pipeline inside a wave, per 64-key tile step j:  [S(j) = K(j) Q^T : 16 MFMAs  ||  max / exp / sum / convert of
+//     tile j - 1]  then  [O += P(j-1) V(j-1) : 16 MFMAs  ||  the rest of the conversions, V / K fragment reads]: the MFMAs of
+//     one tile never wait for the softmax of the same tile;
+//   * staging, rings, swizzles, barrier protocol, masks, lazy rescale (2^8) and the single RNE-rounded 16-bit P (or hi + lo)
+//     are flash_prefill_dma_kernel's: the oracle's p_round = "flash" mode describes both.
+typedef float pf32x16_t __attribute__((ext_vector_type(16)));
+template <typename T>
+struct Pf32Traits;
+template <>
+struct Pf32Traits<bf16_t> {
+  static __device__ __forceinline__ pf32x16_t mfma(pbf16x8_t a, pbf16x8_t b, pf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Pf32Traits<f16_t> {
+  static __device__ __forceinline__ pf32x16_t mfma(pf16x8_t a, pf16x8_t b, pf32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// one tile step of a wave. DO_QK: S(next) = K Q^T of the tile in K ring slot `kslot`; DO_SM: softmax of `sc` (the previous
+// tile's scores, consumed) + O += P V with the tile in V ring slot `vslot`.
+template <typename T, bool P1, bool DO_QK, bool DO_SM>
+__device__ __forceinline__ void pf32_step(pf32x16_t (&sc)[2], pf32x16_t (&sn)[2], pf32x16_t (&acc_o)[4], float& m_run, float& l_run,
+                                          const typename PfTraits<T>::x8 (&qf)[8], const unsigned (&kaddr)[8],
+                                          const unsigned (&vaddr)[4], unsigned kslot, unsigned vslot, bool need_mask, int t0,
+                                          int kv_len, int causal, int window_left, int qpos, int hi, float scale_log2) {
+  using x8 = typename PfTraits<T>::x8;
+  using x4 = typename PfTraits<T>::x4;
+  using elem = typename PfTraits<T>::elem;
+  using M = Pf32Traits<T>;
+  pu32x4_t kf[8];
+  // ---- K fragment reads: fragment I = 8 kb + ks = rows 32 kb + (lane & 31), logical chunk 2 ks + hi; 8 in flight
+#define PF32_K_RD(I_) PF_DSR128(kf[(I_) & 7], kaddr[(I_) & 7], ((I_) >> 3) * 32 * kPf2RowB);
+  if constexpr (DO_QK) {
+    sn[0] = pf32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    sn[1] = sn[0];
+  }
+  unsigned ka[8];
+  if constexpr (DO_QK) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ka[i] = kaddr[i] + kslot;
+  }
+#undef PF32_K_RD
+#define PF32_K_RD(I_) PF_DSR128(kf[(I_) & 7], ka[(I_) & 7], ((I_) >> 3) * 32 * kPf2RowB);
+#define PF32_K_MM(I_, WAIT_)                                                                             \
+  PF_LGKM1(WAIT_, kf[(I_) & 7]);                                                                         \
+  sn[(I_) >> 3] = M::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[(I_) & 7], sn[(I_) >> 3]);
+  if constexpr (DO_QK) { PF32_K_RD(0) PF32_K_RD(1) PF32_K_RD(2) PF32_K_RD(3) PF32_K_RD(4) PF32_K_RD(5) PF32_K_RD(6) PF32_K_RD(7) }
+
+  // ---- softmax part 1 (the row maximum needs every score of the tile): written BETWEEN the MFMAs of the QK block
+  float mx0 = kPfNegBig, mx1 = kPfNegBig;
+  if constexpr (DO_SM) {
+    if (need_mask) {  // wave-uniform: only the diagonal / tail / window-edge tiles of a wave
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tok = t0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool vis = tok < kv_len && (!causal || tok <= qpos) && (window_left < 0 || tok >= qpos - window_left);
+          if (!vis) sc[kb][r] = -INFINITY;
+        }
+    }
+  }
+  // piece I of the QK block: MFMA I (+ the read of fragment I + 8) and 4 of the 32 maxima
+#define PF32_QK_PIECE(I_, WAIT_, RD_)                                                                    \
+  if constexpr (DO_QK) { PF32_K_MM(I_, WAIT_) RD_ }                                                      \
+  if constexpr (DO_SM && (I_) < 8) {                                                                     \
+    mx0 = fmaxf(mx0, fmaxf(sc[(I_) >> 2][((I_) & 3) * 4 + 0], sc[(I_) >> 2][((I_) & 3) * 4 + 1]));       \
+    mx1 = fmaxf(mx1, fmaxf(sc[(I_) >> 2][((I_) & 3) * 4 + 2], sc[(I_) >> 2][((I_) & 3) * 4 + 3]));       \
+  }
+  PF32_QK_PIECE(0, 7, PF32_K_RD(8)) PF32_QK_PIECE(1, 7, PF32_K_RD(9)) PF32_QK_PIECE(2, 7, PF32_K_RD(10)) PF32_QK_PIECE(3, 7, PF32_K_RD(11))
+  PF32_QK_PIECE(4, 7, PF32_K_RD(12)) PF32_QK_PIECE(5, 7, PF32_K_RD(13)) PF32_QK_PIECE(6, 7, PF32_K_RD(14)) PF32_QK_PIECE(7, 7, PF32_K_RD(15))
+  float m_new = m_run, alpha = 1.0f;
+  x8 ph[2][2], pl[2][2];   // [kb][s1]: the B operands of the four PV key steps (hi part / lo part)
+  float psum = 0.0f;
+  if constexpr (DO_SM) {
+    float mx = fmaxf(mx0, mx1);
+    {  // lanes l and l ^ 32 hold the same query: v_permlane32_swap (VALU) exchanges the halves
+      unsigned u = __builtin_bit_cast(unsigned, mx), c;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+      const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
+      mx = fmaxf(as_f32(r32[0]), as_f32(r32[1]));
+    }
+    // lazy rescale (flash_prefill_dma_kernel): the reference maximum only moves when the tile's maximum exceeds it by > 2^8
+    const float mxs = mx * scale_log2;
+    m_new = mxs > m_run + 8.0f ? mxs : m_run;
+    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+  }
+  // P of key step (kb, s1) = scores sc[kb][8 s1 .. 8 s1 + 7]: p = 2^(s * scale - m), row sum in fp32, one RNE 16-bit P (or hi + lo)
+#define PF32_P_CHUNK(KB_, S1_)                                                                           \
+  if constexpr (DO_SM) {                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[KB_][(S1_) * 8 + j], scale_log2, -m_new)); \
+      psum += p;                                                                                         \
+      const elem h = (elem)p;                                                                            \
+      ph[KB_][S1_][j] = h;                                                                               \
+      if constexpr (!P1) pl[KB_][S1_][j] = (elem)(p - (float)h);                                         \
+    }                                                                                                    \
+  }
+  PF32_QK_PIECE(8, 7, ) PF32_P_CHUNK(0, 0)
+  PF32_QK_PIECE(9, 6, ) PF32_QK_PIECE(10, 5, ) PF32_QK_PIECE(11, 4, ) PF32_P_CHUNK(0, 1)
+  PF32_QK_PIECE(12, 3, ) PF32_QK_PIECE(13, 2, ) PF32_QK_PIECE(14, 1, ) PF32_QK_PIECE(15, 0, )
+#undef PF32_QK_PIECE
+#undef PF32_K_MM
+#undef PF32_K_RD
+  if constexpr (!DO_SM) return;
+  // ---- O += P V: key step c = 2 kb + s1 (16 keys), d block db (32 columns); A = V^T by transposed reads in the k-slot key order
+  if (__any(alpha != 1.0f)) {   // the running maximum settles after a few tiles (wave-uniform branch; x 1.0f is exact)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) acc_o[db] *= alpha;
+  }
+  pu32x2_t vt[8][2];
+  unsigned va[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) va[db] = vaddr[db] + vslot;
+#define PF32_V_RD(C_, DB_)                                                                               \
+  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][0], va[DB_], (C_) * 16 * kPf2RowB);                               \
+  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][1], va[DB_], (C_) * 16 * kPf2RowB + 8 * kPf2RowB);
+#define PF32_V_MM(C_, DB_, WAIT_)                                                                        \
+  {                                                                                                      \
+    PF_LGKM2(WAIT_, vt[((C_) & 1) * 4 + (DB_)][0], vt[((C_) & 1) * 4 + (DB_)][1]);                         \
+    const x8 v8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[((C_) & 1) * 4 + (DB_)][0]),           \
+                                          __builtin_bit_cast(x4, vt[((C_) & 1) * 4 + (DB_)][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
+    acc_o[DB_] = M::mfma(v8, ph[(C_) >> 1][(C_) & 1], acc_o[DB_]);                                       \
+    if constexpr (!P1) acc_o[DB_] = M::mfma(v8, pl[(C_) >> 1][(C_) & 1], acc_o[DB_]);                     \
+  }
+  PF32_V_RD(0, 0) PF32_V_RD(0, 1) PF32_V_RD(0, 2) PF32_V_RD(0, 3) PF32_V_RD(1, 0) PF32_V_RD(1, 1) PF32_V_RD(1, 2) PF32_V_RD(1, 3)
+  PF32_V_MM(0, 0, 14) PF32_V_RD(2, 0) PF32_V_MM(0, 1, 14) PF32_V_RD(2, 1)
+  PF32_P_CHUNK(1, 0)
+  PF32_V_MM(0, 2, 14) PF32_V_RD(2, 2) PF32_V_MM(0, 3, 14) PF32_V_RD(2, 3)
+  PF32_V_MM(1, 0, 14) PF32_V_RD(3, 0) PF32_V_MM(1, 1, 14) PF32_V_RD(3, 1)
+  PF32_P_CHUNK(1, 1)
+  PF32_V_MM(1, 2, 14) PF32_V_RD(3, 2) PF32_V_MM(1, 3, 14) PF32_V_RD(3, 3)
+  PF32_V_MM(2, 0, 14) PF32_V_MM(2, 1, 12) PF32_V_MM(2, 2, 10) PF32_V_MM(2, 3, 8)
+  PF32_V_MM(3, 0, 6) PF32_V_MM(3, 1, 4) PF32_V_MM(3, 2, 2) PF32_V_MM(3, 3, 0)
+#undef PF32_V_RD
+#undef PF32_V_MM
+#undef PF32_P_CHUNK
+  l_run = l_run * alpha + psum;
+}
+
+template <typename T, bool PAGED, bool P1>
+__global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, const int32_t* __restrict__ kv_lens,
+    const int32_t* __restrict__ block_table, int max_blocks, int nq, int nkv, int block_size, int64_t q_stride,
+    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left, int n_seqs, int n_qblocks) {
+  using TR = PfTraits<T>;
+  using x8 = typename TR::x8;
+  constexpr int D = 128, ROWB = kPf2RowB, TILEB = kPf2TileB, QB = 128, NDMA = 4;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * TILEB];  // K ring [2] | V ring [2]
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const lds_ptr_t lds3 = (lds_ptr_t)&lds[0];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q32 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.x % nq, b = (blockIdx.x / nq) % n_seqs;
+  const int qb = n_qblocks - 1 - blockIdx.x / (nq * n_seqs);   // heaviest (latest) causal blocks of every sequence first
+  const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
+  const int q0 = qb * QB;
+  if (q0 >= q_len) return;
+  const int kv_len = PAGED ? kv_lens[b] : (cu_k[b + 1] - cu_k[b]);
+  const int k_start = PAGED ? 0 : cu_k[b];
+  const int G = nq / nkv, kvh = h / G;
+  const int kvoff = kv_len - q_len;
+
+  int q_hi = q0 + QB < q_len ? q0 + QB : q_len;
+  int hi_tok = kv_len;
+  if (causal) { int c = kvoff + q_hi; hi_tok = c < kv_len ? c : kv_len; }
+  if (hi_tok < 0) hi_tok = 0;
+  int lo_tok = 0;
+  if (window_left >= 0) { lo_tok = kvoff + q0 - window_left; lo_tok = lo_tok > 0 ? lo_tok : 0; }
+  const int tile_lo = lo_tok / kPf2Tile, tile_hi = (hi_tok + kPf2Tile - 1) / kPf2Tile;
+  const int nt = tile_hi - tile_lo;
+
+  const int32_t* bt_row = PAGED ? block_table + (int64_t)b * max_blocks : nullptr;
+  const int64_t krow = PAGED ? (int64_t)nkv * D : k_stride;  // row pitch in elements
+  const int64_t vrow = PAGED ? (int64_t)nkv * D : v_stride;
+
+  // Q as the B operand: lane (n = query q32, k group hi) holds Q[q][16 ks + 8 hi .. + 7]
+  x8 qf[8];
+  const int qidx = q0 + wave * 32 + q32;
+  {
+    const bool ok = qidx < q_len;
+    const T* qp = q + (int64_t)(q_start + (ok ? qidx : 0)) * q_stride + (int64_t)h * D;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ok) qf[ks] = *reinterpret_cast<const x8*>(qp + ks * 16 + hi * 8);
+      else qf[ks] = x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  const int wq_lo = kvoff + q0 + wave * 32;
+  const int wq_hi = kvoff + (q0 + wave * 32 + 31 < q_len - 1 ? q0 + wave * 32 + 31 : q_len - 1);
+  const bool wave_active = (q0 + wave * 32) < q_len;
+  auto computes = [&](int i) -> bool {  // does this wave have visible keys in tile tile_lo + i ?
+    const int t0 = (tile_lo + i) * kPf2Tile;
+    return i >= 0 && i < nt && wave_active && (!causal || t0 <= wq_hi) && (window_left < 0 || t0 + kPf2Tile > wq_lo - window_left);
+  };
+
+  pf32x16_t acc_o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_o[i] = pf32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float m_run = kPfNegBig, l_run = 0.0f;
+
+  // DMA source offsets: instruction j of wave w fills LDS rows 4 (NDMA w + j) .. + 3 of the tile; lane = (row, physical chunk)
+  int voff_k[4], voff_v[4];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int row = 4 * (NDMA * wave + j) + (lane >> 4), pc = lane & 15;
+    voff_k[j] = row * (int)(krow * 2) + ((pc ^ (row & 15)) << 4);
+    voff_v[j] = row * (int)(vrow * 2) + ((pc ^ ((row & 7) << 1)) << 4);
+  }
+  auto stage = [&](int i, bool is_v) {  // tile tile_lo + i of K or V -> ring slot i & 1
+    const int t0 = (tile_lo + i) * kPf2Tile;
+    int rows = kv_len - t0 < kPf2Tile ? kv_len - t0 : kPf2Tile;
+    rows = rows > 0 ? rows : 0;
+    int64_t row0;
+    if constexpr (PAGED) row0 = (int64_t)bt_row[(t0 < kv_len ? t0 : 0) / block_size] * block_size + t0 % block_size;
+    else row0 = k_start + t0;
+    const int64_t pitch = is_v ? vrow : krow;
+    const T* src = (is_v ? v : k) + row0 * pitch + (int64_t)kvh * D;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(src), 0, rows ? (int)((rows - 1) * pitch * 2) + ROWB : 0, 0x00020000);
+    const lds_ptr_t dst = lds3 + ((is_v ? 2 : 0) + (i & 1)) * TILEB + wave * (NDMA * 1024);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + j * 1024, 16, is_v ? voff_v[j] : voff_k[j], 0, 0, 0);
+  };
+
+  // fragment read offsets inside ring slot 0 (per lane, constant over tiles)
+  const unsigned lds_base = (unsigned)(__UINTPTR_TYPE__)lds3;
+  unsigned kaddr[8], vaddr[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kaddr[ks] = lds_base + q32 * ROWB + (((2 * ks + hi) ^ (q32 & 15)) << 4);   // + 32 kb rows
+  {
+    // V^T fragment of (key step, d block db): the 16 lanes of group (gi = d half, hi) address keys 4 hi + (p16 >> 2) (+ 8 for the
+    // second read) x the four 8-byte column quads of d 32 db + 16 gi .. + 15; lane p16 receives column p16 of that 4 x 16 block
+    const int p16 = lane & 15, gi = (lane >> 4) & 1;
+    const int vr = 4 * hi + (p16 >> 2), ft = vr & 7;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) vaddr[db] = lds_base + 2 * TILEB + vr * ROWB + (((2 * db + gi) ^ ft) << 5) + (p16 & 3) * 8;
+  }
+
+  if (nt > 0) {
+    pf32x16_t sa[2], sb[2];
+    const int qpos = kvoff + qidx;
+#define PF_EVEN_STEP(I_)                                                                                 \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's slices of the requested tiles */      \
+  __syncthreads();                                                                                       \
+  if ((I_) + 1 < nt) stage((I_) + 1, false);                                                             \
+  if ((I_) < nt) stage((I_), true);
+    // step j: barrier (K(j) and V(j - 1) are published; K(j + 1), V(j) are requested) ; S(j) || softmax(j - 1) ; P(j-1) V(j-1)
+    auto step = [&](pf32x16_t (&sc)[2], pf32x16_t (&sn)[2], int j) {
+      const bool do_qk = computes(j), do_sm = computes(j - 1);
+      const int t0 = (tile_lo + j - 1) * kPf2Tile;
+      const bool need_mask = (t0 + kPf2Tile > kv_len) || (causal && t0 + kPf2Tile - 1 > wq_lo) ||
+                             (window_left >= 0 && t0 < wq_hi - window_left);
+      const unsigned kslot = (unsigned)((j & 1) * TILEB), vslot = (unsigned)(((j - 1) & 1) * TILEB);
+      if (do_qk && do_sm)
+        pf32_step<T, P1, true, true>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
+                                     window_left, qpos, hi, scale_log2);
+      else if (do_qk)
+        pf32_step<T, P1, true, false>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
+                                      window_left, qpos, hi, scale_log2);
+      else if (do_sm)
+        pf32_step<T, P1, false, true>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
+                                      window_left, qpos, hi, scale_log2);
+    };
+    stage(0, false);
+    for (int j = 0; j <= nt; j += 2) {
+      PF_EVEN_STEP(j)
+      step(sa, sb, j);          // consumes sa (tile j - 1), produces sb (tile j)
+      if (j + 1 > nt) break;
+      PF_EVEN_STEP(j + 1)
+      step(sb, sa, j + 1);
+    }
+#undef PF_EVEN_STEP
+  }
+
+  // ---- epilogue: the two halves of a query's row sum meet, O^T -> O rows by v_permlane32_swap, 16-byte stores
+  {
+    unsigned u = __builtin_bit_cast(unsigned, l_run), c;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
+    const float l = as_f32(r32[0]) + as_f32(r32[1]);
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    const bool ok = qidx < q_len;
+    T* op = out + (int64_t)(q_start + (ok ? qidx : 0)) * nq * D + (int64_t)h * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        // register group rg = 2 pr (+ 1) holds d = 32 db + 8 rg + 4 hi + 0..3: pack each to two dwords, swap the halves so that the
+        // hi = 0 lane owns d 32 db + 16 pr + 0..7 and the hi = 1 lane d + 8..15
+        unsigned w[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r0 = (2 * pr + e) * 4;
+          uint16_t hv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            T t = from_f32<T>(acc_o[db][r0 + r] * inv);
+            __builtin_memcpy(&hv[r], &t, 2);
+          }
+          w[e][0] = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+          w[e][1] = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+        }
+        // swap(a = rg even data, b = rg odd data) -> r[0] = [a_lo | b_lo] , r[1] = [a_hi | b_hi] (rows of 32 lanes):
+        // hi = 0 lanes end with (a own, a partner) = d + 0..3, d + 4..7; hi = 1 lanes with (b partner, b own) = d + 8..11, d + 12..15
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        if (ok)
+          *reinterpret_cast<uint4*>(op + db * 32 + pr * 16 + hi * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+  }
+}
+
 template <typename T, int D, bool PAGED>
 int launch_flash_prefill(const void* q, const void* k, const void* v, void* out, const int32_t* cu_q,
                          const int32_t* cu_k, const int32_t* kv_lens, const int32_t* block_table, int64_t max_blocks,
@@ -769,7 +1101,16 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
         // 2 = P = hi + lo (two MFMAs per block: fp32-P accuracy, 1e-4, at 1.34x the time)
         static int p_mode = -1;
         if (p_mode < 0) p_mode = xm_switch("XLLM_MI355_PREFILL_P", kPfDefaultPMode);   // product switch, read once
-        if (p_mode == 1)
+        XM_TUNE_VAR(m32_mode, "XLLM_MI355_PREFILL_M32", 0);   // 1: the 32x32x16 kernel (round 6, work in progress; tuning flavour A/B)
+        if (m32_mode && p_mode == 1)
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, true>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+                             (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
+                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
+        else if (m32_mode)
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, false>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+                             (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
+                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
+        else if (p_mode == 1)
           hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3((unsigned)(nq * batch * qblocks)),
                              dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table,
                              (int)max_blocks, (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl,

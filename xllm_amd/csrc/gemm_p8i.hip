@@ -231,6 +231,9 @@ __device__ __forceinline__ void p8i_epilogue_gate_up(i32x4_t (&acc)[8][4], uint8
 
 // ADDEND: GemmEpi::addend in the dequant epilogue -- its own instantiation, so the plain kernel's code is untouched (with a run-time
 // branch the plain gate_up GEMM at M = 8192 measured +0.45 %: profiles/r04_gemm_addend.txt)
+#ifdef P8I_TIMING  /* timing build (tools/p8i_timing.py): wall-clock (100 MHz) and shader-clock spans of one workgroup's phases */
+__device__ long long p8i_dbg[16];
+#endif
 template <bool SPLITK, bool ADDEND = false>
 __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* __restrict__ A_in,
                                                                 const uint8_t* __restrict__ W_in, int M_in, int N,
@@ -246,6 +249,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: wr is the phase group
+#ifdef P8I_TIMING
+  const long long tm_w0 = wall_clock64(), tm_c0 = clock64();
+#endif
 
   // XCD-aware rasterisation: block b runs on XCD b%8; every XCD walks its own super-blocks of 32 tiles
   // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
@@ -470,11 +476,17 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
     __builtin_amdgcn_s_barrier();
   };
 
+#ifdef P8I_TIMING
+  const long long tm_w1 = wall_clock64(), tm_c1 = clock64();
+#endif
   for (int t = 0; t < nk; t += 2) {
     ktile(std::integral_constant<int, 0>{}, kt_begin + t);
     if (t + 1 >= nk) break;
     ktile(std::integral_constant<int, 1>{}, kt_begin + t + 1);
   }
+#ifdef P8I_TIMING
+  const long long tm_w2 = wall_clock64(), tm_c2 = clock64();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail prefetches must land before the LDS is released
   if (wr == 0) __builtin_amdgcn_s_barrier();        // balance group 1's extra barrier
 #undef P8I_MMA
@@ -489,6 +501,17 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
   }
   if (epi.out_bf16) p8i_epilogue<SPLITK, true, ADDEND>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
   else p8i_epilogue<SPLITK, false, ADDEND>(acc, lds, M, N, m0, n0, wr, wc, wave, lane, epi);
+#ifdef P8I_TIMING
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epilogue's stores have been accepted
+    const long long tm_w3 = wall_clock64(), tm_c3 = clock64();
+    if (blockIdx.x == (gridDim.x / 2 & ~7u) + 3 && tid == 0) {
+      p8i_dbg[0] = tm_w1 - tm_w0; p8i_dbg[1] = tm_w2 - tm_w1; p8i_dbg[2] = tm_w3 - tm_w2;
+      p8i_dbg[3] = tm_c1 - tm_c0; p8i_dbg[4] = tm_c2 - tm_c1; p8i_dbg[5] = tm_c3 - tm_c2;
+      p8i_dbg[6] = nk;
+    }
+  }
+#endif
 }
 
 // same grid / envelope as launch_gemm_p8 (gemm_p8.hip decides which of the two int8 kernels runs)
@@ -510,3 +533,9 @@ int launch_gemm_p8i(const void* A, const void* W, int64_t M, int64_t N, int64_t 
 }
 
 }  // namespace xm
+
+#ifdef P8I_TIMING
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_p8i(long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(xm::p8i_dbg), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif

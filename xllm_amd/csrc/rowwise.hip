@@ -64,6 +64,24 @@ __global__ __launch_bounds__(256) void block_copy_kernel(const int64_t* __restri
   V* kc = reinterpret_cast<V*>(static_cast<uintptr_t>(k_ptrs[blockIdx.z]));
   V* vc = v_ptrs ? reinterpret_cast<V*>(static_cast<uintptr_t>(v_ptrs[blockIdx.z])) : nullptr;
   const int64_t base = (int64_t)blockIdx.x * (256 * kBlockCopyChunks) + threadIdx.x;
+  // The unit width is chosen on the host from the block size alone; the cache BASE addresses live in device arrays. A base that
+  // is not a multiple of the unit (a cache view at an odd offset; torch allocations never are) takes a byte-wise walk of the same
+  // units instead of a misaligned vector access (round-5 advisor). Workgroup-uniform branch.
+  if (sizeof(V) > 1 && (((uintptr_t)kc | (uintptr_t)vc) & (sizeof(V) - 1)) != 0) {
+    for (int c = 0; c < kBlockCopyChunks; ++c) {
+      const int64_t i = base + c * 256;
+      if (i >= units_per_block) continue;
+      const uint8_t* ks = reinterpret_cast<const uint8_t*>(kc + so + i);
+      uint8_t* kd = reinterpret_cast<uint8_t*>(kc + dof + i);
+      for (int bb = 0; bb < (int)sizeof(V); ++bb) kd[bb] = ks[bb];
+      if (vc) {
+        const uint8_t* vs = reinterpret_cast<const uint8_t*>(vc + so + i);
+        uint8_t* vd = reinterpret_cast<uint8_t*>(vc + dof + i);
+        for (int bb = 0; bb < (int)sizeof(V); ++bb) vd[bb] = vs[bb];
+      }
+    }
+    return;
+  }
   V kr[kBlockCopyChunks], vr[kBlockCopyChunks];
 #pragma unroll
   for (int c = 0; c < kBlockCopyChunks; ++c) {

@@ -457,12 +457,11 @@ class DeepseekV2Attention:
             self.q_w = rnd(self.h * (nope + rope), hidden)
         self.kv_a_w, self.kv_a_norm_w = rnd(kv_lora + rope, hidden), ones(kv_lora)
         kv_b = rnd(self.h * (nope + v_dim), kv_lora).unflatten(0, (self.h, nope + v_dim))
-        self.w_kc = kv_b[:, :nope].contiguous()                       # [h, nope, kv_lora]
-        self.w_vc = kv_b[:, nope:].transpose(1, 2).contiguous()       # [h, kv_lora, v]  (load_state_dict :335-339)
-        # what ops.bmm_heads reads (round 5): every head's matrix K-contiguous per output column, [h, N, K]. For W_vc that is the
-        # slice of kv_b_proj's weight itself (a VIEW, before the reference transposes it for torch::bmm); W_kc is transposed once here
-        self.w_kc_nk = self.w_kc.transpose(1, 2).contiguous()         # [h, kv_lora, nope]
-        self.w_vc_nk = kv_b[:, nope:]                                 # [h, v, kv_lora] (strided over h)
+        # ONE orientation of each absorbed weight (the reference's w_kc_ [h, nope, kv_lora] / w_vc_ [h, kv_lora, v], load_state_dict
+        # :335-339), stored the way ops.bmm_heads reads them (round 5): every head's matrix K-contiguous per output column,
+        # [h, N, K]. For W_vc that is the slice of kv_b_proj's weight itself (a VIEW); W_kc is transposed once here.
+        self.w_kc_nk = kv_b[:, :nope].transpose(1, 2).contiguous()    # [h, kv_lora, nope] = w_kc^T per head
+        self.w_vc_nk = kv_b[:, nope:]                                 # [h, v, kv_lora] = w_vc^T per head (strided over h)
         self.o_w = rnd(hidden, self.h * v_dim)
         if quant != "16bit":
             assert q_lora > 0 and quant == "fp8"

@@ -382,7 +382,7 @@ class OneShotAllReduce:
             (n16, ysum) = self.allreduce_add_rms_norm(pat * float(rank + 1), res, w, 1e-6, quantize=False, want_sum=True)
             ok = ok and bool(torch.equal(ysum, pat * float(tri))) and bool(torch.equal(res, pat * float(tri) + 1.0))
             ok = ok and bool(torch.isfinite(n16.float()).all())
-            if self.grid_limit > 64:
+            if self.grid_limit > 64 and 256 * H * 2 <= self.max_bytes:   # (a buffer too small for it is rank-invariant: skipped by all)
                 # one row per block (grid_limit = 256, every rank on a GPU of its own): production decode sends M = 256 rows, which
                 # uses flag rows 64 .. 255 and relies on 256 co-resident blocks per rank -- the 8-row message above never touches
                 # either (round-4 advisor): send one message of that regime before the verdict is agreed
