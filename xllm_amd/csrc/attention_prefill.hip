@@ -518,6 +518,49 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
 #endif
 }
 
+// ---- block -> (q head, sequence, q block) of the LDS-DMA flash kernels, XCD-aware (round 6). Block b runs on XCD b % 8 (observed,
+// relied on for speed only). The K / V stream of one (sequence, kv head) pair is shared by the G q heads of its group and by every
+// q block: with the heads as the fastest block index the seven heads of a group sat on seven DIFFERENT XCDs and each XCD's L2
+// fetched the same tiles again (1.8 GB of L2 fills per 2 x 4096-token launch for 16 MB of K / V). Here a pair is pinned to one XCD
+// (P = n_seqs * nkv pairs dealt round robin over the 8 XCDs; P < 8 dividing 8: 8 / P XCDs share a pair's blocks), and inside an
+// XCD the order stays "q block slowest and descending (heaviest causal blocks first), then pair, then head". Returns false for
+// the padding blocks of the rounded-up grid.
+__device__ __forceinline__ bool pf_block_coords(int nq, int nkv, int n_seqs, int n_qblocks, int& h, int& b, int& qb) {
+  const int G = nq / nkv, P = n_seqs * nkv;
+  const int bx = blockIdx.x, x = bx & 7, j = bx >> 3;
+  int pair, g, qbi;
+  if (P >= 8) {
+    const int pairs_x = (P - x + 7) / 8;            // pairs x, x + 8, ... live on this XCD
+    if (pairs_x <= 0) return false;
+    g = j % G;
+    const int t = j / G;
+    pair = x + 8 * (t % pairs_x);
+    qbi = t / pairs_x;
+  } else if (8 % P == 0) {
+    const int r = 8 / P, u = j * r + (x % r);        // the pair's blocks dealt over its r XCDs
+    pair = x / r;
+    g = u % G;
+    qbi = u / G;
+  } else {                                           // no even deal: the plain order
+    const int u = bx;
+    h = u % nq;
+    b = (u / nq) % n_seqs;
+    qb = n_qblocks - 1 - u / (nq * n_seqs);
+    return qb >= 0;
+  }
+  if (qbi >= n_qblocks) return false;
+  b = pair / nkv;
+  h = (pair % nkv) * G + g;
+  qb = n_qblocks - 1 - qbi;
+  return true;
+}
+inline unsigned pf_grid_blocks(int64_t nq, int64_t nkv, int64_t n_seqs, int64_t n_qblocks) {
+  const int64_t G = nq / nkv, P = n_seqs * nkv;
+  if (P >= 8) return (unsigned)(8 * ((P + 7) / 8) * G * n_qblocks);
+  if (8 % P == 0) { const int64_t r = 8 / P; return (unsigned)(8 * ((G * n_qblocks + r - 1) / r)); }
+  return (unsigned)(nq * n_seqs * n_qblocks);
+}
+
 // NW = 8: ping-pong groups, 256 queries per workgroup, one workgroup per CU. NW = 4: one group, 128 queries per
 // workgroup, two workgroups per CU (short query blocks: no second group to alternate with).
 template <typename T, bool PAGED, int NW, bool MIDBAR, bool P1 = false>
@@ -543,8 +586,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
   // 1-D grid, dispatched in order: the q block is the SLOWEST index and runs from the last (heaviest under a causal
   // mask) to the first, so the long workgroups of EVERY sequence start first and the short ones fill the tail
   // (with a (head, q block, sequence) grid the heaviest blocks of the last sequence started last: +12 % makespan)
-  const int h = blockIdx.x % nq, b = (blockIdx.x / nq) % n_seqs;
-  const int qb = n_qblocks - 1 - blockIdx.x / (nq * n_seqs);
+  int h, b, qb;
+  if (!pf_block_coords(nq, nkv, n_seqs, n_qblocks, h, b, qb)) return;
   const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
   const int q0 = qb * QB;
   if (q0 >= q_len) return;
@@ -758,6 +801,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
 //   * staging, rings, swizzles, barrier protocol, masks, lazy rescale (2^8) and the single RNE-rounded 16-bit P (or hi + lo)
 //     are flash_prefill_dma_kernel's: the oracle's p_round = "flash" mode describes both.
 typedef float pf32x16_t __attribute__((ext_vector_type(16)));
+#ifdef PF32_TIMING  /* timing build (tools/pf32_timing.py): shader cycles per phase of one wave, summed over its tiles */
+__device__ long long pf32_dbg[16];
+#define PF32_T(I_, DEP_)                                                    \
+  {                                                                         \
+    float dep_;                                                             \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(dep_) : "v"(DEP_));              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
+    const long long now_ = clock64();                                       \
+    tph[I_] += now_ - tph_t;                                                \
+    tph_t = now_;                                                           \
+  }
+#define PF32_TARGS , long long (&tph)[6], long long& tph_t
+#define PF32_TPASS , tph, tph_t
+#else
+#define PF32_T(I_, DEP_)
+#define PF32_TARGS
+#define PF32_TPASS
+#endif
 template <typename T>
 struct Pf32Traits;
 template <>
@@ -773,127 +834,127 @@ struct Pf32Traits<f16_t> {
   }
 };
 
-// one tile step of a wave. DO_QK: S(next) = K Q^T of the tile in K ring slot `kslot`; DO_SM: softmax of `sc` (the previous
-// tile's scores, consumed) + O += P V with the tile in V ring slot `vslot`.
-template <typename T, bool P1, bool DO_QK, bool DO_SM>
-__device__ __forceinline__ void pf32_step(pf32x16_t (&sc)[2], pf32x16_t (&sn)[2], pf32x16_t (&acc_o)[4], float& m_run, float& l_run,
-                                          const typename PfTraits<T>::x8 (&qf)[8], const unsigned (&kaddr)[8],
-                                          const unsigned (&vaddr)[4], unsigned kslot, unsigned vslot, bool need_mask, int t0,
-                                          int kv_len, int causal, int window_left, int qpos, int hi, float scale_log2) {
+// one tile of a wave: S = K Q^T (16 MFMAs, K ring slot PAR), softmax, O += P V (16 MFMAs, V ring slot PAR). The ring slot is
+// compile-time (the caller unrolls the tile loop by two), so every LDS offset is an immediate. The conversions of key steps 1-3
+// sit between the PV MFMAs of the step before them; the row maximum and the first conversion are exposed to the wave itself and
+// covered by the SIMD's other wave (two workgroups per CU, not in lockstep: each has its own barriers).
+// (A two-tile pipeline -- S(j + 1) under the softmax of tile j -- needs a second score block: 32 more registers than the 256 a
+// wave has at two waves per SIMD; it compiled with 400+ spilled registers and was dropped.)
+template <typename T, bool P1, int PAR>
+__device__ __forceinline__ void pf32_step(pf32x16_t (&acc_o)[4], float& m_run, float& l_run, const typename PfTraits<T>::x8 (&qf)[8],
+                                          const unsigned (&kaddr)[8], const unsigned (&vaddr)[4], bool need_mask, int t0, int kv_len,
+                                          int causal, int window_left, int qpos, int hi, float scale_log2 PF32_TARGS) {
   using x8 = typename PfTraits<T>::x8;
   using x4 = typename PfTraits<T>::x4;
   using elem = typename PfTraits<T>::elem;
   using M = Pf32Traits<T>;
-  pu32x4_t kf[8];
-  // ---- K fragment reads: fragment I = 8 kb + ks = rows 32 kb + (lane & 31), logical chunk 2 ks + hi; 8 in flight
-#define PF32_K_RD(I_) PF_DSR128(kf[(I_) & 7], kaddr[(I_) & 7], ((I_) >> 3) * 32 * kPf2RowB);
-  if constexpr (DO_QK) {
-    sn[0] = pf32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    sn[1] = sn[0];
-  }
-  unsigned ka[8];
-  if constexpr (DO_QK) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ka[i] = kaddr[i] + kslot;
-  }
-#undef PF32_K_RD
-#define PF32_K_RD(I_) PF_DSR128(kf[(I_) & 7], ka[(I_) & 7], ((I_) >> 3) * 32 * kPf2RowB);
+  constexpr int SLOT = PAR * kPf2TileB;
+  PF32_T(0, m_run)   // barrier wait + DMA issue
+
+  pf32x16_t sc[2];
+  sc[0] = pf32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  sc[1] = sc[0];
+  {
+    // ---- K fragment reads: fragment I = 2 ks + kb = rows 32 kb + (lane & 31), logical chunk 2 ks + hi; eight in flight.
+    // Consecutive MFMAs alternate between the two score blocks: an instruction between two MFMAs on the SAME accumulator costs
+    // ~43 cycles, on different accumulators ~6 (MI355X_MICROARCH.md, per-instruction constants).
+    pu32x4_t kf[8];
+#define PF32_K_RD(I_) PF_DSR128(kf[(I_) & 7], kaddr[(I_) >> 1], SLOT + ((I_) & 1) * 32 * kPf2RowB);
 #define PF32_K_MM(I_, WAIT_)                                                                             \
   PF_LGKM1(WAIT_, kf[(I_) & 7]);                                                                         \
-  sn[(I_) >> 3] = M::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[(I_) & 7], sn[(I_) >> 3]);
-  if constexpr (DO_QK) { PF32_K_RD(0) PF32_K_RD(1) PF32_K_RD(2) PF32_K_RD(3) PF32_K_RD(4) PF32_K_RD(5) PF32_K_RD(6) PF32_K_RD(7) }
-
-  // ---- softmax part 1 (the row maximum needs every score of the tile): written BETWEEN the MFMAs of the QK block
-  float mx0 = kPfNegBig, mx1 = kPfNegBig;
-  if constexpr (DO_SM) {
-    if (need_mask) {  // wave-uniform: only the diagonal / tail / window-edge tiles of a wave
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int tok = t0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const bool vis = tok < kv_len && (!causal || tok <= qpos) && (window_left < 0 || tok >= qpos - window_left);
-          if (!vis) sc[kb][r] = -INFINITY;
-        }
-    }
-  }
-  // piece I of the QK block: MFMA I (+ the read of fragment I + 8) and 4 of the 32 maxima
-#define PF32_QK_PIECE(I_, WAIT_, RD_)                                                                    \
-  if constexpr (DO_QK) { PF32_K_MM(I_, WAIT_) RD_ }                                                      \
-  if constexpr (DO_SM && (I_) < 8) {                                                                     \
-    mx0 = fmaxf(mx0, fmaxf(sc[(I_) >> 2][((I_) & 3) * 4 + 0], sc[(I_) >> 2][((I_) & 3) * 4 + 1]));       \
-    mx1 = fmaxf(mx1, fmaxf(sc[(I_) >> 2][((I_) & 3) * 4 + 2], sc[(I_) >> 2][((I_) & 3) * 4 + 3]));       \
-  }
-  PF32_QK_PIECE(0, 7, PF32_K_RD(8)) PF32_QK_PIECE(1, 7, PF32_K_RD(9)) PF32_QK_PIECE(2, 7, PF32_K_RD(10)) PF32_QK_PIECE(3, 7, PF32_K_RD(11))
-  PF32_QK_PIECE(4, 7, PF32_K_RD(12)) PF32_QK_PIECE(5, 7, PF32_K_RD(13)) PF32_QK_PIECE(6, 7, PF32_K_RD(14)) PF32_QK_PIECE(7, 7, PF32_K_RD(15))
-  float m_new = m_run, alpha = 1.0f;
-  x8 ph[2][2], pl[2][2];   // [kb][s1]: the B operands of the four PV key steps (hi part / lo part)
-  float psum = 0.0f;
-  if constexpr (DO_SM) {
-    float mx = fmaxf(mx0, mx1);
-    {  // lanes l and l ^ 32 hold the same query: v_permlane32_swap (VALU) exchanges the halves
-      unsigned u = __builtin_bit_cast(unsigned, mx), c;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
-      const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
-      mx = fmaxf(as_f32(r32[0]), as_f32(r32[1]));
-    }
-    // lazy rescale (flash_prefill_dma_kernel): the reference maximum only moves when the tile's maximum exceeds it by > 2^8
-    const float mxs = mx * scale_log2;
-    m_new = mxs > m_run + 8.0f ? mxs : m_run;
-    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-  }
-  // P of key step (kb, s1) = scores sc[kb][8 s1 .. 8 s1 + 7]: p = 2^(s * scale - m), row sum in fp32, one RNE 16-bit P (or hi + lo)
-#define PF32_P_CHUNK(KB_, S1_)                                                                           \
-  if constexpr (DO_SM) {                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[KB_][(S1_) * 8 + j], scale_log2, -m_new)); \
-      psum += p;                                                                                         \
-      const elem h = (elem)p;                                                                            \
-      ph[KB_][S1_][j] = h;                                                                               \
-      if constexpr (!P1) pl[KB_][S1_][j] = (elem)(p - (float)h);                                         \
-    }                                                                                                    \
-  }
-  PF32_QK_PIECE(8, 7, ) PF32_P_CHUNK(0, 0)
-  PF32_QK_PIECE(9, 6, ) PF32_QK_PIECE(10, 5, ) PF32_QK_PIECE(11, 4, ) PF32_P_CHUNK(0, 1)
-  PF32_QK_PIECE(12, 3, ) PF32_QK_PIECE(13, 2, ) PF32_QK_PIECE(14, 1, ) PF32_QK_PIECE(15, 0, )
-#undef PF32_QK_PIECE
+  sc[(I_) & 1] = M::mfma(__builtin_bit_cast(x8, kf[(I_) & 7]), qf[(I_) >> 1], sc[(I_) & 1]);
+    PF32_K_RD(0) PF32_K_RD(1) PF32_K_RD(2) PF32_K_RD(3) PF32_K_RD(4) PF32_K_RD(5) PF32_K_RD(6) PF32_K_RD(7)
+    PF32_K_MM(0, 7) PF32_K_RD(8) PF32_K_MM(1, 7) PF32_K_RD(9) PF32_K_MM(2, 7) PF32_K_RD(10) PF32_K_MM(3, 7) PF32_K_RD(11)
+    PF32_K_MM(4, 7) PF32_K_RD(12) PF32_K_MM(5, 7) PF32_K_RD(13) PF32_K_MM(6, 7) PF32_K_RD(14) PF32_K_MM(7, 7) PF32_K_RD(15)
+    PF32_K_MM(8, 7) PF32_K_MM(9, 6) PF32_K_MM(10, 5) PF32_K_MM(11, 4) PF32_K_MM(12, 3) PF32_K_MM(13, 2) PF32_K_MM(14, 1) PF32_K_MM(15, 0)
 #undef PF32_K_MM
 #undef PF32_K_RD
-  if constexpr (!DO_SM) return;
+  }
+  PF32_T(1, sc[1][15])   // K reads + QK^T
+  // ---- the V^T fragments of key step 0 are requested before the softmax starts
+  pu32x2_t vt[8][2];   // fragment pair of (key step c, d block db) lives in slot 4 (c & 1) + db; eight pairs in flight
+#define PF32_V_RD(C_, DB_)                                                                               \
+  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][0], vaddr[DB_], 2 * kPf2TileB + SLOT + (C_) * 16 * kPf2RowB);    \
+  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][1], vaddr[DB_], 2 * kPf2TileB + SLOT + (C_) * 16 * kPf2RowB + 8 * kPf2RowB);
+  PF32_V_RD(0, 0) PF32_V_RD(0, 1) PF32_V_RD(0, 2) PF32_V_RD(0, 3) PF32_V_RD(1, 0) PF32_V_RD(1, 1) PF32_V_RD(1, 2) PF32_V_RD(1, 3)
+  if (need_mask) {  // wave-uniform: only the diagonal / tail / window-edge tiles of a wave
+    // (the empty asm keeps this a BRANCH: hipcc if-converted the block into ~230 compare / select instructions executed for
+    // every tile, more than the whole softmax)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tok = t0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool vis = tok < kv_len && (!causal || tok <= qpos) && (window_left < 0 || tok >= qpos - window_left);
+        if (!vis) sc[kb][r] = -INFINITY;
+      }
+  }
+  // 32 scores -> 16 v_max3_f32 (as asm: hipcc puts a canonicalising v_max_f32 x, x, x in front of every fmaxf on an MFMA
+  // result -- 57 instructions for this reduction instead of 17)
+  float mx0 = kPfNegBig, mx1 = kPfNegBig;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx0) : "v"(mx0), "v"(sc[kb][r]), "v"(sc[kb][r + 1]));
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx1) : "v"(mx1), "v"(sc[kb][r + 2]), "v"(sc[kb][r + 3]));
+    }
+  float mx;
+  asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx0), "v"(mx1));
+  {  // lanes l and l ^ 32 hold the same query: v_permlane32_swap (VALU) exchanges the halves
+    unsigned u = __builtin_bit_cast(unsigned, mx), c;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(u));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(u, c, false, false);
+    mx = fmaxf(as_f32(r32[0]), as_f32(r32[1]));
+  }
+  // lazy rescale (flash_prefill_dma_kernel): the reference maximum only moves when the tile's maximum exceeds it by > 2^8
+  const float mxs = mx * scale_log2;
+  const float m_new = mxs > m_run + 8.0f ? mxs : m_run;
+  const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  m_run = m_new;
+  x8 ph[2][2], pl[2][2];   // [kb][s1]: the B operands of the four PV key steps (hi part / lo part)
+  float psum = 0.0f;
+  // P of key step (kb, s1) = scores sc[kb][8 s1 .. 8 s1 + 7]: p = 2^(s * scale - m), row sum in fp32, one RNE 16-bit P (or hi + lo)
+#define PF32_P_CHUNK(KB_, S1_)                                                                           \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[KB_][(S1_) * 8 + j], scale_log2, -m_new));  \
+    psum += p;                                                                                           \
+    const elem h = (elem)p;                                                                              \
+    ph[KB_][S1_][j] = h;                                                                                 \
+    if constexpr (!P1) pl[KB_][S1_][j] = (elem)(p - (float)h);                                           \
+  }
+  PF32_P_CHUNK(0, 0)
+  PF32_T(2, psum)        // mask, row maximum, first conversion
+
   // ---- O += P V: key step c = 2 kb + s1 (16 keys), d block db (32 columns); A = V^T by transposed reads in the k-slot key order
   if (__any(alpha != 1.0f)) {   // the running maximum settles after a few tiles (wave-uniform branch; x 1.0f is exact)
 #pragma unroll
     for (int db = 0; db < 4; ++db) acc_o[db] *= alpha;
   }
-  pu32x2_t vt[8][2];
-  unsigned va[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) va[db] = vaddr[db] + vslot;
-#define PF32_V_RD(C_, DB_)                                                                               \
-  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][0], va[DB_], (C_) * 16 * kPf2RowB);                               \
-  PF_DSR64TR(vt[((C_) & 1) * 4 + (DB_)][1], va[DB_], (C_) * 16 * kPf2RowB + 8 * kPf2RowB);
 #define PF32_V_MM(C_, DB_, WAIT_)                                                                        \
   {                                                                                                      \
-    PF_LGKM2(WAIT_, vt[((C_) & 1) * 4 + (DB_)][0], vt[((C_) & 1) * 4 + (DB_)][1]);                         \
+    PF_LGKM2(WAIT_, vt[((C_) & 1) * 4 + (DB_)][0], vt[((C_) & 1) * 4 + (DB_)][1]);                       \
     const x8 v8 = __builtin_shufflevector(__builtin_bit_cast(x4, vt[((C_) & 1) * 4 + (DB_)][0]),           \
                                           __builtin_bit_cast(x4, vt[((C_) & 1) * 4 + (DB_)][1]), 0, 1, 2, 3, 4, 5, 6, 7); \
     acc_o[DB_] = M::mfma(v8, ph[(C_) >> 1][(C_) & 1], acc_o[DB_]);                                       \
     if constexpr (!P1) acc_o[DB_] = M::mfma(v8, pl[(C_) >> 1][(C_) & 1], acc_o[DB_]);                     \
   }
-  PF32_V_RD(0, 0) PF32_V_RD(0, 1) PF32_V_RD(0, 2) PF32_V_RD(0, 3) PF32_V_RD(1, 0) PF32_V_RD(1, 1) PF32_V_RD(1, 2) PF32_V_RD(1, 3)
   PF32_V_MM(0, 0, 14) PF32_V_RD(2, 0) PF32_V_MM(0, 1, 14) PF32_V_RD(2, 1)
-  PF32_P_CHUNK(1, 0)
+  PF32_P_CHUNK(0, 1)
   PF32_V_MM(0, 2, 14) PF32_V_RD(2, 2) PF32_V_MM(0, 3, 14) PF32_V_RD(2, 3)
   PF32_V_MM(1, 0, 14) PF32_V_RD(3, 0) PF32_V_MM(1, 1, 14) PF32_V_RD(3, 1)
-  PF32_P_CHUNK(1, 1)
+  PF32_P_CHUNK(1, 0)
   PF32_V_MM(1, 2, 14) PF32_V_RD(3, 2) PF32_V_MM(1, 3, 14) PF32_V_RD(3, 3)
-  PF32_V_MM(2, 0, 14) PF32_V_MM(2, 1, 12) PF32_V_MM(2, 2, 10) PF32_V_MM(2, 3, 8)
+  PF32_V_MM(2, 0, 14) PF32_V_MM(2, 1, 12)
+  PF32_P_CHUNK(1, 1)
+  PF32_V_MM(2, 2, 10) PF32_V_MM(2, 3, 8)
   PF32_V_MM(3, 0, 6) PF32_V_MM(3, 1, 4) PF32_V_MM(3, 2, 2) PF32_V_MM(3, 3, 0)
 #undef PF32_V_RD
 #undef PF32_V_MM
 #undef PF32_P_CHUNK
   l_run = l_run * alpha + psum;
+  PF32_T(3, acc_o[3][15])   // PV + the other conversions
 }
 
 template <typename T, bool PAGED, bool P1>
@@ -912,8 +973,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q32 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.x % nq, b = (blockIdx.x / nq) % n_seqs;
-  const int qb = n_qblocks - 1 - blockIdx.x / (nq * n_seqs);   // heaviest (latest) causal blocks of every sequence first
+  int h, b, qb;
+  if (!pf_block_coords(nq, nkv, n_seqs, n_qblocks, h, b, qb)) return;
   const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
   const int q0 = qb * QB;
   if (q0 >= q_len) return;
@@ -996,43 +1057,50 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     const int p16 = lane & 15, gi = (lane >> 4) & 1;
     const int vr = 4 * hi + (p16 >> 2), ft = vr & 7;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) vaddr[db] = lds_base + 2 * TILEB + vr * ROWB + (((2 * db + gi) ^ ft) << 5) + (p16 & 3) * 8;
+    for (int db = 0; db < 4; ++db) vaddr[db] = lds_base + vr * ROWB + (((2 * db + gi) ^ ft) << 5) + (p16 & 3) * 8;   // + the V ring base
   }
 
   if (nt > 0) {
-    pf32x16_t sa[2], sb[2];
     const int qpos = kvoff + qidx;
-#define PF_EVEN_STEP(I_)                                                                                 \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's slices of the requested tiles */      \
+    // step j: barrier (K(j), V(j) are published; tile j + 1 is requested into the slots tile j - 1 was read from) ; the tile
+#define PF32_BARRIER(I_)                                                                                 \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's slices of the requested tile */       \
   __syncthreads();                                                                                       \
-  if ((I_) + 1 < nt) stage((I_) + 1, false);                                                             \
-  if ((I_) < nt) stage((I_), true);
-    // step j: barrier (K(j) and V(j - 1) are published; K(j + 1), V(j) are requested) ; S(j) || softmax(j - 1) ; P(j-1) V(j-1)
-    auto step = [&](pf32x16_t (&sc)[2], pf32x16_t (&sn)[2], int j) {
-      const bool do_qk = computes(j), do_sm = computes(j - 1);
-      const int t0 = (tile_lo + j - 1) * kPf2Tile;
-      const bool need_mask = (t0 + kPf2Tile > kv_len) || (causal && t0 + kPf2Tile - 1 > wq_lo) ||
-                             (window_left >= 0 && t0 < wq_hi - window_left);
-      const unsigned kslot = (unsigned)((j & 1) * TILEB), vslot = (unsigned)(((j - 1) & 1) * TILEB);
-      if (do_qk && do_sm)
-        pf32_step<T, P1, true, true>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
-                                     window_left, qpos, hi, scale_log2);
-      else if (do_qk)
-        pf32_step<T, P1, true, false>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
-                                      window_left, qpos, hi, scale_log2);
-      else if (do_sm)
-        pf32_step<T, P1, false, true>(sc, sn, acc_o, m_run, l_run, qf, kaddr, vaddr, kslot, vslot, need_mask, t0, kv_len, causal,
-                                      window_left, qpos, hi, scale_log2);
-    };
+  if ((I_) + 1 < nt) { stage((I_) + 1, false); stage((I_) + 1, true); }
+#define PF32_STEP(J_, PAR_)                                                                                              \
+  {                                                                                                                      \
+    const int j_ = (J_);                                                                                                 \
+    if (computes(j_)) {                                                                                                  \
+      const int t0 = (tile_lo + j_) * kPf2Tile;                                                                          \
+      const bool need_mask = (t0 + kPf2Tile > kv_len) || (causal && t0 + kPf2Tile - 1 > wq_lo) ||                        \
+                             (window_left >= 0 && t0 < wq_hi - window_left);                                             \
+      pf32_step<T, P1, PAR_>(acc_o, m_run, l_run, qf, kaddr, vaddr, need_mask, t0, kv_len, causal, window_left, qpos, hi, \
+                             scale_log2 PF32_TPASS);                                                                     \
+    }                                                                                                                    \
+  }
+#ifdef PF32_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tph_t = clock64();
+    const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
     stage(0, false);
-    for (int j = 0; j <= nt; j += 2) {
-      PF_EVEN_STEP(j)
-      step(sa, sb, j);          // consumes sa (tile j - 1), produces sb (tile j)
-      if (j + 1 > nt) break;
-      PF_EVEN_STEP(j + 1)
-      step(sb, sa, j + 1);
+    stage(0, true);
+    for (int j = 0; j < nt; j += 2) {
+      PF32_BARRIER(j)
+      PF32_STEP(j, 0)
+      if (j + 1 >= nt) break;
+      PF32_BARRIER(j + 1)
+      PF32_STEP(j + 1, 1)
     }
-#undef PF_EVEN_STEP
+#undef PF32_STEP
+#undef PF32_BARRIER
+#ifdef PF32_TIMING
+    if (qb == n_qblocks - 4 && h == 5 && b == 0 && lane == 0 && wave == 3) {   // a long (late-query) block, its last wave
+      for (int i = 0; i < 4; ++i) pf32_dbg[i] = tph[i];
+      pf32_dbg[4] = clock64() - t_c0;
+      pf32_dbg[5] = wall_clock64() - t_w0;
+      pf32_dbg[6] = nt;
+    }
+#endif
   }
 
   // ---- epilogue: the two halves of a query's row sum meet, O^T -> O rows by v_permlane32_swap, 16-byte stores
@@ -1101,22 +1169,22 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
         // 2 = P = hi + lo (two MFMAs per block: fp32-P accuracy, 1e-4, at 1.34x the time)
         static int p_mode = -1;
         if (p_mode < 0) p_mode = xm_switch("XLLM_MI355_PREFILL_P", kPfDefaultPMode);   // product switch, read once
-        XM_TUNE_VAR(m32_mode, "XLLM_MI355_PREFILL_M32", 0);   // 1: the 32x32x16 kernel (round 6, work in progress; tuning flavour A/B)
+        XM_TUNE_VAR(m32_mode, "XLLM_MI355_PREFILL_M32", 1);   // 0: the 16x16x32 kernel of rounds 1-5 (A/B in the tuning flavour: 293 vs 259 us)
         if (m32_mode && p_mode == 1)
-          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, true>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, true>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)), dim3(256), 0, s,
                              (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
                              (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
         else if (m32_mode)
-          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, false>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, false>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)), dim3(256), 0, s,
                              (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
                              (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
         else if (p_mode == 1)
-          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3((unsigned)(nq * batch * qblocks)),
+          hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)),
                              dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table,
                              (int)max_blocks, (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl,
                              (int)batch, qblocks);
         else
-        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false>), dim3((unsigned)(nq * batch * qblocks)), dim3(256), 0, s,
+        hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)), dim3(256), 0, s,
                            (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
                            (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch,
                            qblocks);
@@ -1146,6 +1214,11 @@ XM_INST_PREFILL(f16_t, 64, false)
 
 }  // namespace xm
 
+#ifdef PF32_TIMING
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_pf32(long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(xm::pf32_dbg), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef XM_ABL_PF_TIMING
 extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_pf(long long* out4) {
   return hipMemcpyFromSymbol(out4, HIP_SYMBOL(xm::pf_dbg), 12 * sizeof(long long)) == hipSuccess ? 0 : -1;
