@@ -1155,18 +1155,30 @@ def engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, steps, margs
     g = torch.Generator().manual_seed(4321)
     blocks = torch.randperm(n_blocks, generator=g)[: B * pages].view(B, pages).tolist()
     first = torch.randint(0, margs.vocab_size, (B,), generator=g).to(torch.int32).to(dev)
-    eng = engine.DecodeEngine(model, kv_caches, block_size, [ctx - 1] * B, blocks, first, ctx + warm + steps, 0.0)
-    for _ in range(warm):
-        eng.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.step()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    return {"ms_per_step": round(el / steps * 1e3, 4), "tokens_per_s": round(B * steps / el, 2), "steps": steps,
-            "what": "xllm_amd.engine.DecodeEngine: host batch builder + H2D + device metadata refresh + graph replay + "
-                    "argmax + D2H per step, sequences grow from ctx-1"}
+    def run(temperature, **kw):
+        eng = engine.DecodeEngine(model, kv_caches, block_size, [ctx - 1] * B, blocks, first, ctx + warm + steps, temperature, **kw)
+        for _ in range(warm):
+            eng.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    el = run(0.0)
+    out = {"ms_per_step": round(el / steps * 1e3, 4), "tokens_per_s": round(B * steps / el, 2), "steps": steps,
+           "what": "xllm_amd.engine.DecodeEngine: host batch builder + H2D + device metadata refresh + graph replay + "
+                   "argmax + D2H per step, sequences grow from ctx-1"}
+    try:   # the random path of Sampler::forward (sampler.cpp:100-137): temperature 0.8, top-k 50, top-p 0.9 on every row
+        el_r = run(0.8, top_k=50, top_p=0.9, seed=1)
+        out["random_sampling"] = {"ms_per_step": round(el_r / steps * 1e3, 4), "over_greedy": round(el_r / el - 1.0, 4),
+                                  "what": "the same steps with temperature 0.8 + top-k 50 + top-p 0.9 sampling: lm_head -> "
+                                          "apply_top_k_top_p in place on the 16-bit logits -> softmax + random_sample in one launch "
+                                          "(no fp32 copy of the logits, no [B, V] probabilities)"}
+    except Exception as e:  # noqa: BLE001
+        out["random_sampling"] = {"error": repr(e)}
+    return out
 
 
 def prefill_leg(model, margs, kv_caches, block_size, ctx, dev, world, tp_size, dp_size, sync_all):

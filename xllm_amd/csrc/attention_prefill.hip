@@ -799,7 +799,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
 //     tile j - 1]  then  [O += P(j-1) V(j-1) : 16 MFMAs  ||  the rest of the conversions, V / K fragment reads]: the MFMAs of
 //     one tile never wait for the softmax of the same tile;
 //   * staging, rings, swizzles, barrier protocol, masks, lazy rescale (2^8) and the single RNE-rounded 16-bit P (or hi + lo)
-//     are flash_prefill_dma_kernel's: the oracle's p_round = "flash" mode describes both.
+//     are flash_prefill_dma_kernel's: the checker's "flash" cast-point mode (64-key tiles, 2^8 threshold) describes both.
 typedef float pf32x16_t __attribute__((ext_vector_type(16)));
 #ifdef PF32_TIMING  /* timing build (tools/pf32_timing.py): shader cycles per phase of one wave, summed over its tiles */
 __device__ long long pf32_dbg[16];

@@ -103,6 +103,9 @@ struct LpShared {
   uint32_t prefix;
   unsigned long long carried;
   unsigned int remaining;
+  unsigned int ties;             // columns equal to the k-th key (counted by the first top-p sweep)
+  unsigned int kth_live;         // ... of which top-k keeps this many
+  unsigned long long target;     // p * Z in 2^-40 fixed point
 };
 
 // top-k / top-p for one row. rule: 0 = "one of them" (exclusive prefix), 1 = "both" (inclusive prefix, at least one); k <= 0 disables top-k under both
@@ -133,10 +136,42 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   }
   // (a division, not a reciprocal multiply: bit-equal to logits.div_(t))
   auto value = [&](int i) { const float x = lp_load(row, i); return scale ? r16<T>(x / temp) : x; };
+  // One sweep over the row, order-free: f(value) for every column. 16-byte loads (8 / 4 columns per thread and instruction; round
+  // 6: the sweeps were 2-byte loads, 150 per thread and sweep) when the row is 16-byte aligned, scalar head / tail otherwise.
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int v_lo = (int)((16 - ((uintptr_t)row & 15)) & 15) / (int)sizeof(T);      // columns before the first aligned one
+  const int v_head = v_lo < V ? v_lo : V;
+  const int v_n = (V - v_head) / VEC;                                               // whole vectors
+  auto sweep = [&](auto&& f) {
+    for (int i = tid; i < v_head; i += kLpThreads) f(value(i));
+    for (int k = tid; k < v_n; k += kLpThreads) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(row + v_head + k * VEC);
+      T e[VEC];
+      __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float x = to_f32<T>(e[j]);
+        f(scale ? r16<T>(x / temp) : x);
+      }
+    }
+    for (int i = v_head + v_n * VEC + tid; i < V; i += kLpThreads) f(value(i));
+  };
 
-  // ---- pass 0: row maximum
+  // ---- pass 0: row maximum -- found by the sweep of the first top-k digit when there is one (round 6: one sweep less)
+  long long k = top_k ? top_k[b] : 0;
+  if (rule == 1 && k > V) k = V;
+  const bool want_k = top_k && k > 0 && k < V;
   float mx = -__builtin_inff();
-  for (int i = tid; i < V; i += kLpThreads) mx = fmaxf(mx, value(i));
+  if (want_k) {
+    for (int i = tid; i < 256; i += kLpThreads) sh.cnt[i] = 0;
+    __syncthreads();
+    sweep([&](float x) {
+      mx = fmaxf(mx, x);
+      atomicAdd(&sh.cnt[(lp_key(x) >> 24) & 255u], 1u);
+    });
+  } else {
+    sweep([&](float x) { mx = fmaxf(mx, x); });
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if (lane == 0) sh.red[wave] = mx;
@@ -153,24 +188,23 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   // a row without a finite maximum (all -inf, all NaN) has no ranking and no probability mass (x - mx is NaN): it is left
   // unfiltered -- only the temperature is applied -- instead of running the selections on garbage (round-4 advisor)
   const bool degenerate = !(mx > -__builtin_inff());
-  long long k = top_k ? top_k[b] : 0;
-  if (rule == 1 && k > V) k = V;
-  const bool use_k = top_k && k > 0 && k < V && !degenerate;
+  const bool use_k = want_k && !degenerate;
   uint32_t kth_key = 0u;             // keep every key >= kth_key ...
   unsigned k_rem = 0xffffffffu;      // ... but of the ties at kth_key only the first k_rem by index
   if (use_k) {
     uint32_t prefix = 0u;
     unsigned remaining = (unsigned)k;
     for (int shift = 24; shift >= kLowShift; shift -= 8) {
-      // (the generic histogram with the temperature applied inline)
-      for (int i = tid; i < 256; i += kLpThreads) sh.cnt[i] = 0;
-      __syncthreads();
       const uint32_t hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-      for (int i = tid; i < V; i += kLpThreads) {
-        const uint32_t kk = lp_key(value(i));
-        if ((kk & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.cnt[(kk >> shift) & 255u], 1u);
+      if (shift != 24) {   // (the first digit's histogram was filled by the sweep that found the maximum)
+        for (int i = tid; i < 256; i += kLpThreads) sh.cnt[i] = 0;
+        __syncthreads();
+        sweep([&](float x) {
+          const uint32_t kk = lp_key(x);
+          if ((kk & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.cnt[(kk >> shift) & 255u], 1u);
+        });
+        __syncthreads();
       }
-      __syncthreads();
       if (tid == 0) {
         unsigned acc = 0;
         int bsel = 0;
@@ -195,45 +229,45 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   unsigned p_keep = 0xffffffffu;
   if (top_p && !degenerate) {
     const float p = top_p[b];
-    // Z = sum of the kept masses (the ties at kth_key count k_rem times)
-    unsigned long long z = 0ull;
-    unsigned kth_cnt = 0;
-    for (int i = tid; i < V; i += kLpThreads) {
-      const float x = value(i);
-      const uint32_t kk = lp_key(x);
-      if (kk > kth_key) z += lp_mass(x, mx);
-      else if (kk == kth_key) ++kth_cnt;
-    }
-    for (int i = tid; i < 256; i += kLpThreads) { sh.mass[i] = 0ull; sh.cnt[i] = 0; }
-    __syncthreads();
-    atomicAdd(&sh.mass[0], z);
-    atomicAdd(&sh.cnt[0], kth_cnt);
-    __syncthreads();
-    const unsigned kth_total = sh.cnt[0];
-    const unsigned kth_live = use_k ? (k_rem < kth_total ? k_rem : kth_total) : kth_total;
     const unsigned long long q_kth = lp_mass(lp_unkey(kth_key), mx);
-    const unsigned long long Z = sh.mass[0] + (unsigned long long)kth_live * q_kth;
-    __syncthreads();
-    // target = p * Z in fixed point (fp64: exact enough for 2^-40 granules); p >= 1 keeps everything, p < 0 keeps rank 0 only
-    const double tgt_d = (double)p * (double)Z;
-    const unsigned long long target = tgt_d <= 0.0 ? 0ull : (tgt_d >= 1.8e19 ? ~0ull : (unsigned long long)tgt_d);
+    unsigned long long target = 0ull;
     uint32_t prefix = 0u;
     unsigned long long carried = 0ull;   // mass of every kept key above the current prefix range
     for (int shift = 24; shift >= kLowShift; shift -= 8) {
+      const bool first = shift == 24;
       for (int i = tid; i < 256; i += kLpThreads) { sh.cnt[i] = 0; sh.mass[i] = 0ull; }
+      if (first && tid == 0) sh.ties = 0u;
       __syncthreads();
-      const uint32_t hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-      for (int i = tid; i < V; i += kLpThreads) {
-        const float x = value(i);
+      const uint32_t hi_mask = first ? 0u : (0xffffffffu << (shift + 8));
+      unsigned my_ties = 0;
+      sweep([&](float x) {
         const uint32_t kk = lp_key(x);
-        if ((kk & hi_mask) != (prefix & hi_mask) || kk < kth_key) continue;
+        if ((kk & hi_mask) != (prefix & hi_mask) || kk < kth_key) return;
         const unsigned bb = (kk >> shift) & 255u;
-        if (kk == kth_key && use_k) continue;              // the boundary ties are added once below, kth_live times
+        if (kk == kth_key && use_k) { ++my_ties; return; }   // the boundary ties are added once below, kth_live times
         atomicAdd(&sh.cnt[bb], 1u);
         atomicAdd(&sh.mass[bb], lp_mass(x, mx));
+      });
+      if (first && use_k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_ties += __shfl_xor(my_ties, o);
+        if (lane == 0 && my_ties) atomicAdd(&sh.ties, my_ties);
       }
       __syncthreads();
       if (tid == 0) {
+        if (first) {
+          // Z = sum of the kept masses = this sweep's bins + the boundary ties top-k keeps (round 6: the separate Z sweep is gone);
+          // target = p * Z in fixed point (fp64: exact enough for 2^-40 granules); p >= 1 keeps everything, p < 0 rank 0 only
+          const unsigned kth_total = sh.ties;
+          const unsigned live = use_k ? (k_rem < kth_total ? k_rem : kth_total) : 0u;
+          unsigned long long Z = (unsigned long long)live * q_kth;
+          for (int bb = 0; bb < 256; ++bb) Z += sh.mass[bb];
+          const double tgt_d = (double)p * (double)Z;
+          sh.target = tgt_d <= 0.0 ? 0ull : (tgt_d >= 1.8e19 ? ~0ull : (unsigned long long)tgt_d);
+          sh.kth_live = live;
+        }
+        const unsigned long long tgt = sh.target;
+        const unsigned kth_live = sh.kth_live;
         if (use_k && (kth_key & hi_mask) == (prefix & hi_mask)) {
           const unsigned bb = (kth_key >> shift) & 255u;
           sh.cnt[bb] += kth_live;
@@ -246,7 +280,7 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
         unsigned long long acc_sel = carried;
         for (int bb = 255; bb >= 0; --bb) {
           if (sh.cnt[bb] == 0) continue;
-          if (acc > target && bsel >= 0) break;
+          if (acc > tgt && bsel >= 0) break;
           bsel = bb;
           acc_sel = acc;
           acc += sh.mass[bb];
@@ -258,6 +292,7 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
       __syncthreads();
       prefix = sh.prefix;
       carried = sh.carried;
+      target = sh.target;
       __syncthreads();
     }
     p_key = lp_low(prefix);
@@ -277,11 +312,103 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
     if (p_keep == 0 && p_key == lp_key(mx)) p_keep = 1;
   }
 
-  // ---- ordered tie ranks. Each wave owns a contiguous segment of the row; lanes interleave inside it (coalesced loads). A tie's
-  // rank = ties in earlier waves + ties earlier in this wave (a ballot prefix per 64-column step).
+  // ---- ordered tie ranks + the final pass. Each wave owns a contiguous segment of the row. Rows that are 16-byte aligned with a
+  // whole number of 16-byte vectors (the model's vocabularies) take the vector form (round 6): a lane holds VEC consecutive columns
+  // per step, the index order inside a step is lane-major, so a tie's rank = ties of earlier waves + of earlier steps + of lower
+  // lanes (a wave scan, only in steps that hold a tie) + of its own earlier columns. Otherwise: one column per lane and step.
+  const bool need_k_rank = use_k, need_p_rank = top_p != nullptr;
+  const float ninf = -__builtin_inff();
+  if (v_head == 0 && v_n * VEC == V) {
+    constexpr int STEP = 64 * VEC;
+    const int seg = ((V + kLpWaves - 1) / kLpWaves + STEP - 1) / STEP * STEP;
+    const int s0 = wave * seg, s1 = s0 + seg < V ? s0 + seg : V;
+    auto load_keys = [&](int i0, float (&x)[VEC], uint32_t (&kk)[VEC]) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(row + i0);
+      T e[VEC];
+      __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float v = to_f32<T>(e[j]);
+        x[j] = scale ? r16<T>(v / temp) : v;
+        kk[j] = lp_key(x[j]);
+      }
+    };
+    unsigned c_k = 0, c_p = 0;
+    if (need_k_rank || need_p_rank) {
+      for (int base = s0; base < s1; base += STEP) {
+        const int i0 = base + lane * VEC;
+        if (i0 >= s1) continue;
+        float x[VEC];
+        uint32_t kk[VEC];
+        load_keys(i0, x, kk);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          c_k += (need_k_rank && kk[j] == kth_key) ? 1u : 0u;
+          c_p += (need_p_rank && kk[j] == p_key) ? 1u : 0u;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { c_k += __shfl_xor(c_k, o); c_p += __shfl_xor(c_p, o); }
+    }
+    if (lane == 0) { sh.wave_ties[0][wave] = c_k; sh.wave_ties[1][wave] = c_p; }
+    __syncthreads();
+    unsigned r_k = 0, r_p = 0;
+    for (int w = 0; w < wave; ++w) { r_k += sh.wave_ties[0][w]; r_p += sh.wave_ties[1][w]; }
+    for (int base = s0; base < s1; base += STEP) {
+      const int i0 = base + lane * VEC;
+      const bool in = i0 < s1;
+      float x[VEC];
+      uint32_t kk[VEC];
+      if (in) load_keys(i0, x, kk);
+      unsigned mk = 0, mp = 0;          // this lane's tie columns, one bit each
+      if (in) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          mk |= (need_k_rank && kk[j] == kth_key) ? (1u << j) : 0u;
+          mp |= (need_p_rank && kk[j] == p_key) ? (1u << j) : 0u;
+        }
+      }
+      unsigned ex_k = 0, ex_p = 0;      // ties in lower lanes of this step
+      if (__ballot(mk != 0 || mp != 0)) {   // (wave-uniform: most steps hold no boundary tie at all)
+        unsigned ik = __popc(mk), ip = __popc(mp);
+        const unsigned ck0 = ik, cp0 = ip;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned tk = __shfl_up(ik, o), tp = __shfl_up(ip, o);
+          if (lane >= o) { ik += tk; ip += tp; }
+        }
+        ex_k = ik - ck0;
+        ex_p = ip - cp0;
+        const unsigned tot_k = __shfl(ik, 63), tot_p = __shfl(ip, 63);
+        ex_k += r_k;
+        ex_p += r_p;
+        r_k += tot_k;
+        r_p += tot_p;
+      } else {
+        ex_k = r_k;
+        ex_p = r_p;
+      }
+      if (!in) continue;
+      T o[VEC];
+      bool dirty = scale;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        bool keep = true;
+        if (use_k) keep = kk[j] > kth_key || (kk[j] == kth_key && ex_k + __popc(mk & ((1u << j) - 1u)) < k_rem);
+        if (keep && top_p) keep = kk[j] > p_key || (kk[j] == p_key && ex_p + __popc(mp & ((1u << j) - 1u)) < p_keep);
+        o[j] = from_f32<T>(keep ? x[j] : ninf);
+        dirty = dirty || !keep;
+      }
+      if (dirty) {   // (an untouched vector is not rewritten)
+        uint4 raw;
+        __builtin_memcpy(&raw, o, 16);
+        *reinterpret_cast<uint4*>(row + i0) = raw;
+      }
+    }
+    return;
+  }
   const int seg = ((V + kLpWaves - 1) / kLpWaves + 63) / 64 * 64;
   const int s0 = wave * seg, s1 = s0 + seg < V ? s0 + seg : V;
-  const bool need_k_rank = use_k, need_p_rank = top_p != nullptr;
   unsigned c_k = 0, c_p = 0;
   for (int base = s0; base < s1; base += 64) {
     const int i = base + lane;
@@ -294,7 +421,6 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
   unsigned r_k = 0, r_p = 0;
   for (int w = 0; w < wave; ++w) { r_k += sh.wave_ties[0][w]; r_p += sh.wave_ties[1][w]; }
   // ---- final pass: temperature-scaled value or -inf
-  const float ninf = -__builtin_inff();
   for (int base = s0; base < s1; base += 64) {
     const int i = base + lane;
     const bool in = i < s1;
