@@ -932,6 +932,35 @@ def test_moe_group_gemm_w8a8(T, topk, E, K, N):
     assert torch.equal(fused, got)
 
 
+def test_moe_group_gemm_w8a8_beyond_the_inline_plan():
+    """more than 256 experts: the 8-phase kernels take their slots from the table group_plan_kernel builds (round 6: up to 256
+    experts every workgroup plans for itself, no plan launch) -- the same bits as the oracle's scaled_matmul per expert, with
+    empty experts, one-row experts and experts that straddle a 256-row tile"""
+    E, K, N = 300, 256, 256
+    g = torch.Generator().manual_seed(E)
+    sizes = torch.randint(40, 130, (E,), generator=g, dtype=torch.int32)
+    sizes[[0, 7, 150, 299]] = 0
+    sizes[[3, 200]] = 1
+    sizes[100] = 700
+    rows = int(sizes.sum())
+    xq = torch.randint(-127, 128, (rows, K), generator=g, dtype=torch.int8)
+    xs = torch.rand(rows, generator=g) * 0.02 + 0.001
+    wq = torch.randint(-127, 128, (E, N, K), generator=g, dtype=torch.int8)
+    ws = torch.rand(E, N, generator=g) * 0.02 + 0.001
+    got = ops.group_gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), sizes.to(DEV)).cpu()
+    off = 0
+    for e in range(E):
+        c = int(sizes[e])
+        if c and e in (1, 3, 99, 100, 101, 200, 298):      # sampled experts (the oracle's GEMM on every one of 300 is slow)
+            ref = orc.scaled_matmul(xq[off:off + c].contiguous(), wq[e], xs[off:off + c].contiguous(), ws[e], torch.bfloat16, None)
+            assert torch.equal(got[off:off + c], ref), e
+        off += c
+    # ... and against the inline plan on a sub-problem of the same data (the first 200 experts)
+    r200 = int(sizes[:200].sum())
+    sub = ops.group_gemm_w8a8(xq[:r200].to(DEV), xs[:r200].to(DEV), wq[:200].to(DEV), ws[:200].to(DEV), sizes[:200].to(DEV)).cpu()
+    assert torch.equal(sub, got[:r200])
+
+
 def test_fused_moe_layer_matches_dense_reference_and_unfused_operators():
     """FusedMoE.forward_experts (fused_moe.cpp:217-337): (a) fused expand / un-sort == the reference operator sequence,
     bit for bit; (b) == a dense per-token evaluation of the selected experts with the same rounding points

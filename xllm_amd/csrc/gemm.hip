@@ -1011,8 +1011,10 @@ static int group_gemm_impl(const void* a, const void* w, const int32_t* token_co
   if (p8_mode && scratch && scratch_bytes >= table_bytes + 64 && n_experts <= 1024 && max_rows >= 256 * 4 &&
       max_rows >= 64 * n_experts) {
     int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));
-    hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
     GemmEpi e2 = epi;
+    e2.group_inline = n_experts <= 256 ? 1 : 0;   // the workgroups plan for themselves (gemm_types.h: group_locate): no plan launch
+    if (!e2.group_inline)
+      hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
     e2.group_tiles = table;
     e2.gather_rows = gather_rows;
     e2.gather_div = (int)gather_div;
@@ -1056,8 +1058,10 @@ int xllm_mi355_group_gemm_w8a8(const int8_t* a, int64_t a_rows, const float* a_s
   if (!scratch || scratch_bytes < table_bytes + 64) return XM_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   int32_t* table = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(scratch) + ((scratch_bytes - table_bytes) & ~(size_t)15));
-  hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
   GemmEpi epi{a_scale, max_rows, w_scale, N, nullptr, out, nullptr, out_dtype == XM_BF16, token_count, (int)n_experts};
+  epi.group_inline = n_experts <= 256 ? 1 : 0;     // the workgroups plan for themselves (gemm_types.h: group_locate): no plan launch
+  if (!epi.group_inline)
+    hipLaunchKernelGGL(group_plan_kernel, dim3(1), dim3(1024), 0, s, token_count, (int)n_experts, 256, table, (int)slots);
   epi.group_tiles = table;
   epi.gather_rows = row_index;
   epi.gather_div = (int)index_div;

@@ -217,20 +217,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
   // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
   // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
   int mt, nt;
-  if (epi.group_tiles) {
-    // grouped (MoE) mode, round 6: the table's live m-tile slots are COMPACT at its front (experts in order, group_plan_kernel)
-    // and how many there are is known on the device only (the plan kernel leaves the count behind the last slot). The
-    // super-block walk below put them on whichever XCDs the first super-blocks belong to (cfg5: 32-40 live m tiles of 48 slots =
-    // two rounds of workgroups on XCDs 0 and 1, none on XCDs 4 and 5). Here the live (m slot, n tile) units, n tile fastest, are
-    // cut into eight equal contiguous ranges, one per XCD (block b runs on XCD b % 8): every XCD gets the same number of
-    // workgroups whatever the routing, the n tiles of an m slot -- one gathered activation panel -- and an expert's m slots --
-    // one weight panel -- stay neighbours on one XCD, and the surplus blocks of the worst-case grid exit at once.
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int live = __builtin_amdgcn_readfirstlane(epi.group_tiles[4 * m_tiles]) * n_tiles;
-    const int lo = (int)((int64_t)xcd * live / 8), hi = (int)((int64_t)(xcd + 1) * live / 8);
-    if (lo + j >= hi) return;
-    mt = (lo + j) / n_tiles;
-    nt = (lo + j) % n_tiles;
+  GroupSlot gslot{0, 0, 0, 0};
+  if (epi.group_tiles) {   // grouped (MoE) mode: balanced over the XCDs, slot from the plan table or inline (gemm_types.h)
+    if (!group_locate(epi, m_tiles, n_tiles, P8_BM, lane, mt, nt, gslot)) return;
   } else {
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
@@ -248,12 +237,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8_kernel(const uint8_t* _
     // grouped (MoE) mode, reference dcu::group_gemm (kernels/dcu/group_gemm.cpp:25-74): rows of A are sorted by expert,
     // expert e owns rows [off, off + cnt) and weight W[e]. m-tile slot mt -> (e, off, cnt, tile inside e) from the
     // table group_plan_kernel built on the DEVICE from the expert sizes (no host sync: graph-capturable)
-    const int4 gt = reinterpret_cast<const int4*>(epi.group_tiles)[mt];
-    const int ge = __builtin_amdgcn_readfirstlane(gt.x);
-    if (ge < 0) return;  // surplus slot (the grid is sized for the worst case)
-    const int goff = __builtin_amdgcn_readfirstlane(gt.y);
-    M = __builtin_amdgcn_readfirstlane(gt.z);
-    mt = __builtin_amdgcn_readfirstlane(gt.w);
+    const int ge = gslot.e, goff = gslot.off;
+    M = gslot.cnt;
+    mt = gslot.tile;
     if (!epi.gather_rows) A += (int64_t)goff * Kb;
     W += (int64_t)ge * N * Kb;
     epi.out = reinterpret_cast<uint8_t*>(epi.out) + (int64_t)goff * N * 2;

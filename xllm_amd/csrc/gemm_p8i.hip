@@ -257,20 +257,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
   // (2^lm m-tiles x 2^(5-lm) n-tiles = the 32 workgroups resident on its 32 CUs), so the operands of a super-block
   // are fetched into that XCD's L2 once and re-used 4-8 times while the K loops advance together.
   int mt, nt;
-  if (epi.group_tiles) {
-    // grouped (MoE) mode, round 6: the table's live m-tile slots are COMPACT at its front (experts in order, group_plan_kernel)
-    // and how many there are is known on the device only (the plan kernel leaves the count behind the last slot). The
-    // super-block walk below put them on whichever XCDs the first super-blocks belong to (cfg5: 32-40 live m tiles of 48 slots =
-    // two rounds of workgroups on XCDs 0 and 1, none on XCDs 4 and 5). Here the live (m slot, n tile) units, n tile fastest, are
-    // cut into eight equal contiguous ranges, one per XCD (block b runs on XCD b % 8): every XCD gets the same number of
-    // workgroups whatever the routing, the n tiles of an m slot -- one gathered activation panel -- and an expert's m slots --
-    // one weight panel -- stay neighbours on one XCD, and the surplus blocks of the worst-case grid exit at once.
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int live = __builtin_amdgcn_readfirstlane(epi.group_tiles[4 * m_tiles]) * n_tiles;
-    const int lo = (int)((int64_t)xcd * live / 8), hi = (int)((int64_t)(xcd + 1) * live / 8);
-    if (lo + j >= hi) return;
-    mt = (lo + j) / n_tiles;
-    nt = (lo + j) % n_tiles;
+  GroupSlot gslot{0, 0, 0, 0};
+  if (epi.group_tiles) {   // grouped (MoE) mode: balanced over the XCDs, slot from the plan table or inline (gemm_types.h)
+    if (!group_locate(epi, m_tiles, n_tiles, P8_BM, lane, mt, nt, gslot)) return;
   } else {
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
@@ -287,12 +276,9 @@ __global__ __launch_bounds__(P8_THREADS, 1) void gemm_p8i_kernel(const uint8_t* 
     // grouped (MoE) W8A8: see gemm_p8_kernel. Expert e owns sorted rows [off, off + cnt), weight W[e] and the weight
     // scales w_scale[e * N ..]; the per-token activation scales follow the rows (a_scale[off + m], or -- with the
     // expand fused in -- a_scale[gather_rows[off + m] / gather_div] of the un-expanded activations)
-    const int4 gt = reinterpret_cast<const int4*>(epi.group_tiles)[mt];
-    const int ge = __builtin_amdgcn_readfirstlane(gt.x);
-    if (ge < 0) return;  // surplus slot (the grid is sized for the worst case)
-    const int goff = __builtin_amdgcn_readfirstlane(gt.y);
-    M = __builtin_amdgcn_readfirstlane(gt.z);
-    mt = __builtin_amdgcn_readfirstlane(gt.w);
+    const int ge = gslot.e, goff = gslot.off;
+    M = gslot.cnt;
+    mt = gslot.tile;
     if (epi.gather_rows) epi.gather_rows += goff;  // row r of the expert -> source row gather_rows[r] / gather_div
     else { A += (int64_t)goff * Kb; epi.a_scale += goff; }
     W += (int64_t)ge * N * Kb;

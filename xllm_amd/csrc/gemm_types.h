@@ -106,6 +106,9 @@ struct GemmEpi {
   // then a 16-bit add, i.e. bit-identical to scaled_matmul followed by the residual add of fused_add_rms_norm. May alias `out`
   // (every element is read by the lane that then writes it). 8-phase int8 kernel only.
   const void* addend;
+  // round 6: grouped GEMM on the 256x256 kernels WITHOUT the plan launch -- every workgroup derives its slot from group_counts
+  // itself (group_locate below; n_groups <= 256). group_tiles still points at valid scratch (unused) so the mode checks stay one test.
+  int group_inline;
 };
 
 // torch.argmax order: NaN above every number, the first index among equals
@@ -113,6 +116,78 @@ __device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) 
   const bool vn = v != v, bn = bv != bv;
   if (vn || bn) return vn && (!bn || i < bi);
   return v > bv || (v == bv && i < bi);
+}
+
+// ---- grouped (MoE) mode of the 256x256 8-phase kernels: which (m-tile slot, n tile) a block owns, and the slot's expert.
+// The live m-tile slots are COMPACT (experts in order, ceil(rows / bm) slots each) and how many there are is known on the device
+// only. The live (m slot, n tile) units, n tile fastest, are cut into eight equal contiguous ranges, one per XCD (block b runs on
+// XCD b % 8): every XCD gets the same number of workgroups whatever the routing, the n tiles of an m slot -- one gathered
+// activation panel -- and an expert's m slots -- one weight panel -- stay neighbours on one XCD, and the surplus blocks of the
+// worst-case grid exit at once (round 6; before, the super-block walk put cfg5's 32-40 live m tiles of 48 slots on XCDs 0-3 and
+// 6-7 in two rounds). Slot lookup: from the table group_plan_kernel built, or -- group_inline, n_groups <= 256 -- straight from
+// the expert sizes: every wave redundantly scans them in registers (4 experts per lane, one wave scan), no plan launch.
+struct GroupSlot { int e, off, cnt, tile; };
+__device__ __forceinline__ bool group_locate(const GemmEpi& epi, int m_slots, int n_tiles, int bm, int lane, int& mt, int& nt,
+                                             GroupSlot& gs) {
+  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  int used;
+  int ct = 0, cr = 0, it = 0, ir = 0;      // inline: this lane's tiles / rows, inclusive scans over the lanes
+  int c4[4] = {0, 0, 0, 0};
+  if (epi.group_inline) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane * 4 + q;
+      c4[q] = e < epi.n_groups ? epi.group_counts[e] : 0;
+      c4[q] = c4[q] > 0 ? c4[q] : 0;
+      ct += (c4[q] + bm - 1) / bm;
+      cr += c4[q];
+    }
+    it = ct;
+    ir = cr;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int tt = __shfl_up(it, o), tr = __shfl_up(ir, o);
+      if (lane >= o) { it += tt; ir += tr; }
+    }
+    used = __shfl(it, 63);
+    used = used < m_slots ? used : m_slots;
+  } else {
+    used = epi.group_tiles[4 * m_slots];
+  }
+  used = __builtin_amdgcn_readfirstlane(used);
+  const int live = used * n_tiles;
+  const int lo = (int)((int64_t)xcd * live / 8), hi = (int)((int64_t)(xcd + 1) * live / 8);
+  if (lo + j >= hi) return false;
+  mt = (lo + j) / n_tiles;
+  nt = (lo + j) % n_tiles;
+  if (epi.group_inline) {
+    const int ex_t = it - ct;                 // slots before this lane's experts
+    const bool mine = mt >= ex_t && mt < it;
+    const int owner = __builtin_ctzll(__ballot(mine));   // (mt < used: exactly one lane owns it)
+    int e = 0, off = ir - cr, cnt = 0, tile = 0;
+    if (mine) {
+      int s = ex_t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int tq = (c4[q] + bm - 1) / bm;
+        if (mt >= s && mt < s + tq) { e = lane * 4 + q; cnt = c4[q]; tile = mt - s; break; }
+        s += tq;
+        off += c4[q];
+      }
+    }
+    gs.e = __shfl(e, owner);
+    gs.off = __shfl(off, owner);
+    gs.cnt = __shfl(cnt, owner);
+    gs.tile = __shfl(tile, owner);
+  } else {
+    const int4 gt = reinterpret_cast<const int4*>(epi.group_tiles)[mt];
+    gs.e = gt.x; gs.off = gt.y; gs.cnt = gt.z; gs.tile = gt.w;
+  }
+  gs.e = __builtin_amdgcn_readfirstlane(gs.e);
+  gs.off = __builtin_amdgcn_readfirstlane(gs.off);
+  gs.cnt = __builtin_amdgcn_readfirstlane(gs.cnt);
+  gs.tile = __builtin_amdgcn_readfirstlane(gs.tile);
+  return gs.e >= 0;
 }
 
 // Epilogue modes a launcher can honour. Every launcher starts with epi_fits(epi, its capabilities): a mode the selected kernel
