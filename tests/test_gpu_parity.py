@@ -625,6 +625,13 @@ PREFILL_CASES = [
     (16, 8, 128, [128, 128]),
     (14, 2, 64, [77, 200]),
     (4, 4, 128, [513]),
+    # round 6, the block -> XCD mapping of the head-dim-128 kernels (pf_block_coords): P = sequences x kv heads pairs dealt over 8 XCDs
+    (8, 1, 128, [200, 130, 64]),      # P = 3: no even deal, the plain order
+    (6, 2, 128, [150, 90, 300]),      # P = 6: the same
+    (7, 1, 128, [260]),               # P = 1: the pair's blocks dealt over all 8 XCDs
+    (8, 2, 128, [100]),               # P = 2: over 4 XCDs each
+    (12, 4, 128, [40, 70]),           # P = 8: one pair per XCD
+    (4, 2, 128, [33, 65, 129, 257, 64]),   # P = 10: two pairs on XCDs 0 and 1, one elsewhere
 ]
 
 
@@ -901,7 +908,8 @@ def test_moe_group_gemm_tile_table_path(T, topk, E, K, N):
     assert fused is not None or T * topk < max(1024, 64 * E) or os.environ.get("XLLM_MI355_GROUP_P8") == "0"
 
 
-@pytest.mark.parametrize("T,topk,E,K,N", [(1024, 8, 128, 2048, 1536), (700, 4, 16, 768, 2048), (1200, 2, 5, 256, 520)])
+@pytest.mark.parametrize("T,topk,E,K,N", [(1024, 8, 128, 2048, 1536), (700, 4, 16, 768, 2048), (1200, 2, 5, 256, 520),
+                                          (900, 2, 256, 256, 256), (300, 1, 1, 512, 264)])
 def test_moe_group_gemm_w8a8(T, topk, E, K, N):
     """W8A8 grouped GEMM on the int8 8-phase kernel == the oracle's scaled_matmul per expert, bit for bit (exact int32 sums,
     same fp32 dequant expression); the gather form (each token quantised once, expanded inside the A staging) == the
