@@ -12,7 +12,8 @@ from xllm_amd import ops  # noqa: E402
 dev = "cuda"
 B, V = int(os.environ.get("SB_B", "256")), int(os.environ.get("SB_V", "152064"))
 torch.manual_seed(0)
-logits16 = (torch.randn(B, V, device=dev) * 3.0).bfloat16()
+STD = float(os.environ.get("SB_STD", "3.0"))   # 0.5: the narrow logits of a random-init model (almost every column in two exponent bins)
+logits16 = (torch.randn(B, V, device=dev) * STD).bfloat16()
 temps = torch.full((B,), 0.8, device=dev)
 top_k = torch.full((B,), 50, dtype=torch.int64, device=dev)
 top_p = torch.full((B,), 0.9, device=dev)
@@ -31,7 +32,7 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-print(f"[sampler] B={B} V={V}")
+print(f"[sampler] B={B} V={V} std={STD}")
 print(f"[sampler] float():            {timeit(lambda: logits16.float()):8.1f} us")
 l32 = logits16.float()
 for name, k, p in (("top_k only", top_k, None), ("top_p only", None, top_p), ("both", top_k, top_p), ("temperature only", None, None)):

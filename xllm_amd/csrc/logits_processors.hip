@@ -94,9 +94,15 @@ __device__ __forceinline__ unsigned long long lp_mass(float x, float mx) {
   return e == e ? (unsigned long long)e : 0ull;
 }
 
+// The histograms are filled through kLpRep lane-salted replicas (round 6): most logits of a row share a handful of exponent bins, so
+// the 64 lanes of an atomic instruction hit ONE counter and serialise (measured: the first digit's sweep dominated the kernel on
+// model-like logits); with bin * 16 + (lane & 15) at most four lanes share an address. The replicas are summed before the scan.
+constexpr int kLpRep = 16;
 struct LpShared {
   unsigned int cnt[256];
   unsigned long long mass[256];
+  unsigned int cnt_r[256 * kLpRep];
+  unsigned long long mass_r[256 * kLpRep];
   unsigned int wave_ties[2][kLpWaves];
   float red[kLpWaves];
   // broadcast slots
@@ -157,17 +163,34 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
     for (int i = v_head + v_n * VEC + tid; i < V; i += kLpThreads) f(value(i));
   };
 
+  const unsigned salt = (unsigned)lane & (kLpRep - 1);
+  auto fold_cnt = [&]() {    // replicas -> sh.cnt (every thread of the block calls it, between two barriers)
+    for (int bb = tid; bb < 256; bb += kLpThreads) {
+      unsigned c = 0;
+#pragma unroll
+      for (int r = 0; r < kLpRep; ++r) c += sh.cnt_r[bb * kLpRep + r];
+      sh.cnt[bb] = c;
+    }
+  };
+  auto fold_mass = [&]() {
+    for (int bb = tid; bb < 256; bb += kLpThreads) {
+      unsigned long long m = 0ull;
+#pragma unroll
+      for (int r = 0; r < kLpRep; ++r) m += sh.mass_r[bb * kLpRep + r];
+      sh.mass[bb] = m;
+    }
+  };
   // ---- pass 0: row maximum -- found by the sweep of the first top-k digit when there is one (round 6: one sweep less)
   long long k = top_k ? top_k[b] : 0;
   if (rule == 1 && k > V) k = V;
   const bool want_k = top_k && k > 0 && k < V;
   float mx = -__builtin_inff();
   if (want_k) {
-    for (int i = tid; i < 256; i += kLpThreads) sh.cnt[i] = 0;
+    for (int i = tid; i < 256 * kLpRep; i += kLpThreads) sh.cnt_r[i] = 0;
     __syncthreads();
     sweep([&](float x) {
       mx = fmaxf(mx, x);
-      atomicAdd(&sh.cnt[(lp_key(x) >> 24) & 255u], 1u);
+      atomicAdd(&sh.cnt_r[((lp_key(x) >> 24) & 255u) * kLpRep + salt], 1u);
     });
   } else {
     sweep([&](float x) { mx = fmaxf(mx, x); });
@@ -197,14 +220,16 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
     for (int shift = 24; shift >= kLowShift; shift -= 8) {
       const uint32_t hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
       if (shift != 24) {   // (the first digit's histogram was filled by the sweep that found the maximum)
-        for (int i = tid; i < 256; i += kLpThreads) sh.cnt[i] = 0;
+        for (int i = tid; i < 256 * kLpRep; i += kLpThreads) sh.cnt_r[i] = 0;
         __syncthreads();
         sweep([&](float x) {
           const uint32_t kk = lp_key(x);
-          if ((kk & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.cnt[(kk >> shift) & 255u], 1u);
+          if ((kk & hi_mask) == (prefix & hi_mask)) atomicAdd(&sh.cnt_r[((kk >> shift) & 255u) * kLpRep + salt], 1u);
         });
         __syncthreads();
       }
+      fold_cnt();
+      __syncthreads();
       if (tid == 0) {
         unsigned acc = 0;
         int bsel = 0;
@@ -235,7 +260,7 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
     unsigned long long carried = 0ull;   // mass of every kept key above the current prefix range
     for (int shift = 24; shift >= kLowShift; shift -= 8) {
       const bool first = shift == 24;
-      for (int i = tid; i < 256; i += kLpThreads) { sh.cnt[i] = 0; sh.mass[i] = 0ull; }
+      for (int i = tid; i < 256 * kLpRep; i += kLpThreads) { sh.cnt_r[i] = 0; sh.mass_r[i] = 0ull; }
       if (first && tid == 0) sh.ties = 0u;
       __syncthreads();
       const uint32_t hi_mask = first ? 0u : (0xffffffffu << (shift + 8));
@@ -245,14 +270,17 @@ __global__ __launch_bounds__(kLpThreads) void top_k_top_p_kernel(T* __restrict__
         if ((kk & hi_mask) != (prefix & hi_mask) || kk < kth_key) return;
         const unsigned bb = (kk >> shift) & 255u;
         if (kk == kth_key && use_k) { ++my_ties; return; }   // the boundary ties are added once below, kth_live times
-        atomicAdd(&sh.cnt[bb], 1u);
-        atomicAdd(&sh.mass[bb], lp_mass(x, mx));
+        atomicAdd(&sh.cnt_r[bb * kLpRep + salt], 1u);
+        atomicAdd(&sh.mass_r[bb * kLpRep + salt], lp_mass(x, mx));
       });
       if (first && use_k) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) my_ties += __shfl_xor(my_ties, o);
         if (lane == 0 && my_ties) atomicAdd(&sh.ties, my_ties);
       }
+      __syncthreads();
+      fold_cnt();
+      fold_mass();
       __syncthreads();
       if (tid == 0) {
         if (first) {
