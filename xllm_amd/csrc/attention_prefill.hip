@@ -521,14 +521,20 @@ __device__ __forceinline__ void pf2_softmax(pf32x4_t (&s)[2][4], typename PfTrai
 // ---- block -> (q head, sequence, q block) of the LDS-DMA flash kernels, XCD-aware (round 6). Block b runs on XCD b % 8 (observed,
 // relied on for speed only). The K / V stream of one (sequence, kv head) pair is shared by the G q heads of its group and by every
 // q block: with the heads as the fastest block index the seven heads of a group sat on seven DIFFERENT XCDs and each XCD's L2
-// fetched the same tiles again (1.8 GB of L2 fills per 2 x 4096-token launch for 16 MB of K / V). Here a pair is pinned to one XCD
+// fetched the same tiles again (587 MB of fabric reads per 2 x 4096-token launch by PMC against 91 MB pinned; Q + K + V are 75 MB). Here a pair is pinned to one XCD
 // (P = n_seqs * nkv pairs dealt round robin over the 8 XCDs; P < 8 dividing 8: 8 / P XCDs share a pair's blocks), and inside an
 // XCD the order stays "q block slowest and descending (heaviest causal blocks first), then pair, then head". Returns false for
 // the padding blocks of the rounded-up grid.
-__device__ __forceinline__ bool pf_block_coords(int nq, int nkv, int n_seqs, int n_qblocks, int& h, int& b, int& qb) {
+__device__ __forceinline__ bool pf_block_coords(int nq, int nkv, int n_seqs, int n_qblocks, int& h, int& b, int& qb, int plain = 0) {
   const int G = nq / nkv, P = n_seqs * nkv;
   const int bx = blockIdx.x, x = bx & 7, j = bx >> 3;
   int pair, g, qbi;
+  if (plain) {                                       // tuning arm (XLLM_MI355_PREFILL_XCD=0): the round-5 order, heads fastest
+    h = bx % nq;
+    b = (bx / nq) % n_seqs;
+    qb = n_qblocks - 1 - bx / (nq * n_seqs);
+    return qb >= 0;
+  }
   if (P >= 8) {
     const int pairs_x = (P - x + 7) / 8;            // pairs x, x + 8, ... live on this XCD
     if (pairs_x <= 0) return false;
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, const int32_t* __restrict__ kv_lens,
     const int32_t* __restrict__ block_table, int max_blocks, int nq, int nkv, int block_size, int64_t q_stride,
-    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left, int n_seqs, int n_qblocks) {
+    int64_t k_stride, int64_t v_stride, float scale_log2, int causal, int window_left, int n_seqs, int n_qblocks, int plain_map) {
   using TR = PfTraits<T>;
   using x8 = typename TR::x8;
   constexpr int D = 128, ROWB = kPf2RowB, TILEB = kPf2TileB, QB = 128, NDMA = 4;
@@ -974,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q32 = lane & 31, hi = lane >> 5;
   int h, b, qb;
-  if (!pf_block_coords(nq, nkv, n_seqs, n_qblocks, h, b, qb)) return;
+  if (!pf_block_coords(nq, nkv, n_seqs, n_qblocks, h, b, qb, plain_map)) return;
   const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
   const int q0 = qb * QB;
   if (q0 >= q_len) return;
@@ -1169,15 +1175,18 @@ int launch_flash_prefill(const void* q, const void* k, const void* v, void* out,
         // 2 = P = hi + lo (two MFMAs per block: fp32-P accuracy, 1e-4, at 1.34x the time)
         static int p_mode = -1;
         if (p_mode < 0) p_mode = xm_switch("XLLM_MI355_PREFILL_P", kPfDefaultPMode);   // product switch, read once
+        XM_TUNE_VAR(xcd_map, "XLLM_MI355_PREFILL_XCD", 1);    // 0: heads the fastest block index (round-5 order; A/B + PMC in the tuning flavour)
+        const int plain_map = xcd_map ? 0 : 1;
+        const dim3 grid32(plain_map ? (unsigned)(nq * batch * qblocks) : pf_grid_blocks(nq, nkv, batch, qblocks));
         XM_TUNE_VAR(m32_mode, "XLLM_MI355_PREFILL_M32", 1);   // 0: the 16x16x32 kernel of rounds 1-5 (A/B in the tuning flavour: 293 vs 259 us)
         if (m32_mode && p_mode == 1)
-          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, true>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)), dim3(256), 0, s,
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, true>), grid32, dim3(256), 0, s,
                              (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
-                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
+                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks, plain_map);
         else if (m32_mode)
-          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, false>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)), dim3(256), 0, s,
+          hipLaunchKernelGGL((flash_prefill_m32_kernel<T, PAGED, false>), grid32, dim3(256), 0, s,
                              (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table, (int)max_blocks,
-                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks);
+                             (int)nq, (int)nkv, (int)block_size, q_stride, k_stride, v_stride, sl2, causal, wl, (int)batch, qblocks, plain_map);
         else if (p_mode == 1)
           hipLaunchKernelGGL((flash_prefill_dma_kernel<T, PAGED, 4, false, true>), dim3(pf_grid_blocks(nq, nkv, batch, qblocks)),
                              dim3(256), 0, s, (const T*)q, (const T*)k, (const T*)v, (T*)out, cu_q, cu_k, kv_lens, block_table,
