@@ -651,6 +651,28 @@ def test_prefill_attention(nq, nkv, d, lens):
     assert_prefill_close(out, q, k, v, cu, scale)
 
 
+def test_prefill_attention_f16():
+    """the f16 instantiation of the head-dim-128 flash kernel (v_mfma_f32_32x32x16_f16; one RNE-rounded f16 P per score): against the
+    fp32-P oracle computed from the same f16 inputs -- f16 carries 3 more mantissa bits than bf16, so the single-P result sits
+    well inside 1e-3"""
+    nq, nkv, d, lens = 8, 2, 128, [190, 77]
+    g = torch.Generator().manual_seed(7)
+    T = sum(lens)
+    qkv = torch.randn(T, (nq + 2 * nkv) * d, generator=g).half()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    q = qkv[:, :nq * d].unflatten(-1, (nq, d))
+    k = qkv[:, nq * d:(nq + nkv) * d].unflatten(-1, (nkv, d))
+    v = qkv[:, (nq + nkv) * d:].unflatten(-1, (nkv, d))
+    scale = d ** -0.5
+    qd = qkv.to(DEV)
+    out = ops.prefill_attention(qd[:, :nq * d].unflatten(-1, (nq, d)), qd[:, nq * d:(nq + nkv) * d].unflatten(-1, (nkv, d)),
+                                qd[:, (nq + nkv) * d:].unflatten(-1, (nkv, d)), cu.to(DEV), cu.to(DEV), max(lens), scale)
+    ref = orc.attention_varlen(q, k, v, cu, cu, scale, causal=True)
+    assert out.dtype == torch.float16 and torch.isfinite(out.float()).all()
+    err = ((out.float().cpu() - ref.float()).norm() / ref.float().norm()).item()
+    assert err <= 1e-3, err
+
+
 @pytest.mark.parametrize("bs", [128, 16])
 def test_chunked_prefill_bottom_right_causal(bs):
     B, nq, nkv, d = 3, 14, 2, 128
