@@ -1172,8 +1172,8 @@ def test_decode_int8_fusion_on_split_plans_equals_the_two_operators(B, S, nq, nk
     ref = ops.paged_attention(qd, kcd, vcd, None, kv_d, bt, 1, max(kv_lens), 128 ** -0.5)
     rq, rs = ops.scaled_quantize(ref)
     r = ops.paged_decode_attention_int8(qd, kcd, vcd, kv_d, bt, max(kv_lens), 128 ** -0.5, want_16bit=True)
-    if os.environ.get("XLLM_MI355_ATTN_FINISH", "0") != "1":
-        assert r is None or torch.equal(r[0], rq)        # default: decline, the caller runs the two operators
+    if os.environ.get("XLLM_MI355_ATTN_FINISH", "1") != "1":
+        assert r is None or torch.equal(r[0], rq)        # switched off: decline, the caller runs the two operators
         return
     assert r is not None or not must_fuse
     if r is None:

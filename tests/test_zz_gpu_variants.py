@@ -72,9 +72,9 @@ def test_group_gemm_parity_on_the_fallback_kernel():
 
 
 @pytest.mark.parametrize("env", [
-    {"XLLM_MI355_ATTN_FINISH": "1"},                         # split-KV partials merged + quantised in one finishing launch
+    {"XLLM_MI355_ATTN_FINISH": "0"},                         # split-KV partials: merge launch + scaled_quantize instead of ONE finishing launch
     {"XLLM_MI355_QKV_ROPE": "0"},                            # qkv projection, RoPE and KV write as separate operators
-], ids=["attn_finish_int8", "qkv_rope_unfused"])
+], ids=["attn_finish_off", "qkv_rope_unfused"])
 def test_decode_fusion_switches(env):
     e = dict(os.environ)
     e.update(env)

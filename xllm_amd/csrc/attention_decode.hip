@@ -461,51 +461,98 @@ __global__ void paged_decode_merge_kernel(const float* __restrict__ part_o, cons
 // merge + per-token int8 quantisation in one launch (N1 fusion for the plans whose workgroups do not hold a whole token:
 // fewer than all kv heads per workgroup, or grid-level split-KV): one workgroup per token merges the nsplit partials of all
 // nq heads exactly like paged_decode_merge_kernel, rounds to T, and quantises the row like scaled_quantize -- the bits of
-// paged_attention followed by scaled_quantize, one launch and one 16-bit round trip less
-template <typename T, int D, int VPT>
-__global__ __launch_bounds__(256) void paged_decode_finish_int8_kernel(const float* __restrict__ part_o,
+// paged_attention followed by scaled_quantize, one launch and one 16-bit round trip less.
+// NSP > 0 (round 6): at most NSP splits, and EVERY load of the launch -- the (m, l) pairs and all partial rows -- is requested
+// before anything is consumed: the launch is one memory latency deep instead of 1 + nsplit (the round-2 form, NSP = 0, waited
+// for the (m, l) pairs, then for each split's rows in turn: 12.7 us against 4.9 + 4.8 for the two launches it replaces)
+template <typename T, int D, int VPT, int NSP, int NT>
+__global__ __launch_bounds__(NT) void paged_decode_finish_int8_kernel(const float* __restrict__ part_o,
                                                                        const float* __restrict__ part_ml, T* __restrict__ out,
                                                                        int8_t* __restrict__ out_q, float* __restrict__ out_scale,
                                                                        int nq, int nsplit) {
-  constexpr int kMaxHeads = 32, kMaxSplit = 32;     // nq <= 32 (VPT * 256 / D), nsplit <= 32 (decode_num_splits)
+  constexpr int kMaxHeads = 32, kMaxSplit = 32;     // nq <= 32 (VPT * NT / D), nsplit <= 32 (decode_num_splits)
   __shared__ float red[32];
   __shared__ float fs[kMaxHeads][kMaxSplit];        // exp2(m_s - m*) per (head, split)
   __shared__ float ls[kMaxHeads];                   // merged denominators
   const int b = blockIdx.x;
   const int n = nq * D;
-  // phase A: one thread per head turns the (m, l) pairs into the split weights -- ONE dependent load level for everybody after
-  if ((int)threadIdx.x < nq) {
-    const int head = threadIdx.x;
-    const int64_t base = ((int64_t)b * nq + head) * nsplit;
-    float m_star = kNegBig;
-    for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
-    float l = 0.0f;
-    for (int s = 0; s < nsplit; ++s) {
-      const float f = exp2f(part_ml[(base + s) * 2] - m_star);
-      fs[head][s] = f;
-      l += f * part_ml[(base + s) * 2 + 1];
-    }
-    ls[head] = l;
-  }
-  __syncthreads();
-  // phase B: o = sum_s f_s * o_s in split order (the merge kernel's order), all of a thread's elements per split at once
   float v[VPT];
+  if constexpr (NSP > 0) {
+    float po[NSP][VPT];
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) v[i] = 0.0f;
-  for (int s = 0; s < nsplit; ++s) {
+    for (int s = 0; s < NSP; ++s)
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const int e = threadIdx.x + i * 256;
-      if (e < n) {
-        const int head = e / D, d = e % D;
-        v[i] += fs[head][s] * part_o[(((int64_t)b * nq + head) * nsplit + s) * D + d];
+      for (int i = 0; i < VPT; ++i) {
+        const int e = threadIdx.x + i * NT;
+        po[s][i] = (s < nsplit && e < n) ? part_o[(((int64_t)b * nq + e / D) * nsplit + s) * D + e % D] : 0.0f;
+      }
+    if ((int)threadIdx.x < nq) {
+      const int head = threadIdx.x;
+      const int64_t base = ((int64_t)b * nq + head) * nsplit;
+      float2 ml[NSP];
+#pragma unroll
+      for (int s = 0; s < NSP; ++s)
+        ml[s] = s < nsplit ? *reinterpret_cast<const float2*>(part_ml + (base + s) * 2) : make_float2(kNegBig, 0.0f);
+      float m_star = kNegBig;
+#pragma unroll
+      for (int s = 0; s < NSP; ++s)
+        if (s < nsplit) m_star = fmaxf(m_star, ml[s].x);
+      float l = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NSP; ++s)
+        if (s < nsplit) {
+          const float f = exp2f(ml[s].x - m_star);
+          fs[head][s] = f;
+          l += f * ml[s].y;
+        }
+      ls[head] = l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) v[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NSP; ++s)
+      if (s < nsplit) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+          const int e = threadIdx.x + i * NT;
+          if (e < n) v[i] += fs[e / D][s] * po[s][i];
+        }
+      }
+  } else {
+    // phase A: one thread per head turns the (m, l) pairs into the split weights
+    if ((int)threadIdx.x < nq) {
+      const int head = threadIdx.x;
+      const int64_t base = ((int64_t)b * nq + head) * nsplit;
+      float m_star = kNegBig;
+      for (int s = 0; s < nsplit; ++s) m_star = fmaxf(m_star, part_ml[(base + s) * 2]);
+      float l = 0.0f;
+      for (int s = 0; s < nsplit; ++s) {
+        const float f = exp2f(part_ml[(base + s) * 2] - m_star);
+        fs[head][s] = f;
+        l += f * part_ml[(base + s) * 2 + 1];
+      }
+      ls[head] = l;
+    }
+    __syncthreads();
+    // phase B: o = sum_s f_s * o_s in split order (the merge kernel's order), all of a thread's elements per split at once
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) v[i] = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+      for (int i = 0; i < VPT; ++i) {
+        const int e = threadIdx.x + i * NT;
+        if (e < n) {
+          const int head = e / D, d = e % D;
+          v[i] += fs[head][s] * part_o[(((int64_t)b * nq + head) * nsplit + s) * D + d];
+        }
       }
     }
   }
   float amax = 0.0f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int e = threadIdx.x + i * 256;
+    const int e = threadIdx.x + i * NT;
     if (e < n) {
       const float l = ls[e / D];
       v[i] = r16<T>(l > 0.0f ? v[i] / l : 0.0f);
@@ -517,7 +564,7 @@ __global__ __launch_bounds__(256) void paged_decode_finish_int8_kernel(const flo
   const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int e = threadIdx.x + i * 256;
+    const int e = threadIdx.x + i * NT;
     if (e < n) out_q[(int64_t)b * n + e] = (int8_t)fmaxf(-127.0f, fminf(127.0f, rintf(v[i] * qinv)));
   }
   if (threadIdx.x == 0) out_scale[b] = amax / 127.0f;
@@ -545,7 +592,7 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
   // finishing launch would only replace scaled_quantize by a launch of the same cost -- measured -- so they are declined)
   if (out_q && nsplit == 1 && nkv / hpw != 1) return XM_ERR_UNSUPPORTED;
   const bool finish = out_q && nsplit != 1;
-  if (finish && (ws_bytes < (size_t)nsplit * per_split || nq * D > 256 * 16 || nq > 32 || cu_q)) return XM_ERR_UNSUPPORTED;
+  if (finish && (ws_bytes < (size_t)nsplit * per_split || nq * D > 1024 * 4 || nq > 32 || cu_q)) return XM_ERR_UNSUPPORTED;
   // degrade the split count to what the caller's workspace holds (1 split needs none)
   if ((size_t)nsplit * per_split > ws_bytes) nsplit = (int)(ws_bytes / per_split);
   if (nsplit < 1) nsplit = 1;
@@ -579,13 +626,20 @@ int launch_paged_decode(const void* q, const void* kc, const void* vc, void* out
 #undef XM_DECODE_LAUNCH
   if (finish) {
     const int vpt = (int)((nq * D + 255) / 256);
-#define XM_FINISH(V_)                                                                                                   \
-  hipLaunchKernelGGL((paged_decode_finish_int8_kernel<T, D, V_>), dim3((unsigned)batch), dim3(256), 0, s, part_o, part_ml, \
-                     (T*)out, out_q, out_scale, (int)nq, nsplit)
-    if (vpt <= 4) XM_FINISH(4);
-    else if (vpt <= 8) XM_FINISH(8);
-    else XM_FINISH(16);
+#define XM_FINISH_(V_, N_, T_)                                                                                           \
+  hipLaunchKernelGGL((paged_decode_finish_int8_kernel<T, D, V_, N_, T_>), dim3((unsigned)batch), dim3(T_), 0, s, part_o,  \
+                     part_ml, (T*)out, out_q, out_scale, (int)nq, nsplit)
+#define XM_FINISH(V_, T_)                                                                                               \
+  {                                                                                                                     \
+    if (nsplit <= 2) XM_FINISH_(V_, 2, T_);                                                                             \
+    else if (nsplit <= 4) XM_FINISH_(V_, 4, T_);                                                                        \
+    else XM_FINISH_(V_, 0, T_);                                                                                         \
+  }
+    // rows beyond 1024 elements: 1024 threads (few tokens per launch there -- the launch is latency, not throughput)
+    if (vpt <= 4) XM_FINISH(4, 256)
+    else XM_FINISH(4, 1024)
 #undef XM_FINISH
+#undef XM_FINISH_
   } else if (nsplit > 1) {
     hipLaunchKernelGGL((paged_decode_merge_kernel<T, D>), dim3((unsigned)(batch * nq)), dim3(D), 0, s, part_o,
                        part_ml, (T*)out, cu_q, (int)nq, nsplit);

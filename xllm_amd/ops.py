@@ -957,10 +957,11 @@ def scaled_matmul_rope_cache(a, b_packed, a_scale, b_scale, bias, positions, cos
     return out
 
 
-# merge + int8 quantisation of split-KV partials in one finishing launch: built, bit-identical, and NOT faster (one workgroup per
-# token, 12.7 us at 32 tokens, against 4.9 + 4.8 us for the merge and quantise launches it replaces, profiles/r02_fusions.txt:
-# the row maximum is a whole-row dependency, so the launch cannot be spread like the qkv fusion above) -- opt-in
-_ATTN_FINISH = os.environ.get("XLLM_MI355_ATTN_FINISH", "0") == "1"
+# merge + int8 quantisation of split-KV partials in ONE finishing launch (bit-identical to paged_attention + scaled_quantize).
+# Default since round 6: with every load of the launch in flight at once (and 1024 threads per token for rows beyond 1024
+# elements) it takes 4.7 us against 4.7 + 4.6 us for the merge and quantise launches it replaces (round 2's form waited for the
+# (m, l) pairs and then for each split in turn: 12.7 us, opt-in only); XLLM_MI355_ATTN_FINISH=0 = the two operators
+_ATTN_FINISH = os.environ.get("XLLM_MI355_ATTN_FINISH", "1") == "1"
 
 
 def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, max_kv_len, scale, window_left=-1,
@@ -974,8 +975,8 @@ def paged_decode_attention_int8(q, k_cache, v_cache, kv_seq_lens, block_table, m
     os_ = torch.empty(B, dtype=torch.float32, device=q.device)
     o16 = torch.empty(B, nq * d, dtype=q.dtype, device=q.device) if want_16bit else None
     bt = block_table if block_table.is_contiguous() else block_table.contiguous()
-    # XLLM_MI355_ATTN_FINISH=1: plans that split the token range over the grid finish through ONE merge + quantise launch
-    # (default: decline, the caller runs paged_attention + scaled_quantize)
+    # plans that split the token range over the grid finish through ONE merge + quantise launch
+    # (XLLM_MI355_ATTN_FINISH=0: decline, the caller runs paged_attention + scaled_quantize)
     ws = None
     if _ATTN_FINISH:
         ws = _attn_workspace(q.device, _lib.lib().xllm_mi355_paged_attention_workspace_bytes(B, nq, d, 1, B))
