@@ -14,5 +14,6 @@ out = (ctypes.c_longlong * 16)()
 rc = _lib.lib().xllm_mi355_debug_pf32(out)
 ph = [out[i] for i in range(4)]
 tot, wall, nt = out[4], out[5], out[6]
-print(f"[pf32 timing] rc={rc} tiles {nt}: per tile  barrier+DMA {ph[0]/max(nt,1):.0f} | QK^T {ph[1]/max(nt,1):.0f} | mask+max+P0 {ph[2]/max(nt,1):.0f} | PV+P1..3 {ph[3]/max(nt,1):.0f} "
-      f"| sum {sum(ph)/max(nt,1):.0f} cycles  (loop {tot/max(nt,1):.0f} cycles/tile, clock {tot/max(wall,1)/10:.2f} GHz; each mark drains the LDS queue)")
+print(f"[pf32 timing] of the first phase: own DMA slices landing (vmcnt) {out[7]/max(nt,1):.0f} | workgroup barrier {out[8]/max(nt,1):.0f} | K DMA issue {out[9]/max(nt,1):.0f} | V DMA issue {out[10]/max(nt,1):.0f} | up to the first fragment read {ph[0]/max(nt,1):.0f} cycles per tile")
+print(f"[pf32 timing] rc={rc} tiles {nt}: per tile  barrier+DMA {(ph[0]+out[7]+out[8]+out[9]+out[10])/max(nt,1):.0f} | QK^T {ph[1]/max(nt,1):.0f} | mask+max+P0 {ph[2]/max(nt,1):.0f} | PV+P1..3 {ph[3]/max(nt,1):.0f} "
+      f"| sum {(sum(ph)+out[7]+out[8]+out[9]+out[10])/max(nt,1):.0f} cycles  (loop {tot/max(nt,1):.0f} cycles/tile, clock {tot/max(wall,1)/10:.2f} GHz; each mark drains the LDS queue)")

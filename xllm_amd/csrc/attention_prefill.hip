@@ -807,6 +807,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void flash_prefill_dma_ke
 //   * staging, rings, swizzles, barrier protocol, masks, lazy rescale (2^8) and the single RNE-rounded 16-bit P (or hi + lo)
 //     are flash_prefill_dma_kernel's: the checker's "flash" cast-point mode (64-key tiles, 2^8 threshold) describes both.
 typedef float pf32x16_t __attribute__((ext_vector_type(16)));
+#ifdef PF32_TRACE  /* trace build (tools/pf32_trace.py): per workgroup, 100-MHz wall clock at entry / first tile / last tile / exit + where it ran */
+__device__ long long pf32_trace[16384 * 8];
+#endif
 #ifdef PF32_TIMING  /* timing build (tools/pf32_timing.py): shader cycles per phase of one wave, summed over its tiles */
 __device__ long long pf32_dbg[16];
 #define PF32_T(I_, DEP_)                                                    \
@@ -818,7 +821,7 @@ __device__ long long pf32_dbg[16];
     tph[I_] += now_ - tph_t;                                                \
     tph_t = now_;                                                           \
   }
-#define PF32_TARGS , long long (&tph)[6], long long& tph_t
+#define PF32_TARGS , long long (&tph)[8], long long& tph_t
 #define PF32_TPASS , tph, tph_t
 #else
 #define PF32_T(I_, DEP_)
@@ -979,6 +982,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q32 = lane & 31, hi = lane >> 5;
+#ifdef PF32_TRACE
+  const long long tr_t0 = wall_clock64();
+#endif
   int h, b, qb;
   if (!pf_block_coords(nq, nkv, n_seqs, n_qblocks, h, b, qb, plain_map)) return;
   const int q_start = cu_q[b], q_len = cu_q[b + 1] - q_start;
@@ -1066,13 +1072,23 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     for (int db = 0; db < 4; ++db) vaddr[db] = lds_base + vr * ROWB + (((2 * db + gi) ^ ft) << 5) + (p16 & 3) * 8;   // + the V ring base
   }
 
+#ifdef PF32_TRACE
+  long long tr_t1 = 0, tr_t2 = 0;
+#endif
   if (nt > 0) {
     const int qpos = kvoff + qidx;
     // step j: barrier (K(j), V(j) are published; tile j + 1 is requested into the slots tile j - 1 was read from) ; the tile
+#ifdef PF32_TIMING
+#define PF32_TB(I_) { const long long now_ = clock64(); tph[I_] += now_ - tph_t; tph_t = now_; }
+#else
+#define PF32_TB(I_)
+#endif
 #define PF32_BARRIER(I_)                                                                                 \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's slices of the requested tile */       \
+  PF32_TB(4)                                                                                             \
   __syncthreads();                                                                                       \
-  if ((I_) + 1 < nt) { stage((I_) + 1, false); stage((I_) + 1, true); }
+  PF32_TB(5)                                                                                             \
+  if ((I_) + 1 < nt) { stage((I_) + 1, false); PF32_TB(6) stage((I_) + 1, true); PF32_TB(7) }
 #define PF32_STEP(J_, PAR_)                                                                                              \
   {                                                                                                                      \
     const int j_ = (J_);                                                                                                 \
@@ -1085,8 +1101,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     }                                                                                                                    \
   }
 #ifdef PF32_TIMING
-    long long tph[6] = {0, 0, 0, 0, 0, 0}, tph_t = clock64();
+    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph_t = clock64();
     const long long t_c0 = clock64(), t_w0 = wall_clock64();
+#endif
+#ifdef PF32_TRACE
+    tr_t1 = wall_clock64();
 #endif
     stage(0, false);
     stage(0, true);
@@ -1099,12 +1118,20 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     }
 #undef PF32_STEP
 #undef PF32_BARRIER
+#undef PF32_TB
+#ifdef PF32_TRACE
+    tr_t2 = wall_clock64();
+#endif
 #ifdef PF32_TIMING
     if (qb == n_qblocks - 4 && h == 5 && b == 0 && lane == 0 && wave == 3) {   // a long (late-query) block, its last wave
       for (int i = 0; i < 4; ++i) pf32_dbg[i] = tph[i];
       pf32_dbg[4] = clock64() - t_c0;
       pf32_dbg[5] = wall_clock64() - t_w0;
       pf32_dbg[6] = nt;
+      pf32_dbg[7] = tph[4];   // of phase 0: this wave's own DMA slices landing (s_waitcnt vmcnt(0))
+      pf32_dbg[8] = tph[5];   // of phase 0: the workgroup barrier
+      pf32_dbg[9] = tph[6];   // of phase 0: issue of the K tile's four DMA pieces
+      pf32_dbg[10] = tph[7];  // of phase 0: issue of the V tile's four DMA pieces
     }
 #endif
   }
@@ -1145,6 +1172,16 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
           *reinterpret_cast<uint4*>(op + db * 32 + pr * 16 + hi * 8) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       }
   }
+#ifdef PF32_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 0 && lane == 0 && blockIdx.x < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* o = pf32_trace + (size_t)blockIdx.x * 8;
+    o[0] = tr_t0; o[1] = tr_t1; o[2] = tr_t2; o[3] = wall_clock64(); o[4] = nt; o[5] = hw; o[6] = xcc; o[7] = qb;
+  }
+#endif
 }
 
 template <typename T, int D, bool PAGED>
@@ -1226,6 +1263,11 @@ XM_INST_PREFILL(f16_t, 64, false)
 #ifdef PF32_TIMING
 extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_pf32(long long* out16) {
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(xm::pf32_dbg), 16 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef PF32_TRACE
+extern "C" __attribute__((visibility("default"))) int xllm_mi355_debug_pf32_trace(long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(xm::pf32_trace), (size_t)n_blocks * 8 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef XM_ABL_PF_TIMING
