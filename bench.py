@@ -1149,6 +1149,7 @@ def engine_leg(model, kv_caches, B, ctx, block_size, n_blocks, dev, steps, margs
     headline number (which times the graph alone): the difference is the per-step host work + the D2H sync."""
     from xllm_amd import engine
     warm = 2
+    steps = max(steps, 20)     # (the greedy / random difference is ~0.2 ms: ten steps do not resolve it)
     pages = (ctx + warm + steps + block_size - 1) // block_size
     if B * pages > n_blocks:
         return None

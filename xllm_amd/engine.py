@@ -60,6 +60,7 @@ class DecodeEngine:
         self._tokens64 = torch.zeros(B, dtype=torch.int64, device=self.dev)
         self._pos64 = torch.zeros(B, dtype=torch.int64, device=self.dev)
         self._uniform = torch.zeros(B, dtype=torch.float32, device=self.dev)
+        self._uniform_for = -1                     # the step whose uniforms self._uniform holds
         # per-sequence sampling parameters (SamplingParameters: temperatures / top_k / top_p tensors, sampling_params.cpp:33-110)
         self._temps = torch.full((B,), float(temperature), dtype=torch.float32, device=self.dev)
         self._top_k = None if top_k is None else torch.full((B,), int(top_k), dtype=torch.int64, device=self.dev)
@@ -110,8 +111,9 @@ class DecodeEngine:
         self._host_batch()
         self._stage.copy_(self._host, non_blocking=True)
         ops.decode_metadata_update(self.src, self.dst, self.B, self.B, self.B, self.n_idx, self.B)
-        if self.temperature > 0.0:
-            self._uniform.copy_(ops.philox_uniform(self.B, self.seed, self.step_no, device=self.dev))
+        if self.temperature > 0.0 and self._uniform_for != self.step_no:   # (only the first step: see below)
+            ops.philox_uniform(self.B, self.seed, self.step_no, device=self.dev, out=self._uniform)
+            self._uniform_for = self.step_no
         if not self._use_graph:
             self._out = self._device_step()
         elif self._graph is None:
@@ -124,6 +126,11 @@ class DecodeEngine:
             g.replay()
         else:
             self._graph.replay()
+        if self.temperature > 0.0:
+            # the NEXT step's uniforms, drawn behind this step in stream order (offset = step: a replay never repeats random
+            # numbers) -- the launch's host time hides under the step the device is still running
+            ops.philox_uniform(self.B, self.seed, self.step_no + 1, device=self.dev, out=self._uniform)
+            self._uniform_for = self.step_no + 1
         out = self._out.cpu()                          # the step's host sync: the scheduler needs the tokens
         tp = getattr(self.model, "tp", None)
         if tp is not None:

@@ -1020,9 +1020,13 @@ def decode_metadata_update(src: dict, dst: dict, actual_num_tokens: int, padded_
 
 
 # ------------------------------------------------------------------------------------------------ N3: sampler
-def philox_uniform(n: int, seed: int, offset: int, device="cuda"):
-    """u[i] = the first hiprand_uniform() of hiprand_init(seed, subsequence=i, offset) (Philox4x32-10)"""
-    out = torch.empty(n, dtype=torch.float32, device=device)
+def philox_uniform(n: int, seed: int, offset: int, device="cuda", out=None):
+    """u[i] = the first hiprand_uniform() of hiprand_init(seed, subsequence=i, offset) (Philox4x32-10); `out` (float32 [n],
+    contiguous) is filled in place when given"""
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=device)
+    elif out.dtype != torch.float32 or out.numel() != n or not out.is_contiguous() or not out.is_cuda:
+        raise Mi355Error("philox_uniform: out must be a contiguous float32 device tensor of n elements")
     check(_lib.lib().xllm_mi355_philox_uniform(_p(out), n, seed, offset, _stream()), "philox_uniform")
     return out
 
