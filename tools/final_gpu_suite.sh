@@ -9,6 +9,6 @@ mkdir -p gpurun_out/final
 O=gpurun_out/final/pytest_gpu.txt
 echo "# source-digest: $(python tools/source_digest.py)" > $O
 echo "# python -m pytest tests -m gpu -x -q   ($(date -u +%Y-%m-%dT%H:%M:%SZ), $(rocminfo 2>/dev/null | grep -m1 gfx9 | xargs))" >> $O
-python -m pytest tests -m gpu -x -q -p no:cacheprovider >> $O 2>&1
+python -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=30 >> $O 2>&1
 echo "# pytest rc=$?" >> $O
 tail -4 $O
