@@ -235,8 +235,12 @@ __global__ __launch_bounds__(kRowThreads) void rms_norm_kernel(
 // expression and rounding as the split-K epilogue: r16(float(acc)*a_s[m]*w_s[n] + bias[n])), re-zeroes the workspace
 // (its invariant), adds the residual, normalises and quantises exactly like rms_norm_kernel<T, true, QUANT>.
 // Bit-identical to scaled_matmul -> fused_add_rms_norm(-> scaled_quantize). QUANT: 0 = 16-bit norm out, 2 = int8.
-template <typename T, int QUANT>
-__global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
+// Round 6: NT threads x NV 16-byte chunks per thread (512 x 1 up to 4096 columns, 512 x 2 up to 8192, 256 x 4 beyond), and EVERY load
+// of the row -- the slabs, both scale vectors, bias, residual, norm weight -- is requested before anything is consumed: the
+// kernel is one memory latency deep instead of five (slabs / scales + residual per chunk iteration, then the norm weight), 8.5 ->
+// 6.x us at M = 256 inside the decode step (profiles/r06_slab_consumers.txt). Same expressions in the same order: bit-identical.
+template <typename T, int QUANT, int NT, int NV>
+__global__ __launch_bounds__(NT) void acc_add_rms_norm_kernel(
     void* __restrict__ out, float* __restrict__ q_scale, int32_t* __restrict__ acc, const float* __restrict__ a_scale,
     const float* __restrict__ w_scale, const T* __restrict__ bias, T* __restrict__ residual,
     const T* __restrict__ weight, float eps, int hidden, int n_slabs, int64_t slab_stride) {
@@ -251,42 +255,56 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
   int32_t* acc_row = acc + t * (int64_t)hidden;
   T* res_row = residual + t * (int64_t)hidden;
   const float as = a_scale[t];
-  RowVec<T> xv[kMaxVec];
+  RowVec<T> xv[NV];
+  i32x4 a0[NV], a1[NV], b0[NV][7], b1[NV][7];
+  float4 w0[NV], w1[NV];
+  RowVec<T> bv[NV], rv[NV], nw[NV];
+  // ---- every load of the row in flight (chunks past the row read chunk 0 and are ignored)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = threadIdx.x + i * NT;
+    const int c = c0 < nvec ? c0 : 0;
+    a0[i] = reinterpret_cast<const i32x4*>(acc_row)[2 * c];
+    a1[i] = reinterpret_cast<const i32x4*>(acc_row)[2 * c + 1];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {   // slabs 1..7 (the planner makes at most 8 slices; more: the loop below)
+      b0[i][u] = i32x4{0, 0, 0, 0};
+      b1[i][u] = i32x4{0, 0, 0, 0};
+      if (1 + u < n_slabs) {
+        const int32_t* p = acc_row + (1 + u) * slab_stride;
+        b0[i][u] = reinterpret_cast<const i32x4*>(p)[2 * c];
+        b1[i][u] = reinterpret_cast<const i32x4*>(p)[2 * c + 1];
+      }
+    }
+    w0[i] = reinterpret_cast<const float4*>(w_scale)[2 * c];
+    w1[i] = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
+    bv[i].raw = bias ? reinterpret_cast<const uint4*>(bias)[c] : make_uint4(0, 0, 0, 0);
+    rv[i].raw = reinterpret_cast<const uint4*>(res_row)[c];
+    nw[i].raw = reinterpret_cast<const uint4*>(weight)[c];
+  }
   float ss = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
-    const int c = threadIdx.x + i * kRowThreads;
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + i * NT;
     if (c < nvec) {
-      i32x4 a0 = reinterpret_cast<const i32x4*>(acc_row)[2 * c], a1 = reinterpret_cast<const i32x4*>(acc_row)[2 * c + 1];
       if (n_slabs == 0) {
         reinterpret_cast<i32x4*>(acc_row)[2 * c] = i32x4{0, 0, 0, 0};
         reinterpret_cast<i32x4*>(acc_row)[2 * c + 1] = i32x4{0, 0, 0, 0};
       }
-      // the slabs in groups of seven with every load of a group in flight at once (round 3: the one-slab-at-a-time loop of
-      // round 2 paid one memory latency per slab, up to eight per row); integer sums: any order is exact
-      for (int sl = 1; sl < n_slabs; sl += 7) {   // (the planner makes at most 8 slices: one pass)
-        i32x4 b0[7], b1[7];
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-          const bool ok = sl + u < n_slabs;
-          const int32_t* p = acc_row + (ok ? sl + u : 0) * slab_stride;
-          b0[u] = reinterpret_cast<const i32x4*>(p)[2 * c];
-          b1[u] = reinterpret_cast<const i32x4*>(p)[2 * c + 1];
-          if (!ok) { b0[u] = i32x4{0, 0, 0, 0}; b1[u] = i32x4{0, 0, 0, 0}; }
-        }
-        a0 += ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b0[4] + b0[5]) + b0[6]);
-        a1 += ((b1[0] + b1[1]) + (b1[2] + b1[3])) + ((b1[4] + b1[5]) + b1[6]);
+      // integer sums: any order is exact (the grouping of round 3's loop is kept)
+      i32x4 s0 = a0[i] + (((b0[i][0] + b0[i][1]) + (b0[i][2] + b0[i][3])) + ((b0[i][4] + b0[i][5]) + b0[i][6]));
+      i32x4 s1 = a1[i] + (((b1[i][0] + b1[i][1]) + (b1[i][2] + b1[i][3])) + ((b1[i][4] + b1[i][5]) + b1[i][6]));
+      for (int sl = 8; sl < n_slabs; ++sl) {   // (not reached by the planner's plans)
+        const int32_t* p = acc_row + sl * slab_stride;
+        s0 += reinterpret_cast<const i32x4*>(p)[2 * c];
+        s1 += reinterpret_cast<const i32x4*>(p)[2 * c + 1];
       }
-      const float4 w0 = reinterpret_cast<const float4*>(w_scale)[2 * c], w1 = reinterpret_cast<const float4*>(w_scale)[2 * c + 1];
-      const int av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-      RowVec<T> bv, rv;
-      bv.raw = bias ? reinterpret_cast<const uint4*>(bias)[c] : make_uint4(0, 0, 0, 0);
-      rv.raw = reinterpret_cast<const uint4*>(res_row)[c];
+      const int av[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      const float wv[8] = {w0[i].x, w0[i].y, w0[i].z, w0[i].w, w1[i].x, w1[i].y, w1[i].z, w1[i].w};
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        const float y = r16<T>((float)av[j] * as * wv[j] + (bias ? bv.get(j) : 0.0f));  // the GEMM's 16-bit output
-        xv[i].set(j, y + rv.get(j));                                                      // r16(y + residual)
+        const float y = r16<T>((float)av[j] * as * wv[j] + (bias ? bv[i].get(j) : 0.0f));  // the GEMM's 16-bit output
+        xv[i].set(j, y + rv[i].get(j));                                                      // r16(y + residual)
       }
       reinterpret_cast<uint4*>(res_row)[c] = xv[i].raw;
 #pragma unroll
@@ -297,14 +315,12 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
   const float inv = 1.0f / sqrtf(ss / (float)hidden + eps);
   float amax = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
-    const int c = threadIdx.x + i * kRowThreads;
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + i * NT;
     if (c < nvec) {
-      RowVec<T> wv;
-      wv.raw = reinterpret_cast<const uint4*>(weight)[c];
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        float y = r16<T>(r16<T>(xv[i].get(j) * inv) * wv.get(j));
+        float y = r16<T>(r16<T>(xv[i].get(j) * inv) * nw[i].get(j));
         xv[i].set(j, y);
         amax = fmaxf(amax, fabsf(y));
       }
@@ -315,8 +331,8 @@ __global__ __launch_bounds__(kRowThreads) void acc_add_rms_norm_kernel(
     amax = block_max(amax, smem);
     const float qinv = (amax > 1e-10f) ? 127.0f / amax : 0.0f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-      const int c = threadIdx.x + i * kRowThreads;
+    for (int i = 0; i < NV; ++i) {
+      const int c = threadIdx.x + i * NT;
       if (c < nvec) {
         uint32_t pk[2];
 #pragma unroll
@@ -344,14 +360,21 @@ int launch_acc_add_rms_norm(void* out, float* q_scale, int32_t* acc, const float
   if (N % 8 != 0 || N > (int64_t)kRowThreads * kMaxVec * 8) return XM_ERR_UNSUPPORTED;
   if (((uintptr_t)out | (uintptr_t)residual | (uintptr_t)weight | (uintptr_t)bias | (uintptr_t)w_scale | (uintptr_t)acc) % 16)
     return XM_ERR_UNSUPPORTED;
+#define XM_ACC_NORM(Q_, NT_, NV_)                                                                                       \
+  hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, Q_, NT_, NV_>), dim3(M), dim3(NT_), 0, s, out, q_scale, acc, a_scale,  \
+                     w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N, n_slabs, M * N)
   XM_DISPATCH_HALF(dtype, T, {
-    if (quant)
-      hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 2>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
-                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N, n_slabs, M * N);
-    else
-      hipLaunchKernelGGL((acc_add_rms_norm_kernel<T, 0>), dim3(M), dim3(kRowThreads), 0, s, out, q_scale, acc, a_scale,
-                         w_scale, (const T*)bias, (T*)residual, (const T*)weight, eps, (int)N, n_slabs, M * N);
+    if (quant) {
+      if (N <= 4096) XM_ACC_NORM(2, 512, 1);
+      else if (N <= 8192) XM_ACC_NORM(2, 512, 2);
+      else XM_ACC_NORM(2, 256, 4);
+    } else {
+      if (N <= 4096) XM_ACC_NORM(0, 512, 1);
+      else if (N <= 8192) XM_ACC_NORM(0, 512, 2);
+      else XM_ACC_NORM(0, 256, 4);
+    }
   });
+#undef XM_ACC_NORM
   return hip_check_launch();
 }
 
@@ -621,25 +644,36 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
   if (item >= n_pq + n_tq + n_vq) return;
   const float as = a_scale[t];
   const int32_t* acc_row = slabs + t * (int64_t)n_cols;
-  auto value4 = [&](int c, float (&v)[4]) {   // the four 16-bit qkv elements c .. c + 3 the GEMM epilogue would have written
-    i32x4 a = *reinterpret_cast<const i32x4*>(acc_row + c);
-    for (int sl = 1; sl < n_slabs; sl += 7) {   // (at most 8 slices: one pass with every load in flight)
-      i32x4 b[7];
+  // the four 16-bit qkv elements c .. c + 3 the GEMM epilogue would have written, in two steps (round 6): load4 REQUESTS everything
+  // (slab 0, slabs 1..7, scales, bias), finish4 consumes -- a thread issues the loads of both of its column groups and the cos / sin
+  // pair before it waits for any of them (before: slabs -> scales + bias, once per group: four dependent memory latencies)
+  struct Pending4 {
+    i32x4 a, b[7];
+    float4 w;
+    uint2 braw;
+    int c;
+  };
+  auto load4 = [&](int c) {
+    Pending4 p;
+    p.c = c;
+    p.a = *reinterpret_cast<const i32x4*>(acc_row + c);
 #pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        const bool ok = sl + u < n_slabs;
-        b[u] = *reinterpret_cast<const i32x4*>(acc_row + (ok ? sl + u : 0) * slab_stride + c);
-        if (!ok) b[u] = i32x4{0, 0, 0, 0};
-      }
-      a += ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + b[6]);
+    for (int u = 0; u < 7; ++u) {
+      p.b[u] = i32x4{0, 0, 0, 0};
+      if (1 + u < n_slabs) p.b[u] = *reinterpret_cast<const i32x4*>(acc_row + (1 + u) * slab_stride + c);
     }
-    const float4 w = *reinterpret_cast<const float4*>(w_scale + c);
-    const float wv[4] = {w.x, w.y, w.z, w.w};
+    p.w = *reinterpret_cast<const float4*>(w_scale + c);
+    p.braw = bias ? *reinterpret_cast<const uint2*>(bias + c) : make_uint2(0u, 0u);
+    return p;
+  };
+  auto finish4 = [&](const Pending4& p, float (&v)[4]) {
+    i32x4 a = p.a + (((p.b[0] + p.b[1]) + (p.b[2] + p.b[3])) + ((p.b[4] + p.b[5]) + p.b[6]));
+    for (int sl = 8; sl < n_slabs; ++sl) a += *reinterpret_cast<const i32x4*>(acc_row + sl * slab_stride + p.c);   // (no plan makes > 8)
+    const float wv[4] = {p.w.x, p.w.y, p.w.z, p.w.w};
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
-      const uint2 braw = *reinterpret_cast<const uint2*>(bias + c);
       T b4[4];
-      __builtin_memcpy(b4, &braw, 8);
+      __builtin_memcpy(b4, &p.braw, 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = to_f32(b4[e]);
     }
@@ -660,6 +694,7 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
     const int hq = half / 4;
     const int h = item / hq, j = (item - h * hq) * 4;   // pairs j .. j + 3 of head h
     const int base = h * head_size;
+    const Pending4 p0 = load4(NEOX ? base + j : base + 2 * j), p1 = load4(NEOX ? base + half + j : base + 2 * j + 4);
     const T* cp = cache + positions[t] * rot_dim;
     uint2 craw = *reinterpret_cast<const uint2*>(cp + j), sraw = *reinterpret_cast<const uint2*>(cp + half + j);
     T c4[4], s4[4];
@@ -668,12 +703,12 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
     float x[4], y[4];
     T nx[4], ny[4];
     if constexpr (NEOX) {
-      value4(base + j, x);
-      value4(base + half + j, y);
+      finish4(p0, x);
+      finish4(p1, y);
     } else {                       // interleaved: elements 2 j .. 2 j + 7 = (x0 y0 x1 y1 | x2 y2 x3 y3)
       float lo[4], hi[4];
-      value4(base + 2 * j, lo);
-      value4(base + 2 * j + 4, hi);
+      finish4(p0, lo);
+      finish4(p1, hi);
       x[0] = lo[0]; y[0] = lo[1]; x[1] = lo[2]; y[1] = lo[3];
       x[2] = hi[0]; y[2] = hi[1]; x[3] = hi[2]; y[3] = hi[3];
     }
@@ -703,7 +738,7 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
     const int i2 = item - n_pq, tq = tail / 4;
     const int h = i2 / tq, e = rot_dim + (i2 - h * tq) * 4;
     float v[4];
-    value4(h * head_size + e, v);
+    finish4(load4(h * head_size + e), v);
     const T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
     store4(out_row + h * head_size + e, o);
     if (h >= nq && store) store4(kc_row + (h - nq) * head_size + e, o);
@@ -711,7 +746,7 @@ __global__ __launch_bounds__(256) void slab_rope_and_cache_vec_kernel(
     const int i2 = (item - n_pq - n_tq) * 4;
     const int c = (nq + nk) * head_size + i2;
     float v[4];
-    value4(c, v);
+    finish4(load4(c), v);
     const T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
     store4(out_row + c, o);
     if (store) store4(vc_row + i2, o);
