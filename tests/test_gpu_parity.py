@@ -766,10 +766,12 @@ def test_mlu_golden_vectors_through_hip():
 
 
 @pytest.mark.parametrize("M,N,K,dtype", [(64, 3584, 18944, torch.bfloat16), (64, 4608, 3584, torch.bfloat16),
-                                         (256, 3584, 3584, torch.float16), (7, 1000, 8192, torch.bfloat16)])
+                                         (256, 3584, 3584, torch.float16), (7, 1000, 8192, torch.bfloat16),
+                                         (2048, 128, 2048, torch.bfloat16), (1100, 72, 1024, torch.float16)])
 def test_matmul_16bit_split_k_is_deterministic_and_keeps_the_workspace_zero(M, N, K, dtype):
-    """decode-shaped 16-bit GEMMs split K through fp32 slabs in the workspace: == oracle (<= 1 ulp), identical bits run to
-    run, and the workspace is zero again afterwards (an int8 split-K GEMM right after stays exact)"""
+    """decode-shaped 16-bit GEMMs -- and tall ones with few columns (MoE router gates: few 128 x 128 tiles, round 6) -- split K
+    through fp32 slabs in the workspace: == oracle (<= 1 ulp), identical bits run to run, and the workspace is zero again
+    afterwards (an int8 split-K GEMM right after stays exact)"""
     g = torch.Generator().manual_seed(M + N)
     a = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)

@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(const uint8_t* __restri
           const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
           store16(out_base, idx, as * (ws * acc[i][j][r]) + bs, epi.out_bf16);
         } else {
-          store16(out_base, idx, acc[i][j][r] + bs, epi.out_bf16);
+          if constexpr (SPLITK)   // 16-bit kinds: this K slice's fp32 partial into its slab (plain store; f32_splitk_reduce_zero_kernel sums in order)
+            reinterpret_cast<float*>(epi.acc_out)[(int64_t)blockIdx.z * M * N + idx] = acc[i][j][r];
+          else
+            store16(out_base, idx, acc[i][j][r] + bs, epi.out_bf16);
         }
       }
     }
@@ -677,6 +680,22 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
       splits = splits > 16 ? 16 : splits;
     }
   }
+  if constexpr (KIND == kBF16 || KIND == kF16) {
+    // Tall problems with few columns (MoE router gates: [T, n_experts] at T = 8192 is 64 tiles of 128 x 128 on 256 CUs, each
+    // workgroup alone on its CU with every stage -> barrier -> MFMA latency exposed: 50 us for 33 MB, round 6): split K through
+    // fp32 slabs in the registered workspace, summed in slice order by f32_splitk_reduce_zero_kernel (deterministic), as the
+    // skinny kernel does for decode shapes.
+    const int64_t tiles = (int64_t)m_tiles * n_tiles;
+    if (workspace && tiles < 128 && ksteps >= 8 && N % 4 == 0 && ((uintptr_t)epi.out % 8) == 0 && !epi.acc_out && epi.out &&
+        !epi.group_counts) {
+      int64_t sp = 256 / tiles;
+      const int64_t fit = (int64_t)(ws_bytes / ((size_t)M * N * 4));
+      sp = sp > ksteps / 4 ? ksteps / 4 : sp;
+      sp = sp > fit ? fit : sp;
+      sp = sp > 16 ? 16 : sp;
+      if (sp >= 2) splits = (int)sp;
+    }
+  }
   const int per = (ksteps + splits - 1) / splits;
   splits = (ksteps + per - 1) / per;
   // rasterised grid (see the kernel): super-blocks of 8x8 tiles, padded to a multiple of 8 super-blocks
@@ -696,6 +715,15 @@ int launch_gemm(const void* A, const void* W, int64_t M, int64_t N, int64_t Kb, 
       blocks = blocks > 2048 ? 2048 : blocks;
       hipLaunchKernelGGL(i8_splitk_epilogue_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                          reinterpret_cast<int32_t*>(workspace), M, N, epi);
+    } else if constexpr (KIND == kBF16 || KIND == kF16) {
+      GemmEpi e2 = epi;
+      e2.acc_out = reinterpret_cast<int32_t*>(workspace);   // (fp32 slabs: the kernel re-interprets)
+      hipLaunchKernelGGL((gemm_kernel<KIND, true, 128, 2>), grid, dim3(256), 0, s, (const uint8_t*)A, (const uint8_t*)W,
+                         (int)M, (int)N, Kb, m_tiles, n_tiles, per, e2);
+      int64_t blocks = (M * N / 4 + 255) / 256;
+      blocks = blocks > 1024 ? 1024 : blocks;
+      hipLaunchKernelGGL(f32_splitk_reduce_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                         reinterpret_cast<float*>(workspace), M, N, splits, epi);
     }
   } else {
     // K step 64 B + 4 workgroups per CU (4 waves/SIMD) measured +17 % over 128 B + 2 workgroups at M = 8192

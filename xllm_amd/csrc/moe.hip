@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void moe_combine_sorted_kernel(T* __restrict__
 // ------------------------------------------------------------------------------------------------
 constexpr int kTopkMaxPerLane = 8;
 
-template <typename T>
+// PL = experts per lane (ceil(E / 64) rounded up to 1, 2, 4, 8: round 6 -- every per-expert loop ran all 8 slots at E = 128)
+template <typename T, int PL>
 __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict__ gating, int n_tokens, int E, int topk,
                                                              int renormalize, const float* __restrict__ bias,
                                                              int sigmoid, float* __restrict__ out_w,
@@ -194,17 +195,17 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= n_tokens) return;
   const T* row = gating + (int64_t)tok * E;
-  float v[kTopkMaxPerLane];
+  float v[PL];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+  for (int j = 0; j < PL; ++j) {
     const int e = lane + 64 * j;
     v[j] = e < E ? to_f32(row[e]) : -INFINITY;
     mx = fmaxf(mx, v[j]);
   }
   if (sigmoid) {
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       const int e = lane + 64 * j;
       if (e < E) {
         float sg = 1.0f / (1.0f + expf(-v[j]));
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       const int e = lane + 64 * j;
       v[j] = e < E ? expf(v[j] - mx) : 0.0f;
       sum += v[j];
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       const int e = lane + 64 * j;
       v[j] = e < E ? v[j] * inv : -INFINITY;
     }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
     float best = -INFINITY;
     int best_e = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       const int e = lane + 64 * j;
       if (e < E && (v[j] > best || (v[j] == best && e < best_e))) { best = v[j]; best_e = e; }
     }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
     }
     if ((best_e & 63) == lane) {  // the owner retires the expert
 #pragma unroll
-      for (int j = 0; j < kTopkMaxPerLane; ++j)
+      for (int j = 0; j < PL; ++j)
         if (lane + 64 * j == best_e) v[j] = -INFINITY;
     }
     float w = best;
@@ -274,34 +275,34 @@ __global__ __launch_bounds__(256) void moe_fused_topk_kernel(const T* __restrict
 // One wave per token as in moe_fused_topk_kernel; the choice scores go through 2 KB of LDS per wave once so that lane g
 // can walk group g's experts (a wave's own LDS writes are visible to its later reads: no barrier).
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int PL>
 __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restrict__ gating, int n_tokens, int E, int topk,
                                                                int G, int topk_group, int renormalize,
                                                                const float* __restrict__ bias, int sigmoid,
                                                                float route_scale, float* __restrict__ out_w,
                                                                int32_t* __restrict__ out_id) {
-  __shared__ float choice[4][64 * kTopkMaxPerLane];
+  __shared__ float choice[4][64 * PL];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tok = blockIdx.x * 4 + wv;
   if (tok >= n_tokens) return;
   const T* row = gating + (int64_t)tok * E;
-  float sc[kTopkMaxPerLane], v[kTopkMaxPerLane];
+  float sc[PL], v[PL];
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+  for (int j = 0; j < PL; ++j) {
     const int e = lane + 64 * j;
     sc[j] = e < E ? to_f32(row[e]) : -INFINITY;
     mx = fmaxf(mx, sc[j]);
   }
   if (sigmoid) {
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) sc[j] = lane + 64 * j < E ? 1.0f / (1.0f + expf(-sc[j])) : 0.0f;
+    for (int j = 0; j < PL; ++j) sc[j] = lane + 64 * j < E ? 1.0f / (1.0f + expf(-sc[j])) : 0.0f;
   } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       sc[j] = lane + 64 * j < E ? expf(sc[j] - mx) : 0.0f;
       sum += sc[j];
     }
@@ -309,10 +310,10 @@ __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restri
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) sc[j] = sc[j] * inv;
+    for (int j = 0; j < PL; ++j) sc[j] = sc[j] * inv;
   }
 #pragma unroll
-  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+  for (int j = 0; j < PL; ++j) {
     const int e = lane + 64 * j;
     v[j] = e < E ? (bias ? sc[j] + bias[e] : sc[j]) : -INFINITY;
     if (e < E) choice[wv][e] = v[j];
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restri
   }
   const unsigned long long kept = __ballot(lane < G && rank < topk_group);
 #pragma unroll
-  for (int j = 0; j < kTopkMaxPerLane; ++j) {
+  for (int j = 0; j < PL; ++j) {
     const int e = lane + 64 * j;
     if (e < E && !((kept >> (e / EG)) & 1ull)) v[j] = -INFINITY;
   }
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restri
     float best = -INFINITY;
     int best_e = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
       const int e = lane + 64 * j;
       if (e < E && (v[j] > best || (v[j] == best && e < best_e))) { best = v[j]; best_e = e; }
     }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void moe_grouped_topk_kernel(const T* __restri
     }
     float ws = 0.0f;              // the owner retires the expert and supplies its unbiased score
 #pragma unroll
-    for (int j = 0; j < kTopkMaxPerLane; ++j)
+    for (int j = 0; j < PL; ++j)
       if (lane + 64 * j == best_e) { ws = sc[j]; v[j] = -INFINITY; }
     const float w = __shfl(ws, best_e & 63);
     wsum += w;
@@ -455,11 +456,17 @@ extern "C" int xllm_mi355_moe_fused_topk(const void* gating, int dtype, int64_t 
   if (n_experts > 64 * kTopkMaxPerLane || topk > 64 || topk > n_experts) return XM_ERR_UNSUPPORTED;
   if (n_tokens == 0) return XM_OK;
   const dim3 grid((unsigned)((n_tokens + 3) / 4));
+#define XM_FUSED_TOPK(PL_)                                                                                          \
+  hipLaunchKernelGGL((moe_fused_topk_kernel<T, PL_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,     \
+                     (int)n_tokens, (int)n_experts, (int)topk, renormalize, correction_bias, scoring, topk_weights,  \
+                     topk_ids)
   XM_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((moe_fused_topk_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,
-                       (int)n_tokens, (int)n_experts, (int)topk, renormalize, correction_bias, scoring, topk_weights,
-                       topk_ids);
+    if (n_experts <= 64) XM_FUSED_TOPK(1);
+    else if (n_experts <= 128) XM_FUSED_TOPK(2);
+    else if (n_experts <= 256) XM_FUSED_TOPK(4);
+    else XM_FUSED_TOPK(8);
   });
+#undef XM_FUSED_TOPK
   return hip_check_launch();
 }
 
@@ -477,10 +484,16 @@ extern "C" int xllm_mi355_moe_grouped_topk(const void* gating, int dtype, int64_
   if (n_experts > 64 * kTopkMaxPerLane || topk > 64 || num_expert_group > 64) return XM_ERR_UNSUPPORTED;
   if (n_tokens == 0) return XM_OK;
   const dim3 grid((unsigned)((n_tokens + 3) / 4));
+#define XM_GROUPED_TOPK(PL_)                                                                                        \
+  hipLaunchKernelGGL((moe_grouped_topk_kernel<T, PL_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,   \
+                     (int)n_tokens, (int)n_experts, (int)topk, (int)num_expert_group, (int)topk_group, renormalize,  \
+                     correction_bias, scoring, routed_scaling_factor, topk_weights, topk_ids)
   XM_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((moe_grouped_topk_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)gating,
-                       (int)n_tokens, (int)n_experts, (int)topk, (int)num_expert_group, (int)topk_group, renormalize,
-                       correction_bias, scoring, routed_scaling_factor, topk_weights, topk_ids);
+    if (n_experts <= 64) XM_GROUPED_TOPK(1);
+    else if (n_experts <= 128) XM_GROUPED_TOPK(2);
+    else if (n_experts <= 256) XM_GROUPED_TOPK(4);
+    else XM_GROUPED_TOPK(8);
   });
+#undef XM_GROUPED_TOPK
   return hip_check_launch();
 }

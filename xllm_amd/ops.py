@@ -629,8 +629,9 @@ def matmul(a, b, bias=None, b_packed=None):
         if rc not in (-2, -4):
             check(rc, "matmul_packed")
             return out.view(*a.shape[:-1], N)
-    if a2.size(0) <= 512:
-        _ensure_gemm_workspace(a.device, 1)  # decode shapes may split K through it (fp32 slabs, deterministic reduce)
+    if a2.size(0) <= 512 or ((a2.size(0) + 127) // 128) * ((N + 127) // 128) < 128:
+        # decode shapes -- and tall problems with few columns (router gates) -- may split K through it (fp32 slabs, deterministic reduce)
+        _ensure_gemm_workspace(a.device, 1)
     b_c = b.contiguous()  # keep the (possibly new) tensor alive across the call
     check(_lib.lib().xllm_mi355_matmul(_p(a2), _p(b_c), _p(bias), _p(out), a2.size(0), N, K, _dt(a),
                                       _stream()), "matmul")
