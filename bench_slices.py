@@ -75,13 +75,29 @@ def cfg4_slice(a, dev):
     x = torch.randn(B, H, device=dev, generator=gen).bfloat16()
     pos = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
 
+    # post_attention_layernorm (deepseek_v2 decoder layer: residual add + RMSNorm between the attention and the MoE block). Round 6:
+    # without it the gate saw the raw attention output (|h| ~ 0.04 at random init), the correction bias (sigma 0.1) decided the
+    # routing and all 128 tokens chose the same ~10 experts -- 128 rows per expert, eight 16-row passes over their weights, nothing
+    # like a decode step's ~4 rows on (nearly) all 256 experts. With the norm the logits have sigma ~ 1 and the routing is balanced.
+    post_w = torch.ones(H, device=dev, dtype=torch.bfloat16)
+    resid = x.clone()
+    route_seen = []
+
     def step():
         h = attn.forward(pos, x, md, cache)                 # (all-reduce over the 8 ranks here)
-        return moe.forward_experts(h, ops.matmul(h, gate_w))   # (all-reduce over the 8 ranks here)
+        r = resid.clone()
+        ops.fused_add_rms_norm(h, r, post_w, 1e-6)          # h <- RMSNorm(h + residual)
+        logits = ops.matmul(h, gate_w)
+        if not route_seen:
+            route_seen.append(logits)
+        return moe.forward_experts(h, logits)               # (all-reduce over the 8 ranks here)
 
     sync = torch.cuda.synchronize
     step()
     sync()
+    _w, _ids = ops.moe_active_topk(route_seen[0].reshape(B, -1), topk, n_group, topk_group, True, bias, "sigmoid", 2.5)
+    _cnt = torch.bincount(_ids.flatten().long(), minlength=E)
+    routing = {"experts_with_rows": int((_cnt > 0).sum()), "max_rows_per_expert": int(_cnt.max()), "rows": int(_cnt.sum())}
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         step()
@@ -137,11 +153,11 @@ def cfg4_slice(a, dev):
     return {
         "metric": "decode tokens/s through one DeepSeek-V3 layer of one TP=8 rank (cfg4-slice)",
         "value": round(B / dt, 1), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "fp8",
-        "config": {"workload": "deepseek_v3 layer slice: MLA decode (16 heads/rank, fp8 q_b/o projections) + 256-expert top-8 "
-                               "routed MoE (intermediate 2048/8), bs=128 ctx=8192, paged latent cache block=64 bf16, "
+        "config": {"workload": "deepseek_v3 layer slice: MLA decode (16 heads/rank, fp8 q_b/o projections) + residual add / RMSNorm + "
+                               "256-expert top-8 routed MoE (intermediate 2048/8), bs=128 ctx=8192, paged latent cache block=64 bf16, "
                                "random-init weights", "global_batch": B, "ctx": ctx, "per_gpu_batch": B,
                    "parallelism": "rank 0 of tp8 (shard shapes, no exchange timed)", "collectives_per_step": 2,
-                   "hip_graph": True,
+                   "hip_graph": True, "routing": routing,
                    # round 5: the two absorbed-weight batch GEMMs (q_nope x w_kc, attn x w_vc; torch::bmm = rocBLAS in the reference,
                    # deepseek_v2_attention.cpp:180-187, 310-311) run on this backend's per-head GEMM (xllm_mi355_bmm_heads), in place
                    # on the token-major tensors; what is left of the vendor library on the measured path is copy / embedding glue

@@ -512,10 +512,12 @@ def test_matmul_weight_stream_rows(M, N, K, dtype):
     assert torch.equal(ops.matmul(ad, wd), ops.matmul(ad, wd, torch.zeros_like(bd)))      # no bias == zero bias
 
 
-def test_group_gemm_few_rows_per_expert():
+@pytest.mark.parametrize("H,N", [(512, 384), (256, 512), (512, 768), (1024, 512)])
+def test_group_gemm_few_rows_per_expert(H, N):
     """MoE decode shape: a handful of rows per expert (gemm_wsb.hip grouped form): experts without a row, experts with more
-    than one 16-row pass, the expand fused as an index (group_gemm_gather == index_select + group_gemm bit for bit)"""
-    T, topk, E, H, N = 24, 4, 32, 512, 384
+    than one 16-row pass, the expand fused as an index (group_gemm_gather == index_select + group_gemm bit for bit); K = H <= 512
+    with N % 256 == 0 takes the per-wave column tiles (round 6: w2 of a decode step), the others the K split over the waves"""
+    T, topk, E = 24, 4, 32
     g = torch.Generator().manual_seed(17)
     ids = torch.randint(0, E, (T, topk), generator=g, dtype=torch.int32)
     ids[:20, 0] = 5                                           # expert 5 gets >= 20 rows: two passes of 16

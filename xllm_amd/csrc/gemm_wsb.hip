@@ -111,7 +111,10 @@ __device__ __forceinline__ void wsb_wait(wsb_u32x4 (&wr)[4][2], wsb_u32x4 (&xr)[
   for (int mb = 0; mb < MB; ++mb) asm volatile("" : "+v"(xr[mb][0]), "+v"(xr[mb][1]));
 }
 
-template <typename T, int MB, bool GROUPED>
+// WAVE_COLS (round 6, short K: the w2 of a MoE decode step, K = moe_intermediate / tp = 256): the four waves do not split the K
+// steps (one step each, no pipeline, a 32-KiB weight block per workgroup behind a per-workgroup prologue) -- every wave owns its OWN
+// 64 columns over all K steps, a workgroup covers 256 columns, no cross-wave sum.
+template <typename T, int MB, bool GROUPED, bool WAVE_COLS = false>
 __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                        T* __restrict__ out, float* __restrict__ slabs,
                                                        const T* __restrict__ bias, int M, int N, int K, int steps_per_slice,
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p16 = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * kWsbCols;
+  const int n0 = WAVE_COLS ? (blockIdx.x * 4 + wave) * kWsbCols : blockIdx.x * kWsbCols;
   const int n_steps = K / kWsbK;
 
   int row0 = 0, cnt = M, slice = 0;
@@ -142,9 +145,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
   const int s_lo = slice * steps_per_slice;
   int s_hi = s_lo + steps_per_slice;
   s_hi = s_hi < n_steps ? s_hi : n_steps;
-  // this wave's steps: s_lo + wave, + 4, ... (a wave without a step adds a zero tile)
-  const int my_first = s_lo + wave;
-  const int my_n = my_first < s_hi ? (s_hi - my_first + 3) / 4 : 0;
+  // this wave's steps: s_lo + wave, + 4, ... (a wave without a step adds a zero tile); WAVE_COLS: all of them
+  constexpr int kStride = WAVE_COLS ? 1 : 4;
+  const int my_first = WAVE_COLS ? s_lo : s_lo + wave;
+  const int my_n = my_first < s_hi ? (s_hi - my_first + kStride - 1) / kStride : 0;
 
   // per-lane byte offsets of the 4 column blocks' rows inside the workgroup's 64 rows of w (< 2^31: checked on the host)
   const char* const wbase = reinterpret_cast<const char*>(wb + (int64_t)n0 * K);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
     wsb_u32x4 wr0[4][2], wr1[4][2], wr2[4][2], xr0[MB][2], xr1[MB][2];
     auto koff_of = [&](int i) -> int64_t {     // byte offset of the wave's step i along K (wave-uniform: SGPRs)
       i = i < my_n ? i : my_n - 1;
-      return (int64_t)(my_first + 4 * i) * (kWsbK * 2);
+      return (int64_t)(my_first + kStride * i) * (kWsbK * 2);
     };
 #define WSB_STEP(I_, WC_, WN_, XC_, XN_)                                                        \
   {                                                                                              \
@@ -246,17 +250,19 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
         *reinterpret_cast<wsb_f32x4*>(mine + (mb * 16 + p16) * kWsbPad + (((nb * 4 + kq) ^ p16) << 2)) = acc[nb][mb];
-    __syncthreads();
+    if constexpr (!WAVE_COLS) __syncthreads();   // (WAVE_COLS: a wave re-reads only its own tile)
     int rows = cnt - rb0;
     rows = rows < 16 * MB ? rows : 16 * MB;
-    for (int idx = threadIdx.x; idx < rows * 16; idx += 256) {
+    for (int idx = WAVE_COLS ? lane : (int)threadIdx.x; idx < rows * 16; idx += WAVE_COLS ? 64 : 256) {
       const int m = idx >> 4, c4 = (idx & 15) * 4;
       const int sw = ((idx & 15) ^ (m & 15)) << 2;
-      wsb_f32x4 v = *reinterpret_cast<const wsb_f32x4*>(red + m * kWsbPad + sw);
+      wsb_f32x4 v = *reinterpret_cast<const wsb_f32x4*>((WAVE_COLS ? mine : red) + m * kWsbPad + sw);
+      if constexpr (!WAVE_COLS) {
 #pragma unroll
-      for (int wv = 1; wv < 4; ++wv) {
-        const wsb_f32x4 t = *reinterpret_cast<const wsb_f32x4*>(red + wv * (16 * MB * kWsbPad) + m * kWsbPad + sw);
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        for (int wv = 1; wv < 4; ++wv) {
+          const wsb_f32x4 t = *reinterpret_cast<const wsb_f32x4*>(red + wv * (16 * MB * kWsbPad) + m * kWsbPad + sw);
+          v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
       }
       const int64_t o = (int64_t)(row0 + rb0 + m) * N + n0 + c4;
       if (slabs) {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wsb_kernel(const T* __restrict__ 
             make_uint2((uint32_t)hv[0] | ((uint32_t)hv[1] << 16), (uint32_t)hv[2] | ((uint32_t)hv[3] << 16));
       }
     }
-    __syncthreads();   // the next row pass reuses the LDS tiles
+    if constexpr (!WAVE_COLS) __syncthreads();   // the next row pass reuses the LDS tiles
   }
 }
 
@@ -317,11 +323,11 @@ static void wsb_env() {
   if (g_wsb_mode == -2) g_wsb_mode = xm_switch("XLLM_MI355_WSB", 1);
 }
 
-template <typename T, int MB, bool GROUPED>
+template <typename T, int MB, bool GROUPED, bool WAVE_COLS = false>
 static void wsb_launch(dim3 grid, hipStream_t s, const T* x, const T* w, T* out, float* slabs, const T* bias, int M, int N,
                        int K, int per, WsbGroup g) {
   const size_t lds = (size_t)4 * 16 * MB * kWsbPad * sizeof(float);   // 16 / 32 / 64 KiB
-  hipLaunchKernelGGL((gemm_wsb_kernel<T, MB, GROUPED>), grid, dim3(256), lds, s, x, w, out, slabs, bias, M, N, K, per, g);
+  hipLaunchKernelGGL((gemm_wsb_kernel<T, MB, GROUPED, WAVE_COLS>), grid, dim3(256), lds, s, x, w, out, slabs, bias, M, N, K, per, g);
 }
 
 // dense: returns XM_ERR_UNSUPPORTED when the shape is not this kernel's (the caller keeps its tiled kernels)
@@ -374,10 +380,23 @@ int launch_gemm_wsb_grouped(const void* x, const void* w, const int32_t* counts,
       64 * K * 2 >= (1ll << 31) || max_rows * K * 2 >= (1ll << 31) ||
       ((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 8))
     return XM_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)(N / kWsbCols), (unsigned)n_experts);
   const WsbGroup g{counts, row_index, (int)n_experts, (int)(index_div > 0 ? index_div : 1)};
-  wsb_launch<T, 1, true>(grid, s, (const T*)x, (const T*)w, (T*)out, nullptr, nullptr, (int)max_rows, (int)N, (int)K,
-                         (int)(K / kWsbK), g);
+  // Plan (round 6, tools/group_gemm_decode_ab.sh, profiles/r06_group_gemm_decode.txt; 256 experts, 1024 rows, uniform / skewed):
+  //   * rows per pass stay 16: 32 (experts with 17-32 rows read their weights once instead of twice) loses on every shape but the
+  //     longest K under skewed routing (250 vs 261 us) -- 327 -> 344, 287 -> 432 us with 4 rows per expert (tuning arm only);
+  //   * K <= 512 (w2 of a decode step): every wave owns its own 64 columns over all K steps (WAVE_COLS): 287 -> 195 us at
+  //     [256, 7168, 256], 123 -> 103 us at K = 512; longer K keeps the K split over the waves (K = 2048: 111 vs 130 us).
+  XM_TUNE_VAR(grp_mb, "XLLM_MI355_WSB_GROUP_MB", 0);
+  const bool mb2 = grp_mb == 2;
+  XM_TUNE_VAR(wave_cols, "XLLM_MI355_WSB_WAVE_COLS", -1);
+  const bool wc = (wave_cols < 0 ? K / kWsbK <= 8 : wave_cols != 0) && N % (4 * kWsbCols) == 0;
+  const dim3 grid((unsigned)(N / (wc ? 4 * kWsbCols : kWsbCols)), (unsigned)n_experts);
+#define XM_WSB_G(MB_, WC_)                                                                                             \
+  wsb_launch<T, MB_, true, WC_>(grid, s, (const T*)x, (const T*)w, (T*)out, nullptr, nullptr, (int)max_rows, (int)N,  \
+                                (int)K, (int)(K / kWsbK), g)
+  if (wc) { if (mb2) XM_WSB_G(2, true); else XM_WSB_G(1, true); }
+  else { if (mb2) XM_WSB_G(2, false); else XM_WSB_G(1, false); }
+#undef XM_WSB_G
   return hip_check_launch();
 }
 
