@@ -309,6 +309,12 @@ XM_API int xllm_mi355_static_scaled_fp8_quant(uint8_t* out, const void* input, c
  * scale_in != NULL => static (scale_out ignored). */
 XM_API int xllm_mi355_fp8_scaled_quantize(uint8_t* out, const void* input, const float* scale_in,
                                           float* scale_out, int64_t numel, int dtype, void* stream);
+/* The dynamic form in TWO launches instead of four graph nodes (memset, amax with atomics, scale, quantise): one maximum per block
+   into `workspace` (>= xllm_mi355_fp8_scaled_quantize_workspace_bytes(), caller-owned, private to the launching stream), folded
+   by every block of the quantising launch. Same bits as xllm_mi355_fp8_scaled_quantize(out, input, NULL, scale_out, ...). */
+XM_API size_t xllm_mi355_fp8_scaled_quantize_workspace_bytes(void);
+XM_API int xllm_mi355_fp8_scaled_quantize_ws(uint8_t* out, const void* input, float* scale_out, int64_t numel, int dtype,
+                                             void* workspace, size_t ws_bytes, void* stream);
 /* kernel::fp8_scaled_matmul (ops_api.h:156) -> cutlass_scaled_mm (cutlass_w8a8/scaled_mm_entry.cu:55-116):
  * out = r16( a_scale * (w_scale * sum_fp32 a*w) + bias ); a [M,K] e4m3, w [N,K] e4m3 row-major
  * (the reference passes b.t() of it); a_scale numel 1 or M, w_scale numel 1 or N. K % 128 == 0. */

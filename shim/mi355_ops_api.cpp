@@ -167,9 +167,18 @@ std::tuple<torch::Tensor, torch::Tensor> fp8_scaled_quantize(const torch::Tensor
   const bool is_static = scale.has_value() && scale->defined();
   torch::Tensor s = is_static ? *scale : torch::empty({1}, input.options().dtype(torch::kFloat32));
   auto x = input.contiguous();
-  check(xllm_mi355_fp8_scaled_quantize(static_cast<uint8_t*>(p(q)), p(x), is_static ? s.data_ptr<float>() : nullptr,
-                                       is_static ? nullptr : s.data_ptr<float>(), x.numel(), dt(x), cur_stream()),
-        "fp8_scaled_quantize");
+  if (is_static) {
+    check(xllm_mi355_fp8_scaled_quantize(static_cast<uint8_t*>(p(q)), p(x), s.data_ptr<float>(), nullptr, x.numel(), dt(x),
+                                         cur_stream()),
+          "fp8_scaled_quantize");
+  } else {
+    // dynamic scale: per-block maxima in a transient buffer of this call, then fold + quantise (two launches, no memset node)
+    torch::Tensor ws = torch::empty({(int64_t)xllm_mi355_fp8_scaled_quantize_workspace_bytes()},
+                                    input.options().dtype(torch::kUInt8));
+    check(xllm_mi355_fp8_scaled_quantize_ws(static_cast<uint8_t*>(p(q)), p(x), s.data_ptr<float>(), x.numel(), dt(x), p(ws),
+                                            (size_t)ws.numel(), cur_stream()),
+          "fp8_scaled_quantize");
+  }
   return {q, s};
 }
 

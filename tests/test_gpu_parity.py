@@ -464,6 +464,19 @@ def test_fp8_quant_static_and_dynamic():
     out = torch.empty(x.shape, dtype=torch.uint8, device=DEV)
     ops.static_scaled_fp8_quant(out, x.to(DEV), scale.to(DEV))
     assert torch.equal(out.cpu(), orc.static_scaled_fp8_quant(x, scale))
+    # the workspace-free entry (memset + atomic amax + scale + quantise: four graph nodes) and the two-launch form ops uses
+    # (xllm_mi355_fp8_scaled_quantize_ws, round 6) give the same bits; odd sizes (scalar tail), f16, a tensor of zeros
+    from xllm_amd import _lib
+    for shape, dt_ in (((37, 3584), torch.bfloat16), ((3, 1001), torch.float16), ((128, 1536), torch.bfloat16), ((5, 64), torch.bfloat16)):
+        for zero in (False, True):
+            xd = torch.zeros(shape, dtype=dt_, device=DEV) if zero else (torch.randn(shape, generator=g) * 3).to(dt_).to(DEV)
+            q2, s2 = ops.fp8_scaled_quantize(xd)
+            q1 = torch.empty(shape, dtype=torch.uint8, device=DEV)
+            s1 = torch.empty(1, dtype=torch.float32, device=DEV)
+            rc = _lib.lib().xllm_mi355_fp8_scaled_quantize(q1.data_ptr(), xd.data_ptr(), 0, s1.data_ptr(), xd.numel(),
+                                                           ops._dt(xd), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            assert torch.equal(s1, s2) and torch.equal(q1, q2.view(torch.uint8))
 
 
 @pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True)])

@@ -93,6 +93,7 @@ _SIGS = {
     "xllm_mi355_quantize_with_row_amax": ([vp, vp, vp, vp, i64, i64, ci, vp], ci),
     "xllm_mi355_static_scaled_fp8_quant": ([vp, vp, vp, i64, ci, vp], ci),
     "xllm_mi355_fp8_scaled_quantize": ([vp, vp, vp, vp, i64, ci, vp], ci),
+    "xllm_mi355_fp8_scaled_quantize_ws": ([vp, vp, vp, i64, ci, vp, sz, vp], ci),
     "xllm_mi355_fp8_scaled_matmul": ([vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, i64, ci, vp], ci),
     "xllm_mi355_pack_weight_fp8": ([vp, vp, i64, i64, vp], ci),
     "xllm_mi355_fp8_scaled_matmul_packed": ([vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, i64, ci, vp, sz, vp], ci),

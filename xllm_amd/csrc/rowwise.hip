@@ -1190,6 +1190,67 @@ __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ in, int
   m = block_max(m, red);
   if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(m));
 }
+// Round 6: the dynamic per-tensor quant in TWO launches instead of four graph nodes (memset, amax with atomics, finalize, quant: ~19 us
+// for a [128, 1536] decode operand): amax_partial_kernel leaves one maximum per block in a scratch buffer (plain stores, nothing to
+// zero), fp8_quant_dyn_kernel folds them (<= 1024 floats from the L2) in every block, evaluates fp8_scale_finalize_kernel's
+// expression itself and quantises; block 0 writes the scale. Same bits as the four-node form.
+template <typename T>
+__global__ __launch_bounds__(256) void amax_partial_kernel(const T* __restrict__ in, int64_t n, float* __restrict__ part, bool vec) {
+  __shared__ float red[32];
+  constexpr int N = RowVec<T>::N;
+  float m = 0.0f;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t nvec = n / N;
+    for (int64_t c = tid; c < nvec; c += nthr) {
+      RowVec<T> v;
+      v.raw = reinterpret_cast<const uint4*>(in)[c];
+#pragma unroll
+      for (int j = 0; j < N; ++j) m = fmaxf(m, fabsf(v.get(j)));
+    }
+    for (int64_t i = nvec * N + tid; i < n; i += nthr) m = fmaxf(m, fabsf(to_f32(in[i])));
+  } else {
+    for (int64_t i = tid; i < n; i += nthr) m = fmaxf(m, fabsf(to_f32(in[i])));
+  }
+  m = block_max(m, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_dyn_kernel(uint8_t* __restrict__ out, const T* __restrict__ in,
+                                                            const float* __restrict__ part, int n_part,
+                                                            float* __restrict__ scale_out, int64_t n, bool vec) {
+  __shared__ float red[32];
+  constexpr int N = RowVec<T>::N;
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) m = fmaxf(m, part[i]);
+  m = block_max(m, red);
+  float sc = r16<T>(m / 448.0f);                       // fp8_scale_finalize_kernel's expression
+  sc = r16<T>(fmaxf(sc, r16<T>(1e-12f)));
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = sc;
+  const float sinv = 1.0f / sc;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t nvec = n / N;
+    for (int64_t c = tid; c < nvec; c += nthr) {
+      RowVec<T> v;
+      v.raw = reinterpret_cast<const uint4*>(in)[c];
+      uint32_t pk[N / 4];
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= (uint32_t)f32_to_e4m3_sat(v.get(j + e) * sinv) << (8 * e);
+        pk[j / 4] = w;
+      }
+      if constexpr (N == 8) reinterpret_cast<uint2*>(out)[c] = make_uint2(pk[0], pk[1]);
+      else reinterpret_cast<uint32_t*>(out)[c] = pk[0];
+    }
+    for (int64_t i = nvec * N + tid; i < n; i += nthr) out[i] = f32_to_e4m3_sat(to_f32(in[i]) * sinv);
+  } else {
+    for (int64_t i = tid; i < n; i += nthr) out[i] = f32_to_e4m3_sat(to_f32(in[i]) * sinv);
+  }
+}
+
 template <typename T>
 __global__ void fp8_scale_finalize_kernel(float* scale) {
   float s = r16<T>(scale[0] / 448.0f);
@@ -1746,6 +1807,27 @@ int xllm_mi355_fp8_scaled_quantize(uint8_t* out, const void* input, const float*
   int rc = hip_check_launch();
   if (rc) return rc;
   return xllm_mi355_static_scaled_fp8_quant(out, input, scale_out, numel, dtype, stream);
+}
+
+size_t xllm_mi355_fp8_scaled_quantize_workspace_bytes(void) { return 1024 * sizeof(float); }
+
+int xllm_mi355_fp8_scaled_quantize_ws(uint8_t* out, const void* input, float* scale_out, int64_t numel, int dtype,
+                                      void* workspace, size_t ws_bytes, void* stream) {
+  if (!out || !input || !scale_out || numel < 0) return XM_ERR_INVALID;
+  if (!workspace || ws_bytes < 1024 * sizeof(float) || ((uintptr_t)workspace % 4)) return XM_ERR_WORKSPACE;
+  if (numel == 0) return xllm_mi355_fp8_scaled_quantize(out, input, nullptr, scale_out, numel, dtype, stream);
+  hipStream_t s = (hipStream_t)stream;
+  XM_DISPATCH_FLOAT(dtype, T, {
+    constexpr int N = Vec16B<T>::N;
+    const bool vec = ((uintptr_t)input % 16 == 0) && ((uintptr_t)out % 8 == 0);
+    int64_t blocks = (numel / N + 255) / 256;
+    blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL((amax_partial_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)input, numel,
+                       reinterpret_cast<float*>(workspace), vec);
+    hipLaunchKernelGGL((fp8_quant_dyn_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, out, (const T*)input,
+                       reinterpret_cast<const float*>(workspace), (int)blocks, scale_out, numel, vec);
+  });
+  return hip_check_launch();
 }
 
 }  // extern "C"
