@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
   for (int j = 0; j < NDMA; ++j) {
     const int row = 4 * (NDMA * wave + j) + (lane >> 4), pc = lane & 15;
     voff_k[j] = row * (int)(krow * 2) + ((pc ^ (row & 15)) << 4);
-    voff_v[j] = row * (int)(vrow * 2) + ((pc ^ ((row & 7) << 1)) << 4);
+    voff_v[j] = row * (int)(vrow * 2) + ((pc ^ ((row & 3) << 2)) << 4);   // V: 32-byte units XOR 2 (row & 3), see vaddr
   }
   auto stage = [&](int i, bool is_v) {  // tile tile_lo + i of K or V -> ring slot i & 1
     const int t0 = (tile_lo + i) * kPf2Tile;
@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_m32_kernel(
     // V^T fragment of (key step, d block db): the 16 lanes of group (gi = d half, hi) address keys 4 hi + (p16 >> 2) (+ 8 for the
     // second read) x the four 8-byte column quads of d 32 db + 16 gi .. + 15; lane p16 receives column p16 of that 4 x 16 block
     const int p16 = lane & 15, gi = (lane >> 4) & 1;
-    const int vr = 4 * hi + (p16 >> 2), ft = vr & 7;
+    // (round 6: the unit swizzle was (row & 7): inside a 32-lane pass the rows are 4 hi + 0..3 and the d halves gi = 0, 1, and
+    // (2 db + gi) ^ (row & 3) hits only FOUR of the eight 32-byte bank groups -- a 2-way conflict on every transposed read, 1.3
+    // conflict cycles per LDS instruction by PMC (SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS); 2 (row & 3) leaves the gi bit alone: eight groups)
+    const int vr = 4 * hi + (p16 >> 2), ft = 2 * (vr & 3);
 #pragma unroll
     for (int db = 0; db < 4; ++db) vaddr[db] = lds_base + vr * ROWB + (((2 * db + gi) ^ ft) << 5) + (p16 & 3) * 8;   // + the V ring base
   }
