@@ -530,7 +530,14 @@ def fp8_scaled_quantize(input, output=None, scale=None):
     s = torch.empty(1, dtype=torch.float32, device=input.device)
     # dynamic per-tensor scale: two launches (per-block maxima in a transient, stream-private scratch -> fold + quantise) instead of
     # the four graph nodes of the workspace-free entry (memset, amax with atomics, scale, quantise); same bits
-    ws = _attn_workspace(input.device, 4096)
+    try:
+        ws = _attn_workspace(input.device, 4096)
+    except Mi355Error:      # first call inside a graph capture (no scratch yet, none may be allocated now): the workspace-free entry
+        ws = None
+    if ws is None:
+        check(_lib.lib().xllm_mi355_fp8_scaled_quantize(_p(q), _p(x), 0, _p(s), x.numel(), _dt(x), _stream()),
+              "fp8_scaled_quantize")
+        return q, s
     check(_lib.lib().xllm_mi355_fp8_scaled_quantize_ws(_p(q), _p(x), _p(s), x.numel(), _dt(x), ws.data_ptr(), ws.numel(),
                                                        _stream()), "fp8_scaled_quantize")
     return q, s
