@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of the slab consumers (acc_add_rms_norm & co. with every load in flight) on the decode steps: new library vs XLLM_MI355_LIB=<old build>
+# (the old build: `git show <commit before 90a3ea2>:xllm_amd/csrc/rowwise.hip` compiled to an object, linked with the other objects of
+#  xllm_amd/csrc/build/ into xllm_amd/lib/libxllm_mi355_oldrow.so -- not kept in the tree)
 R=$GRAFT_REPO_ROOT
 OLD=$R/xllm_amd/lib/libxllm_mi355_oldrow.so
 F="--no-cpu-baseline --no-prefill --no-engine --no-gemm --no-pmc --no-per-rank --no-allocator-pages --steps 20 --warmup 3"
