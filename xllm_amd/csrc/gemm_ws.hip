@@ -1016,27 +1016,50 @@ __global__ __launch_bounds__(256) void ws_slab_epilogue_kernel(const int32_t* __
   const int64_t total = M * N;
   for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x * 4) {
-    acc_t a = *reinterpret_cast<const acc_t*>(slabs + idx);
-    for (int s = 1; s < n_slices; ++s) a += *reinterpret_cast<const acc_t*>(slabs + (int64_t)s * total + idx);
+    // every load of the element group is requested before the first is consumed (round 6: the slab loop, then the scales, then the
+    // bias were up to ten dependent memory latencies of a 5.8-us launch); sums in slice order as before (fp32 kinds: same bits)
     const int64_t m = idx / N, n = idx - m * N;
+    acc_t sl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      sl[s] = acc_t{0, 0, 0, 0};
+      if (s < n_slices) sl[s] = *reinterpret_cast<const acc_t*>(slabs + (int64_t)s * total + idx);
+    }
+    float as = 1.0f, wsv[4] = {1.f, 1.f, 1.f, 1.f}, bsv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.out) {
+      if constexpr (KIND == kI8) {
+        as = epi.a_scale[m];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsv[e] = epi.w_scale[n + e];
+      } else if constexpr (KIND == kFP8) {
+        as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wsv[e] = epi.w_scale[epi.w_scale_n > 1 ? n + e : 0];
+      }
+      if (epi.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bsv[e] = load16(epi.bias, n + e, epi.out_bf16);
+      }
+    }
+    acc_t a = sl[0];
+#pragma unroll
+    for (int s = 1; s < 8; ++s)
+      if (s < n_slices) a += sl[s];
+    for (int s = 8; s < n_slices; ++s) a += *reinterpret_cast<const acc_t*>(slabs + (int64_t)s * total + idx);   // (no plan makes > 8)
     if constexpr (KIND == kI8) {
       if (epi.acc_out) *reinterpret_cast<i32x4_t*>(epi.acc_out + idx) = a;
     }
     if (!epi.out) continue;
     float v[4];
     if constexpr (KIND == kI8) {
-      const float as = epi.a_scale[m];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = (float)a[e] * as * epi.w_scale[n + e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+      for (int e = 0; e < 4; ++e) v[e] = (float)a[e] * as * wsv[e] + bsv[e];
     } else if constexpr (KIND == kFP8) {
-      const float as = epi.a_scale[epi.a_scale_n > 1 ? m : 0];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = as * (epi.w_scale[epi.w_scale_n > 1 ? n + e : 0] * a[e]) + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+      for (int e = 0; e < 4; ++e) v[e] = as * (wsv[e] * a[e]) + bsv[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = a[e] + (epi.bias ? load16(epi.bias, n + e, epi.out_bf16) : 0.0f);
+      for (int e = 0; e < 4; ++e) v[e] = a[e] + bsv[e];
     }
     uint2 pk;
     if (epi.out_bf16) { pk.x = pack2x16<true>(v[0], v[1]); pk.y = pack2x16<true>(v[2], v[3]); }

@@ -860,16 +860,35 @@ __global__ __launch_bounds__(256) void act_and_mul_kernel(T* __restrict__ out, c
   T* o = out + t * (int64_t)d;
   if (vec) {
     const int nvec = d / N;
-    for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
-      RowVec<T> xv, yv;
-      xv.raw = reinterpret_cast<const uint4*>(x)[c];
-      yv.raw = reinterpret_cast<const uint4*>(y)[c];
+    // five chunk pairs of a thread requested before the first is consumed (round 6: one pair per loop iteration was ten dependent
+    // round trips per row at d = 18944: 8.3 us for [256, 2 x 18944]); native vector registers (HIP uint4 arrays spill, see below)
+    typedef unsigned avec_t __attribute__((ext_vector_type(4)));
+    constexpr int U = 5;
+    // gridDim.y workgroups share a row (elementwise: no dependency inside a row); few rows (decode) then still put enough bytes in
+    // flight per CU -- one 256-thread workgroup per 113-KB row pair kept 40 KB in flight and the launch at 3.5 TB/s
+    for (int c0 = blockIdx.y * U * blockDim.x + threadIdx.x; c0 < nvec; c0 += gridDim.y * U * blockDim.x) {
+      avec_t xr[U], yr[U];
 #pragma unroll
-      for (int j = 0; j < N; ++j) xv.set(j, r16<T>(act_f<MODE>(xv.get(j))) * yv.get(j));
-      reinterpret_cast<uint4*>(o)[c] = xv.raw;
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * blockDim.x;
+        const int cc = c < nvec ? c : c0;
+        xr[u] = reinterpret_cast<const avec_t*>(x)[cc];
+        yr[u] = reinterpret_cast<const avec_t*>(y)[cc];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * blockDim.x;
+        if (c >= nvec) break;
+        RowVec<T> xv, yv;
+        xv.raw = make_uint4(xr[u][0], xr[u][1], xr[u][2], xr[u][3]);
+        yv.raw = make_uint4(yr[u][0], yr[u][1], yr[u][2], yr[u][3]);
+#pragma unroll
+        for (int j = 0; j < N; ++j) xv.set(j, r16<T>(act_f<MODE>(xv.get(j))) * yv.get(j));
+        reinterpret_cast<uint4*>(o)[c] = xv.raw;
+      }
     }
   } else {
-    for (int i = threadIdx.x; i < d; i += blockDim.x)
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < d; i += gridDim.y * blockDim.x)
       o[i] = from_f32<T>(r16<T>(act_f<MODE>(to_f32(x[i]))) * to_f32(y[i]));
   }
 }
@@ -1085,7 +1104,9 @@ __global__ __launch_bounds__(TH) void scaled_quantize_i8_kernel(const T* __restr
                                                                 float* __restrict__ scales, int K, bool vec, bool nt) {
   __shared__ float red[32];
   constexpr int N = RowVec<T>::N;
-  constexpr int kCache = 4;
+  // chunks cached per thread: 512 x 5 x 8 covers the longest decode row (Qwen2-7B's 18944) in ONE round trip -- with 4 the last 2560
+  // elements were a second (and, for the quantising pass, a third) dependent latency of a 5-us launch (round 6)
+  constexpr int kCache = TH >= 512 ? 5 : 4;
   const int64_t m = blockIdx.x;
   const T* xr = x + m * (int64_t)K;
   int8_t* orow = out + m * (int64_t)K;
@@ -1094,10 +1115,15 @@ __global__ __launch_bounds__(TH) void scaled_quantize_i8_kernel(const T* __restr
     const int nvec = K / N;
     RowVec<T> xv[kCache];
 #pragma unroll
+    for (int i = 0; i < kCache; ++i) {          // all requests first
+      const int c = threadIdx.x + i * TH;
+      xv[i].raw = make_uint4(0u, 0u, 0u, 0u);
+      if (c < nvec) xv[i].raw = rw_ld16(reinterpret_cast<const uint4*>(xr) + c, nt);
+    }
+#pragma unroll
     for (int i = 0; i < kCache; ++i) {
       const int c = threadIdx.x + i * TH;
       if (c < nvec) {
-        xv[i].raw = rw_ld16(reinterpret_cast<const uint4*>(xr) + c, nt);
 #pragma unroll
         for (int j = 0; j < N; ++j) amax = fmaxf(amax, fabsf(xv[i].get(j)));
       }
@@ -1565,17 +1591,23 @@ template <typename T>
 static int launch_act(void* out, const void* input, int64_t n_tokens, int64_t d, int act_mode, hipStream_t s) {
   constexpr int N = Vec16B<T>::N;
   const bool vec = (d % N == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)input % 16 == 0);
+  // workgroups per row: enough for ~4 workgroups per CU when the rows alone are few, each at least one 5-chunk batch per thread
+  int64_t per_row = (1024 + n_tokens - 1) / n_tokens;
+  const int64_t batches = (d / N + 5 * 256 - 1) / (5 * 256);
+  per_row = per_row > batches ? batches : per_row;
+  per_row = per_row < 1 ? 1 : per_row;
+  const dim3 grid_am((unsigned)n_tokens, (unsigned)per_row);
   switch (act_mode) {
     case XM_ACT_SILU:
-      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_SILU>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_SILU>), grid_am, dim3(256), 0, s, (T*)out,
                          (const T*)input, (int)d, vec);
       break;
     case XM_ACT_GELU:
-      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU>), grid_am, dim3(256), 0, s, (T*)out,
                          (const T*)input, (int)d, vec);
       break;
     case XM_ACT_GELU_TANH:
-      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU_TANH>), dim3(n_tokens), dim3(256), 0, s, (T*)out,
+      hipLaunchKernelGGL((act_and_mul_kernel<T, XM_ACT_GELU_TANH>), grid_am, dim3(256), 0, s, (T*)out,
                          (const T*)input, (int)d, vec);
       break;
     default: return XM_ERR_UNSUPPORTED;
